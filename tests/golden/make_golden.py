@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by IMPORTING THE REFERENCE (build container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference (/root/reference, ramanakumars/patchGAN v0.2.2) is imported, driven
+on CPU with seeded inputs, and only DATA (inputs' seeds, initial weights, loss
+curves, probes) is written to ``tests/golden/*.npz``.  No reference source or
+bytecode is copied.  The GPU box has no /root/reference: tests there read the
+committed ``.npz`` files only.
+"""
+import io
+import os
+import sys
+import tempfile
+import contextlib
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name, kwargs
+CONFIGS = {
+    # cfg2-shaped (leakyrelu/sigmoid/tversky/no-norm D) at nf=ndf=4
+    'a_lrelu_tversky': dict(in_nc=3, out_nc=1, nf=4, ndf=4, n_layers=3, norm=False, activation='leakyrelu',
+                            final_act='sigmoid', loss_type='tversky', B=2, size=256),
+    # tanh + normed D + multi-class weighted BCE with sigmoid head
+    'b_tanh_wbce_norm': dict(in_nc=3, out_nc=3, nf=4, ndf=4, n_layers=3, norm=True, activation='tanh',
+                             final_act='sigmoid', loss_type='weighted_bce', B=2, size=256),
+    # relu + MAE + 5-layer D (COCO-yaml-like: nf 2x ndf, n_layers 5)
+    'c_relu_mae_l5': dict(in_nc=3, out_nc=1, nf=8, ndf=4, n_layers=5, norm=False, activation='relu',
+                          final_act='sigmoid', loss_type='MAE', B=2, size=256),
+    # softmax head, multi-class tversky, single-sample batch, normed 5-layer D
+    'd_softmax_tversky': dict(in_nc=3, out_nc=4, nf=4, ndf=8, n_layers=5, norm=True, activation='leakyrelu',
+                              final_act='softmax', loss_type='tversky', B=1, size=256),
+    # single-class weighted_bce (weight = ones branch), 1-channel input
+    'e_wbce_c1': dict(in_nc=1, out_nc=1, nf=4, ndf=4, n_layers=3, norm=False, activation='leakyrelu',
+                      final_act='sigmoid', loss_type='weighted_bce', B=2, size=256),
+}
+NSTEPS = 10
+MODEL_SEED = 1234
+DATA_SEED = 7
+LR = 1e-3
+NSAMP = 64
+
+
+def make_inputs(cfg):
+    """Same recipe as SURVEY 8(d): x ~ U[0,1), y = (U > 0.7)."""
+    g = torch.Generator().manual_seed(DATA_SEED)
+    x = torch.rand(cfg['B'], cfg['in_nc'], cfg['size'], cfg['size'], generator=g)
+    y = (torch.rand(cfg['B'], cfg['out_nc'], cfg['size'], cfg['size'], generator=g) > 0.7).float()
+    return x, y
+
+
+def probe(t, nsamp=NSAMP):
+    """(sum, abs-sum, strided samples) of a tensor, float64."""
+    f = t.detach().double().flatten()
+    n = f.numel()
+    idx = (torch.arange(nsamp, dtype=torch.int64) * 2654435761 % n)
+    return np.concatenate([[f.sum().item(), f.abs().sum().item()], f[idx].numpy()])
+
+
+def run_config(name, cfg):
+    sys.path.insert(0, REF)
+    from patchgan import UNet, Discriminator, Trainer
+    torch.manual_seed(MODEL_SEED)
+    g = UNet(cfg['in_nc'], cfg['out_nc'], cfg['nf'], use_dropout=False,
+             activation=cfg['activation'], final_act=cfg['final_act'])
+    d = Discriminator(cfg['in_nc'] + cfg['out_nc'], cfg['ndf'], n_layers=cfg['n_layers'], norm=cfg['norm'])
+    out = {}
+    for k, v in g.state_dict().items():
+        out['g0/' + k] = v.detach().numpy().copy()
+    for k, v in d.state_dict().items():
+        out['d0/' + k] = v.detach().numpy().copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        t = Trainer(g, d, tempfile.mkdtemp(), device='cpu')
+    t.loss_type = cfg['loss_type']
+    t.seg_alpha = 200
+    t.gen_optimizer = torch.optim.Adam(g.parameters(), lr=LR, betas=(0.9, 0.999))
+    t.disc_optimizer = torch.optim.Adam(d.parameters(), lr=LR, betas=(0.9, 0.999))
+    x, y = make_inputs(cfg)
+
+    # forward probes at the initial weights (train mode; dropout off)
+    g.train()
+    d.train()
+    acts = {}
+    hooks = []
+    for i, blk in enumerate(g.encoder):
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: acts.__setitem__(f'enc{i}', o)))
+    for i, blk in enumerate(g.decoder):
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: acts.__setitem__(f'dec{i}', o)))
+    with torch.no_grad():
+        gen0, hid0 = g(x, return_hidden=True)
+        dfake0 = d(torch.cat((x, gen0), 1))
+        dreal0 = d(torch.cat((x, y), 1))
+    for h in hooks:
+        h.remove()
+    for k, v in acts.items():
+        out['fwd/' + k] = probe(v)
+    out['fwd/hidden'] = probe(hid0)
+    out['fwd/disc_fake'] = probe(dfake0)
+    out['fwd/disc_real'] = probe(dreal0)
+    out['fwd/disc_shape'] = np.array(dfake0.shape)
+
+    # eval-mode batch (train=False) at initial weights
+    ev = t.batch(x, y, train=False)
+    out['eval_losses'] = np.array([ev[k] for k in ['gen', 'gen_loss', 'gdisc', 'discr', 'discf', 'disc']])
+
+    # 10 training steps; gradient probes after step 1
+    curve = []
+    for s in range(NSTEPS):
+        l = t.batch(x, y, train=True)
+        curve.append([l[k] for k in ['gen', 'gen_loss', 'gdisc', 'discr', 'discf', 'disc']])
+        if s == 0:
+            for k, p in g.named_parameters():
+                out['ggrad1/' + k] = probe(p.grad)
+            for k, p in d.named_parameters():
+                out['dgrad1/' + k] = probe(p.grad)
+            for k, v in g.state_dict().items():
+                out['g1/' + k] = probe(v)
+            for k, v in d.state_dict().items():
+                out['d1/' + k] = probe(v)
+    out['losses'] = np.array(curve, dtype=np.float64)
+    for k, v in g.state_dict().items():
+        out['g10/' + k] = probe(v)
+    for k, v in d.state_dict().items():
+        out['d10/' + k] = probe(v)
+    with torch.no_grad():
+        out['gen_img10'] = probe(g(x))
+    out['cfg_keys'] = np.array(list(cfg.keys()))
+    out['cfg_vals'] = np.array([str(v) for v in cfg.values()])
+    out['meta'] = np.array([MODEL_SEED, DATA_SEED, NSTEPS, NSAMP])
+    np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+    print(name, 'loss[0]', curve[0][0], 'loss[-1]', curve[-1][0], flush=True)
+
+
+def run_train_driver():
+    """Trainer.train (trainer.py:117-279): LR schedule + per-epoch loss means + resume."""
+    sys.path.insert(0, REF)
+    from patchgan import UNet, Discriminator, Trainer
+    cfg = CONFIGS['a_lrelu_tversky']
+    x, y = make_inputs(cfg)
+    data = [(x[:1], y[:1]), (x[1:], y[1:])]
+    out = {}
+    lrs = []
+    for epochs in range(1, 7):
+        torch.manual_seed(MODEL_SEED)
+        g = UNet(3, 1, 4, use_dropout=False, activation='leakyrelu', final_act='sigmoid')
+        d = Discriminator(4, 4, n_layers=3)
+        tmp = tempfile.mkdtemp()
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            t = Trainer(g, d, tmp, device='cpu')
+            G_ep, D_ep = t.train(data, data[:1], epochs, gen_learning_rate=1e-3, dsc_learning_rate=2e-3,
+                                 lr_decay=0.9, decay_freq=2, save_freq=3)
+        lrs.append([t.gen_optimizer.param_groups[0]['lr'], t.disc_optimizer.param_groups[0]['lr']])
+        if epochs == 6:
+            out['G_loss_ep'] = np.array(G_ep)
+            out['D_loss_ep'] = np.array(D_ep)
+            out['ckpt_files'] = np.array(sorted(os.listdir(tmp)))
+            # resume: load_last_checkpoint -> start = 7; LR = lr*decay^((start-1)/decay_freq)
+            torch.manual_seed(MODEL_SEED)
+            g2 = UNet(3, 1, 4, use_dropout=False, activation='leakyrelu', final_act='sigmoid')
+            d2 = Discriminator(4, 4, n_layers=3)
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                t2 = Trainer(g2, d2, tmp, device='cpu')
+                t2.load_last_checkpoint()
+                G2, D2 = t2.train(data, data[:1], 7, gen_learning_rate=1e-3, dsc_learning_rate=2e-3,
+                                  lr_decay=0.9, decay_freq=2, save_freq=3)
+            out['resume_start'] = np.array([t2.start])
+            out['resume_G_loss_ep'] = np.array(G2)
+            out['resume_D_loss_ep'] = np.array(D2)
+            out['resume_lr'] = np.array([t2.gen_optimizer.param_groups[0]['lr'],
+                                         t2.disc_optimizer.param_groups[0]['lr']])
+    out['lr_after_epochs'] = np.array(lrs)
+    np.savez_compressed(os.path.join(HERE, 'train_driver.npz'), **out)
+    print('train_driver', out['G_loss_ep'], out['lr_after_epochs'][:, 0], out['resume_start'], flush=True)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or (list(CONFIGS) + ['train_driver'])
+    for name in which:
+        if name == 'train_driver':
+            run_train_driver()
+        else:
+            run_config(name, CONFIGS[name])
