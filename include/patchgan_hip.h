@@ -1,0 +1,177 @@
+/*
+ * patchgan_hip.h -- C ABI of libpatchgan_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (ramanakumars/patchGAN v0.2.2) has no native layer of its own:
+ * every entry point below replaces the ATen operator that a line of the
+ * reference's Python invokes, cited as file:line into /root/reference.
+ *
+ * Conventions
+ *   - every tensor is fp32, device memory, NHWC ("pixel-major"): element
+ *     (n, h, w, c) of a tensor with pixel stride `ld` lives at
+ *     base[((n*H + h)*W + w)*ld + c].  `ld >= C` lets a tensor be a channel
+ *     slice of a wider buffer, which is how torch.cat (unet.py:127,
+ *     trainer.py:65,96,98) is made free.  Base pointers, `ld` and channel
+ *     counts must be multiples of 4 floats (16 B) unless stated otherwise.
+ *   - 4x4 convolution weights are kept in ONE packed layout for all uses:
+ *         P[tap = kh*4 + kw][a][b]          (a*b floats per tap, b fastest)
+ *     where a torch weight tensor W[a][b][kh][kw] has (a, b) = (Cout, Cin) for
+ *     nn.Conv2d and (Cin, Cout) for nn.ConvTranspose2d.  Channel dim `a` lives
+ *     on the SMALL spatial side (conv output / convT input), `b` on the BIG side
+ *     (conv input / convT output);  big = stride*small - 1 + k.
+ *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*),
+ *     never allocate, never synchronise; the caller owns all memory including
+ *     the workspace.  Return 0 on success or a negative PG_E* code; nothing is
+ *     launched when an error is returned.
+ *   - thread-compatible: no global mutable state.
+ */
+#ifndef PATCHGAN_HIP_H
+#define PATCHGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_OK 0
+#define PG_EINVAL (-1)   /* bad shape / null pointer / misaligned pointer or ld */
+#define PG_EWORKSPACE (-2) /* workspace too small */
+#define PG_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after a launch */
+
+/* activation codes (unet.py:12-17,42-51; disc.py:20,29,39,46) */
+#define PG_ACT_NONE 0
+#define PG_ACT_LEAKY 1   /* LeakyReLU(0.2) */
+#define PG_ACT_RELU 2
+#define PG_ACT_TANH 3
+#define PG_ACT_SIGMOID 4
+
+/* algorithm selector for the three conv entry points */
+#define PG_ALGO_AUTO 0
+#define PG_ALGO_DIRECT 1 /* one-thread-per-output reference-quality kernels (any channel count) */
+#define PG_ALGO_MFMA 2   /* LDS-tiled implicit GEMM on v_mfma_f32_32x32x2_f32 (channels % 4 == 0) */
+
+typedef struct pg_conv_geom {
+    int N;        /* batch */
+    int Hb, Wb;   /* big spatial extent  (conv input  / convT output) */
+    int Hs, Ws;   /* small spatial extent (conv output / convT input)  */
+    int Ca;       /* channels on the small side = weight dim a */
+    int Cb;       /* channels on the big side   = weight dim b */
+    int stride;   /* 1 or 2; kernel 4x4, padding 1 always (unet.py:80-81, disc.py:16-17) */
+} pg_conv_geom;
+
+int pg_version(void);
+
+/* Bytes of workspace that lets op (0 = big2small, 1 = small2big, 2 = wgrad) use its preferred
+ * split-K factor for geometry g.  A smaller (or NULL) workspace is legal: the split shrinks. */
+size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);
+
+/* small[n,p,q,a] = act( sum_{kh,kw,b} big[n, s*p-1+kh, s*q-1+kw, b] * P[kh*4+kw][a][b] + bias[a] )
+ * Replaces: nn.Conv2d forward (unet.py:19; disc.py:19,27,37,45) with (a,b) = (Cout,Cin), and the
+ * data-gradient of nn.ConvTranspose2d (unet.py:53, aten::convolution_backward) with (a,b) = (Cin,Cout).
+ * bias may be NULL; act is a PG_ACT_* code applied in the epilogue. */
+int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const float* bias,
+                         float* small, int ld_small, const pg_conv_geom* g, int act, int algo,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* big[n,h,w,b] = act( sum_{kh,kw,a : (h+1-kh)%s==0, (w+1-kw)%s==0}
+ *                      small[n,(h+1-kh)/s,(w+1-kw)/s,a] * P[kh*4+kw][a][b] + bias[b] )
+ * Replaces: nn.ConvTranspose2d forward (unet.py:53) with (a,b) = (Cin,Cout), and the data-gradient of
+ * nn.Conv2d (aten::convolution_backward) with (a,b) = (Cout,Cin). */
+int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const float* bias,
+                         float* big, int ld_big, const pg_conv_geom* g, int act, int algo,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* dP[kh*4+kw][a][b] = sum_{n,p,q} small[n,p,q,a] * big[n, s*p-1+kh, s*q-1+kw, b]
+ * Replaces: the weight-gradient half of aten::convolution_backward for both nn.Conv2d
+ * (small = dL/dy, big = x) and nn.ConvTranspose2d (small = x, big = dL/dy).
+ * Deterministic (fixed-order split-K slabs, no float atomics).  dbias (may be NULL) receives
+ * sum_{n,p,q} small[n,p,q,a] (the Conv2d bias gradient, disc.py:19,45). */
+int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_big,
+                     float* dP, float* dbias, const pg_conv_geom* g, int algo,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* InstanceNorm2d(eps, biased var, no affine; unet.py:20,55, disc.py:32,42) + activation + Dropout(p)
+ * (unet.py:28,65) over y[N, HW, C]:   out = dropout(act((y - mean_nc) * rstd_nc)).
+ * stats[(n*C + c)*2 + {0,1}] receives (mean, rstd).  drop_p == 0 disables dropout; otherwise element e =
+ * (n*HW + pix)*C + c is kept iff pg_dropout_keep(seed, e) and scaled by 1/(1-p). */
+int pg_instnorm_act_fwd(const float* y, int ld_y, float* out, int ld_out, float* stats,
+                        int N, int HW, int C, int act, float eps,
+                        float drop_p, uint64_t seed, void* stream);
+
+/* Backward of the block above: given g = dL/dout (= g1 + g2, g2 may be NULL: the skip connection's
+ * second consumer), the saved y and stats, writes dy = dL/dy. */
+int pg_instnorm_act_bwd(const float* g1, int ld_g1, const float* g2, int ld_g2,
+                        const float* y, int ld_y, const float* stats, float* dy, int ld_dy,
+                        int N, int HW, int C, int act, float drop_p, uint64_t seed, void* stream);
+
+/* Backward of a plain activation (+dropout) from its OUTPUT a:  dy = (g1+g2) * keep/(1-p) * act'(a).
+ * act' from the output: leaky a>0?1:0.2, relu a>0, tanh 1-a^2, sigmoid a(1-a), none 1.  `a` may be NULL for
+ * PG_ACT_NONE. */
+int pg_act_bwd(const float* g1, int ld_g1, const float* g2, int ld_g2, const float* a, int ld_a,
+               float* dy, int ld_dy, long npix, int C, int act, float drop_p, uint64_t seed, void* stream);
+
+/* Elementwise activation (+dropout) forward, for blocks without a norm whose conv could not fuse it. */
+int pg_act_fwd(const float* y, int ld_y, float* out, int ld_out, long npix, int C, int act,
+               float drop_p, uint64_t seed, void* stream);
+
+/* Softmax over the channel dim (nn.Softmax(dim=1), unet.py:48-49); C need not be a multiple of 4. */
+int pg_softmax_fwd(const float* y, int ld_y, float* out, int ld_out, long npix, int C, void* stream);
+int pg_softmax_bwd(const float* g1, int ld_g1, const float* g2, int ld_g2, const float* out, int ld_out,
+                   float* dy, int ld_dy, long npix, int C, void* stream);
+
+/* Writes the dropout keep-mask (1.0 / 0.0) the kernels above use, for tests. */
+int pg_dropout_mask(float* mask, long nelem, float drop_p, uint64_t seed, void* stream);
+
+/* ---- losses (losses.py:18-39, trainer.py:71-85,101-103) ------------------------------------------
+ * Stage 1 (per rank): pg_loss_reduce accumulates, for each (sample n, channel c), the five sums
+ *   S[n][c][0..4] = { sum y*p, sum y, sum p, sum bce_elem(p, y), sum |p - y| }       (double)
+ * over HW, where y is the target tensor or, when y == NULL, the constant `tconst`;
+ * bce_elem = -( y*max(log p,-100) + (1-y)*max(log(1-p),-100) ).  C need not be a multiple of 4. */
+int pg_loss_reduce(const float* p, int ld_p, const float* y, int ld_y, float tconst,
+                   int N, int HW, int C, double* S, void* stream);
+
+/* Stage 2: gradient of a scalar loss wrt p from per-(n,c) coefficients:
+ *   mode 0 (affine in y; focal-Tversky):   g = coef[n][c][0] * y + coef[n][c][1]
+ *   mode 1 (BCE):                           g = coef[n][c][0] * (p - y) / max(p*(1-p), 1e-12)
+ *   mode 2 (MAE):                           g = coef[n][c][0] * sign(p - y)
+ * coef is float [N][C][2] on the device. */
+int pg_loss_grad(const float* p, int ld_p, const float* y, int ld_y, float tconst,
+                 const float* coef, float* g, int ld_g, int N, int HW, int C, int mode, void* stream);
+
+/* Stage 1b: local2[0] = sum_n (1 - T_n) with T_n = (tp+1)/(tp + beta*fn + (1-beta)*fp + 1) (losses.py:20-26,
+ * tp/fn/fp summed over all channels of sample n); local2[1] = sum_{n,c} S[n][c][1] (= torch.sum(target),
+ * trainer.py:77).  Under data parallelism the caller all-reduces local2 (sum) before stage 2. */
+int pg_loss_prepare(const double* S, int N, int C, float beta, double* local2, void* stream);
+
+/* Stage 2: from S and the (global) sums gsum2, write the loss value and the coefficients for pg_loss_grad.
+ * Bglobal = global batch size (N on one GPU).  Gradients are seeded for a SUM all-reduce across ranks.
+ *   PG_LOSS_TVERSKY : loss = alpha * (gsum2[0]/Bglobal)^gamma                          (global value)
+ *   PG_LOSS_WBCE    : loss = alpha * sum w[n][c]*S[n][c][3] / (Bglobal*C*HW), w = C>1 ? 1 - S[n][c][1]/gsum2[1] : 1
+ *   PG_LOSS_MAE     : loss = alpha * sum S[n][c][4] / (Bglobal*C*HW)
+ *   PG_LOSS_BCE     : loss = alpha * sum S[n][c][3] / (Bglobal*C*HW)     (nn.BCELoss, mean; alpha = 1 or 0.5)
+ * For the last three the value is this rank's partial (sum over ranks = global loss). */
+#define PG_LOSS_TVERSKY 0
+#define PG_LOSS_WBCE 1
+#define PG_LOSS_MAE 2
+#define PG_LOSS_BCE 3
+int pg_loss_finalize(const double* S, const double* gsum2, int mode, int N, int C, int HW, int Bglobal,
+                     float alpha, float beta, float gamma, float* coef, float* loss_out, void* stream);
+
+/* ---- optimizer (torch.optim.Adam defaults, trainer.py:169-172) -----------------------------------
+ * m += (g-m)*(1-b1); v = v*b2 + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt_bc2 + eps)
+ * over n contiguous floats; bc1 = 1-b1^t and sqrt_bc2 = sqrt(1-b2^t) are computed by the caller. */
+int pg_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                 float eps, float bc1, float sqrt_bc2, void* stream);
+
+/* ---- layout (the reference is NCHW end to end; trainer.py:55-66) ---------------------------------- */
+int pg_nchw_to_nhwc(const float* src, float* dst, int ld_dst, int N, int C, int H, int W, void* stream);
+int pg_nhwc_to_nchw(const float* src, int ld_src, float* dst, int N, int C, int H, int W, void* stream);
+/* dst[pix*ld_dst + c] = src[pix*ld_src + c] for c < C  (channel-slice copy; C need not be a multiple of 4) */
+int pg_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, long npix, int C, void* stream);
+int pg_fill(float* dst, long n, float value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATCHGAN_HIP_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of libpatchgan_hip.so (the C ABI declared in include/patchgan_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this module raises.  The
+library is built in-tree by ``__graft_entry__.build()`` / ``make -C patchgan_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpatchgan_hip.so')
+
+ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+ACT_CODES = {None: ACT_NONE, 'none': ACT_NONE, 'leakyrelu': ACT_LEAKY, 'relu': ACT_RELU, 'tanh': ACT_TANH,
+             'sigmoid': ACT_SIGMOID}
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+LOSS_TVERSKY, LOSS_WBCE, LOSS_MAE, LOSS_BCE = 0, 1, 2, 3
+OP_BIG2SMALL, OP_SMALL2BIG, OP_WGRAD = 0, 1, 2
+
+_ERR = {-1: 'PG_EINVAL (bad shape / null or misaligned pointer)', -2: 'PG_EWORKSPACE (workspace too small)',
+        -3: 'PG_ELAUNCH (HIP launch failed)'}
+
+
+class ConvGeom(ctypes.Structure):
+    """struct pg_conv_geom"""
+    _fields_ = [('N', ctypes.c_int), ('Hb', ctypes.c_int), ('Wb', ctypes.c_int), ('Hs', ctypes.c_int),
+                ('Ws', ctypes.c_int), ('Ca', ctypes.c_int), ('Cb', ctypes.c_int), ('stride', ctypes.c_int)]
+
+    def key(self):
+        return (self.N, self.Hb, self.Wb, self.Hs, self.Ws, self.Ca, self.Cb, self.stride)
+
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_l = ctypes.c_long
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+_u64 = ctypes.c_uint64
+_G = ctypes.POINTER(ConvGeom)
+
+# name -> (restype, argtypes); mirrors include/patchgan_hip.h one to one
+SIGNATURES = {
+    'pg_version': (_i, []),
+    'pg_conv_workspace_bytes': (_sz, [_G, _i]),
+    'pg_conv4x4_big2small': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p]),
+    'pg_conv4x4_small2big': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p]),
+    'pg_conv4x4_wgrad': (_i, [_p, _i, _p, _i, _p, _p, _G, _i, _p, _sz, _p]),
+    'pg_instnorm_act_fwd': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _f, _u64, _p]),
+    'pg_instnorm_act_bwd': (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p]),
+    'pg_act_bwd': (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _i, _f, _u64, _p]),
+    'pg_act_fwd': (_i, [_p, _i, _p, _i, _l, _i, _i, _f, _u64, _p]),
+    'pg_softmax_fwd': (_i, [_p, _i, _p, _i, _l, _i, _p]),
+    'pg_softmax_bwd': (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _p]),
+    'pg_dropout_mask': (_i, [_p, _l, _f, _u64, _p]),
+    'pg_loss_reduce': (_i, [_p, _i, _p, _i, _f, _i, _i, _i, _p, _p]),
+    'pg_loss_prepare': (_i, [_p, _i, _i, _f, _p, _p]),
+    'pg_loss_finalize': (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p]),
+    'pg_loss_grad': (_i, [_p, _i, _p, _i, _f, _p, _p, _i, _i, _i, _i, _i, _p]),
+    'pg_adam_step': (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p]),
+    'pg_nchw_to_nhwc': (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    'pg_nhwc_to_nchw': (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    'pg_copy_channels': (_i, [_p, _i, _p, _i, _l, _i, _p]),
+    'pg_fill': (_i, [_p, _l, _f, _p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise HipLibraryError (never fall back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C patchgan_amd/csrc` (hipcc --offload-arch=gfx950). patchgan_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def ptr(t, offset=0):
+    """Device address of element `offset` (in elements) of a torch tensor, or None."""
+    if t is None:
+        return None
+    return t.data_ptr() + offset * t.element_size()

@@ -1,0 +1,61 @@
+"""Shared nn.Module plumbing: parameters that are strided views of one flat packed buffer."""
+import torch
+from torch import nn
+
+from . import engine as E
+
+
+class FlatParamModule(nn.Module):
+    """Holds `self.flat` (packed weights, see engine.py) and registers one nn.Parameter per state_dict key of
+    the reference, each a strided view of the flat buffer -- so state_dict()/load_state_dict()/parameters()/
+    to()/apply() behave like the reference's modules while kernels, Adam and all-reduce see one buffer."""
+
+    def _init_flat(self, layers, nparams):
+        self._layers = layers
+        flat = torch.zeros(nparams, dtype=torch.float32)
+        E.default_init_(flat, layers)
+        self._bind(flat)
+
+    def _bind(self, flat):
+        object.__setattr__(self, 'flat', flat)
+        object.__setattr__(self, 'grad_flat', None)
+        views = E.torch_views(flat, self._layers)
+        for key, v in views.items():
+            mod, leaf = self._owner(key)
+            if leaf in mod._parameters and mod._parameters[leaf] is not None:
+                mod._parameters[leaf].data = v
+            else:
+                mod.register_parameter(leaf, nn.Parameter(v))
+
+    def _owner(self, key):
+        parts = key.split('.')
+        mod = self
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        return mod, parts[-1]
+
+    def _apply(self, fn, recurse=True):
+        # .to()/.cuda()/.cpu(): move the flat buffer, then re-point every parameter at its view of it
+        new_flat = fn(self.flat.detach())
+        if new_flat.dtype != torch.float32:
+            raise TypeError("patchgan_amd networks are fp32 only")
+        self._bind(new_flat.contiguous())
+        for p in self.parameters():
+            p.grad = None
+        return self
+
+    def ensure_grad_flat(self):
+        """Flat gradient buffer in the packed layout; every parameter's .grad is a view of it."""
+        if self.grad_flat is None or self.grad_flat.device != self.flat.device:
+            g = torch.zeros_like(self.flat)
+            object.__setattr__(self, 'grad_flat', g)
+            for key, v in E.torch_views(g, self._layers).items():
+                mod, leaf = self._owner(key)
+                mod._parameters[leaf].grad = v
+        return self.grad_flat
+
+    def state_dict_contiguous(self):
+        """state_dict() with every tensor in the reference's contiguous NCHW layout (what save() writes)."""
+        return {k: v.detach().contiguous().clone() for k, v in self.state_dict().items()}

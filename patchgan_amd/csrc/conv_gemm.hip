@@ -1,0 +1,885 @@
+// conv_gemm.hip -- the three GEMM-shaped 4x4 convolution kernels of the patchGAN hot path for gfx950.
+//
+//   big2small : small[n,p,q,a]   = sum_{tap,b} big[n,s*p-1+kh,s*q-1+kw,b] * P[tap][a][b]      (conv fwd, convT dgrad)
+//   small2big : big[n,h,w,b]     = sum_{tap,a} small[n,(h+1-kh)/s,(w+1-kw)/s,a] * P[tap][a][b]  (convT fwd, conv dgrad)
+//   wgrad     : dP[tap][a][b]    = sum_{n,p,q} small[n,p,q,a] * big[n,s*p-1+kh,s*q-1+kw,b]     (both weight grads)
+//
+// Each is an im2col-free implicit GEMM: 256-thread workgroups (4 waves of 64), operand tiles staged
+// global -> registers -> LDS (prefetch of chunk c+1 issued before the MFMAs of chunk c), fp32 MFMA
+// v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD), deterministic split-K through slabs.
+// NHWC: a K-chunk of 32 consecutive (tap, channel) indices is 128 contiguous bytes of one input pixel.
+//
+// MFMA operand maps (cdna_hip_programming.md section 3): lane l holds A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// K-contiguous operands are read from LDS as one ds_read_b128 per lane per 8 k: lane (row, h) takes
+// k = 8*kk + 4*h + j (j = 0..3) for MFMA j, the same permutation of K on both operands.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "patchgan_hip.h"
+#include "pg_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Geom {
+    int N, Hb, Wb, Hs, Ws, Ca, Cb, s;
+};
+
+constexpr int KC = 32;        // K-chunk (floats)
+constexpr int LDK = KC + 4;   // LDS row pitch of a K-contiguous tile: 36 floats -> conflict-free ds_read_b128
+
+__device__ __forceinline__ f32x4 ld4(const float* p, bool ok) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return ok ? v : z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// big2small: rows = small pixels (n,p,q), cols = a, K = (tap, b) with b fastest.
+// ------------------------------------------------------------------------------------------------
+template <int MR, int NR, int WM, int WN>
+__global__ __launch_bounds__(256) void k_big2small(const float* __restrict__ big, int ld_big,
+                                                   const float* __restrict__ P, float* __restrict__ out, int ld_out,
+                                                   long slab_stride, Geom g, int chunks_per_slice, int veck,
+                                                   const float* __restrict__ bias, int act) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    float* As = smem;
+    float* Bs = smem + BM * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int M = g.N * g.Hs * g.Ws, K = 16 * g.Cb;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int nchunks = (K + KC - 1) / KC;
+    const int c_begin = blockIdx.z * chunks_per_slice;
+    const int c_end = min(nchunks, c_begin + chunks_per_slice);
+
+    const int kq = tid & 7, r0 = tid >> 3;
+    int a_noff[AI], a_h0[AI], a_w0[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        int m = m0 + r0 + 32 * i;
+        if (m < M) {
+            int n = m / (g.Hs * g.Ws);
+            int rem = m - n * (g.Hs * g.Ws);
+            int p = rem / g.Ws, q = rem - p * g.Ws;
+            a_noff[i] = n * g.Hb * g.Wb;
+            a_h0[i] = g.s * p - 1;
+            a_w0[i] = g.s * q - 1;
+        } else {
+            a_noff[i] = 0;
+            a_h0[i] = -1000000;
+            a_w0[i] = 0;
+        }
+    }
+
+    f32x4 ra[AI], rb[BI];
+    auto load_chunk = [&](int c) {
+        const int k = c * KC + kq * 4;
+        if (veck) {
+            const int tap = k / g.Cb, b = k - tap * g.Cb;
+            const int kh = tap >> 2, kw = tap & 3;
+            const bool kok = k < K;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                int h = a_h0[i] + kh, w = a_w0[i] + kw;
+                bool ok = kok && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
+                const float* p = ok ? big + ((long)(a_noff[i] + h * g.Wb + w) * ld_big + b) : big;
+                ra[i] = ld4(p, ok);
+            }
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+                int a = n0 + r0 + 32 * i;
+                bool ok = kok && a < g.Ca;
+                const float* p = ok ? P + ((long)(tap * g.Ca + a) * g.Cb + b) : P;
+                rb[i] = ld4(p, ok);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ke = k + e;
+                const int tap = ke / g.Cb, b = ke - tap * g.Cb;
+                const int kh = tap >> 2, kw = tap & 3;
+                const bool kok = ke < K;
+#pragma unroll
+                for (int i = 0; i < AI; ++i) {
+                    int h = a_h0[i] + kh, w = a_w0[i] + kw;
+                    bool ok = kok && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
+                    const float* p = ok ? big + ((long)(a_noff[i] + h * g.Wb + w) * ld_big + b) : big;
+                    float v = *p;
+                    ra[i][e] = ok ? v : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < BI; ++i) {
+                    int a = n0 + r0 + 32 * i;
+                    bool ok = kok && a < g.Ca;
+                    const float* p = ok ? P + ((long)(tap * g.Ca + a) * g.Cb + b) : P;
+                    float v = *p;
+                    rb[i][e] = ok ? v : 0.f;
+                }
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDK + kq * 4]) = rb[i];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
+        if (more) load_chunk(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            f32x4 af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MR + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NR + j) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    float* o = out + (long)blockIdx.z * slab_stride;
+    const bool fin = (slab_stride == 0);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + lrow;
+            const float bv = (fin && bias != nullptr && col < g.Ca) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + (wm * MR + i) * 32 + row;
+                if (m < M && col < g.Ca) {
+                    float v = acc[i][j][r];
+                    if (fin) v = pg_act(v + bv, act);
+                    o[(long)m * ld_out + col] = v;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small2big: per output-parity class (stride 2: 4 classes of 2x2 taps; stride 1: 1 class of 4x4 taps):
+// rows = big pixels of the class, cols = b, K = (tloc, a) with a fastest.  A is K-contiguous (small),
+// B rows are N-contiguous (P[tap][a][:]).
+// ------------------------------------------------------------------------------------------------
+template <int MR, int NR, int WM, int WN>
+__global__ __launch_bounds__(256) void k_small2big(const float* __restrict__ small, int ld_small,
+                                                   const float* __restrict__ P, float* __restrict__ out, int ld_out,
+                                                   long slab_stride, Geom g, int chunks_per_slice, int veck, int vecn,
+                                                   const float* __restrict__ bias, int act) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+    constexpr int AI = BM / 32;
+    constexpr int LDB = BN + 4;
+    constexpr int BQ = BN / 4;          // float4 per B row
+    constexpr int BROWS = 256 / BQ;     // B rows per pass
+    constexpr int BI = KC / BROWS;      // passes
+    __shared__ __attribute__((aligned(16))) float smem[BM * LDK + KC * LDB];
+    float* As = smem;
+    float* Bs = smem + BM * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    const int ncls = (g.s == 2) ? 4 : 1;
+    const int cls = blockIdx.z % ncls, slice = blockIdx.z / ncls;
+    const int ah = (g.s == 2) ? (cls >> 1) : 0, aw = (g.s == 2) ? (cls & 1) : 0;
+    const int T = (g.s == 2) ? 2 : 4;                    // taps per dim in this class
+    const int Hc = (g.s == 2) ? (g.Hb - ah + 1) / 2 : g.Hb;
+    const int Wc = (g.s == 2) ? (g.Wb - aw + 1) / 2 : g.Wb;
+    const int kh0 = (g.s == 2) ? (1 - ah) : 0, kw0 = (g.s == 2) ? (1 - aw) : 0;
+    const int Mc = g.N * Hc * Wc, K = T * T * g.Ca;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= Mc) return;   // uniform per block (classes can differ in size for odd Hb/Wb)
+    const int nchunks = (K + KC - 1) / KC;
+    const int c_begin = slice * chunks_per_slice;
+    const int c_end = min(nchunks, c_begin + chunks_per_slice);
+
+    const int kq = tid & 7, r0 = tid >> 3;
+    int a_noff[AI], a_ib[AI], a_jb[AI];   // small-pixel base: ih = ib - th, iw = jb - tw
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        int m = m0 + r0 + 32 * i;
+        if (m < Mc) {
+            int n = m / (Hc * Wc);
+            int rem = m - n * (Hc * Wc);
+            int ii = rem / Wc, jj = rem - ii * Wc;
+            a_noff[i] = n * g.Hs * g.Ws;
+            a_ib[i] = (g.s == 2) ? ii + ah : ii + 1;
+            a_jb[i] = (g.s == 2) ? jj + aw : jj + 1;
+        } else {
+            a_noff[i] = 0;
+            a_ib[i] = -1000000;
+            a_jb[i] = 0;
+        }
+    }
+    const int bq = tid % BQ, brow0 = tid / BQ;
+
+    f32x4 ra[AI], rb[BI];
+    auto load_chunk = [&](int c) {
+        const int k = c * KC + kq * 4;
+        if (veck) {
+            const int tl = k / g.Ca, a = k - tl * g.Ca;
+            const int th = tl / T, tw = tl - th * T;
+            const bool kok = k < K;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                int ih = a_ib[i] - th, iw = a_jb[i] - tw;
+                bool ok = kok && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws;
+                const float* p = ok ? small + ((long)(a_noff[i] + ih * g.Ws + iw) * ld_small + a) : small;
+                ra[i] = ld4(p, ok);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ke = k + e;
+                const int tl = ke / g.Ca, a = ke - tl * g.Ca;
+                const int th = tl / T, tw = tl - th * T;
+                const bool kok = ke < K;
+#pragma unroll
+                for (int i = 0; i < AI; ++i) {
+                    int ih = a_ib[i] - th, iw = a_jb[i] - tw;
+                    bool ok = kok && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws;
+                    const float* p = ok ? small + ((long)(a_noff[i] + ih * g.Ws + iw) * ld_small + a) : small;
+                    float v = *p;
+                    ra[i][e] = ok ? v : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int kr = c * KC + brow0 + BROWS * i;
+            const int tl = kr / g.Ca, a = kr - tl * g.Ca;
+            const int th = tl / T, tw = tl - th * T;
+            const int tap = (kh0 + g.s * th) * 4 + (kw0 + g.s * tw);
+            const int b = n0 + bq * 4;
+            const bool kok = kr < K;
+            const float* row = P + (long)(tap * g.Ca + a) * g.Cb;
+            if (vecn) {
+                bool ok = kok && b < g.Cb;
+                rb[i] = ld4(ok ? row + b : P, ok);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bool ok = kok && (b + e) < g.Cb;
+                    float v = *(ok ? row + b + e : P);
+                    rb[i][e] = ok ? v : 0.f;
+                }
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow0 + BROWS * i) * LDB + bq * 4]) = rb[i];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
+        if (more) load_chunk(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            f32x4 af[MR];
+            float bf[NR][4];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MR + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bf[j][e] = Bs[(kk * 8 + lh * 4 + e) * LDB + (wn * NR + j) * 32 + lrow];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: row m of the class -> big pixel (n, s*ii+ah, s*jj+aw); slabs mirror the [N,Hb,Wb,Cb] layout.
+    const bool fin = (slab_stride == 0);
+    float* o = out + (long)slice * slab_stride;
+    const int ldo = fin ? ld_out : g.Cb;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int m = m0 + (wm * MR + i) * 32 + row;
+            if (m < Mc) {
+                int n = m / (Hc * Wc);
+                int rem = m - n * (Hc * Wc);
+                int ii = rem / Wc, jj = rem - ii * Wc;
+                int h = (g.s == 2) ? 2 * ii + ah : ii, w = (g.s == 2) ? 2 * jj + aw : jj;
+                float* orow = o + (long)((n * g.Hb + h) * g.Wb + w) * ldo;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int col = n0 + (wn * NR + j) * 32 + lrow;
+                    if (col < g.Cb) {
+                        float v = acc[i][j][r];
+                        if (fin) v = pg_act(v + (bias ? bias[col] : 0.f), act);
+                        orow[col] = v;
+                    }
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: per tap, rows = a, cols = b, K = small pixels.  Both operands are contiguous along their
+// non-K dim, so LDS tiles are [k][m] / [k][n] and fragments are single ds_read_b32 (natural K order).
+// grid: x = tilesA*tilesB, y = 16 taps, z = K slices.  Output slab z is [16][Ca][Cb].
+// ------------------------------------------------------------------------------------------------
+template <int MR, int NR, int WM, int WN>
+__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ small, int ld_small,
+                                               const float* __restrict__ big, int ld_big,
+                                               float* __restrict__ out, long slab_stride, Geom g,
+                                               int chunks_per_slice, int tilesB, int vecm, int vecn) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int AQ = BM / 4, AROWS = 256 / AQ, AI = KC / AROWS;
+    constexpr int BQ = BN / 4, BROWS = 256 / BQ, BI = KC / BROWS;
+    __shared__ __attribute__((aligned(16))) float smem[KC * LDA + KC * LDB];
+    float* As = smem;
+    float* Bs = smem + KC * LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int tile_a = blockIdx.x / tilesB, tile_b = blockIdx.x % tilesB;
+    const int m0 = tile_a * BM, n0 = tile_b * BN;
+    const int tap = blockIdx.y, kh = tap >> 2, kw = tap & 3;
+    const int Kp = g.N * g.Hs * g.Ws;   // pixels
+    const int nchunks = (Kp + KC - 1) / KC;
+    const int c_begin = blockIdx.z * chunks_per_slice;
+    const int c_end = min(nchunks, c_begin + chunks_per_slice);
+
+    const int aq = tid % AQ, arow0 = tid / AQ;
+    const int bq = tid % BQ, brow0 = tid / BQ;
+
+    f32x4 ra[AI], rb[BI];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int pix = c * KC + arow0 + AROWS * i;
+            const int a = m0 + aq * 4;
+            const bool pok = pix < Kp;
+            const float* row = small + (long)pix * ld_small;
+            if (vecm) {
+                bool ok = pok && a < g.Ca;
+                ra[i] = ld4(ok ? row + a : small, ok);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bool ok = pok && (a + e) < g.Ca;
+                    float v = *(ok ? row + a + e : small);
+                    ra[i][e] = ok ? v : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int pix = c * KC + brow0 + BROWS * i;
+            const int b = n0 + bq * 4;
+            bool pok = pix < Kp;
+            int n = pix / (g.Hs * g.Ws);
+            int rem = pix - n * (g.Hs * g.Ws);
+            int p = rem / g.Ws, q = rem - p * g.Ws;
+            int h = g.s * p - 1 + kh, w = g.s * q - 1 + kw;
+            pok = pok && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
+            const float* row = big + (long)((n * g.Hb + h) * g.Wb + w) * ld_big;
+            if (vecn) {
+                bool ok = pok && b < g.Cb;
+                rb[i] = ld4(ok ? row + b : big, ok);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bool ok = pok && (b + e) < g.Cb;
+                    float v = *(ok ? row + b + e : big);
+                    rb[i][e] = ok ? v : 0.f;
+                }
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(arow0 + AROWS * i) * LDA + aq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow0 + BROWS * i) * LDB + bq * 4]) = rb[i];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
+        if (more) load_chunk(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) {
+            float af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) af[i] = As[(kk * 2 + lh) * LDA + (wm * MR + i) * 32 + lrow];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) bf[j] = Bs[(kk * 2 + lh) * LDB + (wn * NR + j) * 32 + lrow];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    float* o = out + (long)blockIdx.z * slab_stride + (long)tap * g.Ca * g.Cb;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int a = m0 + (wm * MR + i) * 32 + row;
+                if (a < g.Ca && col < g.Cb) o[(long)a * g.Cb + col] = acc[i][j][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-K reduce (+ bias + activation):  out[r*ld_out + c] = act(sum_z slab[z][r*cols + c] + bias[c])
+// ------------------------------------------------------------------------------------------------
+__global__ void k_slab_reduce(const float* __restrict__ slabs, long slab_stride, int S, float* __restrict__ out,
+                              int ld_out, long rows, int cols, const float* __restrict__ bias, int act) {
+    const long total = rows * cols;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        float v = slabs[i];
+        for (int z = 1; z < S; ++z) v += slabs[(long)z * slab_stride + i];
+        if (bias) v += bias[c];
+        out[r * ld_out + c] = pg_act(v, act);
+    }
+}
+
+// column sums of a [rows][C] matrix (pixel stride ld): partial[chunk][c] over row chunks (bias gradient)
+__global__ void k_colsum_partial(const float* __restrict__ x, int ld, long rows, int C, long rows_per_chunk,
+                                 float* __restrict__ partial) {
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long r_begin = blockIdx.x * rows_per_chunk;
+    const long r_end = min(rows, r_begin + rows_per_chunk);
+    float s = 0.f;
+    for (long r = r_begin; r < r_end; ++r) s += x[r * ld + c];
+    partial[(long)blockIdx.x * C + c] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct kernels: one thread per output element, no LDS, no MFMA.  Any channel count / alignment.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_big2small_direct(const float* __restrict__ big, int ld_big, const float* __restrict__ P,
+                                   const float* __restrict__ bias, float* __restrict__ small, int ld_small, Geom g,
+                                   int act) {
+    const long total = (long)g.N * g.Hs * g.Ws * g.Ca;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(idx % g.Ca);
+        const long m = idx / g.Ca;
+        const int n = (int)(m / (g.Hs * g.Ws));
+        const int rem = (int)(m - (long)n * g.Hs * g.Ws);
+        const int p = rem / g.Ws, q = rem - p * g.Ws;
+        float acc = 0.f;
+        for (int kh = 0; kh < 4; ++kh) {
+            const int h = g.s * p - 1 + kh;
+            if ((unsigned)h >= (unsigned)g.Hb) continue;
+            for (int kw = 0; kw < 4; ++kw) {
+                const int w = g.s * q - 1 + kw;
+                if ((unsigned)w >= (unsigned)g.Wb) continue;
+                const float* xi = big + (long)((n * g.Hb + h) * g.Wb + w) * ld_big;
+                const float* wi = P + (long)((kh * 4 + kw) * g.Ca + a) * g.Cb;
+                for (int b = 0; b < g.Cb; ++b) acc = fmaf(xi[b], wi[b], acc);
+            }
+        }
+        if (bias) acc += bias[a];
+        small[m * ld_small + a] = pg_act(acc, act);
+    }
+}
+
+__global__ void k_small2big_direct(const float* __restrict__ small, int ld_small, const float* __restrict__ P,
+                                   const float* __restrict__ bias, float* __restrict__ big, int ld_big, Geom g,
+                                   int act) {
+    const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx % g.Cb);
+        const long m = idx / g.Cb;
+        const int n = (int)(m / (g.Hb * g.Wb));
+        const int rem = (int)(m - (long)n * g.Hb * g.Wb);
+        const int h = rem / g.Wb, w = rem - h * g.Wb;
+        float acc = 0.f;
+        for (int kh = 0; kh < 4; ++kh) {
+            const int hh = h + 1 - kh;
+            if (hh < 0 || (hh % g.s) != 0) continue;
+            const int ih = hh / g.s;
+            if (ih >= g.Hs) continue;
+            for (int kw = 0; kw < 4; ++kw) {
+                const int ww = w + 1 - kw;
+                if (ww < 0 || (ww % g.s) != 0) continue;
+                const int iw = ww / g.s;
+                if (iw >= g.Ws) continue;
+                const float* xi = small + (long)((n * g.Hs + ih) * g.Ws + iw) * ld_small;
+                const float* wi = P + (long)(kh * 4 + kw) * g.Ca * g.Cb + b;
+                for (int a = 0; a < g.Ca; ++a) acc = fmaf(xi[a], wi[(long)a * g.Cb], acc);
+            }
+        }
+        if (bias) acc += bias[b];
+        big[m * ld_big + b] = pg_act(acc, act);
+    }
+}
+
+// one thread per (slice, tap, a, b); pixels of the slice summed serially (deterministic)
+__global__ void k_wgrad_direct(const float* __restrict__ small, int ld_small, const float* __restrict__ big,
+                               int ld_big, float* __restrict__ out, long slab_stride, Geom g, long pix_per_slice) {
+    const long per = 16L * g.Ca * g.Cb;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= per) return;
+    const int b = (int)(idx % g.Cb);
+    const int a = (int)((idx / g.Cb) % g.Ca);
+    const int tap = (int)(idx / ((long)g.Cb * g.Ca));
+    const int kh = tap >> 2, kw = tap & 3;
+    const long Kp = (long)g.N * g.Hs * g.Ws;
+    const long p_begin = blockIdx.y * pix_per_slice;
+    const long p_end = min(Kp, p_begin + pix_per_slice);
+    float acc = 0.f;
+    for (long pix = p_begin; pix < p_end; ++pix) {
+        const int n = (int)(pix / (g.Hs * g.Ws));
+        const int rem = (int)(pix - (long)n * g.Hs * g.Ws);
+        const int p = rem / g.Ws, q = rem - p * g.Ws;
+        const int h = g.s * p - 1 + kh, w = g.s * q - 1 + kw;
+        if ((unsigned)h >= (unsigned)g.Hb || (unsigned)w >= (unsigned)g.Wb) continue;
+        acc = fmaf(small[pix * ld_small + a], big[(long)((n * g.Hb + h) * g.Wb + w) * ld_big + b], acc);
+    }
+    out[(long)blockIdx.y * slab_stride + idx] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+bool geom_ok(const pg_conv_geom* g) {
+    if (!g) return false;
+    if (g->N <= 0 || g->Hb <= 0 || g->Wb <= 0 || g->Hs <= 0 || g->Ws <= 0 || g->Ca <= 0 || g->Cb <= 0) return false;
+    if (g->stride != 1 && g->stride != 2) return false;
+    // small = floor((big + 2 - 4)/s) + 1 (nn.Conv2d) ; for stride 2 the big side may also be 2*small (convT)
+    const int hs = (g->Hb - 2) / g->stride + 1, ws = (g->Wb - 2) / g->stride + 1;
+    if (g->Hb < 2 || g->Wb < 2) return false;
+    if (hs != g->Hs || ws != g->Ws) return false;
+    // 32-bit index headroom inside the kernels
+    const double big_elems = (double)g->N * g->Hb * g->Wb, small_elems = (double)g->N * g->Hs * g->Ws;
+    if (big_elems > 2.0e9 || small_elems > 2.0e9) return false;
+    if (16.0 * g->Ca * g->Cb > 2.0e9) return false;
+    return true;
+}
+
+Geom to_geom(const pg_conv_geom* g) { return Geom{g->N, g->Hb, g->Wb, g->Hs, g->Ws, g->Ca, g->Cb, g->stride}; }
+
+struct Tile {
+    int id, bm, bn;
+};
+// tile ids: 0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 64x128, 4 = 64x64
+Tile pick_tile(long rows, int cols) {
+    if (rows > 64) {
+        if (cols > 64) return {0, 128, 128};
+        if (cols > 32) return {1, 128, 64};
+        return {2, 128, 32};
+    }
+    if (cols > 64) return {3, 64, 128};
+    if (cols > 32) return {4, 64, 64};
+    return {2, 128, 32};
+}
+
+constexpr int TARGET_BLOCKS = 512;
+
+int pick_split(long tiles, int nchunks, int min_chunks) {
+    if (tiles >= 256) return 1;
+    long s = (TARGET_BLOCKS + tiles - 1) / tiles;
+    long smax = nchunks / min_chunks;
+    if (smax < 1) smax = 1;
+    if (s > smax) s = smax;
+    if (s > 1024) s = 1024;
+    return (int)s;
+}
+
+struct Plan {
+    Tile t;
+    int tiles_m, tiles_n, ncls, nchunks, split, cps;
+    long out_elems;   // elements of one slab
+};
+
+Plan plan_b2s(const pg_conv_geom* g) {
+    Plan p;
+    const long M = (long)g->N * g->Hs * g->Ws;
+    p.t = pick_tile(M, g->Ca);
+    p.tiles_m = (int)((M + p.t.bm - 1) / p.t.bm);
+    p.tiles_n = (g->Ca + p.t.bn - 1) / p.t.bn;
+    p.ncls = 1;
+    p.nchunks = (16 * g->Cb + KC - 1) / KC;
+    p.split = pick_split((long)p.tiles_m * p.tiles_n, p.nchunks, 8);
+    p.out_elems = M * g->Ca;
+    return p;
+}
+
+Plan plan_s2b(const pg_conv_geom* g) {
+    Plan p;
+    p.ncls = (g->stride == 2) ? 4 : 1;
+    const int Hc = (g->stride == 2) ? (g->Hb + 1) / 2 : g->Hb, Wc = (g->stride == 2) ? (g->Wb + 1) / 2 : g->Wb;
+    const long Mc = (long)g->N * Hc * Wc;   // largest class
+    p.t = pick_tile(Mc, g->Cb);
+    p.tiles_m = (int)((Mc + p.t.bm - 1) / p.t.bm);
+    p.tiles_n = (g->Cb + p.t.bn - 1) / p.t.bn;
+    const int taps = (g->stride == 2) ? 4 : 16;
+    p.nchunks = (taps * g->Ca + KC - 1) / KC;
+    p.split = pick_split((long)p.tiles_m * p.tiles_n * p.ncls, p.nchunks, 8);
+    p.out_elems = (long)g->N * g->Hb * g->Wb * g->Cb;
+    return p;
+}
+
+Plan plan_wgrad(const pg_conv_geom* g) {
+    Plan p;
+    p.t = pick_tile(g->Ca, g->Cb);
+    p.tiles_m = (g->Ca + p.t.bm - 1) / p.t.bm;
+    p.tiles_n = (g->Cb + p.t.bn - 1) / p.t.bn;
+    p.ncls = 16;
+    const long Kp = (long)g->N * g->Hs * g->Ws;
+    p.nchunks = (int)((Kp + KC - 1) / KC);
+    p.split = pick_split((long)p.tiles_m * p.tiles_n * 16, p.nchunks, 8);
+    p.out_elems = 16L * g->Ca * g->Cb;
+    return p;
+}
+
+constexpr int DIRECT_WGRAD_SLICES = 64;
+constexpr int COLSUM_CHUNKS = 256;
+
+void clamp_split(Plan& p, size_t ws_bytes, size_t reserved) {
+    size_t avail = ws_bytes > reserved ? ws_bytes - reserved : 0;
+    long smax = (long)(avail / (sizeof(float) * (size_t)p.out_elems));
+    if (p.split > 1 && smax < p.split) p.split = smax < 2 ? 1 : (int)smax;
+    p.cps = (p.nchunks + p.split - 1) / p.split;
+    p.split = (p.nchunks + p.cps - 1) / p.cps;   // drop empty slices
+}
+
+int launch_reduce(const float* slabs, long slab_stride, int S, float* out, int ld_out, long rows, int cols,
+                  const float* bias, int act, hipStream_t st) {
+    const long total = rows * cols;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, st, slabs, slab_stride, S, out, ld_out, rows, cols,
+                       bias, act);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+}
+
+#define PG_DISPATCH_TILE(KERNEL, tile_id, grid, st, ...)                                                   \
+    switch (tile_id) {                                                                                     \
+        case 0: hipLaunchKernelGGL((KERNEL<2, 2, 2, 2>), grid, dim3(256), 0, st, __VA_ARGS__); break;      \
+        case 1: hipLaunchKernelGGL((KERNEL<2, 1, 2, 2>), grid, dim3(256), 0, st, __VA_ARGS__); break;      \
+        case 2: hipLaunchKernelGGL((KERNEL<1, 1, 4, 1>), grid, dim3(256), 0, st, __VA_ARGS__); break;      \
+        case 3: hipLaunchKernelGGL((KERNEL<1, 2, 2, 2>), grid, dim3(256), 0, st, __VA_ARGS__); break;      \
+        default: hipLaunchKernelGGL((KERNEL<1, 1, 2, 2>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
+    }
+
+}  // namespace
+
+extern "C" {
+
+size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
+    if (!geom_ok(g)) return 0;
+    Plan p = (op == 0) ? plan_b2s(g) : (op == 1) ? plan_s2b(g) : plan_wgrad(g);
+    size_t bytes = 0;
+    int split = p.split;
+    if (op == 2 && split < DIRECT_WGRAD_SLICES) split = DIRECT_WGRAD_SLICES;   // the direct algo's slices
+    if (split > 1) bytes = (size_t)split * p.out_elems * sizeof(float);
+    if (op == 2) bytes += ((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255;
+    return (bytes + 255) & ~(size_t)255;
+}
+
+int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const float* bias, float* small,
+                         int ld_small, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
+                         void* stream) {
+    if (!geom_ok(gg) || !big || !P || !small || ld_big < gg->Cb || ld_small < gg->Ca) return PG_EINVAL;
+    if (act < PG_ACT_NONE || act > PG_ACT_SIGMOID) return PG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    Geom g = to_geom(gg);
+    if (algo == PG_ALGO_DIRECT) {
+        const long total = (long)g.N * g.Hs * g.Ws * g.Ca;
+        int blocks = (int)std::min<long>((total + 255) / 256, 65536);
+        hipLaunchKernelGGL(k_big2small_direct, dim3(blocks), dim3(256), 0, st, big, ld_big, P, bias, small, ld_small, g,
+                           act);
+        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+    }
+    Plan p = plan_b2s(gg);
+    if (!ws) ws_bytes = 0;
+    clamp_split(p, ws_bytes, 0);
+    const int veck = (g.Cb % 4 == 0) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P);
+    dim3 grid(p.tiles_m, p.tiles_n, p.split);
+    if (p.split == 1) {
+        PG_DISPATCH_TILE(k_big2small, p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, veck, bias, act);
+        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+    }
+    float* slabs = (float*)ws;
+    PG_DISPATCH_TILE(k_big2small, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps, veck,
+                     (const float*)nullptr, 0);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    return launch_reduce(slabs, p.out_elems, p.split, small, ld_small, (long)g.N * g.Hs * g.Ws, g.Ca, bias, act, st);
+}
+
+int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const float* bias, float* big,
+                         int ld_big, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
+                         void* stream) {
+    if (!geom_ok(gg) || !big || !P || !small || ld_big < gg->Cb || ld_small < gg->Ca) return PG_EINVAL;
+    if (act < PG_ACT_NONE || act > PG_ACT_SIGMOID) return PG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    Geom g = to_geom(gg);
+    if (algo == PG_ALGO_DIRECT) {
+        const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
+        int blocks = (int)std::min<long>((total + 255) / 256, 65536);
+        hipLaunchKernelGGL(k_small2big_direct, dim3(blocks), dim3(256), 0, st, small, ld_small, P, bias, big, ld_big, g,
+                           act);
+        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+    }
+    Plan p = plan_s2b(gg);
+    if (!ws) ws_bytes = 0;
+    clamp_split(p, ws_bytes, 0);
+    const int veck = (g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned16(small);
+    const int vecn = (g.Cb % 4 == 0) && aligned16(P);
+    dim3 grid(p.tiles_m, p.tiles_n, p.ncls * p.split);
+    if (p.split == 1) {
+        PG_DISPATCH_TILE(k_small2big, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, veck, vecn, bias,
+                         act);
+        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+    }
+    float* slabs = (float*)ws;
+    PG_DISPATCH_TILE(k_small2big, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps, veck, vecn,
+                     (const float*)nullptr, 0);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    return launch_reduce(slabs, p.out_elems, p.split, big, ld_big, (long)g.N * g.Hb * g.Wb, g.Cb, bias, act, st);
+}
+
+int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, float* dbias,
+                     const pg_conv_geom* gg, int algo, void* ws, size_t ws_bytes, void* stream) {
+    if (!geom_ok(gg) || !big || !dP || !small || ld_big < gg->Cb || ld_small < gg->Ca) return PG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    Geom g = to_geom(gg);
+    if (!ws) ws_bytes = 0;
+    const long Kp = (long)g.N * g.Hs * g.Ws;
+    size_t reserved = 0;
+    if (dbias) {
+        reserved = ((size_t)COLSUM_CHUNKS * g.Ca * sizeof(float) + 255) & ~(size_t)255;
+        if (ws_bytes < reserved) return PG_EWORKSPACE;
+        float* part = (float*)ws;
+        int chunks = (int)std::min<long>(COLSUM_CHUNKS, Kp);
+        long rpc = (Kp + chunks - 1) / chunks;
+        chunks = (int)((Kp + rpc - 1) / rpc);
+        hipLaunchKernelGGL(k_colsum_partial, dim3(chunks, (g.Ca + 63) / 64), dim3(64), 0, st, small, ld_small, Kp, g.Ca,
+                           rpc, part);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        int rc = launch_reduce(part, g.Ca, chunks, dbias, g.Ca, 1, g.Ca, nullptr, 0, st);
+        if (rc != PG_OK) return rc;
+    }
+    const long per = 16L * g.Ca * g.Cb;
+    if (algo == PG_ALGO_DIRECT) {
+        long smax = (long)((ws_bytes - reserved) / (sizeof(float) * (size_t)per));
+        int slices = (int)std::min<long>(std::min<long>(DIRECT_WGRAD_SLICES, smax), Kp);
+        if (slices < 1) slices = 1;
+        long pps = (Kp + slices - 1) / slices;
+        slices = (int)((Kp + pps - 1) / pps);
+        float* dst = slices == 1 ? dP : (float*)((char*)ws + reserved);
+        hipLaunchKernelGGL(k_wgrad_direct, dim3((int)((per + 255) / 256), slices), dim3(256), 0, st, small, ld_small, big,
+                           ld_big, dst, per, g, pps);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        if (slices == 1) return PG_OK;
+        return launch_reduce(dst, per, slices, dP, g.Cb, 16L * g.Ca, g.Cb, nullptr, 0, st);
+    }
+    Plan p = plan_wgrad(gg);
+    clamp_split(p, ws_bytes, reserved);
+    const int vecm = (g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned16(small);
+    const int vecn = (g.Cb % 4 == 0) && (ld_big % 4 == 0) && aligned16(big);
+    dim3 grid(p.tiles_m * p.tiles_n, 16, p.split);
+    float* dst = p.split == 1 ? dP : (float*)((char*)ws + reserved);
+    PG_DISPATCH_TILE(k_wgrad, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n, vecm,
+                     vecn);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    if (p.split == 1) return PG_OK;
+    return launch_reduce(dst, p.out_elems, p.split, dP, g.Cb, 16L * g.Ca, g.Cb, nullptr, 0, st);
+}
+
+}  // extern "C"

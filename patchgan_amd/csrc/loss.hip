@@ -1,0 +1,183 @@
+// loss.hip -- GAN + segmentation losses of the patchGAN step, value and gradient seed, on the device
+// (no host round trip inside the step).  Tiny, HBM-bound reductions; fp64 accumulators, fixed-order trees.
+//
+//   pg_loss_reduce   per-(n,c) sums over HW of {y*p, y, p, bce_elem, |p-y|}          (stage 1)
+//   pg_loss_prepare  sum_n (1 - T_n), sum y                                          (stage 1b; all-reduced under DP)
+//   pg_loss_finalize loss value + per-(n,c) gradient coefficients                    (stage 2)
+//   pg_loss_grad     elementwise gradient wrt p                                      (stage 3)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "patchgan_hip.h"
+#include "pg_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ p, int ld_p, const float* __restrict__ y,
+                                                     int ld_y, float tconst, int HW, int C, double* __restrict__ S) {
+    __shared__ double red[5][256];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / C, c = blockIdx.x % C;
+    const float* pb = p + (long)n * HW * ld_p + c;
+    const float* yb = y ? y + (long)n * HW * ld_y + c : nullptr;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int i = tid; i < HW; i += 256) {
+        const float pv = pb[(long)i * ld_p];
+        const float yv = yb ? yb[(long)i * ld_y] : tconst;
+        // F.binary_cross_entropy clamps both logs at -100
+        const float lp = fmaxf(logf(pv), -100.f), lq = fmaxf(log1pf(-pv), -100.f);
+        s[0] += (double)(yv * pv);
+        s[1] += (double)yv;
+        s[2] += (double)pv;
+        s[3] += (double)(-(yv * lp + (1.f - yv) * lq));
+        s[4] += (double)fabsf(pv - yv);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) red[k][tid] = s[k];
+    for (int off = 128; off > 0; off >>= 1) {
+        __syncthreads();
+        if (tid < off) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) red[k][tid] += red[k][tid + off];
+        }
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) S[(long)blockIdx.x * 5 + k] = red[k][0];
+    }
+}
+
+__device__ inline void tversky_terms(const double* S, int n, int C, double beta, double& tp, double& denom) {
+    double syp = 0, sy = 0, sp = 0;
+    for (int c = 0; c < C; ++c) {
+        const double* s = S + ((long)n * C + c) * 5;
+        syp += s[0];
+        sy += s[1];
+        sp += s[2];
+    }
+    tp = syp;
+    const double fn = sy - syp, fp = sp - syp;
+    denom = tp + beta * fn + (1.0 - beta) * fp + 1.0;
+}
+
+__global__ void k_loss_prepare(const double* __restrict__ S, int N, int C, float beta, double* __restrict__ local2) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double acc = 0, sy = 0;
+    for (int n = 0; n < N; ++n) {
+        double tp, denom;
+        tversky_terms(S, n, C, (double)beta, tp, denom);
+        acc += 1.0 - (tp + 1.0) / denom;
+        for (int c = 0; c < C; ++c) sy += S[((long)n * C + c) * 5 + 1];
+    }
+    local2[0] = acc;
+    local2[1] = sy;
+}
+
+__global__ void k_loss_finalize(const double* __restrict__ S, const double* __restrict__ gsum2, int mode, int N, int C,
+                                int HW, int Bglobal, float alpha, float beta, float gamma, float* __restrict__ coef,
+                                float* __restrict__ loss_out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const double cnt = (double)Bglobal * C * HW;
+    if (mode == PG_LOSS_TVERSKY) {
+        const double m = gsum2[0] / (double)Bglobal;
+        *loss_out = (float)((double)alpha * pow(m, (double)gamma));
+        // d/dp_i [alpha * m^gamma] = alpha*gamma*m^(gamma-1)/B * d(1-T_n)/dp_i ;  dT/dp_i = (y_i*D - (tp+1)*(1-beta))/D^2
+        const double Kf = (double)alpha * (double)gamma * pow(m, (double)gamma - 1.0) / (double)Bglobal;
+        for (int n = 0; n < N; ++n) {
+            double tp, denom;
+            tversky_terms(S, n, C, (double)beta, tp, denom);
+            const float c1 = (float)(-Kf / denom);
+            const float c0 = (float)(Kf * (tp + 1.0) * (1.0 - (double)beta) / (denom * denom));
+            for (int c = 0; c < C; ++c) {
+                coef[((long)n * C + c) * 2 + 0] = c1;
+                coef[((long)n * C + c) * 2 + 1] = c0;
+            }
+        }
+    } else if (mode == PG_LOSS_WBCE) {
+        double acc = 0;
+        for (int n = 0; n < N; ++n)
+            for (int c = 0; c < C; ++c) {
+                const double* s = S + ((long)n * C + c) * 5;
+                // weight computed in fp32 like the reference: 1 - sum_hw(y)/sum(y)   (trainer.py:77)
+                const float w = (C > 1) ? 1.f - (float)s[1] / (float)gsum2[1] : 1.f;
+                acc += (double)w * s[3];
+                coef[((long)n * C + c) * 2 + 0] = (float)((double)alpha * (double)w / cnt);
+                coef[((long)n * C + c) * 2 + 1] = 0.f;
+            }
+        *loss_out = (float)((double)alpha * acc / cnt);
+    } else {
+        const int k = (mode == PG_LOSS_MAE) ? 4 : 3;
+        double acc = 0;
+        for (int n = 0; n < N; ++n)
+            for (int c = 0; c < C; ++c) {
+                acc += S[((long)n * C + c) * 5 + k];
+                coef[((long)n * C + c) * 2 + 0] = (float)((double)alpha / cnt);
+                coef[((long)n * C + c) * 2 + 1] = 0.f;
+            }
+        *loss_out = (float)((double)alpha * acc / cnt);
+    }
+}
+
+__global__ void k_loss_grad(const float* __restrict__ p, int ld_p, const float* __restrict__ y, int ld_y, float tconst,
+                            const float* __restrict__ coef, float* __restrict__ g, int ld_g, int N, int HW, int C,
+                            int mode) {
+    const long total = (long)N * HW * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        const int n = (int)(pix / HW);
+        const float pv = p[pix * ld_p + c];
+        const float yv = y ? y[pix * ld_y + c] : tconst;
+        const float k0 = coef[((long)n * C + c) * 2 + 0], k1 = coef[((long)n * C + c) * 2 + 1];
+        float r;
+        if (mode == 0) {
+            r = k0 * yv + k1;
+        } else if (mode == 1) {
+            // torch binary_cross_entropy_backward: (p - y) / max((1-p)*p, 1e-12) * grad * weight
+            r = k0 * (pv - yv) / fmaxf((1.f - pv) * pv, 1e-12f);
+        } else {
+            const float d = pv - yv;
+            r = k0 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+        g[pix * ld_g + c] = r;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pg_loss_reduce(const float* p, int ld_p, const float* y, int ld_y, float tconst, int N, int HW, int C, double* S,
+                   void* stream) {
+    if (!p || !S || N <= 0 || HW <= 0 || C <= 0 || ld_p < C || (y && ld_y < C)) return PG_EINVAL;
+    hipLaunchKernelGGL(k_loss_reduce, dim3(N * C), dim3(256), 0, (hipStream_t)stream, p, ld_p, y, ld_y, tconst, HW, C, S);
+    return pg_launch_status();
+}
+
+int pg_loss_prepare(const double* S, int N, int C, float beta, double* local2, void* stream) {
+    if (!S || !local2 || N <= 0 || C <= 0) return PG_EINVAL;
+    hipLaunchKernelGGL(k_loss_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, S, N, C, beta, local2);
+    return pg_launch_status();
+}
+
+int pg_loss_finalize(const double* S, const double* gsum2, int mode, int N, int C, int HW, int Bglobal, float alpha,
+                     float beta, float gamma, float* coef, float* loss_out, void* stream) {
+    if (!S || !gsum2 || !coef || !loss_out || N <= 0 || C <= 0 || HW <= 0 || Bglobal < N) return PG_EINVAL;
+    if (mode < PG_LOSS_TVERSKY || mode > PG_LOSS_BCE) return PG_EINVAL;
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, S, gsum2, mode, N, C, HW, Bglobal,
+                       alpha, beta, gamma, coef, loss_out);
+    return pg_launch_status();
+}
+
+int pg_loss_grad(const float* p, int ld_p, const float* y, int ld_y, float tconst, const float* coef, float* g,
+                 int ld_g, int N, int HW, int C, int mode, void* stream) {
+    if (!p || !coef || !g || N <= 0 || HW <= 0 || C <= 0 || ld_p < C || ld_g < C || (y && ld_y < C)) return PG_EINVAL;
+    if (mode < 0 || mode > 2) return PG_EINVAL;
+    const long total = (long)N * HW * C;
+    long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(k_loss_grad, dim3((int)b), dim3(256), 0, (hipStream_t)stream, p, ld_p, y, ld_y, tconst, coef, g,
+                       ld_g, N, HW, C, mode);
+    return pg_launch_status();
+}
+
+}  // extern "C"

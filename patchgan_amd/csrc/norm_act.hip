@@ -1,0 +1,418 @@
+// norm_act.hip -- InstanceNorm2d + activation + dropout (forward / backward), plain activation
+// forward / backward, channel softmax.  HBM-bound elementwise work over NHWC tensors: 16-byte accesses
+// along the channel dim when alignment allows (VEC = 4), scalar otherwise (VEC = 1).
+//
+// InstanceNorm statistics are per (sample, channel) over HW.  One 256-thread workgroup owns one sample
+// and a group of G channel-units (G*VEC channels); its threads stride over the pixels.  Sums are
+// accumulated in fp64 (torch's CPU batch_norm uses a double accumulator for float input) with a two-pass
+// variance, so the tiny-spatial layers (enc6: 2x2) are not at the mercy of E[x^2]-E[x]^2 cancellation.
+// Reductions are fixed-order LDS trees: bit-reproducible run to run.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "patchgan_hip.h"
+#include "pg_common.h"
+
+namespace {
+
+template <int VEC>
+struct Vec {
+    float v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> vload(const float* p) {
+    Vec<VEC> r;
+    if constexpr (VEC == 4) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else {
+        r.v[0] = *p;
+    }
+    return r;
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float* p, const Vec<VEC>& r) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    } else {
+        *p = r.v[0];
+    }
+}
+
+// tree-reduce red[k][tid] over the pixel-lane dim (tid = pl*G + cu); result in red[k][cu]
+template <int NK>
+__device__ __forceinline__ void lane_tree(double (*red)[256], int tid, int G) {
+    const int PL = 256 / G;
+    for (int off = PL >> 1; off > 0; off >>= 1) {
+        __syncthreads();
+        if (tid < off * G) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) red[k][tid] += red[k][tid + off * G];
+        }
+    }
+    __syncthreads();
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_instnorm_fwd(const float* __restrict__ y, int ld_y, float* __restrict__ out,
+                                                      int ld_out, float* __restrict__ stats, int HW, int C, int G,
+                                                      int act, float eps, float drop_p, uint64_t seed) {
+    __shared__ double red[VEC][256];
+    const int tid = threadIdx.x, cu = tid % G, pl = tid / G, PL = 256 / G;
+    const int c0 = (blockIdx.x * G + cu) * VEC;
+    const int n = blockIdx.y;
+    const bool on = c0 < C;
+    const float* yb = y + (long)n * HW * ld_y + c0;
+    float* ob = out + (long)n * HW * ld_out + c0;
+
+    double s[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s[k] = 0.0;
+    if (on)
+        for (int pix = pl; pix < HW; pix += PL) {
+            Vec<VEC> v = vload<VEC>(yb + (long)pix * ld_y);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s[k] += (double)v.v[k];
+        }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[k][tid] = s[k];
+    lane_tree<VEC>(red, tid, G);
+    double mean[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) mean[k] = red[k][cu] / (double)HW;
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s[k] = 0.0;
+    if (on)
+        for (int pix = pl; pix < HW; pix += PL) {
+            Vec<VEC> v = vload<VEC>(yb + (long)pix * ld_y);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                double d = (double)v.v[k] - mean[k];
+                s[k] += d * d;
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[k][tid] = s[k];
+    lane_tree<VEC>(red, tid, G);
+    float alpha[VEC], beta[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const double var = red[k][cu] / (double)HW;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float mf = (float)mean[k];
+        alpha[k] = rstd;
+        beta[k] = -mf * rstd;
+        if (on && pl == 0) {
+            stats[((long)n * C + c0 + k) * 2 + 0] = mf;
+            stats[((long)n * C + c0 + k) * 2 + 1] = rstd;
+        }
+    }
+    if (!on) return;
+    const float keep_scale = 1.f / (1.f - drop_p);
+    for (int pix = pl; pix < HW; pix += PL) {
+        Vec<VEC> v = vload<VEC>(yb + (long)pix * ld_y);
+        Vec<VEC> o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            // x*alpha + beta, two roundings, as torch's CPU batch_norm transform does
+            float z = __fadd_rn(__fmul_rn(v.v[k], alpha[k]), beta[k]);
+            float a = pg_act(z, act);
+            if (drop_p > 0.f) {
+                const uint64_t e = ((uint64_t)n * HW + pix) * C + c0 + k;
+                a = pg_dropout_keep(seed, e, drop_p) ? a * keep_scale : 0.f;
+            }
+            o.v[k] = a;
+        }
+        vstore<VEC>(ob + (long)pix * ld_out, o);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_instnorm_bwd(const float* __restrict__ g1, int ld_g1,
+                                                      const float* __restrict__ g2, int ld_g2,
+                                                      const float* __restrict__ y, int ld_y,
+                                                      const float* __restrict__ stats, float* __restrict__ dy,
+                                                      int ld_dy, int HW, int C, int G, int act, float drop_p,
+                                                      uint64_t seed) {
+    __shared__ double red[2 * VEC][256];
+    const int tid = threadIdx.x, cu = tid % G, pl = tid / G, PL = 256 / G;
+    const int c0 = (blockIdx.x * G + cu) * VEC;
+    const int n = blockIdx.y;
+    const bool on = c0 < C;
+    const long nb = (long)n * HW;
+    float mean[VEC], rstd[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        mean[k] = on ? stats[((long)n * C + c0 + k) * 2 + 0] : 0.f;
+        rstd[k] = on ? stats[((long)n * C + c0 + k) * 2 + 1] : 0.f;
+    }
+    const float keep_scale = 1.f / (1.f - drop_p);
+
+    auto dz_of = [&](int pix, Vec<VEC>& xm, Vec<VEC>& dz) {
+        Vec<VEC> v = vload<VEC>(y + (nb + pix) * ld_y + c0);
+        Vec<VEC> g = vload<VEC>(g1 + (nb + pix) * ld_g1 + c0);
+        if (g2) {
+            Vec<VEC> h = vload<VEC>(g2 + (nb + pix) * ld_g2 + c0);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) g.v[k] += h.v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float gg = g.v[k];
+            if (drop_p > 0.f) {
+                const uint64_t e = ((uint64_t)n * HW + pix) * C + c0 + k;
+                gg = pg_dropout_keep(seed, e, drop_p) ? gg * keep_scale : 0.f;
+            }
+            const float z = __fadd_rn(__fmul_rn(v.v[k], rstd[k]), -mean[k] * rstd[k]);
+            float d;
+            switch (act) {
+                case PG_ACT_LEAKY: d = z > 0.f ? 1.f : 0.2f; break;
+                case PG_ACT_RELU: d = z > 0.f ? 1.f : 0.f; break;
+                case PG_ACT_TANH: { float t = tanhf(z); d = 1.f - t * t; } break;
+                case PG_ACT_SIGMOID: { float t = 1.f / (1.f + expf(-z)); d = t * (1.f - t); } break;
+                default: d = 1.f;
+            }
+            xm.v[k] = v.v[k] - mean[k];
+            dz.v[k] = gg * d;
+        }
+    };
+
+    double s1[VEC], s2[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s1[k] = s2[k] = 0.0;
+    if (on)
+        for (int pix = pl; pix < HW; pix += PL) {
+            Vec<VEC> xm, dz;
+            dz_of(pix, xm, dz);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                s1[k] += (double)dz.v[k];
+                s2[k] += (double)dz.v[k] * (double)xm.v[k];
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        red[k][tid] = s1[k];
+        red[VEC + k][tid] = s2[k];
+    }
+    lane_tree<2 * VEC>(red, tid, G);
+    float gmean[VEC], kk[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        gmean[k] = (float)(red[k][cu] / (double)HW);
+        kk[k] = (float)(red[VEC + k][cu] * (double)rstd[k] * (double)rstd[k] / (double)HW);
+    }
+    if (!on) return;
+    for (int pix = pl; pix < HW; pix += PL) {
+        Vec<VEC> xm, dz, o;
+        dz_of(pix, xm, dz);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o.v[k] = (dz.v[k] - gmean[k] - xm.v[k] * kk[k]) * rstd[k];
+        vstore<VEC>(dy + (nb + pix) * ld_dy + c0, o);
+    }
+}
+
+template <int VEC>
+__global__ void k_act_fwd(const float* __restrict__ y, int ld_y, float* __restrict__ out, int ld_out, long npix, int C,
+                          int act, float drop_p, uint64_t seed) {
+    const int cq = C / VEC;
+    const long total = npix * cq;
+    const float keep_scale = 1.f / (1.f - drop_p);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cq;
+        const int c0 = (int)(i - pix * cq) * VEC;
+        Vec<VEC> v = vload<VEC>(y + pix * ld_y + c0), o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float a = pg_act(v.v[k], act);
+            if (drop_p > 0.f) a = pg_dropout_keep(seed, (uint64_t)pix * C + c0 + k, drop_p) ? a * keep_scale : 0.f;
+            o.v[k] = a;
+        }
+        vstore<VEC>(out + pix * ld_out + c0, o);
+    }
+}
+
+template <int VEC>
+__global__ void k_act_bwd(const float* __restrict__ g1, int ld_g1, const float* __restrict__ g2, int ld_g2,
+                          const float* __restrict__ a, int ld_a, float* __restrict__ dy, int ld_dy, long npix, int C,
+                          int act, float drop_p, uint64_t seed) {
+    const int cq = C / VEC;
+    const long total = npix * cq;
+    const float keep_scale = 1.f / (1.f - drop_p);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cq;
+        const int c0 = (int)(i - pix * cq) * VEC;
+        Vec<VEC> g = vload<VEC>(g1 + pix * ld_g1 + c0), o;
+        if (g2) {
+            Vec<VEC> h = vload<VEC>(g2 + pix * ld_g2 + c0);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) g.v[k] += h.v[k];
+        }
+        Vec<VEC> av;
+        if (a) av = vload<VEC>(a + pix * ld_a + c0);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float gg = g.v[k];
+            float ao = a ? av.v[k] : 0.f;
+            if (drop_p > 0.f) {
+                // the saved tensor is the post-dropout output: undo the scale to recover the activation output
+                const bool keep = pg_dropout_keep(seed, (uint64_t)pix * C + c0 + k, drop_p);
+                gg = keep ? gg * keep_scale : 0.f;
+                ao = ao * (1.f - drop_p);
+            }
+            o.v[k] = gg * pg_act_grad_from_out(ao, act);
+        }
+        vstore<VEC>(dy + pix * ld_dy + c0, o);
+    }
+}
+
+__global__ void k_softmax_fwd(const float* __restrict__ y, int ld_y, float* __restrict__ out, int ld_out, long npix,
+                              int C) {
+    for (long pix = blockIdx.x * (long)blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+        const float* p = y + pix * ld_y;
+        float m = p[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, p[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(p[c] - m);
+        float* o = out + pix * ld_out;
+        for (int c = 0; c < C; ++c) o[c] = expf(p[c] - m) / s;
+    }
+}
+
+__global__ void k_softmax_bwd(const float* __restrict__ g1, int ld_g1, const float* __restrict__ g2, int ld_g2,
+                              const float* __restrict__ out, int ld_out, float* __restrict__ dy, int ld_dy, long npix,
+                              int C) {
+    for (long pix = blockIdx.x * (long)blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+        const float* o = out + pix * ld_out;
+        const float* a = g1 + pix * ld_g1;
+        const float* b = g2 ? g2 + pix * ld_g2 : nullptr;
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) dot += (a[c] + (b ? b[c] : 0.f)) * o[c];
+        float* d = dy + pix * ld_dy;
+        for (int c = 0; c < C; ++c) d[c] = o[c] * ((a[c] + (b ? b[c] : 0.f)) - dot);
+    }
+}
+
+__global__ void k_dropout_mask(float* __restrict__ mask, long n, float p, uint64_t seed) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        mask[i] = pg_dropout_keep(seed, (uint64_t)i, p) ? 1.f : 0.f;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// channel-units per workgroup: as many as keeps >= ~512 workgroups, at most 32 (128 B per pixel row segment)
+int pick_group(int N, int units) {
+    int G = 1;
+    while (G < 32 && G * 2 <= units && (long)N * ((units + G * 2 - 1) / (G * 2)) >= 512) G *= 2;
+    return G;
+}
+
+int ew_blocks(long total) {
+    long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pg_instnorm_act_fwd(const float* y, int ld_y, float* out, int ld_out, float* stats, int N, int HW, int C,
+                        int act, float eps, float drop_p, uint64_t seed, void* stream) {
+    if (!y || !out || !stats || N <= 0 || HW <= 0 || C <= 0 || ld_y < C || ld_out < C) return PG_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID) return PG_EINVAL;
+    if (N > 65535) return PG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (C % 4 == 0) && (ld_y % 4 == 0) && (ld_out % 4 == 0) && al16(y) && al16(out);
+    if (vec) {
+        const int units = C / 4, G = pick_group(N, units);
+        hipLaunchKernelGGL(k_instnorm_fwd<4>, dim3((units + G - 1) / G, N), dim3(256), 0, st, y, ld_y, out, ld_out, stats,
+                           HW, C, G, act, eps, drop_p, seed);
+    } else {
+        const int G = pick_group(N, C);
+        hipLaunchKernelGGL(k_instnorm_fwd<1>, dim3((C + G - 1) / G, N), dim3(256), 0, st, y, ld_y, out, ld_out, stats, HW,
+                           C, G, act, eps, drop_p, seed);
+    }
+    return pg_launch_status();
+}
+
+int pg_instnorm_act_bwd(const float* g1, int ld_g1, const float* g2, int ld_g2, const float* y, int ld_y,
+                        const float* stats, float* dy, int ld_dy, int N, int HW, int C, int act, float drop_p,
+                        uint64_t seed, void* stream) {
+    if (!g1 || !y || !stats || !dy || N <= 0 || HW <= 0 || C <= 0) return PG_EINVAL;
+    if (ld_g1 < C || ld_y < C || ld_dy < C || (g2 && ld_g2 < C)) return PG_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID || N > 65535) return PG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (C % 4 == 0) && (ld_g1 % 4 == 0) && (ld_y % 4 == 0) && (ld_dy % 4 == 0) && al16(g1) && al16(y) &&
+                     al16(dy) && (!g2 || ((ld_g2 % 4 == 0) && al16(g2)));
+    if (vec) {
+        const int units = C / 4, G = pick_group(N, units);
+        hipLaunchKernelGGL(k_instnorm_bwd<4>, dim3((units + G - 1) / G, N), dim3(256), 0, st, g1, ld_g1, g2, ld_g2, y,
+                           ld_y, stats, dy, ld_dy, HW, C, G, act, drop_p, seed);
+    } else {
+        const int G = pick_group(N, C);
+        hipLaunchKernelGGL(k_instnorm_bwd<1>, dim3((C + G - 1) / G, N), dim3(256), 0, st, g1, ld_g1, g2, ld_g2, y, ld_y,
+                           stats, dy, ld_dy, HW, C, G, act, drop_p, seed);
+    }
+    return pg_launch_status();
+}
+
+int pg_act_fwd(const float* y, int ld_y, float* out, int ld_out, long npix, int C, int act, float drop_p,
+               uint64_t seed, void* stream) {
+    if (!y || !out || npix <= 0 || C <= 0 || ld_y < C || ld_out < C) return PG_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID) return PG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (C % 4 == 0) && (ld_y % 4 == 0) && (ld_out % 4 == 0) && al16(y) && al16(out);
+    if (vec)
+        hipLaunchKernelGGL(k_act_fwd<4>, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, st, y, ld_y, out, ld_out, npix, C,
+                           act, drop_p, seed);
+    else
+        hipLaunchKernelGGL(k_act_fwd<1>, dim3(ew_blocks(npix * C)), dim3(256), 0, st, y, ld_y, out, ld_out, npix, C, act,
+                           drop_p, seed);
+    return pg_launch_status();
+}
+
+int pg_act_bwd(const float* g1, int ld_g1, const float* g2, int ld_g2, const float* a, int ld_a, float* dy,
+               int ld_dy, long npix, int C, int act, float drop_p, uint64_t seed, void* stream) {
+    if (!g1 || !dy || npix <= 0 || C <= 0 || ld_g1 < C || ld_dy < C) return PG_EINVAL;
+    if ((g2 && ld_g2 < C) || (a && ld_a < C) || (!a && act != PG_ACT_NONE)) return PG_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID) return PG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (C % 4 == 0) && (ld_g1 % 4 == 0) && (ld_dy % 4 == 0) && al16(g1) && al16(dy) &&
+                     (!g2 || ((ld_g2 % 4 == 0) && al16(g2))) && (!a || ((ld_a % 4 == 0) && al16(a)));
+    if (vec)
+        hipLaunchKernelGGL(k_act_bwd<4>, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, st, g1, ld_g1, g2, ld_g2, a, ld_a,
+                           dy, ld_dy, npix, C, act, drop_p, seed);
+    else
+        hipLaunchKernelGGL(k_act_bwd<1>, dim3(ew_blocks(npix * C)), dim3(256), 0, st, g1, ld_g1, g2, ld_g2, a, ld_a, dy,
+                           ld_dy, npix, C, act, drop_p, seed);
+    return pg_launch_status();
+}
+
+int pg_softmax_fwd(const float* y, int ld_y, float* out, int ld_out, long npix, int C, void* stream) {
+    if (!y || !out || npix <= 0 || C <= 0 || ld_y < C || ld_out < C) return PG_EINVAL;
+    hipLaunchKernelGGL(k_softmax_fwd, dim3(ew_blocks(npix)), dim3(256), 0, (hipStream_t)stream, y, ld_y, out, ld_out, npix,
+                       C);
+    return pg_launch_status();
+}
+
+int pg_softmax_bwd(const float* g1, int ld_g1, const float* g2, int ld_g2, const float* out, int ld_out, float* dy,
+                   int ld_dy, long npix, int C, void* stream) {
+    if (!g1 || !out || !dy || npix <= 0 || C <= 0 || ld_g1 < C || ld_out < C || ld_dy < C || (g2 && ld_g2 < C))
+        return PG_EINVAL;
+    hipLaunchKernelGGL(k_softmax_bwd, dim3(ew_blocks(npix)), dim3(256), 0, (hipStream_t)stream, g1, ld_g1, g2, ld_g2, out,
+                       ld_out, dy, ld_dy, npix, C);
+    return pg_launch_status();
+}
+
+int pg_dropout_mask(float* mask, long nelem, float drop_p, uint64_t seed, void* stream) {
+    if (!mask || nelem <= 0 || drop_p < 0.f || drop_p >= 1.f) return PG_EINVAL;
+    hipLaunchKernelGGL(k_dropout_mask, dim3(ew_blocks(nelem)), dim3(256), 0, (hipStream_t)stream, mask, nelem, drop_p,
+                       seed);
+    return pg_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// optim_layout.hip -- fused Adam over a flat parameter buffer, NCHW <-> NHWC at the API edge, fills/copies.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "patchgan_hip.h"
+#include "pg_common.h"
+
+namespace {
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_over_bc1, float beta1,
+                                         float beta2, float eps, float sqrt_bc2) {
+    // torch single-tensor Adam: exp_avg.lerp_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2);
+    // denom = sqrt(v)/sqrt(bc2) + eps; p.addcdiv_(m, denom, value=-lr/bc1)
+    m = m + (g - m) * (1.f - beta1);
+    v = v * beta2 + (1.f - beta2) * g * g;
+    const float denom = sqrtf(v) / sqrt_bc2 + eps;
+    p = p - lr_over_bc1 * (m / denom);
+}
+
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       long n, float lr_over_bc1, float beta1, float beta2, float eps, float sqrt_bc2) {
+    const long n4 = n >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        adam_one(pp.x, gg.x, mm.x, vv.x, lr_over_bc1, beta1, beta2, eps, sqrt_bc2);
+        adam_one(pp.y, gg.y, mm.y, vv.y, lr_over_bc1, beta1, beta2, eps, sqrt_bc2);
+        adam_one(pp.z, gg.z, mm.z, vv.z, lr_over_bc1, beta1, beta2, eps, sqrt_bc2);
+        adam_one(pp.w, gg.w, mm.w, vv.w, lr_over_bc1, beta1, beta2, eps, sqrt_bc2);
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride)
+        adam_one(p[i], g[i], m[i], v[i], lr_over_bc1, beta1, beta2, eps, sqrt_bc2);
+}
+
+// dst NHWC (pixel stride ld_dst) <- src NCHW; one thread per (pixel, channel), channel fastest
+__global__ void k_nchw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int ld_dst, int N, int C,
+                               long HW) {
+    const long total = (long)N * HW * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        const long n = pix / HW, hw = pix - n * HW;
+        dst[pix * ld_dst + c] = src[(n * C + c) * HW + hw];
+    }
+}
+
+// dst NCHW <- src NHWC; one thread per NCHW element (pixel fastest)
+__global__ void k_nhwc_to_nchw(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int N, int C,
+                               long HW) {
+    const long total = (long)N * HW * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long hw = i % HW;
+        const long nc = i / HW;
+        const int c = (int)(nc % C);
+        const long n = nc / C;
+        dst[i] = src[(n * HW + hw) * ld_src + c];
+    }
+}
+
+__global__ void k_copy_channels(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
+                                long npix, int C) {
+    const long total = npix * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        dst[pix * ld_dst + c] = src[pix * ld_src + c];
+    }
+}
+
+__global__ void k_fill(float* __restrict__ dst, long n, float value) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = value;
+}
+
+int blocks_for(long total) {
+    long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pg_version(void) { return 1; }
+
+int pg_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                 float bc1, float sqrt_bc2, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || bc1 <= 0.f || sqrt_bc2 <= 0.f) return PG_EINVAL;
+    const uintptr_t al = (uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v;
+    if (al & 15) return PG_EINVAL;
+    hipLaunchKernelGGL(k_adam, dim3(blocks_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr / bc1,
+                       beta1, beta2, eps, sqrt_bc2);
+    return pg_launch_status();
+}
+
+int pg_nchw_to_nhwc(const float* src, float* dst, int ld_dst, int N, int C, int H, int W, void* stream) {
+    if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld_dst < C) return PG_EINVAL;
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(blocks_for((long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       ld_dst, N, C, HW);
+    return pg_launch_status();
+}
+
+int pg_nhwc_to_nchw(const float* src, int ld_src, float* dst, int N, int C, int H, int W, void* stream) {
+    if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld_src < C) return PG_EINVAL;
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(blocks_for((long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                       dst, N, C, HW);
+    return pg_launch_status();
+}
+
+int pg_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, long npix, int C, void* stream) {
+    if (!src || !dst || npix <= 0 || C <= 0 || ld_src < C || ld_dst < C) return PG_EINVAL;
+    hipLaunchKernelGGL(k_copy_channels, dim3(blocks_for(npix * C)), dim3(256), 0, (hipStream_t)stream, src, ld_src, dst,
+                       ld_dst, npix, C);
+    return pg_launch_status();
+}
+
+int pg_fill(float* dst, long n, float value, void* stream) {
+    if (!dst || n <= 0) return PG_EINVAL;
+    hipLaunchKernelGGL(k_fill, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dst, n, value);
+    return pg_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// pg_common.h -- device helpers shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include "patchgan_hip.h"
+
+__device__ __forceinline__ float pg_act(float v, int act) {
+    switch (act) {
+        case PG_ACT_LEAKY: return v > 0.f ? v : 0.2f * v;
+        case PG_ACT_RELU: return v > 0.f ? v : 0.f;
+        case PG_ACT_TANH: return tanhf(v);
+        case PG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+// derivative of the activation expressed through its OUTPUT a (what torch's in-place activations save)
+__device__ __forceinline__ float pg_act_grad_from_out(float a, int act) {
+    switch (act) {
+        case PG_ACT_LEAKY: return a > 0.f ? 1.f : 0.2f;
+        case PG_ACT_RELU: return a > 0.f ? 1.f : 0.f;
+        case PG_ACT_TANH: return 1.f - a * a;
+        case PG_ACT_SIGMOID: return a * (1.f - a);
+        default: return 1.f;
+    }
+}
+
+// Counter-based dropout RNG: keep element e of stream `seed` iff a 64-bit mix of (seed, e) maps to u >= p.
+__device__ __forceinline__ uint64_t pg_mix64(uint64_t x) {
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+__device__ __forceinline__ bool pg_dropout_keep(uint64_t seed, uint64_t e, float p) {
+    const uint64_t h = pg_mix64(seed + 0x9e3779b97f4a7c15ULL * (e + 1));
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0,1)
+    return u >= p;
+}
+
+static inline int pg_launch_status() { return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH; }

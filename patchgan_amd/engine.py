@@ -1,0 +1,558 @@
+"""Device engines for the patchGAN hot path: UNet generator and PatchGAN discriminator forward /
+backward scheduled as explicit HIP kernel launches through the C ABI (include/patchgan_hip.h).
+
+Data layout in HBM
+  * activations: fp32 NHWC.  A `View` is (tensor, element offset, pixel stride ld, N, H, W, C): a channel
+    slice of a wider buffer.  Skip connections (reference unet.py:127 ``torch.cat([x, xencs[i]], dim=1)``)
+    are never materialised by a copy: decoder level i owns one buffer ``cat_i`` of C_dec + C_skip channels;
+    decoder block i-1 writes channels [0, C_dec) and encoder block 6-i writes channels [C_dec, ...) directly.
+    The discriminator input cat(x, mask) (trainer.py:65,96,98) is handled the same way.
+  * weights: ONE flat fp32 buffer per network holding, per layer, the packed block P[16][a][b] (+ bias).  The
+    torch-layout tensor W[a][b][4][4] the reference's state_dict exposes is a *strided view* of that block
+    (strides (b, 1, 4ab, ab)), so checkpoints interchange with the reference without any repack kernel, and
+    Adam / RCCL all-reduce run over the flat buffer in one launch.
+
+Nothing here touches autograd; `patchgan_amd.unet` / `.disc` wrap the engines in torch.autograd.Function and
+`patchgan_amd.trainer` drives them directly.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib as L
+
+_MASK64 = (1 << 64) - 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class View:
+    """NHWC channel-slice of a device buffer."""
+    __slots__ = ('t', 'off', 'ld', 'N', 'H', 'W', 'C')
+
+    def __init__(self, t, off, ld, N, H, W, C):
+        self.t, self.off, self.ld, self.N, self.H, self.W, self.C = t, off, ld, N, H, W, C
+
+    @staticmethod
+    def alloc(N, H, W, C, device, zero=False):
+        t = (torch.zeros if zero else torch.empty)(N * H * W * C, dtype=torch.float32, device=device)
+        return View(t, 0, C, N, H, W, C)
+
+    def ptr(self):
+        return self.t.data_ptr() + self.off * 4
+
+    def channels(self, c0, c):
+        assert 0 <= c0 and c0 + c <= self.C
+        return View(self.t, self.off + c0, self.ld, self.N, self.H, self.W, c)
+
+    def samples(self, n0, n):
+        assert 0 <= n0 and n0 + n <= self.N
+        return View(self.t, self.off + n0 * self.H * self.W * self.ld, self.ld, n, self.H, self.W, self.C)
+
+    @property
+    def HW(self):
+        return self.H * self.W
+
+    @property
+    def npix(self):
+        return self.N * self.H * self.W
+
+    def to_nchw(self):
+        """Materialise as a contiguous NCHW torch tensor (API edge)."""
+        out = torch.empty(self.N, self.C, self.H, self.W, dtype=torch.float32, device=self.t.device)
+        L.check(L.load().pg_nhwc_to_nchw(self.ptr(), self.ld, out.data_ptr(), self.N, self.C, self.H, self.W,
+                                         _stream()), 'pg_nhwc_to_nchw')
+        return out
+
+    def from_nchw(self, src):
+        """Fill from a contiguous NCHW torch tensor of shape [N, C, H, W]."""
+        assert tuple(src.shape) == (self.N, self.C, self.H, self.W), (tuple(src.shape), (self.N, self.C, self.H, self.W))
+        src = src.contiguous()
+        L.check(L.load().pg_nchw_to_nhwc(src.data_ptr(), self.ptr(), self.ld, self.N, self.C, self.H, self.W,
+                                         _stream()), 'pg_nchw_to_nhwc')
+        return self
+
+
+# ------------------------------------------------------------------------------------------------
+# workspace (split-K slabs): one growing buffer per device; all launches are stream-ordered
+# ------------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+class ConvOp:
+    """One 4x4 / padding-1 convolution layer bound to its geometry: the three kernels that touch its weights."""
+
+    def __init__(self, N, Hb, Wb, Ca, Cb, stride, algo=L.ALGO_AUTO):
+        Hs = (Hb - 2) // stride + 1
+        Ws = (Wb - 2) // stride + 1
+        if Hb < 2 or Wb < 2 or Hs < 1 or Ws < 1:
+            raise RuntimeError(f"Kernel size can't be greater than actual input size ({Hb}x{Wb}, 4x4 kernel, pad 1)")
+        self.g = L.ConvGeom(N, Hb, Wb, Hs, Ws, Ca, Cb, stride)
+        self.N, self.Hb, self.Wb, self.Hs, self.Ws, self.Ca, self.Cb, self.stride = N, Hb, Wb, Hs, Ws, Ca, Cb, stride
+        self.algo = algo
+        lib = L.load()
+        self.ws_bytes = max(int(lib.pg_conv_workspace_bytes(ctypes.byref(self.g), op)) for op in (0, 1, 2))
+
+    def _ws(self, device):
+        ws = _workspace(self.ws_bytes, device)
+        return ws.data_ptr(), ws.numel()
+
+    def big2small(self, big, P, p_off, bias, b_off, small, act=L.ACT_NONE):
+        assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
+        assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
+        wp, wn = self._ws(P.device)
+        L.check(L.load().pg_conv4x4_big2small(big.ptr(), big.ld, L.ptr(P, p_off), L.ptr(bias, b_off) if bias is not None else None,
+                                              small.ptr(), small.ld, ctypes.byref(self.g), act, self.algo, wp, wn,
+                                              _stream()), 'pg_conv4x4_big2small')
+
+    def small2big(self, small, P, p_off, bias, b_off, big, act=L.ACT_NONE):
+        assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
+        assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
+        wp, wn = self._ws(P.device)
+        L.check(L.load().pg_conv4x4_small2big(small.ptr(), small.ld, L.ptr(P, p_off), L.ptr(bias, b_off) if bias is not None else None,
+                                              big.ptr(), big.ld, ctypes.byref(self.g), act, self.algo, wp, wn,
+                                              _stream()), 'pg_conv4x4_small2big')
+
+    def wgrad(self, small, big, dP, p_off, dbias=None, b_off=0):
+        assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
+        assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
+        wp, wn = self._ws(dP.device)
+        L.check(L.load().pg_conv4x4_wgrad(small.ptr(), small.ld, big.ptr(), big.ld, L.ptr(dP, p_off),
+                                          L.ptr(dbias, b_off) if dbias is not None else None, ctypes.byref(self.g),
+                                          self.algo, wp, wn, _stream()), 'pg_conv4x4_wgrad')
+
+
+def instnorm_act_fwd(y, out, stats, act, drop_p=0.0, seed=0):
+    if y.HW <= 1:
+        raise ValueError(f"Expected more than 1 spatial element when training, got input size "
+                         f"torch.Size([{y.N}, {y.C}, {y.H}, {y.W}])")
+    L.check(L.load().pg_instnorm_act_fwd(y.ptr(), y.ld, out.ptr(), out.ld, stats.data_ptr(), y.N, y.HW, y.C, act, 1e-5,
+                                         drop_p, seed & _MASK64, _stream()), 'pg_instnorm_act_fwd')
+
+
+def instnorm_act_bwd(g1, g2, y, stats, dy, act, drop_p=0.0, seed=0):
+    L.check(L.load().pg_instnorm_act_bwd(g1.ptr(), g1.ld, g2.ptr() if g2 is not None else None,
+                                         g2.ld if g2 is not None else 0, y.ptr(), y.ld, stats.data_ptr(), dy.ptr(), dy.ld,
+                                         y.N, y.HW, y.C, act, drop_p, seed & _MASK64, _stream()), 'pg_instnorm_act_bwd')
+
+
+def act_bwd(g1, g2, a, dy, act):
+    L.check(L.load().pg_act_bwd(g1.ptr(), g1.ld, g2.ptr() if g2 is not None else None, g2.ld if g2 is not None else 0,
+                                a.ptr() if a is not None else None, a.ld if a is not None else 0, dy.ptr(), dy.ld,
+                                dy.npix, dy.C, act, 0.0, 0, _stream()), 'pg_act_bwd')
+
+
+def softmax_fwd(y, out):
+    L.check(L.load().pg_softmax_fwd(y.ptr(), y.ld, out.ptr(), out.ld, y.npix, y.C, _stream()), 'pg_softmax_fwd')
+
+
+def softmax_bwd(g1, g2, out, dy):
+    L.check(L.load().pg_softmax_bwd(g1.ptr(), g1.ld, g2.ptr() if g2 is not None else None,
+                                    g2.ld if g2 is not None else 0, out.ptr(), out.ld, dy.ptr(), dy.ld, dy.npix, dy.C,
+                                    _stream()), 'pg_softmax_bwd')
+
+
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults (reference trainer.py:169-172); bias corrections in Python doubles like torch."""
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    L.check(L.load().pg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2,
+                                  eps, bc1, math.sqrt(bc2), _stream()), 'pg_adam_step')
+
+
+def _mix_seed(base, *vals):
+    h = (base * 0x9E3779B97F4A7C15 + 0x1234567) & _MASK64
+    for v in vals:
+        h ^= (v + 0x9E3779B97F4A7C15 + ((h << 6) & _MASK64) + (h >> 2)) & _MASK64
+        h = (h * 0xBF58476D1CE4E5B9) & _MASK64
+    return h
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter layout
+# ------------------------------------------------------------------------------------------------
+
+
+class LayerSpec:
+    """One conv layer of a network: state_dict key, torch weight shape [a, b, 4, 4], offsets into the flat buffer."""
+    __slots__ = ('key', 'a', 'b', 'stride', 'transposed', 'p_off', 'bias_key', 'b_off', 'act', 'norm', 'dropout')
+
+    def __init__(self, key, a, b, stride, transposed, act, norm, dropout=False, bias_key=None):
+        self.key, self.a, self.b, self.stride, self.transposed = key, a, b, stride, transposed
+        self.act, self.norm, self.dropout, self.bias_key = act, norm, dropout, bias_key
+        self.p_off = self.b_off = -1
+
+    @property
+    def cout(self):
+        return self.b if self.transposed else self.a
+
+    @property
+    def cin(self):
+        return self.a if self.transposed else self.b
+
+
+def assign_offsets(layers):
+    """Lay the packed blocks out back to back (16-byte aligned); returns the flat length in floats."""
+    off = 0
+    for l in layers:
+        l.p_off = off
+        off += 16 * l.a * l.b
+        if l.bias_key is not None:
+            l.b_off = off
+            off += (l.cout + 3) // 4 * 4
+    return off
+
+
+def torch_views(flat, layers):
+    """{state_dict key: strided view of `flat` with the reference's shape} (weights [a,b,4,4], biases [cout])."""
+    out = {}
+    for l in layers:
+        ab = l.a * l.b
+        out[l.key] = flat.as_strided((l.a, l.b, 4, 4), (l.b, 1, 4 * ab, ab), l.p_off)
+        if l.bias_key is not None:
+            out[l.bias_key] = flat.as_strided((l.cout,), (1,), l.b_off)
+    return out
+
+
+def default_init_(flat, layers, generator=None):
+    """torch's default Conv2d / ConvTranspose2d init (the reference's ``weights_init`` is a no-op,
+    trainer.py:327-343): kaiming_uniform_(a=sqrt(5)) = U(+-1/sqrt(fan_in)), fan_in = size(1)*16; bias
+    U(+-1/sqrt(fan_in)).  Drawn in state_dict order with the CPU generator like nn.Module construction would."""
+    views = torch_views(flat, layers)
+    with torch.no_grad():
+        for l in layers:
+            bound = 1.0 / math.sqrt(l.b * 16)
+            w = torch.empty(l.a, l.b, 4, 4).uniform_(-bound, bound, generator=generator)
+            views[l.key].copy_(w)
+            if l.bias_key is not None:
+                bb = torch.empty(l.cout).uniform_(-bound, bound, generator=generator)
+                views[l.bias_key].copy_(bb)
+
+
+# ------------------------------------------------------------------------------------------------
+# generator
+# ------------------------------------------------------------------------------------------------
+
+
+def unet_layers(input_nc, output_nc, nf, activation, final_act, use_dropout):
+    """Layer plan of reference UNet.__init__ (unet.py:84-107)."""
+    if activation not in ('tanh', 'relu', 'leakyrelu'):
+        raise ValueError(f"activation must be one of tanh|relu|leakyrelu, got {activation!r}")
+    if final_act not in ('tanh', 'relu', 'leakyrelu', 'sigmoid', 'softmax'):
+        raise ValueError(f"final_act must be one of tanh|relu|leakyrelu|sigmoid|softmax, got {final_act!r}")
+    filts = [nf, nf * 2, nf * 4, nf * 8, nf * 8, nf * 8, nf * 8]
+    enc, dec = [], []
+    prev = input_nc
+    for i, f in enumerate(filts):
+        enc.append(LayerSpec(f'encoder.{i}.model.DownConv{i}.weight', f, prev, 2, False, activation, True, use_dropout))
+        prev = f
+    for i, f in enumerate(filts[:-1][::-1]):
+        cin = prev if i == 0 else prev * 2
+        dec.append(LayerSpec(f'decoder.{i}.model.UpConv{i}.weight', cin, f, 2, True, activation, i != 0,
+                             use_dropout and i != 0))
+        prev = f
+    dec.append(LayerSpec('decoder.6.model.UpConv6.weight', nf * 2, output_nc, 2, True, final_act, False, False))
+    return enc, dec
+
+
+class GenContext:
+    """Activations saved by one generator forward (what autograd would have kept)."""
+    pass
+
+
+class GeneratorEngine:
+    def __init__(self, input_nc, output_nc, nf, activation, final_act, use_dropout, algo=L.ALGO_AUTO):
+        self.input_nc, self.output_nc, self.nf = input_nc, output_nc, nf
+        self.activation, self.final_act, self.use_dropout = activation, final_act, use_dropout
+        self.enc, self.dec = unet_layers(input_nc, output_nc, nf, activation, final_act, use_dropout)
+        self.layers = self.enc + self.dec
+        self.nparams = assign_offsets(self.layers)
+        self.algo = algo
+        self._ops = {}
+
+    def ops(self, N, H, W):
+        """ConvOps for input extent (N, H, W); cached."""
+        key = (N, H, W)
+        if key not in self._ops:
+            enc_ops, dec_ops = [], []
+            h, w = H, W
+            for l in self.enc:
+                op = ConvOp(N, h, w, l.a, l.b, 2, self.algo)
+                enc_ops.append(op)
+                h, w = op.Hs, op.Ws
+            sizes = [(op.Hs, op.Ws) for op in enc_ops]   # enc i output extent
+            for i, l in enumerate(self.dec):
+                # convT: small = input (h, w), big = output (2h, 2w)
+                op = ConvOp(N, 2 * h, 2 * w, l.a, l.b, 2, self.algo)
+                assert (op.Hs, op.Ws) == (h, w)
+                dec_ops.append(op)
+                h, w = 2 * h, 2 * w
+                if i < 6:
+                    sh, sw = sizes[5 - i]
+                    if (sh, sw) != (h, w):
+                        raise RuntimeError(f"Sizes of tensors must match except in dimension 1. Expected size {h} but got "
+                                           f"size {sh} for the skip connection of decoder block {i + 1} (input {H}x{W}: "
+                                           "H and W must be multiples of 128)")
+            self._ops[key] = (enc_ops, dec_ops)
+        return self._ops[key]
+
+    def forward(self, flat, xin, gen_out, train, seed=0):
+        """xin: View [N,H,W,input_nc]; gen_out: View [N,H,W,output_nc] to receive final_act(dec6).
+        train selects dropout (InstanceNorm always uses instance statistics, unet.py:77)."""
+        N, H, W = xin.N, xin.H, xin.W
+        dev = flat.device
+        enc_ops, dec_ops = self.ops(N, H, W)
+        F = [l.a for l in self.enc]
+        c = GenContext()
+        c.N, c.H, c.W, c.xin, c.gen_out, c.seed, c.train = N, H, W, xin, gen_out, seed, train
+        # cat_i (i = 1..6): input of decoder i = [dec_{i-1} out | enc_{6-i} out]
+        c.cat = [None] * 7
+        for i in range(1, 7):
+            op = dec_ops[i]
+            c.cat[i] = View.alloc(N, op.Hs, op.Ws, self.dec[i].a, dev)
+        c.hidden = View.alloc(N, enc_ops[6].Hs, enc_ops[6].Ws, F[6], dev)
+        c.y, c.stats, c.enc_out = [], [], []
+        act = L.ACT_CODES[self.activation]
+        src = xin
+        for i, (l, op) in enumerate(zip(self.enc, enc_ops)):
+            y = View.alloc(N, op.Hs, op.Ws, l.a, dev)
+            op.big2small(src, flat, l.p_off, None, 0, y)
+            if i < 6:
+                cat = c.cat[6 - i]
+                out = cat.channels(cat.C - l.a, l.a)
+            else:
+                out = c.hidden
+            stats = torch.empty(N * l.a * 2, dtype=torch.float32, device=dev)
+            drop = 0.2 if (train and l.dropout) else 0.0
+            instnorm_act_fwd(y, out, stats, act, drop, _mix_seed(seed, 1, i))
+            c.y.append(y)
+            c.stats.append(stats)
+            c.enc_out.append(out)
+            src = out
+        c.yd, c.statsd = [None] * 7, [None] * 7
+        src = c.hidden
+        for i, (l, op) in enumerate(zip(self.dec, dec_ops)):
+            if i == 6:
+                if self.final_act == 'softmax':
+                    c.gen_raw = View.alloc(N, op.Hb, op.Wb, l.b, dev)
+                    op.small2big(src, flat, l.p_off, None, 0, c.gen_raw)
+                    softmax_fwd(c.gen_raw, gen_out)
+                else:
+                    op.small2big(src, flat, l.p_off, None, 0, gen_out, L.ACT_CODES[self.final_act])
+                break
+            cat = c.cat[i + 1]
+            out = cat.channels(0, l.b)
+            if l.norm:
+                yd = View.alloc(N, op.Hb, op.Wb, l.b, dev)
+                op.small2big(src, flat, l.p_off, None, 0, yd)
+                stats = torch.empty(N * l.b * 2, dtype=torch.float32, device=dev)
+                drop = 0.2 if (train and l.dropout) else 0.0
+                instnorm_act_fwd(yd, out, stats, act, drop, _mix_seed(seed, 2, i))
+                c.yd[i], c.statsd[i] = yd, stats
+            else:
+                op.small2big(src, flat, l.p_off, None, 0, out, act)
+            src = cat
+        return c
+
+    def backward(self, flat, gflat, c, g1, g2=None, need_dx=False):
+        """g1 (+ g2): Views of dL/d(gen_out).  Writes every weight gradient into `gflat` (packed layout);
+        returns dL/dx as a View if need_dx."""
+        N, dev = c.N, flat.device
+        enc_ops, dec_ops = self.ops(c.N, c.H, c.W)
+        act = L.ACT_CODES[self.activation]
+        # ---- decoder, last to first
+        l, op = self.dec[6], dec_ops[6]
+        dy = View.alloc(N, op.Hb, op.Wb, l.b, dev)
+        if self.final_act == 'softmax':
+            softmax_bwd(g1, g2, c.gen_out, dy)
+        else:
+            act_bwd(g1, g2, c.gen_out, dy, L.ACT_CODES[self.final_act])
+        op.wgrad(c.cat[6], dy, gflat, l.p_off)
+        dcat = View.alloc(N, op.Hs, op.Ws, l.a, dev)
+        op.big2small(dy, flat, l.p_off, None, 0, dcat)
+        dskip = [None] * 7   # dskip[j]: gradient wrt enc_j output arriving through the skip connection
+        for i in range(5, -1, -1):
+            l, op = self.dec[i], dec_ops[i]
+            g = dcat.channels(0, l.b)
+            dskip[5 - i] = dcat.channels(l.b, dcat.C - l.b)
+            dy = View.alloc(N, op.Hb, op.Wb, l.b, dev)
+            if l.norm:
+                drop = 0.2 if (c.train and l.dropout) else 0.0
+                instnorm_act_bwd(g, None, c.yd[i], c.statsd[i], dy, act, drop, _mix_seed(c.seed, 2, i))
+            else:
+                act_bwd(g, None, c.cat[i + 1].channels(0, l.b), dy, act)
+            src = c.hidden if i == 0 else c.cat[i]
+            op.wgrad(src, dy, gflat, l.p_off)
+            dsrc = View.alloc(N, op.Hs, op.Ws, l.a, dev)
+            op.big2small(dy, flat, l.p_off, None, 0, dsrc)
+            dcat = dsrc
+        # ---- encoder, last to first; dcat is now dL/d(hidden)
+        g_main = dcat
+        dx = None
+        for j in range(6, -1, -1):
+            l, op = self.enc[j], enc_ops[j]
+            dy = View.alloc(N, op.Hs, op.Ws, l.a, dev)
+            drop = 0.2 if (c.train and l.dropout) else 0.0
+            instnorm_act_bwd(g_main, dskip[j] if j < 6 else None, c.y[j], c.stats[j], dy, act, drop,
+                             _mix_seed(c.seed, 1, j))
+            src = c.xin if j == 0 else c.enc_out[j - 1]
+            op.wgrad(dy, src, gflat, l.p_off)
+            if j > 0 or need_dx:
+                dsrc = View.alloc(N, op.Hb, op.Wb, l.b, dev)
+                op.small2big(dy, flat, l.p_off, None, 0, dsrc)
+                if j == 0:
+                    dx = dsrc
+                g_main = dsrc
+        return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# discriminator
+# ------------------------------------------------------------------------------------------------
+
+
+def disc_layers(input_nc, ndf, n_layers, norm):
+    """Layer plan of reference Discriminator.__init__ (disc.py:19-46); keys are nn.Sequential indices."""
+    layers = []
+    idx = 0
+    layers.append(LayerSpec(f'model.{idx}.weight', ndf, input_nc, 2, False, 'leakyrelu', False, bias_key=f'model.{idx}.bias'))
+    idx += 2
+    mult = 1
+    for n in range(1, n_layers):
+        prev, mult = mult, min(2 ** n, 8)
+        layers.append(LayerSpec(f'model.{idx}.weight', ndf * mult, ndf * prev, 2, False, 'tanh', norm))
+        idx += 3 if norm else 2
+    prev, mult = mult, min(2 ** n_layers, 8)
+    layers.append(LayerSpec(f'model.{idx}.weight', ndf * mult, ndf * prev, 1, False, 'tanh', norm))
+    idx += 3 if norm else 2
+    layers.append(LayerSpec(f'model.{idx}.weight', 1, ndf * mult, 1, False, 'sigmoid', False, bias_key=f'model.{idx}.bias'))
+    return layers
+
+
+class DiscContext:
+    pass
+
+
+class DiscriminatorEngine:
+    def __init__(self, input_nc, ndf, n_layers, norm, algo=L.ALGO_AUTO):
+        self.input_nc, self.ndf, self.n_layers, self.norm = input_nc, ndf, n_layers, norm
+        self.layers = disc_layers(input_nc, ndf, n_layers, norm)
+        self.nparams = assign_offsets(self.layers)
+        self.algo = algo
+        self._ops = {}
+
+    def ops(self, N, H, W):
+        key = (N, H, W)
+        if key not in self._ops:
+            ops = []
+            h, w = H, W
+            for l in self.layers:
+                op = ConvOp(N, h, w, l.a, l.b, l.stride, self.algo)
+                ops.append(op)
+                h, w = op.Hs, op.Ws
+            self._ops[key] = ops
+        return self._ops[key]
+
+    def out_shape(self, N, H, W):
+        op = self.ops(N, H, W)[-1]
+        return (N, 1, op.Hs, op.Ws)
+
+    def forward(self, flat, din):
+        """din: View [N,H,W,input_nc].  Returns a context; ctx.out is the sigmoid patch map View [N,h,w,1]."""
+        ops = self.ops(din.N, din.H, din.W)
+        dev = flat.device
+        c = DiscContext()
+        c.din, c.N, c.H, c.W = din, din.N, din.H, din.W
+        c.t, c.stats, c.a = [], [], []
+        src = din
+        for l, op in zip(self.layers, ops):
+            t = View.alloc(din.N, op.Hs, op.Ws, l.a, dev)
+            bias = flat if l.bias_key is not None else None
+            op.big2small(src, flat, l.p_off, bias, l.b_off, t, L.ACT_CODES[l.act])   # conv + bias + act fused
+            if l.norm:                                                              # disc.py:31-32: Conv -> Tanh -> IN
+                a = View.alloc(din.N, op.Hs, op.Ws, l.a, dev)
+                stats = torch.empty(din.N * l.a * 2, dtype=torch.float32, device=dev)
+                instnorm_act_fwd(t, a, stats, L.ACT_NONE)
+            else:
+                a, stats = t, None
+            c.t.append(t)
+            c.stats.append(stats)
+            c.a.append(a)
+            src = a
+        c.out = src
+        return c
+
+    def backward(self, flat, gflat, c, gout, need_wgrad=True, need_dx=False):
+        """gout: View of dL/d(out).  need_wgrad=False skips the weight gradients (the generator step's pass
+        through D, whose D-gradients the reference zeroes at trainer.py:93-94)."""
+        ops = self.ops(c.N, c.H, c.W)
+        dev = flat.device
+        g = gout
+        dx = None
+        for li in range(len(self.layers) - 1, -1, -1):
+            l, op = self.layers[li], ops[li]
+            if l.norm:
+                dt = View.alloc(c.N, op.Hs, op.Ws, l.a, dev)
+                instnorm_act_bwd(g, None, c.t[li], c.stats[li], dt, L.ACT_NONE)
+                g = dt
+            dy = View.alloc(c.N, op.Hs, op.Ws, l.a, dev)
+            act_bwd(g, None, c.t[li], dy, L.ACT_CODES[l.act])
+            src = c.din if li == 0 else c.a[li - 1]
+            if need_wgrad:
+                op.wgrad(dy, src, gflat, l.p_off, gflat if l.bias_key is not None else None, l.b_off)
+            if li > 0 or need_dx:
+                dsrc = View.alloc(c.N, op.Hb, op.Wb, l.b, dev)
+                op.small2big(dy, flat, l.p_off, None, 0, dsrc)
+                g = dsrc
+                if li == 0:
+                    dx = dsrc
+        return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# losses on the device
+# ------------------------------------------------------------------------------------------------
+
+
+class LossBuffers:
+    """Scratch for one loss evaluation: S [N*C*5] f64, sums [2] f64, coef [N*C*2] f32."""
+
+    def __init__(self, N, C, device):
+        self.S = torch.empty(N * C * 5, dtype=torch.float64, device=device)
+        self.sums = torch.zeros(2, dtype=torch.float64, device=device)
+        self.coef = torch.empty(N * C * 2, dtype=torch.float32, device=device)
+
+
+def loss_value_and_grad(p, y, tconst, mode, alpha, grad_out, loss_out, loss_slot, bglobal, beta=0.75, gamma=0.75,
+                        allreduce=None):
+    """Evaluate one loss term over prediction View p against target View y (or the constant tconst), write its
+    value into loss_out[loss_slot] and, if grad_out is not None, its gradient wrt p into View grad_out.
+    `allreduce(tensor)` sums the two global reduction terms across ranks under data parallelism."""
+    lib = L.load()
+    buf = LossBuffers(p.N, p.C, p.t.device)
+    st = _stream()
+    L.check(lib.pg_loss_reduce(p.ptr(), p.ld, y.ptr() if y is not None else None, y.ld if y is not None else 0,
+                               float(tconst), p.N, p.HW, p.C, buf.S.data_ptr(), st), 'pg_loss_reduce')
+    L.check(lib.pg_loss_prepare(buf.S.data_ptr(), p.N, p.C, beta, buf.sums.data_ptr(), st), 'pg_loss_prepare')
+    if allreduce is not None:
+        allreduce(buf.sums)
+    L.check(lib.pg_loss_finalize(buf.S.data_ptr(), buf.sums.data_ptr(), mode, p.N, p.C, p.HW, bglobal, alpha, beta, gamma,
+                                 buf.coef.data_ptr(), L.ptr(loss_out, loss_slot), st), 'pg_loss_finalize')
+    if grad_out is not None:
+        gmode = {L.LOSS_TVERSKY: 0, L.LOSS_WBCE: 1, L.LOSS_BCE: 1, L.LOSS_MAE: 2}[mode]
+        L.check(lib.pg_loss_grad(p.ptr(), p.ld, y.ptr() if y is not None else None, y.ld if y is not None else 0,
+                                 float(tconst), buf.coef.data_ptr(), grad_out.ptr(), grad_out.ld, p.N, p.HW, p.C, gmode,
+                                 st), 'pg_loss_grad')
+    return buf

@@ -1,0 +1,309 @@
+"""Trainer with the reference's surface (patchgan/trainer.py:16-321): ``batch`` (one generator + one
+discriminator update), ``train`` (epoch driver, Adam, LR schedule, checkpoints), ``save`` / ``load`` /
+``load_last_checkpoint`` -- the G+D step hand-scheduled on the HIP engines instead of autograd.
+
+Per-step schedule (reference trainer.py:50-115):
+   x, y -> NHWC slices of ONE discriminator-input buffer din[2N] (real half = x|y, fake half = x|G(x)):
+   G fwd (dec6 writes straight into the fake half) -> D fwd(fake) -> seg loss + BCE(D(fake),1) ->
+   dgrad through D (its weight grads are skipped: the reference zeroes them at trainer.py:93-94) ->
+   G bwd -> [all-reduce G grads] -> Adam(G) -> D fwd over din[2N] (real and detached fake in one batch) ->
+   BCE halves -> D bwd -> [all-reduce D grads] -> Adam(D) -> one device->host copy of the loss scalars.
+
+Data parallelism: one process per GPU (torch.distributed, backend "nccl" = RCCL).  InstanceNorm is per sample,
+so the only exchanges are the SUM all-reduce of the flat gradient buffers and of two loss-normalisation terms
+(focal-Tversky's batch mean and weighted-BCE's sum(y) are non-linear in the batch).  Gradient seeds are scaled
+by the GLOBAL batch so the summed gradient equals the single-process large-batch gradient.
+"""
+import glob
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+import tqdm
+
+from . import _lib as L
+from . import engine as E
+
+device = 'cuda' if torch.cuda.is_available() else 'cpu'
+
+_LOSS_MODES = {'tversky': L.LOSS_TVERSKY, 'weighted_bce': L.LOSS_WBCE, 'MAE': L.LOSS_MAE}
+
+
+def weights_init(net, init_type='normal', scaling=0.02):
+    """The reference's ``weights_init`` defines an inner function and never applies it (trainer.py:327-343):
+    a no-op, so torch's default initialisation stays.  Kept as a no-op for parity."""
+    return None
+
+
+class _Dist:
+    """Thin view of torch.distributed (absent / uninitialised -> single process)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.on else 1
+        self.rank = dist.get_rank() if self.on else 0
+
+    def all_reduce(self, t, async_op=False):
+        if self.on:
+            return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=async_op)
+        return None
+
+
+class Trainer:
+    seg_alpha = 200
+    loss_type = 'tversky'
+    tversky_beta = 0.75
+    tversky_gamma = 0.75
+
+    neptune_config = None
+
+    def __init__(self, generator, discriminator, savefolder, device='cuda'):
+        generator.apply(weights_init)
+        discriminator.apply(weights_init)
+        self.generator = generator
+        self.discriminator = discriminator
+        self.device = device
+        if savefolder[-1] != '/':
+            savefolder += '/'
+        self.savefolder = savefolder
+        if not os.path.exists(savefolder):
+            os.makedirs(savefolder, exist_ok=True)
+        self.start = 1
+        self.gen_lr = self.dsc_lr = 1e-3
+        self._adam = None          # (gm, gv, dm, dv) flat moment buffers
+        self._t_g = self._t_d = 0  # Adam step counts
+        self._step = 0
+        self._comm_stream = None
+
+    # -------------------------------------------------------------------------------------- optimizers
+    def setup_optimizers(self, gen_lr=1e-3, dsc_lr=1e-3):
+        """Fresh Adam state (the reference re-creates both optimizers on every train() call, trainer.py:169-172)."""
+        self.gen_lr, self.dsc_lr = gen_lr, dsc_lr
+        g, d = self.generator.flat, self.discriminator.flat
+        self._adam = (torch.zeros_like(g), torch.zeros_like(g), torch.zeros_like(d), torch.zeros_like(d))
+        self._t_g = self._t_d = 0
+
+    # -------------------------------------------------------------------------------------- one G+D step
+    def batch(self, x, y, train=False):
+        G, D = self.generator, self.discriminator
+        dev = G.flat.device
+        if dev.type != 'cuda':
+            raise RuntimeError("patchgan_amd.Trainer needs the networks on a HIP device (generator.to('cuda')); "
+                               "there is no CPU path")
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x), dtype=torch.float)
+            y = torch.as_tensor(np.asarray(y), dtype=torch.float)
+        x = x.to(dev, dtype=torch.float32, non_blocking=True)
+        y = y.to(dev, dtype=torch.float32, non_blocking=True)
+        ge, de = G.engine, D.engine
+        N, Cin, H, W = x.shape
+        Cout = y.shape[1]
+        if Cin != ge.input_nc or Cout != ge.output_nc or Cin + Cout != de.input_nc:
+            raise RuntimeError(f"channel mismatch: x {Cin}, y {Cout} vs generator ({ge.input_nc}->{ge.output_nc}), "
+                               f"discriminator input {de.input_nc}")
+        if train and self._adam is None:
+            self.setup_optimizers(self.gen_lr, self.dsc_lr)
+        dist = _Dist()
+        Bglobal = N * dist.world
+        Cd = Cin + Cout
+        self._step += 1
+
+        # discriminator input buffer: samples [0,N) real = x|y, [N,2N) fake = x|G(x)   (trainer.py:65,96,98)
+        din = E.View.alloc(2 * N, H, W, Cd, dev)
+        real, fake = din.samples(0, N), din.samples(N, N)
+        real.channels(0, Cin).from_nchw(x)
+        fake.channels(0, Cin).from_nchw(x)
+        real.channels(Cin, Cout).from_nchw(y)
+        xin, yv, gen = fake.channels(0, Cin), real.channels(Cin, Cout), fake.channels(Cin, Cout)
+
+        losses = torch.zeros(8, dtype=torch.float32, device=dev)   # seg, gdisc, real*0.5, fake*0.5
+        allred = (lambda t: dist.all_reduce(t)) if dist.on else None
+
+        # ---- generator step
+        seed = E._mix_seed(G._seed_base, self._step) if G.training else 0
+        gc = ge.forward(G.flat, xin, gen, G.training, seed)                                   # trainer.py:63
+        dc = de.forward(D.flat, fake)                                                         # trainer.py:66
+        gseg = E.View.alloc(N, H, W, Cout, dev) if train else None
+        E.loss_value_and_grad(gen, yv, 0.0, _LOSS_MODES[self.loss_type], float(self.seg_alpha), gseg, losses, 0,
+                              Bglobal, self.tversky_beta, self.tversky_gamma, allred)        # trainer.py:71-82
+        o = dc.out
+        gd = E.View.alloc(o.N, o.H, o.W, 1, dev) if train else None
+        E.loss_value_and_grad(o, None, 1.0, L.LOSS_BCE, 1.0, gd, losses, 1, Bglobal)          # trainer.py:84
+        if train:
+            gflat = G.ensure_grad_flat()
+            ddin = de.backward(D.flat, None, dc, gd, need_wgrad=False, need_dx=True)          # dL/d(x|gen)
+            ge.backward(G.flat, gflat, gc, gseg, ddin.channels(Cin, Cout))                    # trainer.py:88-89
+            self._reduce_and_step(dist, G.flat, gflat, self._adam[0], self._adam[1], 'g')     # trainer.py:90
+        del dc
+
+        # ---- discriminator step: real and (pre-update, detached) fake in one 2N batch        trainer.py:96-99
+        dc2 = de.forward(D.flat, din)
+        o2 = dc2.out
+        god = E.View.alloc(o2.N, o2.H, o2.W, 1, dev) if train else None
+        E.loss_value_and_grad(o2.samples(0, N), None, 1.0, L.LOSS_BCE, 0.5, god.samples(0, N) if train else None,
+                              losses, 2, Bglobal)                                             # loss_real
+        E.loss_value_and_grad(o2.samples(N, N), None, 0.0, L.LOSS_BCE, 0.5, god.samples(N, N) if train else None,
+                              losses, 3, Bglobal)                                             # loss_fake
+        if train:
+            dflat = D.ensure_grad_flat()
+            de.backward(D.flat, dflat, dc2, god, need_wgrad=True, need_dx=False)              # trainer.py:106
+            self._reduce_and_step(dist, D.flat, dflat, self._adam[2], self._adam[3], 'd')     # trainer.py:107
+
+        if dist.on:
+            # seg loss: tversky is already global; the BCE/MAE terms are per-rank partial means
+            part = losses.clone()
+            if self.loss_type == 'tversky':
+                part[0] = part[0] / dist.world
+            dist.all_reduce(part)
+            losses = part
+        self._last_gen = gen
+        v = losses.cpu().numpy()                                                              # the step's one sync
+        seg, gdisc = np.float32(v[0]), np.float32(v[1])
+        loss_real, loss_fake = np.float32(v[2]) * np.float32(2), np.float32(v[3]) * np.float32(2)
+        gen_loss = seg + gdisc
+        disc_loss = (loss_fake + loss_real) / np.float32(2)
+        keys = ['gen', 'gen_loss', 'gdisc', 'discr', 'discf', 'disc']
+        vals = [float(gen_loss), float(gen_loss), float(gdisc), float(loss_real), float(loss_fake), float(disc_loss)]
+        return dict(zip(keys, vals))
+
+    def _reduce_and_step(self, dist, flat, gflat, m, v, which):
+        if dist.on:
+            dist.all_reduce(gflat)
+        if which == 'g':
+            self._t_g += 1
+            E.adam_step(flat, gflat, m, v, self._t_g, self.gen_lr)
+        else:
+            self._t_d += 1
+            E.adam_step(flat, gflat, m, v, self._t_d, self.dsc_lr)
+
+    # -------------------------------------------------------------------------------------- epoch driver
+    def train(self, train_data, val_data, epochs, dsc_learning_rate=1.e-3, gen_learning_rate=1.e-3, save_freq=10,
+              lr_decay=None, decay_freq=5, reduce_on_plateau=False):
+        """Reference trainer.py:117-279: Adam(lr, betas=(0.9, 0.999)) for G and D, optional exponential LR decay every
+        `decay_freq` epochs (resumed as lr*decay^((start-1)/decay_freq)), per-epoch train + validation loops, checkpoint
+        every `save_freq` epochs.  Returns (G_loss_ep, D_loss_ep): per-epoch means of the training losses."""
+        if (lr_decay is not None) and not reduce_on_plateau:
+            gen_lr = gen_learning_rate * (lr_decay) ** ((self.start - 1) / (decay_freq))
+            dsc_lr = dsc_learning_rate * (lr_decay) ** ((self.start - 1) / (decay_freq))
+        else:
+            gen_lr, dsc_lr = gen_learning_rate, dsc_learning_rate
+
+        if self.neptune_config is not None:
+            self.neptune_config['model/parameters/gen_learning_rate'] = gen_lr
+            self.neptune_config['model/parameters/dsc_learning_rate'] = dsc_lr
+            self.neptune_config['model/parameters/start'] = self.start
+            self.neptune_config['model/parameters/n_epochs'] = epochs
+
+        self.setup_optimizers(gen_lr, dsc_lr)
+        plateau = None
+        if reduce_on_plateau:
+            plateau = [_Plateau(gen_lr), _Plateau(dsc_lr)]
+            if self.neptune_config is not None:
+                self.neptune_config['model/parameters/scheduler'] = 'ReduceLROnPlateau'
+        elif lr_decay is not None and self.neptune_config is not None:
+            self.neptune_config['model/parameters/scheduler'] = 'ExponentialLR'
+            self.neptune_config['model/parameters/decay_freq'] = decay_freq
+            self.neptune_config['model/parameters/lr_decay'] = lr_decay
+
+        rank0 = _Dist().rank == 0
+        D_loss_ep, G_loss_ep = [], []
+        for epoch in range(self.start, epochs + 1):
+            if rank0:
+                print(f"Epoch {epoch} -- lr: {self.gen_lr:5.3e}, {self.dsc_lr:5.3e}")
+                print("-------------------------------------------------------")
+            pbar = tqdm.tqdm(train_data, desc='Training: ', dynamic_ncols=True, disable=not rank0)
+            if hasattr(train_data, 'shuffle'):
+                train_data.shuffle()
+            self.generator.train()
+            self.discriminator.train()
+            losses = defaultdict(list)
+            loss_mean = {}
+            for i, (input_img, target_mask) in enumerate(pbar):
+                batch_loss = self.batch(input_img, target_mask, train=True)
+                for key, value in batch_loss.items():
+                    losses[key].append(value)
+                    loss_mean[key] = np.mean(losses[key], axis=0)
+                pbar.set_postfix_str(" ".join([f"{key}: {value:.2e}" for key, value in loss_mean.items()]))
+            D_loss_ep.append(loss_mean['disc'])
+            G_loss_ep.append(loss_mean['gen'])
+            if self.neptune_config is not None:
+                self.neptune_config['train/gen_loss'].append(loss_mean['gen'])
+                self.neptune_config['train/disc_loss'].append(loss_mean['disc'])
+
+            self.discriminator.eval()
+            self.generator.eval()
+            pbar = tqdm.tqdm(val_data, desc='Validation: ', disable=not rank0)
+            if hasattr(val_data, 'shuffle'):
+                val_data.shuffle()
+            losses = defaultdict(list)
+            for i, (input_img, target_mask) in enumerate(pbar):
+                batch_loss = self.batch(input_img, target_mask, train=False)
+                for key, value in batch_loss.items():
+                    losses[key].append(value)
+                    loss_mean[key] = np.mean(losses[key], axis=0)
+                pbar.set_postfix_str(" ".join([f"{key}: {value:.2e}" for key, value in loss_mean.items()]))
+            if self.neptune_config is not None:
+                self.neptune_config['eval/gen_loss'].append(loss_mean['gen'])
+                self.neptune_config['eval/disc_loss'].append(loss_mean['disc'])
+
+            if plateau is not None:
+                self.gen_lr = plateau[0].step(loss_mean['gen'])
+                self.dsc_lr = plateau[1].step(loss_mean['disc'])
+            elif lr_decay is not None and epoch % decay_freq == 0:
+                self.gen_lr *= lr_decay        # ExponentialLR.step() (trainer.py:266-270)
+                self.dsc_lr *= lr_decay
+
+            if epoch % save_freq == 0:
+                self.save(epoch)
+        return G_loss_ep, D_loss_ep
+
+    # -------------------------------------------------------------------------------------- checkpoints
+    def save(self, epoch):
+        """generator_ep_%03d.pth / discriminator_ep_%03d.pth holding torch-layout state_dicts (trainer.py:281-287)."""
+        if _Dist().rank != 0:
+            return
+        gen_savefile = f'{self.savefolder}/generator_ep_{epoch:03d}.pth'
+        disc_savefile = f'{self.savefolder}/discriminator_ep_{epoch:03d}.pth'
+        print(f"Saving to {gen_savefile} and {disc_savefile}")
+        torch.save(self.generator.state_dict_contiguous(), gen_savefile)
+        torch.save(self.discriminator.state_dict_contiguous(), disc_savefile)
+
+    def load_last_checkpoint(self):
+        gen_ck = sorted(glob.glob(self.savefolder + "generator_ep*.pth"))
+        dsc_ck = sorted(glob.glob(self.savefolder + "discriminator_ep*.pth"))
+        gen_epochs = set(int(os.path.basename(c).replace('generator_ep_', '')[:-4]) for c in gen_ck)
+        dsc_epochs = set(int(os.path.basename(c).replace('discriminator_ep_', '')[:-4]) for c in dsc_ck)
+        try:
+            assert len(gen_epochs) > 0, "No checkpoints found!"
+            start = max(gen_epochs.union(dsc_epochs))
+            self.load(f"{self.savefolder}/generator_ep_{start:03d}.pth", f"{self.savefolder}/discriminator_ep_{start:03d}.pth")
+            self.start = start + 1
+        except Exception as e:
+            print(e)
+            print("Checkpoints not loaded")
+
+    def load(self, generator_save, discriminator_save):
+        print(generator_save, discriminator_save)
+        dev = self.generator.flat.device
+        self.generator.load_state_dict(torch.load(generator_save, map_location=dev))
+        self.discriminator.load_state_dict(torch.load(discriminator_save, map_location=dev))
+        print(f"Loaded checkpoints from {os.path.basename(generator_save)} and {os.path.basename(discriminator_save)}")
+
+
+class _Plateau:
+    """torch ReduceLROnPlateau defaults (mode min, factor 0.1, patience 10, rel threshold 1e-4) on a scalar LR."""
+
+    def __init__(self, lr):
+        self.lr, self.best, self.bad = lr, float('inf'), 0
+
+    def step(self, metric):
+        if metric < self.best * (1 - 1e-4):
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+        if self.bad > 10:
+            self.lr, self.bad = max(self.lr * 0.1, 0.0), 0
+        return self.lr

@@ -1,0 +1,274 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against the CPU oracle.  Needs an MI355X."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import patchgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# (N, Hb, Wb, Ca, Cb, stride)
+GEOMS = [
+    (2, 16, 16, 8, 4, 2),
+    (2, 16, 16, 64, 32, 2),
+    (1, 8, 8, 160, 96, 2),      # multi-tile N, K not tile multiple
+    (3, 12, 20, 36, 20, 2),     # ragged M/N, non-square
+    (2, 9, 9, 8, 8, 1),         # stride 1
+    (2, 11, 7, 1, 24, 1),       # Ca = 1 (the D head)
+    (2, 16, 16, 16, 3, 2),      # Cb = 3 (RGB input): scalar-K path
+    (2, 16, 16, 12, 1, 2),      # Cb = 1 (mask output)
+    (1, 15, 13, 8, 8, 2),       # odd big extent
+    (2, 4, 4, 512, 64, 2),      # small M, long K: split-K
+    (4, 64, 64, 32, 16, 2),     # many rows
+]
+ACTS = {'none': 0, 'leakyrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
+
+
+def _mk(N, Hb, Wb, Ca, Cb, s, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    Hs, Ws = (Hb - 2) // s + 1, (Wb - 2) // s + 1
+    big = torch.randn(N, Cb, Hb, Wb, generator=g)
+    small = torch.randn(N, Ca, Hs, Ws, generator=g)
+    Wt = torch.randn(Ca, Cb, 4, 4, generator=g) / math.sqrt(Cb * 16)
+    return big, small, Wt, Hs, Ws
+
+
+@pytest.mark.parametrize('algo', [1, 2], ids=['direct', 'mfma'])
+@pytest.mark.parametrize('geom', GEOMS, ids=lambda g: 'x'.join(map(str, g)))
+def test_big2small(geom, algo):
+    from patchgan_amd import engine as E
+    from tests.gpu_util import to_view, empty_view, pack, rel_err
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, _, Wt, Hs, Ws = _mk(*geom)
+    bias = torch.randn(Ca)
+    op = E.ConvOp(N, Hb, Wb, Ca, Cb, s, algo)
+    for act, ld_extra in (('none', 0), ('tanh', 4)):
+        vb = to_view(big, ld=Cb + ld_extra, off=0)
+        vs = empty_view(N, Hs, Ws, Ca, ld=Ca + ld_extra, off=ld_extra // 2)
+        P = pack(Wt)
+        op.big2small(vb, P, 0, bias.cuda(), 0, vs, ACTS[act])
+        want = O.apply_act(F.conv2d(big, Wt, bias, stride=s, padding=1), act)
+        got = vs.to_nchw()
+        torch.cuda.synchronize()
+        assert rel_err(got, want) < 2e-5, (geom, act)
+
+
+@pytest.mark.parametrize('algo', [1, 2], ids=['direct', 'mfma'])
+@pytest.mark.parametrize('geom', GEOMS, ids=lambda g: 'x'.join(map(str, g)))
+def test_small2big(geom, algo):
+    from patchgan_amd import engine as E
+    from tests.gpu_util import to_view, empty_view, pack, rel_err
+    N, Hb, Wb, Ca, Cb, s = geom
+    _, small, Wt, Hs, Ws = _mk(*geom)
+    bias = torch.randn(Cb)
+    op = E.ConvOp(N, Hb, Wb, Ca, Cb, s, algo)
+    for act, ld_extra in (('none', 0), ('sigmoid', 4)):
+        vs = to_view(small, ld=Ca + ld_extra)
+        vb = empty_view(N, Hb, Wb, Cb, ld=Cb + ld_extra, off=ld_extra // 4)
+        op.small2big(vs, pack(Wt), 0, bias.cuda(), 0, vb, ACTS[act])
+        opad = (Hb - ((Hs - 1) * s + 2), Wb - ((Ws - 1) * s + 2))
+        want = F.conv_transpose2d(small, Wt, bias, stride=s, padding=1, output_padding=opad)
+        assert want.shape[2:] == (Hb, Wb)
+        want = O.apply_act(want, act)
+        got = vb.to_nchw()
+        torch.cuda.synchronize()
+        assert rel_err(got, want) < 2e-5, (geom, act)
+
+
+@pytest.mark.parametrize('algo', [1, 2], ids=['direct', 'mfma'])
+@pytest.mark.parametrize('geom', GEOMS, ids=lambda g: 'x'.join(map(str, g)))
+def test_wgrad(geom, algo):
+    from patchgan_amd import engine as E
+    from tests.gpu_util import to_view, unpack, rel_err, DEV
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    op = E.ConvOp(N, Hb, Wb, Ca, Cb, s, algo)
+    Wr = Wt.clone().requires_grad_(True)
+    br = torch.zeros(Ca, requires_grad=True)
+    F.conv2d(big, Wr, br, stride=s, padding=1).backward(small)
+    dP = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+    db = torch.full((Ca + 4,), float('nan'), device=DEV)
+    op.wgrad(to_view(small, ld=Ca + 4, off=4), to_view(big, ld=Cb + 8, off=4), dP, 0, db, 0)
+    torch.cuda.synchronize()
+    assert rel_err(unpack(dP, Ca, Cb), Wr.grad) < 3e-5, geom
+    assert rel_err(db[:Ca], br.grad) < 3e-5, geom
+
+
+def test_mfma_matches_direct_bitwise_shapes():
+    """The two algorithms must agree closely on a cfg2-like layer (enc2 at reduced batch)."""
+    from patchgan_amd import engine as E
+    from tests.gpu_util import to_view, empty_view, pack, rel_err
+    geom = (2, 64, 64, 256, 128, 2)
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    outs = []
+    for algo in (1, 2):
+        op = E.ConvOp(*geom, algo)
+        vs = empty_view(2, Hs, Ws, 256)
+        op.big2small(to_view(big), pack(Wt), 0, None, 0, vs)
+        outs.append(vs.to_nchw())
+    torch.cuda.synchronize()
+    assert rel_err(outs[1], outs[0]) < 1e-5
+    want = F.conv2d(big, Wt, None, stride=2, padding=1)
+    assert rel_err(outs[1], want) < 1e-5
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 4, 4), (2, 64, 16, 16), (3, 6, 5, 7), (2, 512, 2, 2), (1, 4, 64, 64)])
+@pytest.mark.parametrize('act', ['leakyrelu', 'relu', 'tanh', 'none'])
+def test_instnorm_fwd_bwd(shape, act):
+    from patchgan_amd import engine as E
+    from tests.gpu_util import to_view, empty_view, rel_err, DEV
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(1)
+    y = (torch.randn(shape, generator=g) * 2 + 0.5).requires_grad_(True)
+    g1 = torch.randn(shape, generator=g)
+    g2 = torch.randn(shape, generator=g)
+    out = O.apply_act(O.instance_norm(y), act)
+    out.backward(g1 + g2)
+    vy = to_view(y.detach(), ld=C + 4)
+    vo = empty_view(N, H, W, C, ld=C + 8, off=4)
+    stats = torch.empty(N * C * 2, device=DEV)
+    E.instnorm_act_fwd(vy, vo, stats, E.L.ACT_CODES[act])
+    assert rel_err(vo.to_nchw(), out.detach()) < 1e-5
+    vdy = empty_view(N, H, W, C)
+    E.instnorm_act_bwd(to_view(g1), to_view(g2, ld=C + 4), vy, stats, vdy, E.L.ACT_CODES[act])
+    torch.cuda.synchronize()
+    assert rel_err(vdy.to_nchw(), y.grad) < 5e-5
+
+
+def test_instnorm_rejects_single_pixel():
+    from patchgan_amd import engine as E
+    from tests.gpu_util import to_view, empty_view, DEV
+    y = torch.randn(2, 8, 1, 1)
+    with pytest.raises(ValueError):
+        E.instnorm_act_fwd(to_view(y), empty_view(2, 1, 1, 8), torch.empty(32, device=DEV), 0)
+
+
+def test_dropout_forward_backward_with_mask():
+    from patchgan_amd import engine as E
+    from patchgan_amd import _lib as L
+    from tests.gpu_util import to_view, empty_view, rel_err, DEV
+    shape = (2, 16, 8, 8)
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(2)
+    y = torch.randn(shape, generator=g).requires_grad_(True)
+    g1 = torch.randn(shape, generator=g)
+    seed = 0xABCDEF12345
+    mask = torch.empty(N * H * W * C, device=DEV)
+    L.check(L.load().pg_dropout_mask(mask.data_ptr(), mask.numel(), 0.2, seed, torch.cuda.current_stream().cuda_stream), 'mask')
+    m_nchw = mask.view(N, H, W, C).permute(0, 3, 1, 2).cpu()
+    keep = m_nchw.mean().item()
+    assert 0.7 < keep < 0.9
+    out = O.apply_act(O.instance_norm(y), 'leakyrelu') * m_nchw / 0.8
+    out.backward(g1)
+    vy = to_view(y.detach())
+    vo = empty_view(N, H, W, C)
+    stats = torch.empty(N * C * 2, device=DEV)
+    E.instnorm_act_fwd(vy, vo, stats, 1, 0.2, seed)
+    assert rel_err(vo.to_nchw(), out.detach()) < 1e-5
+    vdy = empty_view(N, H, W, C)
+    E.instnorm_act_bwd(to_view(g1), None, vy, stats, vdy, 1, 0.2, seed)
+    torch.cuda.synchronize()
+    assert rel_err(vdy.to_nchw(), y.grad) < 5e-5
+
+
+@pytest.mark.parametrize('act', ['leakyrelu', 'relu', 'tanh', 'sigmoid', 'none'])
+@pytest.mark.parametrize('C', [1, 3, 8])
+def test_act_bwd(act, C):
+    from patchgan_amd import engine as E
+    from tests.gpu_util import to_view, empty_view, rel_err
+    g = torch.Generator().manual_seed(3)
+    y = torch.randn(2, C, 6, 5, generator=g).requires_grad_(True)
+    g1 = torch.randn(2, C, 6, 5, generator=g)
+    a = O.apply_act(y, act)
+    a.backward(g1)
+    vdy = empty_view(2, 6, 5, C)
+    E.act_bwd(to_view(g1, ld=C + 3, off=1), None, to_view(a.detach()), vdy, E.L.ACT_CODES[act])
+    torch.cuda.synchronize()
+    assert rel_err(vdy.to_nchw(), y.grad) < 1e-5
+
+
+@pytest.mark.parametrize('C', [2, 4, 7])
+def test_softmax(C):
+    from patchgan_amd import engine as E
+    from tests.gpu_util import to_view, empty_view, rel_err
+    g = torch.Generator().manual_seed(4)
+    y = (torch.randn(2, C, 9, 4, generator=g) * 3).requires_grad_(True)
+    g1 = torch.randn(2, C, 9, 4, generator=g)
+    out = torch.softmax(y, dim=1)
+    out.backward(g1)
+    vo = empty_view(2, 9, 4, C, ld=C + 1)
+    E.softmax_fwd(to_view(y.detach()), vo)
+    assert rel_err(vo.to_nchw(), out.detach()) < 1e-6
+    vdy = empty_view(2, 9, 4, C)
+    E.softmax_bwd(to_view(g1), None, vo, vdy)
+    torch.cuda.synchronize()
+    assert rel_err(vdy.to_nchw(), y.grad) < 1e-5
+
+
+@pytest.mark.parametrize('loss_type,C', [('tversky', 1), ('tversky', 4), ('weighted_bce', 1), ('weighted_bce', 3), ('MAE', 2)])
+def test_seg_losses(loss_type, C):
+    from patchgan_amd import engine as E
+    from patchgan_amd.trainer import _LOSS_MODES
+    from tests.gpu_util import to_view, empty_view, rel_err, DEV
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 3, 32, 24
+    p = torch.rand(N, C, H, W, generator=g).clamp(1e-4, 1 - 1e-4).requires_grad_(True)
+    y = (torch.rand(N, C, H, W, generator=g) > 0.7).float()
+    want = O.seg_loss(loss_type, p, y, 200)
+    want.backward()
+    out = torch.zeros(4, device=DEV)
+    vg = empty_view(N, H, W, C)
+    E.loss_value_and_grad(to_view(p.detach(), ld=C + 2), to_view(y), 0.0, _LOSS_MODES[loss_type], 200.0, vg, out, 1, N)
+    torch.cuda.synchronize()
+    assert abs(out[1].item() - want.item()) <= 2e-6 * abs(want.item())
+    assert rel_err(vg.to_nchw(), p.grad) < 2e-5
+
+
+@pytest.mark.parametrize('target', [0.0, 1.0])
+def test_bce_const_target(target):
+    from patchgan_amd import engine as E
+    from patchgan_amd import _lib as L
+    from tests.gpu_util import to_view, empty_view, rel_err, DEV
+    g = torch.Generator().manual_seed(6)
+    p = torch.rand(4, 1, 30, 30, generator=g)
+    p[0, 0, 0, 0] = 0.0   # log clamp at -100
+    p[1, 0, 0, 0] = 1.0
+    p = p.requires_grad_(True)
+    want = O.bce(p, torch.full_like(p, target)) * 0.5
+    want.backward()
+    out = torch.zeros(4, device=DEV)
+    vg = empty_view(4, 30, 30, 1)
+    E.loss_value_and_grad(to_view(p.detach()), None, target, L.LOSS_BCE, 0.5, vg, out, 0, 4)
+    torch.cuda.synchronize()
+    assert abs(out[0].item() - want.item()) <= 2e-6 * abs(want.item())
+    assert rel_err(vg.to_nchw(), p.grad) < 2e-5
+
+
+def test_adam_matches_torch():
+    from patchgan_amd import engine as E
+    from tests.gpu_util import DEV
+    g = torch.Generator().manual_seed(7)
+    n = 4099
+    p0 = torch.randn(n, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.9, 0.999))
+    p = torch.zeros(n + 1, device=DEV)[:n]
+    p.copy_(p0)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for t in range(1, 6):
+        grad = torch.randn(n, generator=g) * (10.0 ** (t - 3))
+        ref.grad = grad.clone()
+        opt.step()
+        E.adam_step(p, grad.to(DEV), m, v, t, 1e-3)
+    torch.cuda.synchronize()
+    assert (p.cpu() - ref.detach()).abs().max().item() < 1e-6
+
+
+def test_layout_roundtrip():
+    from tests.gpu_util import to_view
+    x = torch.randn(2, 5, 7, 3)
+    v = to_view(x, ld=9, off=2)
+    torch.cuda.synchronize()
+    assert torch.equal(v.to_nchw().cpu(), x)
