@@ -66,6 +66,12 @@ int pg_version(void);
  * split-K factor for geometry g.  A smaller (or NULL) workspace is legal: the split shrinks. */
 size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);
 
+/* Reports which kernel the MFMA path of op would launch for g with a workspace of ws_bytes: tile_id
+ * (0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 64x128, 4 = 64x64 output tile per workgroup; the kernel symbol is
+ * k_big2small / k_small2big / k_wgrad <MR,NR,WM,WN> with <2,2,2,2>, <2,1,2,2>, <1,1,4,1>, <1,2,2,2>, <1,1,2,2>), the
+ * split-K factor and the number of workgroups.  For profiling / roofline accounting only. */
+int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups);
+
 /* small[n,p,q,a] = act( sum_{kh,kw,b} big[n, s*p-1+kh, s*q-1+kw, b] * P[kh*4+kw][a][b] + bias[a] )
  * Replaces: nn.Conv2d forward (unet.py:19; disc.py:19,27,37,45) with (a,b) = (Cout,Cin), and the
  * data-gradient of nn.ConvTranspose2d (unet.py:53, aten::convolution_backward) with (a,b) = (Cin,Cout).

@@ -255,9 +255,11 @@ class OracleTrainer:
 
     def __init__(self, gw, dw, activation='tanh', final_act='sigmoid', n_layers=3, norm=False,
                  loss_type='tversky', seg_alpha=200, gen_lr=1e-3, dsc_lr=1e-3,
-                 tversky_beta=0.75, tversky_gamma=0.75):
-        self.gw = {k: v.detach().clone().float().requires_grad_(True) for k, v in gw.items()}
-        self.dw = {k: v.detach().clone().float().requires_grad_(True) for k, v in dw.items()}
+                 tversky_beta=0.75, tversky_gamma=0.75, dtype=torch.float32):
+        # dtype=torch.float64 runs the same algorithm in double: the yardstick for fp32 rounding noise
+        self.dtype = dtype
+        self.gw = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in gw.items()}
+        self.dw = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in dw.items()}
         self.activation, self.final_act = activation, final_act
         self.n_layers, self.norm = n_layers, norm
         self.loss_type, self.seg_alpha = loss_type, seg_alpha
@@ -278,8 +280,8 @@ class OracleTrainer:
         return disc_forward(self.dw, x, self.n_layers, self.norm, probes=probes)
 
     def batch(self, x, y, train=False, dropout_masks=None):
-        x = x.float()
-        y = y.float()
+        x = x.to(self.dtype)
+        y = y.to(self.dtype)
         gen_img = self.G(x, dropout_masks)                                      # trainer.py:63
         disc_fake = self.D(torch.cat((x, gen_img), 1))                          # trainer.py:65-66
         ones = torch.ones_like(disc_fake)

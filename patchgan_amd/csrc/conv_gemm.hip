@@ -772,6 +772,17 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
     return (bytes + 255) & ~(size_t)255;
 }
 
+int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups) {
+    if (!geom_ok(g) || op < 0 || op > 2) return PG_EINVAL;
+    Plan p = (op == 0) ? plan_b2s(g) : (op == 1) ? plan_s2b(g) : plan_wgrad(g);
+    size_t reserved = (op == 2) ? (((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255) : 0;
+    clamp_split(p, ws_bytes, reserved);
+    if (tile_id) *tile_id = p.t.id;
+    if (split) *split = p.split;
+    if (workgroups) *workgroups = (long)p.tiles_m * p.tiles_n * p.ncls * p.split;
+    return PG_OK;
+}
+
 int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const float* bias, float* small,
                          int ld_small, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
                          void* stream) {

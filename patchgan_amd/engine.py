@@ -91,6 +91,40 @@ def _workspace(nbytes, device):
     return ws
 
 
+class LaunchProfiler:
+    """Optional per-launch timing of the conv kernels with HIP events on the launch stream (bench.py's roofline
+    leg).  Enabled by assigning an instance to ``engine.PROFILER``; costs two event records per launch."""
+    TILE_NAMES = {0: '<2,2,2,2>', 1: '<2,1,2,2>', 2: '<1,1,4,1>', 3: '<1,2,2,2>', 4: '<1,1,2,2>'}
+    OP_NAMES = {0: 'k_big2small', 1: 'k_small2big', 2: 'k_wgrad'}
+
+    def __init__(self):
+        self.records = []   # (symbol, split, flops, start_event, end_event)
+
+    def launch(self, op, opcode, fn):
+        if op.algo == L.ALGO_DIRECT:
+            return fn()
+        sym, split = op.describe(opcode)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.records.append((sym, split, op.flops, e0, e1))
+
+    def summary(self):
+        """{(symbol, split): dict(launches, ms_total, flops_total)} -- call after a device synchronize."""
+        out = {}
+        for sym, split, flops, e0, e1 in self.records:
+            d = out.setdefault((sym, split), dict(launches=0, ms=0.0, flops=0.0))
+            d['launches'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+            d['flops'] += flops
+        return out
+
+
+PROFILER = None
+
+
 class ConvOp:
     """One 4x4 / padding-1 convolution layer bound to its geometry: the three kernels that touch its weights."""
 
@@ -104,34 +138,59 @@ class ConvOp:
         self.algo = algo
         lib = L.load()
         self.ws_bytes = max(int(lib.pg_conv_workspace_bytes(ctypes.byref(self.g), op)) for op in (0, 1, 2))
+        self._desc = {}
 
     def _ws(self, device):
         ws = _workspace(self.ws_bytes, device)
         return ws.data_ptr(), ws.numel()
 
+    @property
+    def flops(self):
+        """Algorithmic FLOPs of any of the three kernels on this geometry: 2 * N*Hs*Ws * 16 * Ca * Cb."""
+        return 2.0 * self.N * self.Hs * self.Ws * 16 * self.Ca * self.Cb
+
+    def describe(self, opcode):
+        if opcode not in self._desc:
+            t, s, w = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_long(0)
+            L.check(L.load().pg_conv_describe(ctypes.byref(self.g), opcode, max(self.ws_bytes, 1 << 20), ctypes.byref(t),
+                                              ctypes.byref(s), ctypes.byref(w)), 'pg_conv_describe')
+            self._desc[opcode] = (LaunchProfiler.OP_NAMES[opcode] + LaunchProfiler.TILE_NAMES[t.value], s.value)
+        return self._desc[opcode]
+
     def big2small(self, big, P, p_off, bias, b_off, small, act=L.ACT_NONE):
         assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         wp, wn = self._ws(P.device)
-        L.check(L.load().pg_conv4x4_big2small(big.ptr(), big.ld, L.ptr(P, p_off), L.ptr(bias, b_off) if bias is not None else None,
-                                              small.ptr(), small.ld, ctypes.byref(self.g), act, self.algo, wp, wn,
-                                              _stream()), 'pg_conv4x4_big2small')
+
+        def go():
+            L.check(L.load().pg_conv4x4_big2small(big.ptr(), big.ld, L.ptr(P, p_off),
+                                                  L.ptr(bias, b_off) if bias is not None else None, small.ptr(), small.ld,
+                                                  ctypes.byref(self.g), act, self.algo, wp, wn, _stream()),
+                    'pg_conv4x4_big2small')
+        PROFILER.launch(self, 0, go) if PROFILER is not None else go()
 
     def small2big(self, small, P, p_off, bias, b_off, big, act=L.ACT_NONE):
         assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         wp, wn = self._ws(P.device)
-        L.check(L.load().pg_conv4x4_small2big(small.ptr(), small.ld, L.ptr(P, p_off), L.ptr(bias, b_off) if bias is not None else None,
-                                              big.ptr(), big.ld, ctypes.byref(self.g), act, self.algo, wp, wn,
-                                              _stream()), 'pg_conv4x4_small2big')
+
+        def go():
+            L.check(L.load().pg_conv4x4_small2big(small.ptr(), small.ld, L.ptr(P, p_off),
+                                                  L.ptr(bias, b_off) if bias is not None else None, big.ptr(), big.ld,
+                                                  ctypes.byref(self.g), act, self.algo, wp, wn, _stream()),
+                    'pg_conv4x4_small2big')
+        PROFILER.launch(self, 1, go) if PROFILER is not None else go()
 
     def wgrad(self, small, big, dP, p_off, dbias=None, b_off=0):
         assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         wp, wn = self._ws(dP.device)
-        L.check(L.load().pg_conv4x4_wgrad(small.ptr(), small.ld, big.ptr(), big.ld, L.ptr(dP, p_off),
-                                          L.ptr(dbias, b_off) if dbias is not None else None, ctypes.byref(self.g),
-                                          self.algo, wp, wn, _stream()), 'pg_conv4x4_wgrad')
+
+        def go():
+            L.check(L.load().pg_conv4x4_wgrad(small.ptr(), small.ld, big.ptr(), big.ld, L.ptr(dP, p_off),
+                                              L.ptr(dbias, b_off) if dbias is not None else None, ctypes.byref(self.g),
+                                              self.algo, wp, wn, _stream()), 'pg_conv4x4_wgrad')
+        PROFILER.launch(self, 2, go) if PROFILER is not None else go()
 
 
 def instnorm_act_fwd(y, out, stats, act, drop_p=0.0, seed=0):
