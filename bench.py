@@ -38,11 +38,23 @@ def make_inputs(batch, rank):
     return x, y
 
 
+def usable_cpus():
+    """Host threads this process may really use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(max_seconds=25.0):
     """The CPU oracle's G+D step on the same cfg2 workload, all host cores available to this process."""
     import torch
     from oracle import patchgan_oracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = usable_cpus()
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
     gw = O.default_init(O.unet_weight_shapes(3, 1, 64))

@@ -23,6 +23,8 @@ import torch
 from . import _lib as L
 
 _MASK64 = (1 << 64) - 1
+# PATCHGAN_ALGO=direct forces the one-thread-per-output kernels everywhere (debugging aid); default = MFMA path
+DEFAULT_ALGO = {'direct': L.ALGO_DIRECT, 'mfma': L.ALGO_MFMA}.get(__import__('os').environ.get('PATCHGAN_ALGO', ''), L.ALGO_AUTO)
 
 
 def _stream():
@@ -332,13 +334,13 @@ class GenContext:
 
 
 class GeneratorEngine:
-    def __init__(self, input_nc, output_nc, nf, activation, final_act, use_dropout, algo=L.ALGO_AUTO):
+    def __init__(self, input_nc, output_nc, nf, activation, final_act, use_dropout, algo=None):
         self.input_nc, self.output_nc, self.nf = input_nc, output_nc, nf
         self.activation, self.final_act, self.use_dropout = activation, final_act, use_dropout
         self.enc, self.dec = unet_layers(input_nc, output_nc, nf, activation, final_act, use_dropout)
         self.layers = self.enc + self.dec
         self.nparams = assign_offsets(self.layers)
-        self.algo = algo
+        self.algo = DEFAULT_ALGO if algo is None else algo
         self._ops = {}
 
     def ops(self, N, H, W):
@@ -505,11 +507,11 @@ class DiscContext:
 
 
 class DiscriminatorEngine:
-    def __init__(self, input_nc, ndf, n_layers, norm, algo=L.ALGO_AUTO):
+    def __init__(self, input_nc, ndf, n_layers, norm, algo=None):
         self.input_nc, self.ndf, self.n_layers, self.norm = input_nc, ndf, n_layers, norm
         self.layers = disc_layers(input_nc, ndf, n_layers, norm)
         self.nparams = assign_offsets(self.layers)
-        self.algo = algo
+        self.algo = DEFAULT_ALGO if algo is None else algo
         self._ops = {}
 
     def ops(self, N, H, W):
