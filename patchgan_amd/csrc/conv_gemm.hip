@@ -79,10 +79,26 @@ __global__ __launch_bounds__(256) void k_big2small(const float* __restrict__ big
     }
 
     f32x4 ra[AI], rb[BI];
+    // (tap, b) of this thread's float4 advance by KC per chunk: no division in the K loop when Cb >= KC
+    int cur_tap = (c_begin * KC + kq * 4) / g.Cb;
+    int cur_b = (c_begin * KC + kq * 4) - cur_tap * g.Cb;
+    const bool inc_ok = g.Cb >= KC;
     auto load_chunk = [&](int c) {
         const int k = c * KC + kq * 4;
         if (veck) {
-            const int tap = k / g.Cb, b = k - tap * g.Cb;
+            int tap, b;
+            if (inc_ok) {
+                tap = cur_tap;
+                b = cur_b;
+                cur_b += KC;
+                if (cur_b >= g.Cb) {
+                    cur_b -= g.Cb;
+                    ++cur_tap;
+                }
+            } else {
+                tap = k / g.Cb;
+                b = k - tap * g.Cb;
+            }
             const int kh = tap >> 2, kw = tap & 3;
             const bool kok = k < K;
 #pragma unroll
@@ -195,8 +211,10 @@ __global__ __launch_bounds__(256) void k_big2small(const float* __restrict__ big
 
 // ------------------------------------------------------------------------------------------------
 // small2big: per output-parity class (stride 2: 4 classes of 2x2 taps; stride 1: 1 class of 4x4 taps):
-// rows = big pixels of the class, cols = b, K = (tloc, a) with a fastest.  A is K-contiguous (small),
-// B rows are N-contiguous (P[tap][a][:]).
+// rows = big pixels of the class, cols = b, K = (tloc, a) with a fastest.  A is K-contiguous (small).
+// P[tap][a][:] rows are N-contiguous in memory: each lane owns one column n and fetches 4 consecutive k with
+// scalar loads (a wave-load is 64 consecutive floats of one weight row), so the tile lands K-contiguous in
+// LDS and the MFMA loop is the same ds_read_b128 loop as big2small.
 // ------------------------------------------------------------------------------------------------
 template <int MR, int NR, int WM, int WN>
 __global__ __launch_bounds__(256) void k_small2big(const float* __restrict__ small, int ld_small,
@@ -205,11 +223,9 @@ __global__ __launch_bounds__(256) void k_small2big(const float* __restrict__ sma
                                                    const float* __restrict__ bias, int act) {
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
     constexpr int AI = BM / 32;
-    constexpr int LDB = BN + 4;
-    constexpr int BQ = BN / 4;          // float4 per B row
-    constexpr int BROWS = 256 / BQ;     // B rows per pass
-    constexpr int BI = KC / BROWS;      // passes
-    __shared__ __attribute__((aligned(16))) float smem[BM * LDK + KC * LDB];
+    constexpr int BG = 256 / BN;        // thread groups along k
+    constexpr int NQ = 8 / BG;          // k-quads per thread per chunk
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
     float* As = smem;
     float* Bs = smem + BM * LDK;
 
@@ -249,13 +265,39 @@ __global__ __launch_bounds__(256) void k_small2big(const float* __restrict__ sma
             a_jb[i] = 0;
         }
     }
-    const int bq = tid % BQ, brow0 = tid / BQ;
+    const int bn = tid % BN, bg = tid / BN;       // this thread's B column and k-group
+    const int ncol = n0 + bn;
+    const bool n_ok = ncol < g.Cb;
 
-    f32x4 ra[AI], rb[BI];
+    // incremental (tloc, a) for the A float4 and for each B quad (valid when Ca >= KC and Ca % 4 == 0)
+    const bool inc_ok = veck && g.Ca >= KC;
+    int a_tl = (c_begin * KC + kq * 4) / g.Ca;
+    int a_a = (c_begin * KC + kq * 4) - a_tl * g.Ca;
+    int b_tl[NQ], b_a[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int k = c_begin * KC + 4 * (bg + BG * i);
+        b_tl[i] = k / g.Ca;
+        b_a[i] = k - b_tl[i] * g.Ca;
+    }
+
+    f32x4 ra[AI], rb[NQ];
     auto load_chunk = [&](int c) {
         const int k = c * KC + kq * 4;
         if (veck) {
-            const int tl = k / g.Ca, a = k - tl * g.Ca;
+            int tl, a;
+            if (inc_ok) {
+                tl = a_tl;
+                a = a_a;
+                a_a += KC;
+                if (a_a >= g.Ca) {
+                    a_a -= g.Ca;
+                    ++a_tl;
+                }
+            } else {
+                tl = k / g.Ca;
+                a = k - tl * g.Ca;
+            }
             const int th = tl / T, tw = tl - th * T;
             const bool kok = k < K;
 #pragma unroll
@@ -283,22 +325,34 @@ __global__ __launch_bounds__(256) void k_small2big(const float* __restrict__ sma
             }
         }
 #pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int kr = c * KC + brow0 + BROWS * i;
-            const int tl = kr / g.Ca, a = kr - tl * g.Ca;
-            const int th = tl / T, tw = tl - th * T;
-            const int tap = (kh0 + g.s * th) * 4 + (kw0 + g.s * tw);
-            const int b = n0 + bq * 4;
-            const bool kok = kr < K;
-            const float* row = P + (long)(tap * g.Ca + a) * g.Cb;
-            if (vecn) {
-                bool ok = kok && b < g.Cb;
-                rb[i] = ld4(ok ? row + b : P, ok);
+        for (int i = 0; i < NQ; ++i) {
+            const int kb = c * KC + 4 * (bg + BG * i);
+            if (inc_ok) {
+                const int tl = b_tl[i], a = b_a[i];
+                b_a[i] += KC;
+                if (b_a[i] >= g.Ca) {
+                    b_a[i] -= g.Ca;
+                    ++b_tl[i];
+                }
+                const int th = tl / T, tw = tl - th * T;
+                const int tap = (kh0 + g.s * th) * 4 + (kw0 + g.s * tw);
+                const bool ok = n_ok && kb < K;
+                const float* col = ok ? P + (long)(tap * g.Ca + a) * g.Cb + ncol : P;
+                const long st = ok ? g.Cb : 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = col[e * st];
+                    rb[i][e] = ok ? v : 0.f;
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    bool ok = kok && (b + e) < g.Cb;
-                    float v = *(ok ? row + b + e : P);
+                    const int ke = kb + e;
+                    const int tl = ke / g.Ca, a = ke - tl * g.Ca;
+                    const int th = tl / T, tw = tl - th * T;
+                    const int tap = (kh0 + g.s * th) * 4 + (kw0 + g.s * tw);
+                    const bool ok = n_ok && ke < K;
+                    float v = *(ok ? P + (long)(tap * g.Ca + a) * g.Cb + ncol : P);
                     rb[i][e] = ok ? v : 0.f;
                 }
             }
@@ -308,7 +362,7 @@ __global__ __launch_bounds__(256) void k_small2big(const float* __restrict__ sma
 #pragma unroll
         for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow0 + BROWS * i) * LDB + bq * 4]) = rb[i];
+        for (int i = 0; i < NQ; ++i) *reinterpret_cast<f32x4*>(&Bs[bn * LDK + 4 * (bg + BG * i)]) = rb[i];
     };
 
     f32x16 acc[MR][NR];
@@ -329,15 +383,13 @@ __global__ __launch_bounds__(256) void k_small2big(const float* __restrict__ sma
         if (more) load_chunk(c + 1);
 #pragma unroll
         for (int kk = 0; kk < KC / 8; ++kk) {
-            f32x4 af[MR];
-            float bf[NR][4];
+            f32x4 af[MR], bf[NR];
 #pragma unroll
             for (int i = 0; i < MR; ++i)
                 af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MR + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
 #pragma unroll
             for (int j = 0; j < NR; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bf[j][e] = Bs[(kk * 8 + lh * 4 + e) * LDB + (wn * NR + j) * 32 + lrow];
+                bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NR + j) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -357,8 +409,16 @@ __global__ __launch_bounds__(256) void k_small2big(const float* __restrict__ sma
     const bool fin = (slab_stride == 0);
     float* o = out + (long)slice * slab_stride;
     const int ldo = fin ? ld_out : g.Cb;
+    float bv[NR];
 #pragma unroll
-    for (int i = 0; i < MR; ++i)
+    for (int j = 0; j < NR; ++j) {
+        const int col = n0 + (wn * NR + j) * 32 + lrow;
+        bv[j] = (fin && bias != nullptr && col < g.Cb) ? bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        // rows of this lane: base + {0..3} + 8*{0..3} + 4*lh ; decode the first, then step (the 16 rows of a lane
+        // are at most 28 apart, so a carry chain in (jj, ii, n) is cheaper than 16 divisions)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -374,12 +434,13 @@ __global__ __launch_bounds__(256) void k_small2big(const float* __restrict__ sma
                     const int col = n0 + (wn * NR + j) * 32 + lrow;
                     if (col < g.Cb) {
                         float v = acc[i][j][r];
-                        if (fin) v = pg_act(v + (bias ? bias[col] : 0.f), act);
+                        if (fin) v = pg_act(v + bv[j], act);
                         orow[col] = v;
                     }
                 }
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -413,6 +474,16 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ small, 
 
     const int aq = tid % AQ, arow0 = tid / AQ;
     const int bq = tid % BQ, brow0 = tid / BQ;
+    const bool inc_ok = g.Ws >= 16 && g.Hs >= 2;
+    int r_n[BI], r_p[BI], r_q[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int pix = c_begin * KC + brow0 + BROWS * i;
+        r_n[i] = pix / (g.Hs * g.Ws);
+        const int rem = pix - r_n[i] * (g.Hs * g.Ws);
+        r_p[i] = rem / g.Ws;
+        r_q[i] = rem - r_p[i] * g.Ws;
+    }
 
     f32x4 ra[AI], rb[BI];
     auto load_chunk = [&](int c) {
@@ -439,9 +510,26 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ small, 
             const int pix = c * KC + brow0 + BROWS * i;
             const int b = n0 + bq * 4;
             bool pok = pix < Kp;
-            int n = pix / (g.Hs * g.Ws);
-            int rem = pix - n * (g.Hs * g.Ws);
-            int p = rem / g.Ws, q = rem - p * g.Ws;
+            int n, p, q;
+            if (inc_ok) {   // carry chain instead of two divisions per row and chunk
+                n = r_n[i];
+                p = r_p[i];
+                q = r_q[i];
+                r_q[i] += KC;
+                while (r_q[i] >= g.Ws) {
+                    r_q[i] -= g.Ws;
+                    ++r_p[i];
+                }
+                while (r_p[i] >= g.Hs) {
+                    r_p[i] -= g.Hs;
+                    ++r_n[i];
+                }
+            } else {
+                n = pix / (g.Hs * g.Ws);
+                int rem = pix - n * (g.Hs * g.Ws);
+                p = rem / g.Ws;
+                q = rem - p * g.Ws;
+            }
             int h = g.s * p - 1 + kh, w = g.s * q - 1 + kw;
             pok = pok && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
             const float* row = big + (long)((n * g.Hb + h) * g.Wb + w) * ld_big;
@@ -517,6 +605,201 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ small, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// wgrad with the 16 taps folded into the GEMM N dimension, for layers with very few channels on one side
+// (the image-facing layers: enc0 / d0 have Cb = 3..10, dec6 has Cb = output_nc, the D head has Ca = 1).  The
+// per-tap kernel above would pad those channels to a 32-wide MFMA tile 16 times over; here N = 16*C is dense.
+//   MODE 1 (Cb <= 8): rows m = a, cols n = (tap, b), K = small pixels
+//        A[k][m] = small[pix][a]              B[k][n] = big[img, s*p-1+kh, s*q-1+kw][b]
+//   MODE 2 (Ca <= 8): rows m = b, cols n = (tap, a), K = big pixels
+//        A[k][m] = big[pix][b]                B[k][n] = small[img, (h+1-kh)/s, (w+1-kw)/s][a]
+// Output element (tap, a, b) -> slab[(tap*Ca + a)*Cb + b].  X = the row tensor, Y = the gathered tensor.
+// ------------------------------------------------------------------------------------------------
+template <int MR, int NR, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256) void k_wgrad_tapn(const float* __restrict__ X, int ld_x,
+                                                    const float* __restrict__ Y, int ld_y, float* __restrict__ out,
+                                                    long slab_stride, Geom g, int chunks_per_slice, int tilesN,
+                                                    int vecm) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int AQ = BM / 4, AROWS = 256 / AQ, AI = KC / AROWS;
+    constexpr int BQ = BN / 4, BROWS = 256 / BQ, BI = KC / BROWS;
+    __shared__ __attribute__((aligned(16))) float smem[KC * LDA + KC * LDB];
+    float* As = smem;
+    float* Bs = smem + KC * LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int tile_m = blockIdx.x / tilesN, tile_n = blockIdx.x % tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int Cx = (MODE == 1) ? g.Ca : g.Cb;            // channels of the row tensor  (GEMM M)
+    const int Cy = (MODE == 1) ? g.Cb : g.Ca;            // channels of the gathered tensor
+    const int Hx = (MODE == 1) ? g.Hs : g.Hb, Wx = (MODE == 1) ? g.Ws : g.Wb;
+    const int Ndim = 16 * Cy;
+    const int Kp = g.N * Hx * Wx;
+    const int nchunks = (Kp + KC - 1) / KC;
+    const int c_begin = blockIdx.z * chunks_per_slice;
+    const int c_end = min(nchunks, c_begin + chunks_per_slice);
+
+    const int aq = tid % AQ, arow0 = tid / AQ;
+    const int bq = tid % BQ, brow0 = tid / BQ;
+    // this thread's four gathered columns are fixed for the whole K loop
+    int e_kh[4], e_kw[4], e_c[4];
+    bool e_ok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n = n0 + bq * 4 + e;
+        const int tap = n / Cy;
+        e_ok[e] = n < Ndim;
+        e_c[e] = n - tap * Cy;
+        e_kh[e] = tap >> 2;
+        e_kw[e] = tap & 3;
+    }
+
+    const bool inc_ok = Wx >= 16 && Hx >= 2;
+    int r_n[BI], r_p[BI], r_q[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int pix = c_begin * KC + brow0 + BROWS * i;
+        r_n[i] = pix / (Hx * Wx);
+        const int rem = pix - r_n[i] * (Hx * Wx);
+        r_p[i] = rem / Wx;
+        r_q[i] = rem - r_p[i] * Wx;
+    }
+
+    f32x4 ra[AI], rb[BI];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int pix = c * KC + arow0 + AROWS * i;
+            const int m = m0 + aq * 4;
+            const bool pok = pix < Kp;
+            const float* row = X + (long)pix * ld_x;
+            if (vecm) {
+                bool ok = pok && m < Cx;
+                ra[i] = ld4(ok ? row + m : X, ok);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bool ok = pok && (m + e) < Cx;
+                    float v = *(ok ? row + m + e : X);
+                    ra[i][e] = ok ? v : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int pix = c * KC + brow0 + BROWS * i;
+            const bool pok = pix < Kp;
+            int img, r, cc;
+            if (inc_ok) {
+                img = r_n[i];
+                r = r_p[i];
+                cc = r_q[i];
+                r_q[i] += KC;
+                while (r_q[i] >= Wx) {
+                    r_q[i] -= Wx;
+                    ++r_p[i];
+                }
+                while (r_p[i] >= Hx) {
+                    r_p[i] -= Hx;
+                    ++r_n[i];
+                }
+            } else {
+                img = pix / (Hx * Wx);
+                const int rem = pix - img * (Hx * Wx);
+                r = rem / Wx;
+                cc = rem - r * Wx;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bool ok = pok && e_ok[e];
+                long off;
+                if (MODE == 1) {
+                    const int h = g.s * r - 1 + e_kh[e], w = g.s * cc - 1 + e_kw[e];
+                    ok = ok && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
+                    off = (long)((img * g.Hb + h) * g.Wb + w) * ld_y + e_c[e];
+                } else {
+                    const int hh = r + 1 - e_kh[e], ww = cc + 1 - e_kw[e];
+                    ok = ok && hh >= 0 && ww >= 0;
+                    int p = hh, q = ww;
+                    if (g.s == 2) {
+                        ok = ok && ((hh & 1) == 0) && ((ww & 1) == 0);
+                        p = hh >> 1;
+                        q = ww >> 1;
+                    }
+                    ok = ok && p < g.Hs && q < g.Ws;
+                    off = (long)((img * g.Hs + p) * g.Ws + q) * ld_y + e_c[e];
+                }
+                float v = *(ok ? Y + off : Y);
+                rb[i][e] = ok ? v : 0.f;
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(arow0 + AROWS * i) * LDA + aq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow0 + BROWS * i) * LDB + bq * 4]) = rb[i];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
+        if (more) load_chunk(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) {
+            float af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) af[i] = As[(kk * 2 + lh) * LDA + (wm * MR + i) * 32 + lrow];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) bf[j] = Bs[(kk * 2 + lh) * LDB + (wn * NR + j) * 32 + lrow];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    float* o = out + (long)blockIdx.z * slab_stride;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int n = n0 + (wn * NR + j) * 32 + lrow;
+        if (n >= Ndim) continue;
+        const int tap = n / Cy, cy = n - tap * Cy;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + (wm * MR + i) * 32 + row;
+                if (m < Cx) {
+                    const long idx = (MODE == 1) ? ((long)(tap * g.Ca + m) * g.Cb + cy) : ((long)(tap * g.Ca + cy) * g.Cb + m);
+                    o[idx] = acc[i][j][r];
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // split-K reduce (+ bias + activation):  out[r*ld_out + c] = act(sum_z slab[z][r*cols + c] + bias[c])
 // ------------------------------------------------------------------------------------------------
 __global__ void k_slab_reduce(const float* __restrict__ slabs, long slab_stride, int S, float* __restrict__ out,
@@ -532,16 +815,21 @@ __global__ void k_slab_reduce(const float* __restrict__ slabs, long slab_stride,
     }
 }
 
-// column sums of a [rows][C] matrix (pixel stride ld): partial[chunk][c] over row chunks (bias gradient)
-__global__ void k_colsum_partial(const float* __restrict__ x, int ld, long rows, int C, long rows_per_chunk,
-                                 float* __restrict__ partial) {
-    const int c = blockIdx.y * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// column sums of a [rows][C] matrix (pixel stride ld): partial[chunk][c] over row chunks (bias gradient).
+// 256 threads = 64 channels x 4 row lanes; fixed-order combine.
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ x, int ld, long rows, int C,
+                                                        long rows_per_chunk, float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
     const long r_begin = blockIdx.x * rows_per_chunk;
     const long r_end = min(rows, r_begin + rows_per_chunk);
     float s = 0.f;
-    for (long r = r_begin; r < r_end; ++r) s += x[r * ld + c];
-    partial[(long)blockIdx.x * C + c] = s;
+    if (c < C)
+        for (long r = r_begin + rl; r < r_end; r += 4) s += x[r * ld + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) partial[(long)blockIdx.x * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -670,7 +958,9 @@ Tile pick_tile(long rows, int cols) {
 constexpr int TARGET_BLOCKS = 512;
 
 int pick_split(long tiles, int nchunks, int min_chunks) {
-    if (tiles >= 256) return 1;
+    // one 4-wave workgroup per CU leaves the MFMA pipe idle while that workgroup stages its next tile
+    // (measured 55 vs 80 TFLOP/s on the same kernel at 1 vs 2 workgroups per CU): split K until >= 512 workgroups
+    if (tiles >= TARGET_BLOCKS) return 1;
     long s = (TARGET_BLOCKS + tiles - 1) / tiles;
     long smax = nchunks / min_chunks;
     if (smax < 1) smax = 1;
@@ -713,21 +1003,39 @@ Plan plan_s2b(const pg_conv_geom* g) {
     return p;
 }
 
+// wgrad kernel choice: 0 = one GEMM per tap, 1 / 2 = taps folded into N (few big-side / small-side channels)
+int wgrad_mode(const pg_conv_geom* g) {
+    if (g->Cb <= 8) return 1;
+    if (g->Ca <= 8) return 2;
+    return 0;
+}
+
 Plan plan_wgrad(const pg_conv_geom* g) {
     Plan p;
-    p.t = pick_tile(g->Ca, g->Cb);
-    p.tiles_m = (g->Ca + p.t.bm - 1) / p.t.bm;
-    p.tiles_n = (g->Cb + p.t.bn - 1) / p.t.bn;
-    p.ncls = 16;
-    const long Kp = (long)g->N * g->Hs * g->Ws;
+    const int mode = wgrad_mode(g);
+    long Kp;
+    if (mode == 0) {
+        p.t = pick_tile(g->Ca, g->Cb);
+        p.tiles_m = (g->Ca + p.t.bm - 1) / p.t.bm;
+        p.tiles_n = (g->Cb + p.t.bn - 1) / p.t.bn;
+        p.ncls = 16;
+        Kp = (long)g->N * g->Hs * g->Ws;
+    } else {
+        const int Mdim = (mode == 1) ? g->Ca : g->Cb, Ndim = 16 * ((mode == 1) ? g->Cb : g->Ca);
+        p.t = pick_tile(Mdim, Ndim);
+        p.tiles_m = (Mdim + p.t.bm - 1) / p.t.bm;
+        p.tiles_n = (Ndim + p.t.bn - 1) / p.t.bn;
+        p.ncls = 1;
+        Kp = (mode == 1) ? (long)g->N * g->Hs * g->Ws : (long)g->N * g->Hb * g->Wb;
+    }
     p.nchunks = (int)((Kp + KC - 1) / KC);
-    p.split = pick_split((long)p.tiles_m * p.tiles_n * 16, p.nchunks, 8);
+    p.split = pick_split((long)p.tiles_m * p.tiles_n * p.ncls, p.nchunks, 8);
     p.out_elems = 16L * g->Ca * g->Cb;
     return p;
 }
 
 constexpr int DIRECT_WGRAD_SLICES = 64;
-constexpr int COLSUM_CHUNKS = 256;
+constexpr int COLSUM_CHUNKS = 1024;
 
 void clamp_split(Plan& p, size_t ws_bytes, size_t reserved) {
     size_t avail = ws_bytes > reserved ? ws_bytes - reserved : 0;
@@ -757,6 +1065,15 @@ int launch_reduce(const float* slabs, long slab_stride, int S, float* out, int l
         default: hipLaunchKernelGGL((KERNEL<1, 1, 2, 2>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
     }
 
+#define PG_DISPATCH_TAPN(MODE, tile_id, grid, st, ...)                                                              \
+    switch (tile_id) {                                                                                             \
+        case 0: hipLaunchKernelGGL((k_wgrad_tapn<2, 2, 2, 2, MODE>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        case 1: hipLaunchKernelGGL((k_wgrad_tapn<2, 1, 2, 2, MODE>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        case 2: hipLaunchKernelGGL((k_wgrad_tapn<1, 1, 4, 1, MODE>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        case 3: hipLaunchKernelGGL((k_wgrad_tapn<1, 2, 2, 2, MODE>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL((k_wgrad_tapn<1, 1, 2, 2, MODE>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
+    }
+
 }  // namespace
 
 extern "C" {
@@ -777,7 +1094,7 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
     Plan p = (op == 0) ? plan_b2s(g) : (op == 1) ? plan_s2b(g) : plan_wgrad(g);
     size_t reserved = (op == 2) ? (((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255) : 0;
     clamp_split(p, ws_bytes, reserved);
-    if (tile_id) *tile_id = p.t.id;
+    if (tile_id) *tile_id = p.t.id + ((op == 2) ? 10 * wgrad_mode(g) : 0);
     if (split) *split = p.split;
     if (workgroups) *workgroups = (long)p.tiles_m * p.tiles_n * p.ncls * p.split;
     return PG_OK;
@@ -860,7 +1177,7 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
         int chunks = (int)std::min<long>(COLSUM_CHUNKS, Kp);
         long rpc = (Kp + chunks - 1) / chunks;
         chunks = (int)((Kp + rpc - 1) / rpc);
-        hipLaunchKernelGGL(k_colsum_partial, dim3(chunks, (g.Ca + 63) / 64), dim3(64), 0, st, small, ld_small, Kp, g.Ca,
+        hipLaunchKernelGGL(k_colsum_partial, dim3(chunks, (g.Ca + 63) / 64), dim3(256), 0, st, small, ld_small, Kp, g.Ca,
                            rpc, part);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         int rc = launch_reduce(part, g.Ca, chunks, dbias, g.Ca, 1, g.Ca, nullptr, 0, st);
@@ -884,10 +1201,19 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
     clamp_split(p, ws_bytes, reserved);
     const int vecm = (g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned16(small);
     const int vecn = (g.Cb % 4 == 0) && (ld_big % 4 == 0) && aligned16(big);
-    dim3 grid(p.tiles_m * p.tiles_n, 16, p.split);
+    const int mode = wgrad_mode(gg);
     float* dst = p.split == 1 ? dP : (float*)((char*)ws + reserved);
-    PG_DISPATCH_TILE(k_wgrad, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n, vecm,
-                     vecn);
+    if (mode == 0) {
+        dim3 grid(p.tiles_m * p.tiles_n, 16, p.split);
+        PG_DISPATCH_TILE(k_wgrad, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
+                         vecm, vecn);
+    } else if (mode == 1) {
+        dim3 grid(p.tiles_m * p.tiles_n, 1, p.split);
+        PG_DISPATCH_TAPN(1, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n, vecm);
+    } else {
+        dim3 grid(p.tiles_m * p.tiles_n, 1, p.split);
+        PG_DISPATCH_TAPN(2, p.t.id, grid, st, big, ld_big, small, ld_small, dst, p.out_elems, g, p.cps, p.tiles_n, vecn);
+    }
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     if (p.split == 1) return PG_OK;
     return launch_reduce(dst, p.out_elems, p.split, dP, g.Cb, 16L * g.Ca, g.Cb, nullptr, 0, st);

@@ -156,7 +156,11 @@ class ConvOp:
             t, s, w = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_long(0)
             L.check(L.load().pg_conv_describe(ctypes.byref(self.g), opcode, max(self.ws_bytes, 1 << 20), ctypes.byref(t),
                                               ctypes.byref(s), ctypes.byref(w)), 'pg_conv_describe')
-            self._desc[opcode] = (LaunchProfiler.OP_NAMES[opcode] + LaunchProfiler.TILE_NAMES[t.value], s.value)
+            tid, mode = t.value % 10, t.value // 10
+            name = LaunchProfiler.OP_NAMES[opcode] + LaunchProfiler.TILE_NAMES[tid]
+            if mode:
+                name = 'k_wgrad_tapn' + LaunchProfiler.TILE_NAMES[tid][:-1] + f',{mode}>'
+            self._desc[opcode] = (name, s.value)
         return self._desc[opcode]
 
     def big2small(self, big, P, p_off, bias, b_off, small, act=L.ACT_NONE):

@@ -22,6 +22,9 @@ GEOMS = [
     (1, 15, 13, 8, 8, 2),       # odd big extent
     (2, 4, 4, 512, 64, 2),      # small M, long K: split-K
     (4, 64, 64, 32, 16, 2),     # many rows
+    (2, 16, 16, 4, 24, 2),      # Ca <= 8, stride 2: wgrad taps-in-N mode 2
+    (1, 15, 13, 3, 20, 2),      # same, odd extent, Ca % 4 != 0
+    (2, 32, 32, 64, 4, 2),      # d0-like: wgrad taps-in-N mode 1, N = 64
 ]
 ACTS = {'none': 0, 'leakyrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
