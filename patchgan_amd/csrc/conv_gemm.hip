@@ -15,6 +15,7 @@
 // k = 8*kk + 4*h + j (j = 0..3) for MFMA j, the same permutation of K on both operands.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "patchgan_hip.h"
 #include "pg_common.h"
 
@@ -799,6 +800,517 @@ __global__ __launch_bounds__(256) void k_wgrad_tapn(const float* __restrict__ X,
     }
 }
 
+// ================================================================================================
+// Fast variants (the hot path whenever channels are multiples of 4, buffers are 16-byte aligned and every
+// tensor is < 2 GiB): same tiling and MFMA loop as the generic kernels above, but
+//   * operand gathers are raw buffer loads (hardware range check: an out-of-range offset returns 0), so the
+//     zero padding, ragged tiles and K tails cost one v_cndmask instead of a divergent branch per load,
+//   * all offsets are 32-bit element offsets from a per-row base computed once per tile; tap validity is a
+//     16-bit mask per row (one shift+and per load),
+//   * the loads of chunk c+1 are spread over the four 8-k steps of chunk c, inside ONE basic block, so the
+//     scheduler interleaves their address arithmetic with the MFMAs instead of running it ahead of them.
+// ================================================================================================
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int OOB = 0x7fffffff;
+// element offset -> byte offset without signed overflow (sentinel offsets exceed INT_MAX/4 on purpose)
+__device__ __forceinline__ int b4(int elem_off) { return (int)((unsigned)elem_off << 2); }
+
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
+__device__ __noinline__ float pg_act_slow(float v, int act) { return pg_act(v, act); }
+__device__ __forceinline__ float pg_act_epi(float v, int act) {
+    if (act == PG_ACT_NONE) return v;
+    if (act == PG_ACT_LEAKY) return v > 0.f ? v : 0.2f * v;
+    if (act == PG_ACT_RELU) return v > 0.f ? v : 0.f;
+    return pg_act_slow(v, act);
+}
+
+template <int MR, int NR, int WM, int WN>
+__global__ __launch_bounds__(256) void k_b2s_fast(const float* __restrict__ big, int ld_big,
+                                                  const float* __restrict__ P, float* __restrict__ out, int ld_out,
+                                                  long slab_stride, Geom g, int chunks_per_slice,
+                                                  const float* __restrict__ bias, int act, int big_bytes, int p_bytes) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    float* As = smem;
+    float* Bs = smem + BM * LDK;
+    const __amdgpu_buffer_rsrc_t rbig = __builtin_amdgcn_make_buffer_rsrc((void*)big, 0, big_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, p_bytes, 0x00020000);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int M = g.N * g.Hs * g.Ws, K = 16 * g.Cb;     // K % 32 == 0 because Cb % 4 == 0
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int nchunks = K / KC;
+    const int c_begin = blockIdx.z * chunks_per_slice;
+    const int c_end = min(nchunks, c_begin + chunks_per_slice);
+
+    const int kq = tid & 7, r0 = tid >> 3;
+    int a_off[AI], a_mask[AI], b_off[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const int mm = min(m, M - 1);
+        const int n = mm / (g.Hs * g.Ws);
+        const int rem = mm - n * (g.Hs * g.Ws);
+        const int p = rem / g.Ws, q = rem - p * g.Ws;
+        const int h0 = g.s * p - 1, w0 = g.s * q - 1;
+        a_off[i] = ((n * g.Hb + h0) * g.Wb + w0) * ld_big;
+        int mask = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int h = h0 + (t >> 2), w = w0 + (t & 3);
+            if ((unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb) mask |= 1 << t;
+        }
+        a_mask[i] = (m < M) ? mask : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int a = n0 + r0 + 32 * i;
+        b_off[i] = (a < g.Ca) ? a * g.Cb : 0x10000000;
+    }
+    const int CaCb = g.Ca * g.Cb;
+    int cur_tap = (c_begin * KC + kq * 4) / g.Cb;
+    int cur_b = (c_begin * KC + kq * 4) - cur_tap * g.Cb;
+
+    f32x4 ra[AI], rb[BI];
+    int tapoff = 0, pboff = 0, ctap = 0;
+    auto next_tap = [&]() {   // (tap, b) of the next chunk for this thread's float4; Cb >= KC: at most one wrap
+        const int tap = cur_tap, b = cur_b;
+        cur_b += KC;
+        const bool wrap = cur_b >= g.Cb;
+        cur_b = wrap ? cur_b - g.Cb : cur_b;
+        cur_tap = wrap ? cur_tap + 1 : cur_tap;
+        ctap = tap;
+        tapoff = ((tap >> 2) * g.Wb + (tap & 3)) * ld_big + b;
+        pboff = tap * CaCb + b;
+    };
+    auto load_a = [&](int i, bool on) {
+        const bool ok = on && ((a_mask[i] >> ctap) & 1);
+        ra[i] = bload4(rbig, ok ? b4(a_off[i] + tapoff) : OOB);
+    };
+    auto load_b = [&](int i, bool on) { rb[i] = bload4(rP, on ? b4(b_off[i] + pboff) : OOB); };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDK + kq * 4]) = rb[i];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        next_tap();
+#pragma unroll
+        for (int i = 0; i < AI; ++i) load_a(i, true);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) load_b(i, true);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
+        next_tap();
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            f32x4 af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MR + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NR + j) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+            if (kk < AI) load_a(kk, more);
+            if (kk < BI) load_b(kk, more);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    float* o = out + (long)blockIdx.z * slab_stride;
+    const bool fin = (slab_stride == 0);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + lrow;
+            const float bv = (fin && bias != nullptr && col < g.Ca) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + (wm * MR + i) * 32 + row;
+                if (m < M && col < g.Ca) {
+                    float v = acc[i][j][r];
+                    if (fin) v = pg_act_epi(v + bv, act);
+                    o[(long)m * ld_out + col] = v;
+                }
+            }
+        }
+}
+
+template <int MR, int NR, int WM, int WN>
+__global__ __launch_bounds__(256) void k_s2b_fast(const float* __restrict__ small, int ld_small,
+                                                  const float* __restrict__ P, float* __restrict__ out, int ld_out,
+                                                  long slab_stride, Geom g, int chunks_per_slice,
+                                                  const float* __restrict__ bias, int act, int small_bytes,
+                                                  int p_bytes) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+    constexpr int AI = BM / 32;
+    constexpr int BG = 256 / BN;        // thread groups along k
+    constexpr int NQ = 8 / BG;          // k-quads per thread per chunk
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    float* As = smem;
+    float* Bs = smem + BM * LDK;
+    const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)small, 0, small_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, p_bytes, 0x00020000);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    const int ncls = (g.s == 2) ? 4 : 1;
+    const int cls = blockIdx.z % ncls, slice = blockIdx.z / ncls;
+    const int ah = (g.s == 2) ? (cls >> 1) : 0, aw = (g.s == 2) ? (cls & 1) : 0;
+    const int T = (g.s == 2) ? 2 : 4, Tsh = (g.s == 2) ? 1 : 2;
+    const int Hc = (g.s == 2) ? (g.Hb - ah + 1) / 2 : g.Hb;
+    const int Wc = (g.s == 2) ? (g.Wb - aw + 1) / 2 : g.Wb;
+    const int kh0 = (g.s == 2) ? (1 - ah) : 0, kw0 = (g.s == 2) ? (1 - aw) : 0;
+    const int Mc = g.N * Hc * Wc, K = T * T * g.Ca;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= Mc) return;
+    const int nchunks = (K + KC - 1) / KC;
+    const int c_begin = slice * chunks_per_slice;
+    const int c_end = min(nchunks, c_begin + chunks_per_slice);
+
+    const int kq = tid & 7, r0 = tid >> 3;
+    int a_off[AI], a_mask[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const int mm = min(m, Mc - 1);
+        const int n = mm / (Hc * Wc);
+        const int rem = mm - n * (Hc * Wc);
+        const int ii = rem / Wc, jj = rem - ii * Wc;
+        const int ib = (g.s == 2) ? ii + ah : ii + 1, jb = (g.s == 2) ? jj + aw : jj + 1;
+        a_off[i] = ((n * g.Hs + ib) * g.Ws + jb) * ld_small;
+        int mask = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int th = t >> Tsh, tw = t & (T - 1);
+            if (t < T * T && (unsigned)(ib - th) < (unsigned)g.Hs && (unsigned)(jb - tw) < (unsigned)g.Ws) mask |= 1 << t;
+        }
+        a_mask[i] = (m < Mc) ? mask : 0;
+    }
+    const int bn = tid % BN, bg = tid / BN;
+    const int ncol = n0 + bn;
+    const int ncol_off = (ncol < g.Cb) ? ncol : 0x10000000;
+    const int CaCb = g.Ca * g.Cb;
+
+    // incremental (tloc, a) per k-quad: A float4 (index 0) and the NQ quads of B (1..NQ); Ca >= KC: <= 1 wrap
+    int q_tl[NQ + 1], q_a[NQ + 1];
+    {
+        const int k = c_begin * KC + kq * 4;
+        q_tl[0] = k / g.Ca;
+        q_a[0] = k - q_tl[0] * g.Ca;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int k = c_begin * KC + 4 * (bg + BG * i);
+        q_tl[i + 1] = k / g.Ca;
+        q_a[i + 1] = k - q_tl[i + 1] * g.Ca;
+    }
+    auto quad = [&](int qi, int& tl, int& a) {   // returns (tloc, a) of quad qi for the chunk being loaded
+        tl = q_tl[qi];
+        a = q_a[qi];
+        const int na = a + KC;
+        const bool wrap = na >= g.Ca;
+        q_a[qi] = wrap ? na - g.Ca : na;
+        q_tl[qi] = wrap ? tl + 1 : tl;
+    };
+
+    f32x4 ra[AI], rb[NQ];
+    int a_tl = 0, a_koff = OOB;
+    auto next_a = [&](int c) {
+        const int k = c * KC + kq * 4;
+        int tl, a;
+        quad(0, tl, a);
+        a_tl = tl;
+        const int th = tl >> Tsh, tw = tl & (T - 1);
+        a_koff = (k < K) ? (a - (th * g.Ws + tw) * ld_small) : 0x20000000;
+    };
+    auto load_a = [&](int i, bool on) {
+        const bool ok = on && ((a_mask[i] >> a_tl) & 1) && (a_koff < 0x10000000);
+        ra[i] = bload4(rsm, ok ? b4(a_off[i] + a_koff) : OOB);
+    };
+    auto load_b = [&](int i, int c, bool on) {
+        const int kb = c * KC + 4 * (bg + BG * i);
+        int tl, a;
+        quad(i + 1, tl, a);
+        const int th = tl >> Tsh, tw = tl & (T - 1);
+        const int tap = (kh0 + g.s * th) * 4 + (kw0 + g.s * tw);
+        const bool ok = on && kb < K;
+        const int base = ok ? b4(tap * CaCb + a * g.Cb + ncol_off) : OOB;
+        const int st = ok ? g.Cb * 4 : 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rb[i][e] = bload1(rP, base + e * st);
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) *reinterpret_cast<f32x4*>(&Bs[bn * LDK + 4 * (bg + BG * i)]) = rb[i];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        next_a(c_begin);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) load_a(i, true);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) load_b(i, c_begin, true);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
+        next_a(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            f32x4 af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MR + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NR + j) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+            if (kk < AI) load_a(kk, more);
+            if (kk < NQ) load_b(kk, c + 1, more);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    const bool fin = (slab_stride == 0);
+    float* o = out + (long)slice * slab_stride;
+    const int ldo = fin ? ld_out : g.Cb;
+    float bv[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int col = n0 + (wn * NR + j) * 32 + lrow;
+        bv[j] = (fin && bias != nullptr && col < g.Cb) ? bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int m = m0 + (wm * MR + i) * 32 + row;
+            if (m < Mc) {
+                const int n = m / (Hc * Wc);
+                const int rem = m - n * (Hc * Wc);
+                const int ii = rem / Wc, jj = rem - ii * Wc;
+                const int h = (g.s == 2) ? 2 * ii + ah : ii, w = (g.s == 2) ? 2 * jj + aw : jj;
+                float* orow = o + (long)((n * g.Hb + h) * g.Wb + w) * ldo;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int col = n0 + (wn * NR + j) * 32 + lrow;
+                    if (col < g.Cb) {
+                        float v = acc[i][j][r];
+                        if (fin) v = pg_act_epi(v + bv[j], act);
+                        orow[col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MR, int NR, int WM, int WN, bool POW2>
+__global__ __launch_bounds__(256) void k_wgrad_fast(const float* __restrict__ small, int ld_small,
+                                                    const float* __restrict__ big, int ld_big,
+                                                    float* __restrict__ out, long slab_stride, Geom g,
+                                                    int chunks_per_slice, int tilesB, int small_bytes, int big_bytes) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int AQ = BM / 4, AROWS = 256 / AQ, AI = KC / AROWS;
+    constexpr int BQ = BN / 4, BROWS = 256 / BQ, BI = KC / BROWS;
+    __shared__ __attribute__((aligned(16))) float smem[KC * LDA + KC * LDB];
+    float* As = smem;
+    float* Bs = smem + KC * LDA;
+    const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)small, 0, small_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbig = __builtin_amdgcn_make_buffer_rsrc((void*)big, 0, big_bytes, 0x00020000);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int tile_a = blockIdx.x / tilesB, tile_b = blockIdx.x % tilesB;
+    const int m0 = tile_a * BM, n0 = tile_b * BN;
+    const int tap = blockIdx.y, kh = tap >> 2, kw = tap & 3;
+    const int Kp = g.N * g.Hs * g.Ws;
+    const int nchunks = (Kp + KC - 1) / KC;
+    const int c_begin = blockIdx.z * chunks_per_slice;
+    const int c_end = min(nchunks, c_begin + chunks_per_slice);
+
+    const int aq = tid % AQ, arow0 = tid / AQ;
+    const int bq = tid % BQ, brow0 = tid / BQ;
+    const int a_col = (m0 + aq * 4 < g.Ca) ? m0 + aq * 4 : 0x10000000;      // small rows beyond Kp are out of range by
+    const int b_col = (n0 + bq * 4 < g.Cb) ? n0 + bq * 4 : 0x10000000;      // construction of small_bytes
+    // pixel -> (img, p, q): shifts when Hs, Ws are powers of two (every UNet layer), else a branch-free carry chain
+    // (needs Ws >= 16 and Hs >= 2: a step of KC = 32 pixels wraps q at most twice and p at most once)
+    const int lgW = 31 - __builtin_clz(g.Ws), lgH = 31 - __builtin_clz(g.Hs);
+    int r_n[BI], r_p[BI], r_q[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int pix = c_begin * KC + brow0 + BROWS * i;
+        r_n[i] = pix / (g.Hs * g.Ws);
+        const int rem = pix - r_n[i] * (g.Hs * g.Ws);
+        r_p[i] = rem / g.Ws;
+        r_q[i] = rem - r_p[i] * g.Ws;
+    }
+
+    f32x4 ra[AI], rb[BI];
+    auto load_a = [&](int i, int c, bool on) {
+        const int pix = c * KC + arow0 + AROWS * i;
+        const bool ok = on && pix < Kp;
+        ra[i] = bload4(rsm, ok ? b4(pix * ld_small + a_col) : OOB);
+    };
+    auto load_b = [&](int i, int c, bool on) {
+        const int pix = c * KC + brow0 + BROWS * i;
+        int n, p, q;
+        if (POW2) {
+            q = pix & (g.Ws - 1);
+            p = (pix >> lgW) & (g.Hs - 1);
+            n = pix >> (lgW + lgH);
+        } else {
+            n = r_n[i];
+            p = r_p[i];
+            q = r_q[i];
+            int nq = q + KC, np = p, nn = n;
+            bool w = nq >= g.Ws;
+            nq = w ? nq - g.Ws : nq;
+            np = w ? np + 1 : np;
+            w = nq >= g.Ws;
+            nq = w ? nq - g.Ws : nq;
+            np = w ? np + 1 : np;
+            w = np >= g.Hs;
+            np = w ? np - g.Hs : np;
+            nn = w ? nn + 1 : nn;
+            r_q[i] = nq;
+            r_p[i] = np;
+            r_n[i] = nn;
+        }
+        const int h = g.s * p - 1 + kh, w = g.s * q - 1 + kw;
+        const bool ok = on && pix < Kp && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
+        rb[i] = bload4(rbig, ok ? b4(((n * g.Hb + h) * g.Wb + w) * ld_big + b_col) : OOB);
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(arow0 + AROWS * i) * LDA + aq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow0 + BROWS * i) * LDB + bq * 4]) = rb[i];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) load_a(i, c_begin, true);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) load_b(i, c_begin, true);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
+#pragma unroll
+        for (int kq4 = 0; kq4 < 4; ++kq4) {          // 4 groups of 4 k-pairs
+            if (kq4 < AI) load_a(kq4, c + 1, more);
+            if (kq4 < BI) load_b(kq4, c + 1, more);
+            if (kq4 + 4 < AI) load_a(kq4 + 4, c + 1, more);
+            if (kq4 + 4 < BI) load_b(kq4 + 4, c + 1, more);
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int kk = kq4 * 4 + k4;
+                float af[MR], bf[NR];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) af[i] = As[(kk * 2 + lh) * LDA + (wm * MR + i) * 32 + lrow];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) bf[j] = Bs[(kk * 2 + lh) * LDB + (wn * NR + j) * 32 + lrow];
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    float* o = out + (long)blockIdx.z * slab_stride + (long)tap * g.Ca * g.Cb;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int a = m0 + (wm * MR + i) * 32 + row;
+                if (a < g.Ca && col < g.Cb) o[(long)a * g.Cb + col] = acc[i][j][r];
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // split-K reduce (+ bias + activation):  out[r*ld_out + c] = act(sum_z slab[z][r*cols + c] + bias[c])
 // ------------------------------------------------------------------------------------------------
@@ -922,6 +1434,14 @@ __global__ void k_wgrad_direct(const float* __restrict__ small, int ld_small, co
 // host side
 // ------------------------------------------------------------------------------------------------
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// bytes spanned by a [pixels][C] view with pixel stride ld (what the buffer descriptor of the fast kernels covers)
+inline long tensor_bytes(long pixels, int ld, int C) { return ((pixels - 1) * (long)ld + C) * 4; }
+constexpr long FAST_LIMIT = 0x60000000L;   // 1.5 GiB: keeps every 32-bit byte offset, incl. the +0x40000000 sentinel, < 2^32
+inline bool force_generic() {
+    static const bool v = getenv("PATCHGAN_GENERIC_KERNELS") != nullptr;   // debugging aid: disable the fast variants
+    return v;
+}
 
 bool geom_ok(const pg_conv_geom* g) {
     if (!g) return false;
@@ -1074,6 +1594,15 @@ int launch_reduce(const float* slabs, long slab_stride, int S, float* out, int l
         default: hipLaunchKernelGGL((k_wgrad_tapn<1, 1, 2, 2, MODE>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
     }
 
+#define PG_DISPATCH_WGF(POW2, tile_id, grid, st, ...)                                                              \
+    switch (tile_id) {                                                                                            \
+        case 0: hipLaunchKernelGGL((k_wgrad_fast<2, 2, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        case 1: hipLaunchKernelGGL((k_wgrad_fast<2, 1, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        case 2: hipLaunchKernelGGL((k_wgrad_fast<1, 1, 4, 1, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        case 3: hipLaunchKernelGGL((k_wgrad_fast<1, 2, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL((k_wgrad_fast<1, 1, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
+    }
+
 }  // namespace
 
 extern "C" {
@@ -1119,13 +1648,26 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
     clamp_split(p, ws_bytes, 0);
     const int veck = (g.Cb % 4 == 0) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P);
     dim3 grid(p.tiles_m, p.tiles_n, p.split);
+    const long big_bytes = tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb), p_bytes = 16L * g.Ca * g.Cb * 4;
+    const bool fast = veck && g.Cb >= KC && big_bytes < FAST_LIMIT && p_bytes < FAST_LIMIT && !force_generic();
     if (p.split == 1) {
-        PG_DISPATCH_TILE(k_big2small, p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, veck, bias, act);
+        if (fast) {
+            PG_DISPATCH_TILE(k_b2s_fast, p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, bias, act,
+                             (int)big_bytes, (int)p_bytes);
+        } else {
+            PG_DISPATCH_TILE(k_big2small, p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, veck, bias,
+                             act);
+        }
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     float* slabs = (float*)ws;
-    PG_DISPATCH_TILE(k_big2small, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps, veck,
-                     (const float*)nullptr, 0);
+    if (fast) {
+        PG_DISPATCH_TILE(k_b2s_fast, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps,
+                         (const float*)nullptr, 0, (int)big_bytes, (int)p_bytes);
+    } else {
+        PG_DISPATCH_TILE(k_big2small, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps, veck,
+                         (const float*)nullptr, 0);
+    }
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     return launch_reduce(slabs, p.out_elems, p.split, small, ld_small, (long)g.N * g.Hs * g.Ws, g.Ca, bias, act, st);
 }
@@ -1150,14 +1692,26 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
     const int veck = (g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned16(small);
     const int vecn = (g.Cb % 4 == 0) && aligned16(P);
     dim3 grid(p.tiles_m, p.tiles_n, p.ncls * p.split);
+    const long small_bytes = tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca), p_bytes = 16L * g.Ca * g.Cb * 4;
+    const bool fast = veck && g.Ca >= KC && small_bytes < FAST_LIMIT && p_bytes < FAST_LIMIT && !force_generic();
     if (p.split == 1) {
-        PG_DISPATCH_TILE(k_small2big, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, veck, vecn, bias,
-                         act);
+        if (fast) {
+            PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, bias, act,
+                             (int)small_bytes, (int)p_bytes);
+        } else {
+            PG_DISPATCH_TILE(k_small2big, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, veck, vecn,
+                             bias, act);
+        }
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     float* slabs = (float*)ws;
-    PG_DISPATCH_TILE(k_small2big, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps, veck, vecn,
-                     (const float*)nullptr, 0);
+    if (fast) {
+        PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
+                         (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes);
+    } else {
+        PG_DISPATCH_TILE(k_small2big, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps, veck,
+                         vecn, (const float*)nullptr, 0);
+    }
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     return launch_reduce(slabs, p.out_elems, p.split, big, ld_big, (long)g.N * g.Hb * g.Wb, g.Cb, bias, act, st);
 }
@@ -1205,8 +1759,21 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
     float* dst = p.split == 1 ? dP : (float*)((char*)ws + reserved);
     if (mode == 0) {
         dim3 grid(p.tiles_m * p.tiles_n, 16, p.split);
-        PG_DISPATCH_TILE(k_wgrad, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
-                         vecm, vecn);
+        const long small_bytes = tensor_bytes(Kp, ld_small, g.Ca);
+        const long big_bytes = tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb);
+        const bool pow2 = ((g.Hs & (g.Hs - 1)) == 0) && ((g.Ws & (g.Ws - 1)) == 0);
+        const bool fast = vecm && vecn && small_bytes < FAST_LIMIT && big_bytes < FAST_LIMIT && !force_generic() &&
+                          (pow2 || (g.Ws >= 16 && g.Hs >= 2));
+        if (fast && pow2) {
+            PG_DISPATCH_WGF(true, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
+                            (int)small_bytes, (int)big_bytes);
+        } else if (fast) {
+            PG_DISPATCH_WGF(false, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
+                            (int)small_bytes, (int)big_bytes);
+        } else {
+            PG_DISPATCH_TILE(k_wgrad, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps,
+                             p.tiles_n, vecm, vecn);
+        }
     } else if (mode == 1) {
         dim3 grid(p.tiles_m * p.tiles_n, 1, p.split);
         PG_DISPATCH_TAPN(1, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n, vecm);

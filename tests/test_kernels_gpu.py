@@ -25,6 +25,9 @@ GEOMS = [
     (2, 16, 16, 4, 24, 2),      # Ca <= 8, stride 2: wgrad taps-in-N mode 2
     (1, 15, 13, 3, 20, 2),      # same, odd extent, Ca % 4 != 0
     (2, 32, 32, 64, 4, 2),      # d0-like: wgrad taps-in-N mode 1, N = 64
+    (2, 32, 32, 64, 32, 1),     # d3-like stride 1, Hs = 31 (carry-chain pixel decode in the fast wgrad)
+    (3, 34, 38, 40, 36, 2),     # non-power-of-two extents >= 16, ragged channel tiles
+    (2, 64, 64, 128, 64, 2),    # enc-like: all fast kernels, power-of-two decode
 ]
 ACTS = {'none': 0, 'leakyrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
