@@ -104,13 +104,18 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
  * (n*HW + pix)*C + c is kept iff pg_dropout_keep(seed, e) and scaled by 1/(1-p). */
 int pg_instnorm_act_fwd(const float* y, int ld_y, float* out, int ld_out, float* stats,
                         int N, int HW, int C, int act, float eps,
-                        float drop_p, uint64_t seed, void* stream);
+                        float drop_p, uint64_t seed, void* ws, size_t ws_bytes, void* stream);
+
+/* Workspace (fp64 partial sums) that lets the two InstanceNorm entry points use their chunked, fully parallel path on
+ * large planes; with ws == NULL or too small they fall back to one workgroup per (sample, channel group). */
+size_t pg_instnorm_workspace_bytes(int N, int HW, int C);
 
 /* Backward of the block above: given g = dL/dout (= g1 + g2, g2 may be NULL: the skip connection's
  * second consumer), the saved y and stats, writes dy = dL/dy. */
 int pg_instnorm_act_bwd(const float* g1, int ld_g1, const float* g2, int ld_g2,
                         const float* y, int ld_y, const float* stats, float* dy, int ld_dy,
-                        int N, int HW, int C, int act, float drop_p, uint64_t seed, void* stream);
+                        int N, int HW, int C, int act, float drop_p, uint64_t seed,
+                        void* ws, size_t ws_bytes, void* stream);
 
 /* Backward of a plain activation (+dropout) from its OUTPUT a:  dy = (g1+g2) * keep/(1-p) * act'(a).
  * act' from the output: leaky a>0?1:0.2, relu a>0, tanh 1-a^2, sigmoid a(1-a), none 1.  `a` may be NULL for

@@ -1327,6 +1327,23 @@ __global__ void k_slab_reduce(const float* __restrict__ slabs, long slab_stride,
     }
 }
 
+__global__ void k_slab_reduce4(const float* __restrict__ slabs, long slab_stride, int S, float* __restrict__ out,
+                               int ld_out, long rows, int cols, const float* __restrict__ bias, int act) {
+    const int cq = cols >> 2;
+    const long total = rows * cq;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cq;
+        const int c = (int)(i - r * cq) << 2;
+        const long off = r * cols + c;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slabs + off);
+        for (int z = 1; z < S; ++z) v += *reinterpret_cast<const f32x4*>(slabs + (long)z * slab_stride + off);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pg_act_epi(v[e], act);
+        *reinterpret_cast<f32x4*>(out + r * ld_out + c) = v;
+    }
+}
+
 // column sums of a [rows][C] matrix (pixel stride ld): partial[chunk][c] over row chunks (bias gradient).
 // 256 threads = 64 channels x 4 row lanes; fixed-order combine.
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ x, int ld, long rows, int C,
@@ -1567,6 +1584,15 @@ void clamp_split(Plan& p, size_t ws_bytes, size_t reserved) {
 
 int launch_reduce(const float* slabs, long slab_stride, int S, float* out, int ld_out, long rows, int cols,
                   const float* bias, int act, hipStream_t st) {
+    if ((cols % 4 == 0) && (ld_out % 4 == 0) && (slab_stride % 4 == 0) && aligned16(slabs) && aligned16(out) &&
+        (!bias || aligned16(bias))) {
+        const long total4 = rows * (cols / 4);
+        int blocks = (int)std::min<long>((total4 + 255) / 256, 16384);
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_slab_reduce4, dim3(blocks), dim3(256), 0, st, slabs, slab_stride, S, out, ld_out, rows, cols,
+                           bias, act);
+        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+    }
     const long total = rows * cols;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;

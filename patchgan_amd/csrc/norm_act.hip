@@ -39,6 +39,17 @@ __device__ __forceinline__ void vstore(float* p, const Vec<VEC>& r) {
     }
 }
 
+// derivative of the post-norm activation evaluated at the normalised value z
+__device__ __forceinline__ float pg_norm_act_grad(float z, int act) {
+    switch (act) {
+        case PG_ACT_LEAKY: return z > 0.f ? 1.f : 0.2f;
+        case PG_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case PG_ACT_TANH: { float t = tanhf(z); return 1.f - t * t; }
+        case PG_ACT_SIGMOID: { float t = 1.f / (1.f + expf(-z)); return t * (1.f - t); }
+        default: return 1.f;
+    }
+}
+
 // tree-reduce red[k][tid] over the pixel-lane dim (tid = pl*G + cu); result in red[k][cu]
 template <int NK>
 __device__ __forceinline__ void lane_tree(double (*red)[256], int tid, int G) {
@@ -214,6 +225,157 @@ __global__ __launch_bounds__(256) void k_instnorm_bwd(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Chunked path for large planes (HW >= 2048): the single-workgroup-per-(n, channel group) kernels above either
+// run too few workgroups or (G = 1) touch 16 B of every 128-B line per lane.  Here a workgroup owns (n, pixel
+// chunk, channel group) with G as wide as the channel count allows (full-line reads), partial sums go to a
+// workspace in fp64, a tiny merge kernel finishes the statistics in fixed order, and the apply pass is a flat
+// grid-stride elementwise kernel.  fp64 sum / sum-of-squares (squares of fp32 are exact in fp64) replaces the
+// two-pass variance: relative error ~1e-16 * mean^2/var.
+// ------------------------------------------------------------------------------------------------
+template <int VEC, bool BWD>
+__global__ __launch_bounds__(256) void k_in_partial(const float* __restrict__ y, int ld_y,
+                                                    const float* __restrict__ g1, int ld_g1,
+                                                    const float* __restrict__ g2, int ld_g2,
+                                                    const float* __restrict__ stats, double* __restrict__ part, int HW,
+                                                    int C, int G, int pix_per_chunk, int act, float drop_p,
+                                                    uint64_t seed) {
+    __shared__ double red[2 * VEC][256];
+    const int tid = threadIdx.x, cu = tid % G, pl = tid / G, PL = 256 / G;
+    const int c0 = (blockIdx.x * G + cu) * VEC;
+    const int chunk = blockIdx.y, nchunk = gridDim.y, n = blockIdx.z;
+    const bool on = c0 < C;
+    const long nb = (long)n * HW;
+    const int p_begin = chunk * pix_per_chunk, p_end = min(HW, p_begin + pix_per_chunk);
+    float mean[VEC], rstd[VEC];
+    if (BWD) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            mean[k] = on ? stats[((long)n * C + c0 + k) * 2 + 0] : 0.f;
+            rstd[k] = on ? stats[((long)n * C + c0 + k) * 2 + 1] : 0.f;
+        }
+    }
+    const float keep_scale = 1.f / (1.f - drop_p);
+    double s1[VEC], s2[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s1[k] = s2[k] = 0.0;
+    if (on)
+        for (int pix = p_begin + pl; pix < p_end; pix += PL) {
+            Vec<VEC> v = vload<VEC>(y + (nb + pix) * ld_y + c0);
+            if (!BWD) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const double d = (double)v.v[k];
+                    s1[k] += d;
+                    s2[k] += d * d;
+                }
+            } else {
+                Vec<VEC> g = vload<VEC>(g1 + (nb + pix) * ld_g1 + c0);
+                if (g2) {
+                    Vec<VEC> h = vload<VEC>(g2 + (nb + pix) * ld_g2 + c0);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) g.v[k] += h.v[k];
+                }
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float gg = g.v[k];
+                    if (drop_p > 0.f) {
+                        const uint64_t e = ((uint64_t)n * HW + pix) * C + c0 + k;
+                        gg = pg_dropout_keep(seed, e, drop_p) ? gg * keep_scale : 0.f;
+                    }
+                    const float z = __fadd_rn(__fmul_rn(v.v[k], rstd[k]), -mean[k] * rstd[k]);
+                    const float dz = gg * pg_norm_act_grad(z, act);
+                    s1[k] += (double)dz;
+                    s2[k] += (double)dz * (double)(v.v[k] - mean[k]);
+                }
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        red[k][tid] = s1[k];
+        red[VEC + k][tid] = s2[k];
+    }
+    lane_tree<2 * VEC>(red, tid, G);
+    if (on && pl == 0) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            double* o = part + (((long)n * nchunk + chunk) * C + c0 + k) * 2;
+            o[0] = red[k][cu];
+            o[1] = red[VEC + k][cu];
+        }
+    }
+}
+
+// merge the chunk partials of one (n, c) in chunk order.  FWD: stats = (mean, rstd).  BWD: coef = (gmean, kk).
+template <bool BWD>
+__global__ void k_in_merge(const double* __restrict__ part, int nchunk, int NC, int C, int HW, float eps,
+                           float* __restrict__ stats, float* __restrict__ coef) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    const int n = i / C, c = i - n * C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        const double* p = part + (((long)n * nchunk + k) * C + c) * 2;
+        s1 += p[0];
+        s2 += p[1];
+    }
+    if (!BWD) {
+        const double mean = s1 / (double)HW;
+        double var = s2 / (double)HW - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        stats[(long)i * 2 + 0] = (float)mean;
+        stats[(long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+        const double rstd = (double)stats[(long)i * 2 + 1];
+        coef[(long)i * 2 + 0] = (float)(s1 / (double)HW);
+        coef[(long)i * 2 + 1] = (float)(s2 * rstd * rstd / (double)HW);
+    }
+}
+
+template <int VEC, bool BWD>
+__global__ void k_in_apply(const float* __restrict__ y, int ld_y, const float* __restrict__ g1, int ld_g1,
+                           const float* __restrict__ g2, int ld_g2, const float* __restrict__ stats,
+                           const float* __restrict__ coef, float* __restrict__ out, int ld_out, int N, int HW, int C,
+                           int act, float drop_p, uint64_t seed) {
+    const int cq = C / VEC;
+    const long total = (long)N * HW * cq;
+    const float keep_scale = 1.f / (1.f - drop_p);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cq;
+        const int c0 = (int)(i - pix * cq) * VEC;
+        const int n = (int)(pix / HW);
+        const float* st = stats + ((long)n * C + c0) * 2;
+        Vec<VEC> v = vload<VEC>(y + pix * ld_y + c0), o;
+        if (!BWD) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float mf = st[2 * k], rs = st[2 * k + 1];
+                float a = pg_act(__fadd_rn(__fmul_rn(v.v[k], rs), -mf * rs), act);
+                if (drop_p > 0.f) a = pg_dropout_keep(seed, (uint64_t)pix * C + c0 + k, drop_p) ? a * keep_scale : 0.f;
+                o.v[k] = a;
+            }
+        } else {
+            const float* cf = coef + ((long)n * C + c0) * 2;
+            Vec<VEC> g = vload<VEC>(g1 + pix * ld_g1 + c0);
+            if (g2) {
+                Vec<VEC> h = vload<VEC>(g2 + pix * ld_g2 + c0);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) g.v[k] += h.v[k];
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float mf = st[2 * k], rs = st[2 * k + 1];
+                float gg = g.v[k];
+                if (drop_p > 0.f) gg = pg_dropout_keep(seed, (uint64_t)pix * C + c0 + k, drop_p) ? gg * keep_scale : 0.f;
+                const float z = __fadd_rn(__fmul_rn(v.v[k], rs), -mf * rs);
+                const float dz = gg * pg_norm_act_grad(z, act);
+                o.v[k] = (dz - cf[2 * k] - (v.v[k] - mf) * cf[2 * k + 1]) * rs;
+            }
+        }
+        vstore<VEC>(out + pix * ld_out + c0, o);
+    }
+}
+
 template <int VEC>
 __global__ void k_act_fwd(const float* __restrict__ y, int ld_y, float* __restrict__ out, int ld_out, long npix, int C,
                           int act, float drop_p, uint64_t seed) {
@@ -309,6 +471,35 @@ int pick_group(int N, int units) {
     return G;
 }
 
+// chunked InstanceNorm plan: channel-group width G (as wide as the channels allow, <= 64 units), pixel chunks so
+// that the grid has >= ~2048 workgroups; planes under 2048 pixels keep the single-workgroup kernels
+struct ChunkPlan {
+    int G, groups, nchunk, ppc;
+    size_t part_bytes, coef_bytes;
+};
+ChunkPlan chunk_plan(int N, int HW, int C, int vecw) {
+    ChunkPlan p;
+    const int units = C / vecw;
+    int G = 1;
+    while (G < 64 && G * 2 <= units) G *= 2;
+    p.G = G;
+    p.groups = (units + G - 1) / G;
+    int nchunk = 1;
+    if (HW >= 2048) {
+        const int PL = 256 / G;
+        long want = (2048 + (long)N * p.groups - 1) / ((long)N * p.groups);
+        long maxc = HW / (PL * 2);            // at least two pixels per lane per chunk
+        if (want > maxc) want = maxc;
+        if (want > 1024) want = 1024;
+        nchunk = want < 1 ? 1 : (int)want;
+    }
+    p.ppc = (HW + nchunk - 1) / nchunk;
+    p.nchunk = (HW + p.ppc - 1) / p.ppc;
+    p.part_bytes = ((size_t)N * p.nchunk * C * 2 * sizeof(double) + 255) & ~(size_t)255;
+    p.coef_bytes = ((size_t)N * C * 2 * sizeof(float) + 255) & ~(size_t)255;
+    return p;
+}
+
 int ew_blocks(long total) {
     long b = (total + 255) / 256;
     if (b > 8192) b = 8192;
@@ -320,13 +511,44 @@ int ew_blocks(long total) {
 
 extern "C" {
 
+size_t pg_instnorm_workspace_bytes(int N, int HW, int C) {
+    if (N <= 0 || HW <= 0 || C <= 0) return 0;
+    ChunkPlan a = chunk_plan(N, HW, C, 4), b = chunk_plan(N, HW, C, 1);
+    const size_t x = a.part_bytes + a.coef_bytes, y = b.part_bytes + b.coef_bytes;
+    return x > y ? x : y;
+}
+
 int pg_instnorm_act_fwd(const float* y, int ld_y, float* out, int ld_out, float* stats, int N, int HW, int C,
-                        int act, float eps, float drop_p, uint64_t seed, void* stream) {
+                        int act, float eps, float drop_p, uint64_t seed, void* ws, size_t ws_bytes, void* stream) {
     if (!y || !out || !stats || N <= 0 || HW <= 0 || C <= 0 || ld_y < C || ld_out < C) return PG_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID) return PG_EINVAL;
     if (N > 65535) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (C % 4 == 0) && (ld_y % 4 == 0) && (ld_out % 4 == 0) && al16(y) && al16(out);
+    ChunkPlan cp = chunk_plan(N, HW, C, vec ? 4 : 1);
+    if (cp.nchunk > 1 && ws && ws_bytes >= cp.part_bytes) {
+        double* part = (double*)ws;
+        dim3 grid(cp.groups, cp.nchunk, N);
+        if (vec)
+            hipLaunchKernelGGL((k_in_partial<4, false>), grid, dim3(256), 0, st, y, ld_y, (const float*)nullptr, 0,
+                               (const float*)nullptr, 0, (const float*)nullptr, part, HW, C, cp.G, cp.ppc, act, drop_p, seed);
+        else
+            hipLaunchKernelGGL((k_in_partial<1, false>), grid, dim3(256), 0, st, y, ld_y, (const float*)nullptr, 0,
+                               (const float*)nullptr, 0, (const float*)nullptr, part, HW, C, cp.G, cp.ppc, act, drop_p, seed);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        hipLaunchKernelGGL((k_in_merge<false>), dim3((N * C + 255) / 256), dim3(256), 0, st, part, cp.nchunk, N * C, C, HW, eps,
+                           stats, (float*)nullptr);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        if (vec)
+            hipLaunchKernelGGL((k_in_apply<4, false>), dim3(ew_blocks((long)N * HW * (C / 4))), dim3(256), 0, st, y, ld_y,
+                               (const float*)nullptr, 0, (const float*)nullptr, 0, stats, (const float*)nullptr, out,
+                               ld_out, N, HW, C, act, drop_p, seed);
+        else
+            hipLaunchKernelGGL((k_in_apply<1, false>), dim3(ew_blocks((long)N * HW * C)), dim3(256), 0, st, y, ld_y,
+                               (const float*)nullptr, 0, (const float*)nullptr, 0, stats, (const float*)nullptr, out,
+                               ld_out, N, HW, C, act, drop_p, seed);
+        return pg_launch_status();
+    }
     if (vec) {
         const int units = C / 4, G = pick_group(N, units);
         hipLaunchKernelGGL(k_instnorm_fwd<4>, dim3((units + G - 1) / G, N), dim3(256), 0, st, y, ld_y, out, ld_out, stats,
@@ -341,13 +563,36 @@ int pg_instnorm_act_fwd(const float* y, int ld_y, float* out, int ld_out, float*
 
 int pg_instnorm_act_bwd(const float* g1, int ld_g1, const float* g2, int ld_g2, const float* y, int ld_y,
                         const float* stats, float* dy, int ld_dy, int N, int HW, int C, int act, float drop_p,
-                        uint64_t seed, void* stream) {
+                        uint64_t seed, void* ws, size_t ws_bytes, void* stream) {
     if (!g1 || !y || !stats || !dy || N <= 0 || HW <= 0 || C <= 0) return PG_EINVAL;
     if (ld_g1 < C || ld_y < C || ld_dy < C || (g2 && ld_g2 < C)) return PG_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID || N > 65535) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (C % 4 == 0) && (ld_g1 % 4 == 0) && (ld_y % 4 == 0) && (ld_dy % 4 == 0) && al16(g1) && al16(y) &&
                      al16(dy) && (!g2 || ((ld_g2 % 4 == 0) && al16(g2)));
+    ChunkPlan cp = chunk_plan(N, HW, C, vec ? 4 : 1);
+    if (cp.nchunk > 1 && ws && ws_bytes >= cp.part_bytes + cp.coef_bytes) {
+        double* part = (double*)ws;
+        float* coef = (float*)((char*)ws + cp.part_bytes);
+        dim3 grid(cp.groups, cp.nchunk, N);
+        if (vec)
+            hipLaunchKernelGGL((k_in_partial<4, true>), grid, dim3(256), 0, st, y, ld_y, g1, ld_g1, g2, ld_g2, stats, part, HW,
+                               C, cp.G, cp.ppc, act, drop_p, seed);
+        else
+            hipLaunchKernelGGL((k_in_partial<1, true>), grid, dim3(256), 0, st, y, ld_y, g1, ld_g1, g2, ld_g2, stats, part, HW,
+                               C, cp.G, cp.ppc, act, drop_p, seed);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        hipLaunchKernelGGL((k_in_merge<true>), dim3((N * C + 255) / 256), dim3(256), 0, st, part, cp.nchunk, N * C, C, HW, 0.f,
+                           const_cast<float*>(stats), coef);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        if (vec)
+            hipLaunchKernelGGL((k_in_apply<4, true>), dim3(ew_blocks((long)N * HW * (C / 4))), dim3(256), 0, st, y, ld_y, g1,
+                               ld_g1, g2, ld_g2, stats, coef, dy, ld_dy, N, HW, C, act, drop_p, seed);
+        else
+            hipLaunchKernelGGL((k_in_apply<1, true>), dim3(ew_blocks((long)N * HW * C)), dim3(256), 0, st, y, ld_y, g1, ld_g1,
+                               g2, ld_g2, stats, coef, dy, ld_dy, N, HW, C, act, drop_p, seed);
+        return pg_launch_status();
+    }
     if (vec) {
         const int units = C / 4, G = pick_group(N, units);
         hipLaunchKernelGGL(k_instnorm_bwd<4>, dim3((units + G - 1) / G, N), dim3(256), 0, st, g1, ld_g1, g2, ld_g2, y,

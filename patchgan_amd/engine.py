@@ -203,14 +203,18 @@ def instnorm_act_fwd(y, out, stats, act, drop_p=0.0, seed=0):
     if y.HW <= 1:
         raise ValueError(f"Expected more than 1 spatial element when training, got input size "
                          f"torch.Size([{y.N}, {y.C}, {y.H}, {y.W}])")
+    ws = _workspace(int(L.load().pg_instnorm_workspace_bytes(y.N, y.HW, y.C)), y.t.device)
     L.check(L.load().pg_instnorm_act_fwd(y.ptr(), y.ld, out.ptr(), out.ld, stats.data_ptr(), y.N, y.HW, y.C, act, 1e-5,
-                                         drop_p, seed & _MASK64, _stream()), 'pg_instnorm_act_fwd')
+                                         drop_p, seed & _MASK64, ws.data_ptr(), ws.numel(), _stream()),
+            'pg_instnorm_act_fwd')
 
 
 def instnorm_act_bwd(g1, g2, y, stats, dy, act, drop_p=0.0, seed=0):
+    ws = _workspace(int(L.load().pg_instnorm_workspace_bytes(y.N, y.HW, y.C)), y.t.device)
     L.check(L.load().pg_instnorm_act_bwd(g1.ptr(), g1.ld, g2.ptr() if g2 is not None else None,
                                          g2.ld if g2 is not None else 0, y.ptr(), y.ld, stats.data_ptr(), dy.ptr(), dy.ld,
-                                         y.N, y.HW, y.C, act, drop_p, seed & _MASK64, _stream()), 'pg_instnorm_act_bwd')
+                                         y.N, y.HW, y.C, act, drop_p, seed & _MASK64, ws.data_ptr(), ws.numel(), _stream()),
+            'pg_instnorm_act_bwd')
 
 
 def act_bwd(g1, g2, a, dy, act):

@@ -40,7 +40,7 @@ def test_workspace_query_and_arg_validation():
     # argument validation happens before any launch, so it is safe without a GPU
     assert lib.pg_conv4x4_big2small(None, 4, None, None, None, 4, ctypes.byref(g), 0, 0, None, 0, None) == -1
     assert lib.pg_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.1, 0.03, None) == -1
-    assert lib.pg_instnorm_act_fwd(None, 4, None, 4, None, 1, 4, 4, 0, 1e-5, 0.0, 0, None) == -1
+    assert lib.pg_instnorm_act_fwd(None, 4, None, 4, None, 1, 4, 4, 0, 1e-5, 0.0, 0, None, 0, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

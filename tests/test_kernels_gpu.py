@@ -120,7 +120,8 @@ def test_mfma_matches_direct_bitwise_shapes():
     assert rel_err(outs[1], want) < 1e-5
 
 
-@pytest.mark.parametrize('shape', [(2, 8, 4, 4), (2, 64, 16, 16), (3, 6, 5, 7), (2, 512, 2, 2), (1, 4, 64, 64)])
+@pytest.mark.parametrize('shape', [(2, 8, 4, 4), (2, 64, 16, 16), (3, 6, 5, 7), (2, 512, 2, 2), (1, 4, 64, 64),
+                                   (2, 64, 64, 64), (2, 6, 50, 47), (1, 136, 48, 48)])
 @pytest.mark.parametrize('act', ['leakyrelu', 'relu', 'tanh', 'none'])
 def test_instnorm_fwd_bwd(shape, act):
     from patchgan_amd import engine as E
