@@ -435,9 +435,14 @@ class GeneratorEngine:
             src = cat
         return c
 
-    def backward(self, flat, gflat, c, g1, g2=None, need_dx=False):
+    def backward(self, flat, gflat, c, g1, g2=None, need_dx=False, on_ready=None):
         """g1 (+ g2): Views of dL/d(gen_out).  Writes every weight gradient into `gflat` (packed layout);
-        returns dL/dx as a View if need_dx."""
+        returns dL/dx as a View if need_dx.  on_ready(lo, hi) is called after each layer's weight gradient has been
+        enqueued with that layer's range of the flat buffer (last layer first): the hook data parallelism uses to
+        start all-reducing finished buckets under the rest of the backward pass."""
+        def done(l):
+            if on_ready is not None:
+                on_ready(l.p_off, l.p_off + 16 * l.a * l.b)
         N, dev = c.N, flat.device
         enc_ops, dec_ops = self.ops(c.N, c.H, c.W)
         act = L.ACT_CODES[self.activation]
@@ -449,6 +454,7 @@ class GeneratorEngine:
         else:
             act_bwd(g1, g2, c.gen_out, dy, L.ACT_CODES[self.final_act])
         op.wgrad(c.cat[6], dy, gflat, l.p_off)
+        done(l)
         dcat = View.alloc(N, op.Hs, op.Ws, l.a, dev)
         op.big2small(dy, flat, l.p_off, None, 0, dcat)
         dskip = [None] * 7   # dskip[j]: gradient wrt enc_j output arriving through the skip connection
@@ -464,6 +470,7 @@ class GeneratorEngine:
                 act_bwd(g, None, c.cat[i + 1].channels(0, l.b), dy, act)
             src = c.hidden if i == 0 else c.cat[i]
             op.wgrad(src, dy, gflat, l.p_off)
+            done(l)
             dsrc = View.alloc(N, op.Hs, op.Ws, l.a, dev)
             op.big2small(dy, flat, l.p_off, None, 0, dsrc)
             dcat = dsrc
@@ -478,6 +485,7 @@ class GeneratorEngine:
                              _mix_seed(c.seed, 1, j))
             src = c.xin if j == 0 else c.enc_out[j - 1]
             op.wgrad(dy, src, gflat, l.p_off)
+            done(l)
             if j > 0 or need_dx:
                 dsrc = View.alloc(N, op.Hb, op.Wb, l.b, dev)
                 op.small2big(dy, flat, l.p_off, None, 0, dsrc)

@@ -24,6 +24,7 @@ import tqdm
 
 from . import _lib as L
 from . import engine as E
+from .parallel import Dist as _Dist, GradReducer
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
 
@@ -34,22 +35,6 @@ def weights_init(net, init_type='normal', scaling=0.02):
     """The reference's ``weights_init`` defines an inner function and never applies it (trainer.py:327-343):
     a no-op, so torch's default initialisation stays.  Kept as a no-op for parity."""
     return None
-
-
-class _Dist:
-    """Thin view of torch.distributed (absent / uninitialised -> single process)."""
-
-    def __init__(self):
-        import torch.distributed as dist
-        self.dist = dist
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.world = dist.get_world_size() if self.on else 1
-        self.rank = dist.get_rank() if self.on else 0
-
-    def all_reduce(self, t, async_op=False):
-        if self.on:
-            return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=async_op)
-        return None
 
 
 class Trainer:
@@ -76,7 +61,7 @@ class Trainer:
         self._adam = None          # (gm, gv, dm, dv) flat moment buffers
         self._t_g = self._t_d = 0  # Adam step counts
         self._step = 0
-        self._comm_stream = None
+        self.bucket_bytes = 32 << 20   # all-reduce bucket size under data parallelism (parallel.GradReducer)
 
     # -------------------------------------------------------------------------------------- optimizers
     def setup_optimizers(self, gen_lr=1e-3, dsc_lr=1e-3):
@@ -132,11 +117,19 @@ class Trainer:
         o = dc.out
         gd = E.View.alloc(o.N, o.H, o.W, 1, dev) if train else None
         E.loss_value_and_grad(o, None, 1.0, L.LOSS_BCE, 1.0, gd, losses, 1, Bglobal)          # trainer.py:84
+        g_reducer = None
         if train:
             gflat = G.ensure_grad_flat()
             ddin = de.backward(D.flat, None, dc, gd, need_wgrad=False, need_dx=True)          # dL/d(x|gen)
-            ge.backward(G.flat, gflat, gc, gseg, ddin.channels(Cin, Cout))                    # trainer.py:88-89
-            self._reduce_and_step(dist, G.flat, gflat, self._adam[0], self._adam[1], 'g')     # trainer.py:90
+            if dist.on:
+                # buckets of the flat G gradient are all-reduced on RCCL's stream as backward finishes them; the
+                # collective keeps running under the discriminator step below (which does not read G's new weights:
+                # gen_img.detach() is the pre-update output, trainer.py:98)
+                g_reducer = GradReducer(dist, gflat, self.bucket_bytes)
+            ge.backward(G.flat, gflat, gc, gseg, ddin.channels(Cin, Cout),                    # trainer.py:88-89
+                        on_ready=g_reducer.ready if g_reducer is not None else None)
+            if g_reducer is None:
+                self._adam_step('g')                                                          # trainer.py:90
         del dc
 
         # ---- discriminator step: real and (pre-update, detached) fake in one 2N batch        trainer.py:96-99
@@ -150,7 +143,11 @@ class Trainer:
         if train:
             dflat = D.ensure_grad_flat()
             de.backward(D.flat, dflat, dc2, god, need_wgrad=True, need_dx=False)              # trainer.py:106
-            self._reduce_and_step(dist, D.flat, dflat, self._adam[2], self._adam[3], 'd')     # trainer.py:107
+            if g_reducer is not None:
+                g_reducer.finish()                 # G's buckets have been in flight since the generator backward
+                self._adam_step('g')
+                dist.all_reduce(dflat)             # 11 MB at ndf=64: one bucket
+            self._adam_step('d')                                                              # trainer.py:107
 
         if dist.on:
             # seg loss: tversky is already global; the BCE/MAE terms are per-rank partial means
@@ -169,15 +166,14 @@ class Trainer:
         vals = [float(gen_loss), float(gen_loss), float(gdisc), float(loss_real), float(loss_fake), float(disc_loss)]
         return dict(zip(keys, vals))
 
-    def _reduce_and_step(self, dist, flat, gflat, m, v, which):
-        if dist.on:
-            dist.all_reduce(gflat)
+    def _adam_step(self, which):
         if which == 'g':
             self._t_g += 1
-            E.adam_step(flat, gflat, m, v, self._t_g, self.gen_lr)
+            E.adam_step(self.generator.flat, self.generator.grad_flat, self._adam[0], self._adam[1], self._t_g, self.gen_lr)
         else:
             self._t_d += 1
-            E.adam_step(flat, gflat, m, v, self._t_d, self.dsc_lr)
+            E.adam_step(self.discriminator.flat, self.discriminator.grad_flat, self._adam[2], self._adam[3], self._t_d,
+                        self.dsc_lr)
 
     # -------------------------------------------------------------------------------------- epoch driver
     def train(self, train_data, val_data, epochs, dsc_learning_rate=1.e-3, gen_learning_rate=1.e-3, save_freq=10,

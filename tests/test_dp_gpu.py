@@ -1,0 +1,74 @@
+"""Data-parallel G+D step on the GPU: two ranks (gloo over CUDA tensors, both on the one visible GPU) each train on
+half of a golden batch; the all-reduced result must track the single-process golden loss curve.  Needs an MI355X."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q, name, nsteps):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(4)
+    import tempfile
+    import patchgan_amd as pg
+    from patchgan_amd.parallel import shard_batch
+    from tests.golden_util import Golden, LOSS_KEYS
+    gold = Golden(name)
+    c = gold.cfg
+    g = pg.UNet(c['in_nc'], c['out_nc'], c['nf'], activation=c['activation'], final_act=c['final_act'])
+    d = pg.Discriminator(c['in_nc'] + c['out_nc'], c['ndf'], n_layers=c['n_layers'], norm=c['norm'])
+    g.load_state_dict(gold.weights('g0'))
+    d.load_state_dict(gold.weights('d0'))
+    g.cuda()
+    d.cuda()
+    t = pg.Trainer(g, d, tempfile.mkdtemp())
+    t.loss_type = c['loss_type']
+    t.bucket_bytes = 64 << 10          # several buckets even for the nf=4 generator
+    t.setup_optimizers(1e-3, 1e-3)
+    g.train()
+    d.train()
+    x, y = gold.inputs()
+    xs, ys = shard_batch(x, y, rank, world)
+    curve = []
+    for s in range(nsteps):
+        l = t.batch(xs, ys, train=True)
+        curve.append([l[k] for k in LOSS_KEYS])
+    torch.cuda.synchronize()
+    q.put((rank, np.array(curve), g.flat.cpu().numpy(), d.flat.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name', ['a_lrelu_tversky', 'b_tanh_wbce_norm'])
+def test_two_rank_step_matches_single_process_golden(name):
+    from tests.golden_util import Golden
+    gold = Golden(name)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    nsteps = 5
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, name, nsteps)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, c0, g0, d0), (_, c1, g1, d1) = res
+    # both ranks hold identical weights and report identical (all-reduced) losses
+    assert np.array_equal(g0, g1) and np.array_equal(d0, d1)
+    assert np.allclose(c0, c1, rtol=1e-6)
+    want = gold.z['losses'][:nsteps]
+    err = np.abs(c0 - want) / np.maximum(np.abs(want), 1e-6)
+    print(name, 'dp2 vs single-process golden: max rel err per step', err.max(axis=1))
+    assert err.max() < 1e-4, err

@@ -1,0 +1,137 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel plumbing: bucketed asynchronous gradient all-reduce, batch
+sharding, and the exactness recipe for the batch-non-linear losses, checked with the CPU oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+
+
+def _reducer_worker(rank, world, port, q):
+    _init(rank, world, port)
+    from patchgan_amd.parallel import Dist, GradReducer
+    d = Dist()
+    assert d.on and d.world == world and d.rank == rank
+    n = 1000
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    r = GradReducer(d, flat, bucket_bytes=4 * 300)          # 300-element buckets
+    # layers complete last-to-first in uneven pieces
+    edges = [1000, 900, 650, 640, 300, 120, 0]
+    for hi, lo in zip(edges[:-1], edges[1:]):
+        r.ready(lo, hi)
+    with pytest.raises(RuntimeError):
+        r.ready(500, 600)                                    # not contiguous with what came before
+    r.finish()
+    want = torch.arange(n, dtype=torch.float32) * sum(range(1, world + 1))
+    ok = torch.equal(flat, want)
+    # buckets: launched when >= 300 elements are pending, remainder at finish; together they tile [0, n)
+    ranges = sorted(r.launched)
+    tiles = ranges[0][0] == 0 and ranges[-1][1] == n and all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+    q.put((rank, ok, tiles, r.launched))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2():
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, tiles, launched in res:
+        assert ok and tiles, (rank, launched)
+        assert launched[0] == (650, 1000) and launched[1] == (300, 650), launched
+
+
+def _exactness_worker(rank, world, port, q, loss_type):
+    """Each rank differentiates ITS shard with the loss seeded by the global terms; the SUM of the per-rank gradients
+    must equal the single-process gradient of the whole batch (what Trainer + pg_loss_finalize implement on the GPU)."""
+    _init(rank, world, port)
+    from oracle import patchgan_oracle as O
+    from patchgan_amd.parallel import Dist, shard_batch
+    d = Dist()
+    g = torch.Generator().manual_seed(11)
+    B, C = 4, 3
+    p_all = torch.rand(B, C, 16, 16, generator=g).clamp(0.01, 0.99)
+    y_all = (torch.rand(B, C, 16, 16, generator=g) > 0.6).float()
+    # single-process reference
+    pr = p_all.clone().requires_grad_(True)
+    full = O.seg_loss(loss_type, pr, y_all, 200)
+    full.backward()
+    p, y = shard_batch(p_all, y_all, rank, world)
+    p = p.clone().requires_grad_(True)
+    if loss_type == 'tversky':
+        tp = (y * p).sum((1, 2, 3)); fn = ((1 - p) * y).sum((1, 2, 3)); fp = (p * (1 - y)).sum((1, 2, 3))
+        one_minus_t = 1 - (tp + 1) / (tp + 0.75 * fn + 0.25 * fp + 1)
+        s = one_minus_t.sum().detach().clone()
+        d.all_reduce(s)                                        # global sum_b (1 - T_b)
+        m = s / B
+        # d/dp [200 m^g] = 200 g m^(g-1) / B * d(sum_b (1-T_b))/dp : seed the LOCAL sum with the GLOBAL factor
+        local = (200 * 0.75 * m ** (0.75 - 1) / B) * one_minus_t.sum()
+        value = 200 * m ** 0.75
+    elif loss_type == 'weighted_bce':
+        sy = y.sum().clone()
+        d.all_reduce(sy)                                       # global sum(y)
+        w = 1 - y.sum((2, 3), keepdim=True) / sy
+        local = 200 * (torch.nn.functional.binary_cross_entropy(p, y, weight=w, reduction='sum') / (B * C * 256))
+        value = local.detach().clone()
+        d.all_reduce(value)
+    else:
+        local = 200 * (p - y).abs().sum() / (B * C * 256)
+        value = local.detach().clone()
+        d.all_reduce(value)
+    local.backward()
+    gfull = torch.zeros_like(p_all)
+    per = B // world
+    gfull[rank * per:(rank + 1) * per] = p.grad
+    d.all_reduce(gfull)
+    err = ((gfull - pr.grad).abs().max() / pr.grad.abs().max()).item()
+    q.put((rank, err, abs(float(value) - full.item()) / abs(full.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('loss_type', ['tversky', 'weighted_bce', 'MAE'])
+def test_sharded_loss_seeds_are_exact(loss_type):
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exactness_worker, args=(r, 2, port, q, loss_type)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, gerr, verr in res:
+        assert gerr < 1e-5 and verr < 1e-5, (rank, gerr, verr)
+
+
+def test_shard_batch():
+    from patchgan_amd.parallel import shard_batch
+    x = torch.arange(8).view(8, 1)
+    a, b = shard_batch(x, x, 1, 4)
+    assert a.flatten().tolist() == [2, 3]
+    with pytest.raises(ValueError):
+        shard_batch(x, x, 0, 3)
