@@ -178,11 +178,44 @@ def run_train_driver():
     print('train_driver', out['G_loss_ep'], out['lr_after_epochs'][:, 0], out['resume_start'], flush=True)
 
 
+def run_infer_tiles():
+    """n_crop / build_mask of the reference (infer.py:14-68).  patchgan.infer imports torchinfo and torchvision at module
+    scope (absent here); the two functions are pure numpy/torch, so empty placeholder modules are registered for the
+    import only."""
+    import types
+    for name in ('torchinfo', 'torchvision', 'torchvision.io', 'torchvision.transforms'):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.summary = m.read_image = m.ImageReadMode = None
+            sys.modules[name] = m
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    sys.modules['torchvision'].io = sys.modules['torchvision.io']
+    sys.path.insert(0, REF)
+    from patchgan.infer import n_crop, build_mask
+    out = {}
+    g = torch.Generator().manual_seed(3)
+    for tag, (c, h, w, size, overlap, thr) in {'sq1024': (3, 1024, 1024, 256, 0.9, 0.0), 'sq600': (2, 600, 600, 256, 0.9, 0.4),
+                                               'sq300_1c': (1, 300, 300, 256, 0.5, 0.5)}.items():
+        img = torch.rand(c, h, w, generator=g)
+        crops = n_crop(img, size, overlap)
+        out[f'{tag}/ncrops'] = np.array(crops.shape)
+        out[f'{tag}/crop_probe'] = probe(crops)
+        masks = torch.rand(crops.shape[0], c, size, size, generator=g).numpy()
+        m = build_mask(masks, size, (h, w), thr, overlap)
+        out[f'{tag}/mask_shape'] = np.array(m.shape)
+        out[f'{tag}/mask_probe'] = probe(torch.as_tensor(np.ascontiguousarray(m)))
+        out[f'{tag}/params'] = np.array([c, h, w, size, overlap, thr], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, 'infer_tiles.npz'), **out)
+    print('infer_tiles', {k: v.tolist() for k, v in out.items() if k.endswith('ncrops')}, flush=True)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
-    which = sys.argv[1:] or (list(CONFIGS) + ['train_driver'])
+    which = sys.argv[1:] or (list(CONFIGS) + ['train_driver', 'infer_tiles'])
     for name in which:
-        if name == 'train_driver':
+        if name == 'infer_tiles':
+            run_infer_tiles()
+        elif name == 'train_driver':
             run_train_driver()
         else:
             run_config(name, CONFIGS[name])

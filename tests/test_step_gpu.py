@@ -172,3 +172,38 @@ def test_checkpoint_roundtrip(tmp_path):
     assert t.start == 4
     for k, v in gold.weights('g0').items():
         assert torch.equal(t.generator.state_dict()[k].cpu(), v)
+
+
+def test_train_driver_vs_golden(tmp_path):
+    """Trainer.train (epoch loop, Adam re-creation, ExponentialLR every decay_freq epochs, checkpoint cadence, resume)
+    against tests/golden/train_driver.npz produced by the reference's Trainer.train."""
+    import os
+    import patchgan_amd as pg
+    from tests.golden_util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'train_driver.npz'))
+    gold = Golden('a_lrelu_tversky')
+    x, y = gold.inputs()
+    data = [(x[:1], y[:1]), (x[1:], y[1:])]
+
+    def fresh(folder):
+        g = pg.UNet(3, 1, 4, use_dropout=False, activation='leakyrelu', final_act='sigmoid')
+        d = pg.Discriminator(4, 4, n_layers=3)
+        g.load_state_dict(gold.weights('g0'))
+        d.load_state_dict(gold.weights('d0'))
+        return pg.Trainer(g.cuda(), d.cuda(), str(folder))
+
+    t = fresh(tmp_path / 'ck')
+    G_ep, D_ep = t.train(data, data[:1], 6, gen_learning_rate=1e-3, dsc_learning_rate=2e-3, lr_decay=0.9, decay_freq=2,
+                         save_freq=3)
+    np.testing.assert_allclose(G_ep, z['G_loss_ep'], rtol=1e-4)
+    np.testing.assert_allclose(D_ep, z['D_loss_ep'], rtol=1e-4)
+    np.testing.assert_allclose([t.gen_lr, t.dsc_lr], z['lr_after_epochs'][5], rtol=1e-12)
+    assert sorted(os.listdir(tmp_path / 'ck')) == list(z['ckpt_files'])
+    t2 = fresh(tmp_path / 'ck')
+    t2.load_last_checkpoint()
+    assert t2.start == int(z['resume_start'][0])
+    G2, D2 = t2.train(data, data[:1], 7, gen_learning_rate=1e-3, dsc_learning_rate=2e-3, lr_decay=0.9, decay_freq=2,
+                      save_freq=3)
+    np.testing.assert_allclose(G2, z['resume_G_loss_ep'], rtol=1e-4)
+    np.testing.assert_allclose(D2, z['resume_D_loss_ep'], rtol=1e-4)
+    np.testing.assert_allclose([t2.gen_lr, t2.dsc_lr], z['resume_lr'], rtol=1e-12)
