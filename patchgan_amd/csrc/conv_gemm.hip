@@ -812,8 +812,19 @@ __global__ __launch_bounds__(256) void k_wgrad_tapn(const float* __restrict__ X,
 // ================================================================================================
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int OOB = 0x7fffffff;
+// Scheduling fence that only vector-memory instructions may not cross (LLVM sched_barrier mask: ALU | VALU | SALU |
+// DS | DS-read | DS-write may; MFMA and VMEM may not).  Without it hipcc sinks the next chunk's buffer loads to the END of the MFMA
+// sequence (to shorten their destination registers' live ranges), so their latency lands on the barrier instead of
+// under 48 MFMAs.
+#define PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
 // element offset -> byte offset without signed overflow (sentinel offsets exceed INT_MAX/4 on purpose)
 __device__ __forceinline__ int b4(int elem_off) { return (int)((unsigned)elem_off << 2); }
+// byte offset of a gather element, forced out of range (bit 31 set: >= 2 GiB > any descriptor here) when !ok.
+// Written as an OR so the offset arithmetic stays unconditional: with `ok ? off : OOB` hipcc sinks the arithmetic into
+// an exec-masked region per load, which splits the MFMA loop into many scheduling regions.
+__device__ __forceinline__ int voff(int elem_off, bool ok) {
+    return (int)(((unsigned)elem_off << 2) | (ok ? 0u : 0x80000000u));
+}
 
 __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
@@ -863,12 +874,11 @@ __global__ __launch_bounds__(256) void k_b2s_fast(const float* __restrict__ big,
         const int p = rem / g.Ws, q = rem - p * g.Ws;
         const int h0 = g.s * p - 1, w0 = g.s * q - 1;
         a_off[i] = ((n * g.Hb + h0) * g.Wb + w0) * ld_big;
-        int mask = 0;
+        int wv = 0, mask = 0;          // tap (kh, kw) is inside the image iff row kh and column kw both are
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int h = h0 + (t >> 2), w = w0 + (t & 3);
-            if ((unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb) mask |= 1 << t;
-        }
+        for (int t = 0; t < 4; ++t) wv |= ((unsigned)(w0 + t) < (unsigned)g.Wb) ? (1 << t) : 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mask |= ((unsigned)(h0 + t) < (unsigned)g.Hb) ? (wv << (4 * t)) : 0;
         a_mask[i] = (m < M) ? mask : 0;
     }
 #pragma unroll
@@ -894,9 +904,9 @@ __global__ __launch_bounds__(256) void k_b2s_fast(const float* __restrict__ big,
     };
     auto load_a = [&](int i, bool on) {
         const bool ok = on && ((a_mask[i] >> ctap) & 1);
-        ra[i] = bload4(rbig, ok ? b4(a_off[i] + tapoff) : OOB);
+        ra[i] = bload4(rbig, voff(a_off[i] + tapoff, ok));
     };
-    auto load_b = [&](int i, bool on) { rb[i] = bload4(rP, on ? b4(b_off[i] + pboff) : OOB); };
+    auto load_b = [&](int i, bool on) { rb[i] = bload4(rP, voff(b_off[i] + pboff, on)); };
     auto store_chunk = [&]() {
 #pragma unroll
         for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
@@ -935,6 +945,7 @@ __global__ __launch_bounds__(256) void k_b2s_fast(const float* __restrict__ big,
                 bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NR + j) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
             if (kk < AI) load_a(kk, more);
             if (kk < BI) load_b(kk, more);
+            PIN_VMEM();
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1016,12 +1027,11 @@ __global__ __launch_bounds__(256) void k_s2b_fast(const float* __restrict__ smal
         const int ii = rem / Wc, jj = rem - ii * Wc;
         const int ib = (g.s == 2) ? ii + ah : ii + 1, jb = (g.s == 2) ? jj + aw : jj + 1;
         a_off[i] = ((n * g.Hs + ib) * g.Ws + jb) * ld_small;
-        int mask = 0;
+        int wv = 0, mask = 0;          // local tap (th, tw) reads small pixel (ib - th, jb - tw)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int th = t >> Tsh, tw = t & (T - 1);
-            if (t < T * T && (unsigned)(ib - th) < (unsigned)g.Hs && (unsigned)(jb - tw) < (unsigned)g.Ws) mask |= 1 << t;
-        }
+        for (int t = 0; t < 4; ++t) wv |= (t < T && (unsigned)(jb - t) < (unsigned)g.Ws) ? (1 << t) : 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mask |= (t < T && (unsigned)(ib - t) < (unsigned)g.Hs) ? (wv << (T * t)) : 0;
         a_mask[i] = (m < Mc) ? mask : 0;
     }
     const int bn = tid % BN, bg = tid / BN;
@@ -1063,17 +1073,22 @@ __global__ __launch_bounds__(256) void k_s2b_fast(const float* __restrict__ smal
     };
     auto load_a = [&](int i, bool on) {
         const bool ok = on && ((a_mask[i] >> a_tl) & 1) && (a_koff < 0x10000000);
-        ra[i] = bload4(rsm, ok ? b4(a_off[i] + a_koff) : OOB);
+        ra[i] = bload4(rsm, voff(a_off[i] + a_koff, ok));
     };
     auto load_b = [&](int i, int c, bool on) {
         const int kb = c * KC + 4 * (bg + BG * i);
         int tl, a;
         quad(i + 1, tl, a);
+        if (BN >= 64) {   // a wave shares one k-quad (bg = tid / BN is wave-uniform): keep its decode on the scalar unit
+            tl = __builtin_amdgcn_readfirstlane(tl);
+            a = __builtin_amdgcn_readfirstlane(a);
+        }
         const int th = tl >> Tsh, tw = tl & (T - 1);
         const int tap = (kh0 + g.s * th) * 4 + (kw0 + g.s * tw);
         const bool ok = on && kb < K;
-        const int base = ok ? b4(tap * CaCb + a * g.Cb + ncol_off) : OOB;
-        const int st = ok ? g.Cb * 4 : 0;
+        const int rowoff = tap * CaCb + a * g.Cb;
+        const int base = voff(rowoff + ncol_off, ok);
+        const int st = g.Cb * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) rb[i][e] = bload1(rP, base + e * st);
     };
@@ -1115,6 +1130,7 @@ __global__ __launch_bounds__(256) void k_s2b_fast(const float* __restrict__ smal
                 bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NR + j) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
             if (kk < AI) load_a(kk, more);
             if (kk < NQ) load_b(kk, c + 1, more);
+            PIN_VMEM();
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1141,14 +1157,261 @@ __global__ __launch_bounds__(256) void k_s2b_fast(const float* __restrict__ smal
     }
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
+        // decode the lane's first row with two divisions, then walk the other 15 (at most 28 rows further) with a
+        // carry chain: 64 divisions per thread in the epilogue cost as much as several K-chunks
+        const int mb = m0 + (wm * MR + i) * 32 + 4 * lh;
+        const int mbc = min(mb, Mc - 1);
+        const int nb0 = mbc / (Hc * Wc);
+        const int remb = mbc - nb0 * (Hc * Wc);
+        const int ib0 = remb / Wc, jb0 = remb - ib0 * Wc;
+        const bool chain = Wc >= 16 && Hc >= 2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int m = m0 + (wm * MR + i) * 32 + row;
             if (m < Mc) {
-                const int n = m / (Hc * Wc);
-                const int rem = m - n * (Hc * Wc);
-                const int ii = rem / Wc, jj = rem - ii * Wc;
+                int n, ii, jj;
+                if (chain) {
+                    const int d = (r & 3) + 8 * (r >> 2);      // 0..27 rows past the decoded one
+                    jj = jb0 + d;
+                    ii = ib0;
+                    n = nb0;
+                    bool w1 = jj >= Wc;
+                    jj = w1 ? jj - Wc : jj;
+                    ii = w1 ? ii + 1 : ii;
+                    w1 = jj >= Wc;
+                    jj = w1 ? jj - Wc : jj;
+                    ii = w1 ? ii + 1 : ii;
+                    w1 = ii >= Hc;
+                    ii = w1 ? ii - Hc : ii;
+                    n = w1 ? n + 1 : n;
+                } else {
+                    n = m / (Hc * Wc);
+                    const int rem = m - n * (Hc * Wc);
+                    ii = rem / Wc;
+                    jj = rem - ii * Wc;
+                }
+                const int h = (g.s == 2) ? 2 * ii + ah : ii, w = (g.s == 2) ? 2 * jj + aw : jj;
+                float* orow = o + (long)((n * g.Hb + h) * g.Wb + w) * ldo;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int col = n0 + (wn * NR + j) * 32 + lrow;
+                    if (col < g.Cb) {
+                        float v = acc[i][j][r];
+                        if (fin) v = pg_act_epi(v + bv[j], act);
+                        orow[col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MR, int NR, int WM, int WN>
+__global__ __launch_bounds__(256) void k_s2b_fastn(const float* __restrict__ small, int ld_small,
+                                                  const float* __restrict__ P, float* __restrict__ out, int ld_out,
+                                                  long slab_stride, Geom g, int chunks_per_slice,
+                                                  const float* __restrict__ bias, int act, int small_bytes,
+                                                  int p_bytes) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+    constexpr int AI = BM / 32;
+    constexpr int LDB = BN + 4;
+    constexpr int BQ = BN / 4;          // float4 per B row (a row = one k, BN consecutive b)
+    constexpr int BROWS = 256 / BQ;     // B rows per pass
+    constexpr int NQ = KC / BROWS;      // passes (k rows per thread per chunk)
+    __shared__ __attribute__((aligned(16))) float smem[BM * LDK + KC * LDB];
+    float* As = smem;
+    float* Bs = smem + BM * LDK;
+    const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)small, 0, small_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, p_bytes, 0x00020000);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    const int ncls = (g.s == 2) ? 4 : 1;
+    const int cls = blockIdx.z % ncls, slice = blockIdx.z / ncls;
+    const int ah = (g.s == 2) ? (cls >> 1) : 0, aw = (g.s == 2) ? (cls & 1) : 0;
+    const int T = (g.s == 2) ? 2 : 4, Tsh = (g.s == 2) ? 1 : 2;
+    const int Hc = (g.s == 2) ? (g.Hb - ah + 1) / 2 : g.Hb;
+    const int Wc = (g.s == 2) ? (g.Wb - aw + 1) / 2 : g.Wb;
+    const int kh0 = (g.s == 2) ? (1 - ah) : 0, kw0 = (g.s == 2) ? (1 - aw) : 0;
+    const int Mc = g.N * Hc * Wc, K = T * T * g.Ca;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= Mc) return;
+    const int nchunks = (K + KC - 1) / KC;
+    const int c_begin = slice * chunks_per_slice;
+    const int c_end = min(nchunks, c_begin + chunks_per_slice);
+
+    const int kq = tid & 7, r0 = tid >> 3;
+    int a_off[AI], a_mask[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const int mm = min(m, Mc - 1);
+        const int n = mm / (Hc * Wc);
+        const int rem = mm - n * (Hc * Wc);
+        const int ii = rem / Wc, jj = rem - ii * Wc;
+        const int ib = (g.s == 2) ? ii + ah : ii + 1, jb = (g.s == 2) ? jj + aw : jj + 1;
+        a_off[i] = ((n * g.Hs + ib) * g.Ws + jb) * ld_small;
+        int wv = 0, mask = 0;          // local tap (th, tw) reads small pixel (ib - th, jb - tw)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wv |= (t < T && (unsigned)(jb - t) < (unsigned)g.Ws) ? (1 << t) : 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mask |= (t < T && (unsigned)(ib - t) < (unsigned)g.Hs) ? (wv << (T * t)) : 0;
+        a_mask[i] = (m < Mc) ? mask : 0;
+    }
+    const int bq = tid % BQ, brow0 = tid / BQ;
+    const int ncol = n0 + bq * 4;
+    const int ncol_off = (ncol < g.Cb) ? ncol : 0x10000000;      // Cb % 4 == 0: a float4 is all in or all out
+    const int CaCb = g.Ca * g.Cb;
+
+    // incremental (tloc, a) per k-quad: A float4 (index 0) and the NQ quads of B (1..NQ); Ca >= KC: <= 1 wrap
+    int q_tl[NQ + 1], q_a[NQ + 1];
+    {
+        const int k = c_begin * KC + kq * 4;
+        q_tl[0] = k / g.Ca;
+        q_a[0] = k - q_tl[0] * g.Ca;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int k = c_begin * KC + brow0 + BROWS * i;
+        q_tl[i + 1] = k / g.Ca;
+        q_a[i + 1] = k - q_tl[i + 1] * g.Ca;
+    }
+    auto quad = [&](int qi, int& tl, int& a) {   // returns (tloc, a) of quad qi for the chunk being loaded
+        tl = q_tl[qi];
+        a = q_a[qi];
+        const int na = a + KC;
+        const bool wrap = na >= g.Ca;
+        q_a[qi] = wrap ? na - g.Ca : na;
+        q_tl[qi] = wrap ? tl + 1 : tl;
+    };
+
+    f32x4 ra[AI], rb[NQ];
+    int a_tl = 0, a_koff = OOB;
+    auto next_a = [&](int c) {
+        const int k = c * KC + kq * 4;
+        int tl, a;
+        quad(0, tl, a);
+        a_tl = tl;
+        const int th = tl >> Tsh, tw = tl & (T - 1);
+        a_koff = (k < K) ? (a - (th * g.Ws + tw) * ld_small) : 0x20000000;
+    };
+    auto load_a = [&](int i, bool on) {
+        const bool ok = on && ((a_mask[i] >> a_tl) & 1) && (a_koff < 0x10000000);
+        ra[i] = bload4(rsm, voff(a_off[i] + a_koff, ok));
+    };
+    auto load_b = [&](int i, int c, bool on) {
+        const int kb = c * KC + brow0 + BROWS * i;
+        int tl, a;
+        quad(i + 1, tl, a);
+        const int th = tl >> Tsh, tw = tl & (T - 1);
+        const int tap = (kh0 + g.s * th) * 4 + (kw0 + g.s * tw);
+        const bool ok = on && kb < K;
+        rb[i] = bload4(rP, voff(tap * CaCb + a * g.Cb + ncol_off, ok));
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow0 + BROWS * i) * LDB + bq * 4]) = rb[i];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        next_a(c_begin);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) load_a(i, true);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) load_b(i, c_begin, true);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
+        next_a(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            f32x4 af[MR];
+            float bf[NR][4];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MR + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bf[j][e] = Bs[(kk * 8 + lh * 4 + e) * LDB + (wn * NR + j) * 32 + lrow];
+            if (kk < AI) load_a(kk, more);
+            if (kk < NQ) load_b(kk, c + 1, more);
+            PIN_VMEM();
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    const bool fin = (slab_stride == 0);
+    float* o = out + (long)slice * slab_stride;
+    const int ldo = fin ? ld_out : g.Cb;
+    float bv[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int col = n0 + (wn * NR + j) * 32 + lrow;
+        bv[j] = (fin && bias != nullptr && col < g.Cb) ? bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        // decode the lane's first row with two divisions, then walk the other 15 (at most 28 rows further) with a
+        // carry chain: 64 divisions per thread in the epilogue cost as much as several K-chunks
+        const int mb = m0 + (wm * MR + i) * 32 + 4 * lh;
+        const int mbc = min(mb, Mc - 1);
+        const int nb0 = mbc / (Hc * Wc);
+        const int remb = mbc - nb0 * (Hc * Wc);
+        const int ib0 = remb / Wc, jb0 = remb - ib0 * Wc;
+        const bool chain = Wc >= 16 && Hc >= 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int m = m0 + (wm * MR + i) * 32 + row;
+            if (m < Mc) {
+                int n, ii, jj;
+                if (chain) {
+                    const int d = (r & 3) + 8 * (r >> 2);      // 0..27 rows past the decoded one
+                    jj = jb0 + d;
+                    ii = ib0;
+                    n = nb0;
+                    bool w1 = jj >= Wc;
+                    jj = w1 ? jj - Wc : jj;
+                    ii = w1 ? ii + 1 : ii;
+                    w1 = jj >= Wc;
+                    jj = w1 ? jj - Wc : jj;
+                    ii = w1 ? ii + 1 : ii;
+                    w1 = ii >= Hc;
+                    ii = w1 ? ii - Hc : ii;
+                    n = w1 ? n + 1 : n;
+                } else {
+                    n = m / (Hc * Wc);
+                    const int rem = m - n * (Hc * Wc);
+                    ii = rem / Wc;
+                    jj = rem - ii * Wc;
+                }
                 const int h = (g.s == 2) ? 2 * ii + ah : ii, w = (g.s == 2) ? 2 * jj + aw : jj;
                 float* orow = o + (long)((n * g.Hb + h) * g.Wb + w) * ldo;
 #pragma unroll
@@ -1212,7 +1475,7 @@ __global__ __launch_bounds__(256) void k_wgrad_fast(const float* __restrict__ sm
     auto load_a = [&](int i, int c, bool on) {
         const int pix = c * KC + arow0 + AROWS * i;
         const bool ok = on && pix < Kp;
-        ra[i] = bload4(rsm, ok ? b4(pix * ld_small + a_col) : OOB);
+        ra[i] = bload4(rsm, voff(pix * ld_small + a_col, ok));
     };
     auto load_b = [&](int i, int c, bool on) {
         const int pix = c * KC + brow0 + BROWS * i;
@@ -1241,7 +1504,7 @@ __global__ __launch_bounds__(256) void k_wgrad_fast(const float* __restrict__ sm
         }
         const int h = g.s * p - 1 + kh, w = g.s * q - 1 + kw;
         const bool ok = on && pix < Kp && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
-        rb[i] = bload4(rbig, ok ? b4(((n * g.Hb + h) * g.Wb + w) * ld_big + b_col) : OOB);
+        rb[i] = bload4(rbig, voff(((n * g.Hb + h) * g.Wb + w) * ld_big + b_col, ok));
     };
     auto store_chunk = [&]() {
 #pragma unroll
@@ -1274,6 +1537,7 @@ __global__ __launch_bounds__(256) void k_wgrad_fast(const float* __restrict__ sm
             if (kq4 < BI) load_b(kq4, c + 1, more);
             if (kq4 + 4 < AI) load_a(kq4 + 4, c + 1, more);
             if (kq4 + 4 < BI) load_b(kq4 + 4, c + 1, more);
+            PIN_VMEM();
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
                 const int kk = kq4 * 4 + k4;
@@ -1497,8 +1761,9 @@ constexpr int TARGET_BLOCKS = 512;
 int pick_split(long tiles, int nchunks, int min_chunks) {
     // one 4-wave workgroup per CU leaves the MFMA pipe idle while that workgroup stages its next tile
     // (measured 55 vs 80 TFLOP/s on the same kernel at 1 vs 2 workgroups per CU): split K until >= 512 workgroups
-    if (tiles >= TARGET_BLOCKS) return 1;
-    long s = (TARGET_BLOCKS + tiles - 1) / tiles;
+    static const int target = getenv("PATCHGAN_SPLIT_TARGET") ? atoi(getenv("PATCHGAN_SPLIT_TARGET")) : TARGET_BLOCKS;
+    if (tiles >= target) return 1;
+    long s = (target + tiles - 1) / tiles;
     long smax = nchunks / min_chunks;
     if (smax < 1) smax = 1;
     if (s > smax) s = smax;
@@ -1512,10 +1777,20 @@ struct Plan {
     long out_elems;   // elements of one slab
 };
 
+// A 128x128 tiling that yields 256..511 workgroups would need split-K 2 (slab write + reduce pass) to reach two
+// workgroups per CU; the 128x64 tile reaches the same occupancy without the slabs at the same MFMA efficiency.
+Tile refine_tile(Tile t, long rows, int cols, int ncls) {
+    static const bool off = getenv("PATCHGAN_TILE_REFINE") == nullptr;   // measured slower than split-K 2: off by default
+    if (off || t.id != 0) return t;
+    const long tiles = ((rows + 127) / 128) * ((cols + 127) / 128) * ncls;
+    if (tiles >= 256 && tiles < TARGET_BLOCKS) return {1, 128, 64};
+    return t;
+}
+
 Plan plan_b2s(const pg_conv_geom* g) {
     Plan p;
     const long M = (long)g->N * g->Hs * g->Ws;
-    p.t = pick_tile(M, g->Ca);
+    p.t = refine_tile(pick_tile(M, g->Ca), M, g->Ca, 1);
     p.tiles_m = (int)((M + p.t.bm - 1) / p.t.bm);
     p.tiles_n = (g->Ca + p.t.bn - 1) / p.t.bn;
     p.ncls = 1;
@@ -1530,7 +1805,7 @@ Plan plan_s2b(const pg_conv_geom* g) {
     p.ncls = (g->stride == 2) ? 4 : 1;
     const int Hc = (g->stride == 2) ? (g->Hb + 1) / 2 : g->Hb, Wc = (g->stride == 2) ? (g->Wb + 1) / 2 : g->Wb;
     const long Mc = (long)g->N * Hc * Wc;   // largest class
-    p.t = pick_tile(Mc, g->Cb);
+    p.t = refine_tile(pick_tile(Mc, g->Cb), Mc, g->Cb, p.ncls);
     p.tiles_m = (int)((Mc + p.t.bm - 1) / p.t.bm);
     p.tiles_n = (g->Cb + p.t.bn - 1) / p.t.bn;
     const int taps = (g->stride == 2) ? 4 : 16;
@@ -1720,8 +1995,13 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
     dim3 grid(p.tiles_m, p.tiles_n, p.ncls * p.split);
     const long small_bytes = tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca), p_bytes = 16L * g.Ca * g.Cb * 4;
     const bool fast = veck && g.Ca >= KC && small_bytes < FAST_LIMIT && p_bytes < FAST_LIMIT && !force_generic();
+    static const bool ncontig = getenv("PATCHGAN_S2B_NCONTIG") != nullptr;
+    const bool fastn = fast && ncontig && (g.Cb % 4 == 0) && aligned16(P);
     if (p.split == 1) {
-        if (fast) {
+        if (fastn) {
+            PG_DISPATCH_TILE(k_s2b_fastn, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, bias, act,
+                             (int)small_bytes, (int)p_bytes);
+        } else if (fast) {
             PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, bias, act,
                              (int)small_bytes, (int)p_bytes);
         } else {
@@ -1731,7 +2011,10 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     float* slabs = (float*)ws;
-    if (fast) {
+    if (fastn) {
+        PG_DISPATCH_TILE(k_s2b_fastn, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
+                         (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes);
+    } else if (fast) {
         PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
                          (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes);
     } else {

@@ -99,13 +99,16 @@ class LaunchProfiler:
     TILE_NAMES = {0: '<2,2,2,2>', 1: '<2,1,2,2>', 2: '<1,1,4,1>', 3: '<1,2,2,2>', 4: '<1,1,2,2>'}
     OP_NAMES = {0: 'k_big2small', 1: 'k_small2big', 2: 'k_wgrad'}
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []   # (symbol, split, flops, start_event, end_event)
+        self.only = only    # (symbol, split): time only this kernel's launches
 
     def launch(self, op, opcode, fn):
         if op.algo == L.ALGO_DIRECT:
             return fn()
         sym, split = op.describe(opcode)
+        if self.only is not None and (sym, split) != self.only:
+            return fn()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
