@@ -841,7 +841,10 @@ __device__ __forceinline__ float pg_act_epi(float v, int act) {
     return pg_act_slow(v, act);
 }
 
-template <int MR, int NR, int WM, int WN>
+// ONE = true turns the kernel into a plain row GEMM  out[m][a] = sum_b big[m][b] * P[a][b]  (a 1x1 "convolution" over
+// the N*Hb*Wb pixels of `big`): the first half of the taps-folded-into-N path for layers with <= 8 channels on the
+// output side, whose second half is a col2im / tap-gather pass (k_col2im_small2big, k_gather_big2small).
+template <int MR, int NR, int WM, int WN, bool ONE>
 __global__ __launch_bounds__(256) void k_b2s_fast(const float* __restrict__ big, int ld_big,
                                                   const float* __restrict__ P, float* __restrict__ out, int ld_out,
                                                   long slab_stride, Geom g, int chunks_per_slice,
@@ -857,7 +860,8 @@ __global__ __launch_bounds__(256) void k_b2s_fast(const float* __restrict__ big,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = lane & 31, lh = lane >> 5;
-    const int M = g.N * g.Hs * g.Ws, K = 16 * g.Cb;     // K % 32 == 0 because Cb % 4 == 0
+    const int M = ONE ? g.N * g.Hb * g.Wb : g.N * g.Hs * g.Ws;
+    const int K = ONE ? g.Cb : 16 * g.Cb;               // K % 32 == 0 (Cb % 4 == 0; ONE requires Cb % 32 == 0)
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int nchunks = K / KC;
     const int c_begin = blockIdx.z * chunks_per_slice;
@@ -869,6 +873,11 @@ __global__ __launch_bounds__(256) void k_b2s_fast(const float* __restrict__ big,
     for (int i = 0; i < AI; ++i) {
         const int m = m0 + r0 + 32 * i;
         const int mm = min(m, M - 1);
+        if (ONE) {
+            a_off[i] = mm * ld_big;
+            a_mask[i] = (m < M) ? 1 : 0;
+            continue;
+        }
         const int n = mm / (g.Hs * g.Ws);
         const int rem = mm - n * (g.Hs * g.Ws);
         const int p = rem / g.Ws, q = rem - p * g.Ws;
@@ -1576,6 +1585,80 @@ __global__ __launch_bounds__(256) void k_wgrad_fast(const float* __restrict__ sm
 }
 
 // ------------------------------------------------------------------------------------------------
+// Second halves of the taps-folded-into-N forward paths.  D is the row GEMM's output:
+//   small2big:  D[small pixel][(tap, b)]  ->  big[n,h,w,b] = act(sum over the taps that reach (h,w) + bias[b])
+//   big2small:  D[big pixel][(tap, a)]    ->  small[n,p,q,a] = act(sum_{kh,kw in range} D[(s*p-1+kh, s*q-1+kw)] + bias[a])
+// and the weight re-layout the first needs: W'[(tap*Cb + b)][a] = P[tap][a][b] (a few KB).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_col2im_small2big(const float* __restrict__ D, const float* __restrict__ bias, float* __restrict__ big,
+                                   int ld_big, Geom g, int act) {
+    const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
+    const int Nc = 16 * g.Cb;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx % g.Cb);
+        const long pix = idx / g.Cb;
+        const int n = (int)(pix / (g.Hb * g.Wb));
+        const int rem = (int)(pix - (long)n * g.Hb * g.Wb);
+        const int h = rem / g.Wb, w = rem - h * g.Wb;
+        float acc = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            const int hh = h + 1 - kh;
+            if (hh < 0 || (g.s == 2 && (hh & 1))) continue;
+            const int ih = g.s == 2 ? hh >> 1 : hh;
+            if (ih >= g.Hs) continue;
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int ww = w + 1 - kw;
+                if (ww < 0 || (g.s == 2 && (ww & 1))) continue;
+                const int iw = g.s == 2 ? ww >> 1 : ww;
+                if (iw >= g.Ws) continue;
+                acc += D[(long)((n * g.Hs + ih) * g.Ws + iw) * Nc + (kh * 4 + kw) * g.Cb + b];
+            }
+        }
+        if (bias) acc += bias[b];
+        big[pix * ld_big + b] = pg_act_epi(acc, act);
+    }
+}
+
+__global__ void k_gather_big2small(const float* __restrict__ D, const float* __restrict__ bias,
+                                   float* __restrict__ small, int ld_small, Geom g, int act) {
+    const long total = (long)g.N * g.Hs * g.Ws * g.Ca;
+    const int Nc = 16 * g.Ca;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(idx % g.Ca);
+        const long pix = idx / g.Ca;
+        const int n = (int)(pix / (g.Hs * g.Ws));
+        const int rem = (int)(pix - (long)n * g.Hs * g.Ws);
+        const int p = rem / g.Ws, q = rem - p * g.Ws;
+        float acc = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            const int h = g.s * p - 1 + kh;
+            if ((unsigned)h >= (unsigned)g.Hb) continue;
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int w = g.s * q - 1 + kw;
+                if ((unsigned)w >= (unsigned)g.Wb) continue;
+                acc += D[(long)((n * g.Hb + h) * g.Wb + w) * Nc + (kh * 4 + kw) * g.Ca + a];
+            }
+        }
+        if (bias) acc += bias[a];
+        small[pix * ld_small + a] = pg_act_epi(acc, act);
+    }
+}
+
+__global__ void k_pack_taps_b(const float* __restrict__ P, float* __restrict__ Wp, int Ca, int Cb) {
+    const int total = 16 * Ca * Cb;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int a = i % Ca;                 // Wp[(tap*Cb + b)*Ca + a]
+        const int tb = i / Ca;
+        const int b = tb % Cb, tap = tb / Cb;
+        Wp[i] = P[(long)(tap * Ca + a) * Cb + b];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // split-K reduce (+ bias + activation):  out[r*ld_out + c] = act(sum_z slab[z][r*cols + c] + bias[c])
 // ------------------------------------------------------------------------------------------------
 __global__ void k_slab_reduce(const float* __restrict__ slabs, long slab_stride, int S, float* __restrict__ out,
@@ -1895,6 +1978,23 @@ int launch_reduce(const float* slabs, long slab_stride, int S, float* out, int l
         default: hipLaunchKernelGGL((k_wgrad_tapn<1, 1, 2, 2, MODE>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
     }
 
+// taps-folded-into-N forward paths: eligibility and workspace (floats)
+inline bool s2b_tapn_ok(const Geom& g) { return g.Cb <= 8 && g.Ca % KC == 0 && !force_generic(); }
+inline bool b2s_tapn_ok(const Geom& g) { return g.Ca <= 8 && g.Cb % KC == 0 && !force_generic(); }
+inline size_t s2b_tapn_ws(const Geom& g) {
+    return ((size_t)16 * g.Cb * g.Ca + (size_t)g.N * g.Hs * g.Ws * 16 * g.Cb) * sizeof(float) + 256;
+}
+inline size_t b2s_tapn_ws(const Geom& g) { return (size_t)g.N * g.Hb * g.Wb * 16 * g.Ca * sizeof(float); }
+
+#define PG_DISPATCH_B2SF(ONE, tile_id, grid, st, ...)                                                              \
+    switch (tile_id) {                                                                                            \
+        case 0: hipLaunchKernelGGL((k_b2s_fast<2, 2, 2, 2, ONE>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+        case 1: hipLaunchKernelGGL((k_b2s_fast<2, 1, 2, 2, ONE>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+        case 2: hipLaunchKernelGGL((k_b2s_fast<1, 1, 4, 1, ONE>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+        case 3: hipLaunchKernelGGL((k_b2s_fast<1, 2, 2, 2, ONE>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+        default: hipLaunchKernelGGL((k_b2s_fast<1, 1, 2, 2, ONE>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+    }
+
 #define PG_DISPATCH_WGF(POW2, tile_id, grid, st, ...)                                                              \
     switch (tile_id) {                                                                                            \
         case 0: hipLaunchKernelGGL((k_wgrad_fast<2, 2, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
@@ -1916,6 +2016,9 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
     if (op == 2 && split < DIRECT_WGRAD_SLICES) split = DIRECT_WGRAD_SLICES;   // the direct algo's slices
     if (split > 1) bytes = (size_t)split * p.out_elems * sizeof(float);
     if (op == 2) bytes += ((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255;
+    const Geom gq = to_geom(g);
+    if (op == 0 && b2s_tapn_ok(gq)) bytes = std::max(bytes, b2s_tapn_ws(gq));
+    if (op == 1 && s2b_tapn_ok(gq)) bytes = std::max(bytes, s2b_tapn_ws(gq) + 256);
     return (bytes + 255) & ~(size_t)255;
 }
 
@@ -1925,6 +2028,16 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
     size_t reserved = (op == 2) ? (((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255) : 0;
     clamp_split(p, ws_bytes, reserved);
     if (tile_id) *tile_id = p.t.id + ((op == 2) ? 10 * wgrad_mode(g) : 0);
+    const Geom gq = to_geom(g);
+    if ((op == 0 && b2s_tapn_ok(gq) && ws_bytes >= b2s_tapn_ws(gq)) || (op == 1 && s2b_tapn_ok(gq) && ws_bytes >= s2b_tapn_ws(gq))) {
+        const long M1 = (op == 0) ? (long)g->N * g->Hb * g->Wb : (long)g->N * g->Hs * g->Ws;
+        const int Nc = 16 * ((op == 0) ? g->Ca : g->Cb);
+        Tile t = pick_tile(M1, Nc);
+        if (tile_id) *tile_id = t.id + 30;
+        if (split) *split = 1;
+        if (workgroups) *workgroups = ((M1 + t.bm - 1) / t.bm) * ((Nc + t.bn - 1) / t.bn);
+        return PG_OK;
+    }
     if (split) *split = p.split;
     if (workgroups) *workgroups = (long)p.tiles_m * p.tiles_n * p.ncls * p.split;
     return PG_OK;
@@ -1944,8 +2057,25 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
                            act);
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
-    Plan p = plan_b2s(gg);
     if (!ws) ws_bytes = 0;
+    if (b2s_tapn_ok(g) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P) && aligned16(ws) &&
+        ws_bytes >= b2s_tapn_ws(g) && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT) {
+        // D[big pixel][(tap, a)] = big . P^T (row GEMM over the pixels), then gather the 16 taps per output pixel
+        float* D = (float*)ws;
+        const long Mb = (long)g.N * g.Hb * g.Wb;
+        const int Nc = 16 * g.Ca;
+        Geom g1{g.N, g.Hb, g.Wb, g.Hb, g.Wb, Nc, g.Cb, 1};
+        Tile t = pick_tile(Mb, Nc);
+        dim3 grid((unsigned)((Mb + t.bm - 1) / t.bm), (Nc + t.bn - 1) / t.bn, 1);
+        PG_DISPATCH_B2SF(true, t.id, grid, st, big, ld_big, P, D, Nc, 0L, g1, g.Cb / KC, (const float*)nullptr, 0,
+                         (int)tensor_bytes(Mb, ld_big, g.Cb), (int)(16L * g.Ca * g.Cb * 4));
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        const long total = (long)g.N * g.Hs * g.Ws * g.Ca;
+        hipLaunchKernelGGL(k_gather_big2small, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, D, bias,
+                           small, ld_small, g, act);
+        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+    }
+    Plan p = plan_b2s(gg);
     clamp_split(p, ws_bytes, 0);
     const int veck = (g.Cb % 4 == 0) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P);
     dim3 grid(p.tiles_m, p.tiles_n, p.split);
@@ -1953,7 +2083,7 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
     const bool fast = veck && g.Cb >= KC && big_bytes < FAST_LIMIT && p_bytes < FAST_LIMIT && !force_generic();
     if (p.split == 1) {
         if (fast) {
-            PG_DISPATCH_TILE(k_b2s_fast, p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, bias, act,
+            PG_DISPATCH_B2SF(false, p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, bias, act,
                              (int)big_bytes, (int)p_bytes);
         } else {
             PG_DISPATCH_TILE(k_big2small, p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, veck, bias,
@@ -1963,7 +2093,7 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
     }
     float* slabs = (float*)ws;
     if (fast) {
-        PG_DISPATCH_TILE(k_b2s_fast, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps,
+        PG_DISPATCH_B2SF(false, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps,
                          (const float*)nullptr, 0, (int)big_bytes, (int)p_bytes);
     } else {
         PG_DISPATCH_TILE(k_big2small, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps, veck,
@@ -1987,8 +2117,32 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
                            act);
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
-    Plan p = plan_s2b(gg);
     if (!ws) ws_bytes = 0;
+    if (s2b_tapn_ok(g) && (ld_small % 4 == 0) && aligned16(small) && aligned16(P) && aligned16(ws) &&
+        ws_bytes >= s2b_tapn_ws(g) && tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT) {
+        // D[small pixel][(tap, b)] = small . W' (row GEMM), then col2im: each big pixel sums the taps that reach it
+        const int Nc = 16 * g.Cb;
+        float* Wp = (float*)ws;
+        float* D = Wp + (((size_t)Nc * g.Ca + 63) & ~(size_t)63);
+        const float* W = P;
+        if (g.Cb > 1) {
+            hipLaunchKernelGGL(k_pack_taps_b, dim3((Nc * g.Ca + 255) / 256), dim3(256), 0, st, P, Wp, g.Ca, g.Cb);
+            if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+            W = Wp;
+        }
+        const long Ms = (long)g.N * g.Hs * g.Ws;
+        Geom g1{g.N, g.Hs, g.Ws, g.Hs, g.Ws, Nc, g.Ca, 1};
+        Tile t = pick_tile(Ms, Nc);
+        dim3 grid((unsigned)((Ms + t.bm - 1) / t.bm), (Nc + t.bn - 1) / t.bn, 1);
+        PG_DISPATCH_B2SF(true, t.id, grid, st, small, ld_small, W, D, Nc, 0L, g1, g.Ca / KC, (const float*)nullptr, 0,
+                         (int)tensor_bytes(Ms, ld_small, g.Ca), (int)((long)Nc * g.Ca * 4));
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
+        hipLaunchKernelGGL(k_col2im_small2big, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, D, bias,
+                           big, ld_big, g, act);
+        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+    }
+    Plan p = plan_s2b(gg);
     clamp_split(p, ws_bytes, 0);
     const int veck = (g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned16(small);
     const int vecn = (g.Cb % 4 == 0) && aligned16(P);

@@ -161,7 +161,9 @@ class ConvOp:
                                               ctypes.byref(s), ctypes.byref(w)), 'pg_conv_describe')
             tid, mode = t.value % 10, t.value // 10
             name = LaunchProfiler.OP_NAMES[opcode] + LaunchProfiler.TILE_NAMES[tid]
-            if mode:
+            if mode == 3:
+                name = 'k_b2s_fast' + LaunchProfiler.TILE_NAMES[tid][:-1] + ',true>+' + ('gather' if opcode == 0 else 'col2im')
+            elif mode:
                 name = 'k_wgrad_tapn' + LaunchProfiler.TILE_NAMES[tid][:-1] + f',{mode}>'
             self._desc[opcode] = (name, s.value)
         return self._desc[opcode]

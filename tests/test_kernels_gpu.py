@@ -28,6 +28,11 @@ GEOMS = [
     (2, 32, 32, 64, 32, 1),     # d3-like stride 1, Hs = 31 (carry-chain pixel decode in the fast wgrad)
     (3, 34, 38, 40, 36, 2),     # non-power-of-two extents >= 16, ragged channel tiles
     (2, 64, 64, 128, 64, 2),    # enc-like: all fast kernels, power-of-two decode
+    (2, 16, 16, 1, 64, 1),      # D-head-like: big2small via row GEMM + tap gather
+    (1, 15, 13, 4, 32, 2),      # same path, stride 2, odd extents, 4 output channels
+    (2, 16, 16, 32, 1, 2),      # dec6-like: small2big via row GEMM + col2im, Cb = 1 (no weight re-layout)
+    (2, 12, 20, 64, 3, 2),      # same path with the (tap, b) weight re-layout, Cb = 3
+    (2, 9, 9, 32, 8, 1),        # same path, stride 1
 ]
 ACTS = {'none': 0, 'leakyrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
