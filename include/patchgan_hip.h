@@ -142,6 +142,9 @@ int pg_dropout_mask(float* mask, long nelem, float drop_p, uint64_t seed, void* 
  * bce_elem = -( y*max(log p,-100) + (1-y)*max(log(1-p),-100) ).  C need not be a multiple of 4. */
 int pg_loss_reduce(const float* p, int ld_p, const float* y, int ld_y, float tconst,
                    int N, int HW, int C, double* S, void* stream);
+/* Number of doubles S must hold for pg_loss_reduce(N, HW, C): N*C*5 results, followed by scratch for the per-split
+ * partial sums large maps are reduced through. */
+long pg_loss_reduce_doubles(int N, int HW, int C);
 
 /* Stage 2: gradient of a scalar loss wrt p from per-(n,c) coefficients:
  *   mode 0 (affine in y; focal-Tversky):   g = coef[n][c][0] * y + coef[n][c][1]

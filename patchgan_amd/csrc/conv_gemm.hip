@@ -1691,6 +1691,28 @@ __global__ void k_slab_reduce4(const float* __restrict__ slabs, long slab_stride
     }
 }
 
+// many slabs, few outputs (the taps-in-N weight gradients: up to 512 slabs of a few thousand floats): 8 z-lanes per
+// output share the slab loop, combined through LDS in lane order (deterministic)
+__global__ __launch_bounds__(256) void k_slab_reduce_z(const float* __restrict__ slabs, long slab_stride, int S,
+                                                       float* __restrict__ out, int ld_out, long rows, int cols) {
+    __shared__ float red[8][32];
+    const int ol = threadIdx.x & 31, zl = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + ol;
+    const long total = rows * cols;
+    float v = 0.f;
+    if (i < total)
+        for (int z = zl; z < S; z += 8) v += slabs[(long)z * slab_stride + i];
+    red[zl][ol] = v;
+    __syncthreads();
+    if (zl == 0 && i < total) {
+        float t = red[0][ol];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][ol];
+        const long r = i / cols;
+        out[r * ld_out + (i - r * cols)] = t;
+    }
+}
+
 // column sums of a [rows][C] matrix (pixel stride ld): partial[chunk][c] over row chunks (bias gradient).
 // 256 threads = 64 channels x 4 row lanes; fixed-order combine.
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ x, int ld, long rows, int C,
@@ -1942,6 +1964,12 @@ void clamp_split(Plan& p, size_t ws_bytes, size_t reserved) {
 
 int launch_reduce(const float* slabs, long slab_stride, int S, float* out, int ld_out, long rows, int cols,
                   const float* bias, int act, hipStream_t st) {
+    if (S >= 64 && !bias && act == PG_ACT_NONE && rows * cols <= (1L << 22)) {
+        const long total = rows * cols;
+        hipLaunchKernelGGL(k_slab_reduce_z, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, slabs, slab_stride, S, out,
+                           ld_out, rows, cols);
+        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+    }
     if ((cols % 4 == 0) && (ld_out % 4 == 0) && (slab_stride % 4 == 0) && aligned16(slabs) && aligned16(out) &&
         (!bias || aligned16(bias))) {
         const long total4 = rows * (cols / 4);

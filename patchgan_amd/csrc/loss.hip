@@ -12,6 +12,8 @@
 
 namespace {
 
+// grid (N*C, nsplit): block (nc, z) reduces pixels z, z+nsplit, ... in 256-pixel strides; with nsplit > 1 the partial
+// sums land in Spart[z][nc][5] and k_loss_combine adds them in z order
 __global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ p, int ld_p, const float* __restrict__ y,
                                                      int ld_y, float tconst, int HW, int C, double* __restrict__ S) {
     __shared__ double red[5][256];
@@ -20,7 +22,7 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ p
     const float* pb = p + (long)n * HW * ld_p + c;
     const float* yb = y ? y + (long)n * HW * ld_y + c : nullptr;
     double s[5] = {0, 0, 0, 0, 0};
-    for (int i = tid; i < HW; i += 256) {
+    for (int i = blockIdx.y * 256 + tid; i < HW; i += 256 * gridDim.y) {
         const float pv = pb[(long)i * ld_p];
         const float yv = yb ? yb[(long)i * ld_y] : tconst;
         // F.binary_cross_entropy clamps both logs at -100
@@ -42,8 +44,16 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ p
     }
     if (tid == 0) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) S[(long)blockIdx.x * 5 + k] = red[k][0];
+        for (int k = 0; k < 5; ++k) S[((long)blockIdx.y * gridDim.x + blockIdx.x) * 5 + k] = red[k][0];
     }
+}
+
+__global__ void k_loss_combine(const double* __restrict__ Spart, int nsplit, int n5, double* __restrict__ S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n5) return;
+    double v = 0.0;
+    for (int z = 0; z < nsplit; ++z) v += Spart[(long)z * n5 + i];
+    S[i] = v;
 }
 
 __device__ inline void tversky_terms(const double* S, int n, int C, double beta, double& tp, double& denom) {
@@ -142,14 +152,40 @@ __global__ void k_loss_grad(const float* __restrict__ p, int ld_p, const float* 
     }
 }
 
+// pixel splits per (n, c) so that a loss over a large map runs on >= ~256 workgroups
+int loss_nsplit(int N, int HW, int C) {
+    int ns = 256 / (N * C);
+    const int maxs = HW / 1024;
+    if (ns > maxs) ns = maxs;
+    if (ns > 64) ns = 64;
+    return ns < 1 ? 1 : ns;
+}
+
 }  // namespace
 
 extern "C" {
 
+long pg_loss_reduce_doubles(int N, int HW, int C) {
+    if (N <= 0 || HW <= 0 || C <= 0) return 0;
+    const int ns = loss_nsplit(N, HW, C);
+    return (long)N * C * 5 * (ns > 1 ? 1 + ns : 1);
+}
+
 int pg_loss_reduce(const float* p, int ld_p, const float* y, int ld_y, float tconst, int N, int HW, int C, double* S,
                    void* stream) {
     if (!p || !S || N <= 0 || HW <= 0 || C <= 0 || ld_p < C || (y && ld_y < C)) return PG_EINVAL;
-    hipLaunchKernelGGL(k_loss_reduce, dim3(N * C), dim3(256), 0, (hipStream_t)stream, p, ld_p, y, ld_y, tconst, HW, C, S);
+    // S must hold (1 + nsplit) * N*C*5 doubles when nsplit > 1 (pg_loss_reduce_doubles): partials behind the result
+    const int nsplit = loss_nsplit(N, HW, C);
+    if (nsplit == 1) {
+        hipLaunchKernelGGL(k_loss_reduce, dim3(N * C, 1), dim3(256), 0, (hipStream_t)stream, p, ld_p, y, ld_y, tconst, HW, C, S);
+        return pg_launch_status();
+    }
+    double* part = S + (long)N * C * 5;
+    hipLaunchKernelGGL(k_loss_reduce, dim3(N * C, nsplit), dim3(256), 0, (hipStream_t)stream, p, ld_p, y, ld_y, tconst, HW, C,
+                       part);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    hipLaunchKernelGGL(k_loss_combine, dim3((N * C * 5 + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, nsplit, N * C * 5,
+                       S);
     return pg_launch_status();
 }
 

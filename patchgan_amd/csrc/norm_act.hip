@@ -314,10 +314,12 @@ __global__ void k_in_merge(const double* __restrict__ part, int nchunk, int NC, 
     if (i >= NC) return;
     const int n = i / C, c = i - n * C;
     double s1 = 0.0, s2 = 0.0;
+    const double2* p2 = reinterpret_cast<const double2*>(part) + ((long)n * nchunk) * C + c;
+#pragma unroll 8
     for (int k = 0; k < nchunk; ++k) {
-        const double* p = part + (((long)n * nchunk + k) * C + c) * 2;
-        s1 += p[0];
-        s2 += p[1];
+        const double2 v = p2[(long)k * C];
+        s1 += v.x;
+        s2 += v.y;
     }
     if (!BWD) {
         const double mean = s1 / (double)HW;
@@ -487,7 +489,7 @@ ChunkPlan chunk_plan(int N, int HW, int C, int vecw) {
     int nchunk = 1;
     if (HW >= 2048) {
         const int PL = 256 / G;
-        long want = (2048 + (long)N * p.groups - 1) / ((long)N * p.groups);
+        long want = (1024 + (long)N * p.groups - 1) / ((long)N * p.groups);
         long maxc = HW / (PL * 2);            // at least two pixels per lane per chunk
         if (want > maxc) want = maxc;
         if (want > 1024) want = 1024;

@@ -611,8 +611,8 @@ class DiscriminatorEngine:
 class LossBuffers:
     """Scratch for one loss evaluation: S [N*C*5] f64, sums [2] f64, coef [N*C*2] f32."""
 
-    def __init__(self, N, C, device):
-        self.S = torch.empty(N * C * 5, dtype=torch.float64, device=device)
+    def __init__(self, N, C, device, HW=1):
+        self.S = torch.empty(int(L.load().pg_loss_reduce_doubles(N, HW, C)), dtype=torch.float64, device=device)
         self.sums = torch.zeros(2, dtype=torch.float64, device=device)
         self.coef = torch.empty(N * C * 2, dtype=torch.float32, device=device)
 
@@ -623,7 +623,7 @@ def loss_value_and_grad(p, y, tconst, mode, alpha, grad_out, loss_out, loss_slot
     value into loss_out[loss_slot] and, if grad_out is not None, its gradient wrt p into View grad_out.
     `allreduce(tensor)` sums the two global reduction terms across ranks under data parallelism."""
     lib = L.load()
-    buf = LossBuffers(p.N, p.C, p.t.device)
+    buf = LossBuffers(p.N, p.C, p.t.device, p.HW)
     st = _stream()
     L.check(lib.pg_loss_reduce(p.ptr(), p.ld, y.ptr() if y is not None else None, y.ld if y is not None else 0,
                                float(tconst), p.N, p.HW, p.C, buf.S.data_ptr(), st), 'pg_loss_reduce')
