@@ -38,6 +38,21 @@ def make_inputs(batch, rank):
     return x, y
 
 
+def pmc_traffic(symbol):
+    """HBM bytes per launch of `symbol` from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json: FETCH_SIZE
+    and WRITE_SIZE collected in separate passes, gfx950 corrections applied); None if that kernel was not profiled."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
+        try:
+            k = json.load(open(f))['kernels'].get(symbol.replace(' ', ''))
+        except Exception:
+            k = None
+        if k:
+            best = k['hbm_bytes_per_launch']
+    return best
+
+
 def usable_cpus():
     """Host threads this process may really use: min(affinity mask, cgroup CPU quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -156,7 +171,7 @@ def main():
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
         roofline = {'bound': 'mfma', 'kernel': sym + (f' (split-K {split} + reduce)' if split > 1 else ''),
                     'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                    'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(sym),
                     'launches_per_step': d['launches'] / args.steps,
                     'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                     'kernel_share_of_step': round(d['ms'] / args.steps / (elapsed / args.steps * 1e3), 4),

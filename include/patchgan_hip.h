@@ -70,7 +70,9 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);
  * (0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 64x128, 4 = 64x64 output tile per workgroup; the kernel symbol is
  * k_big2small / k_small2big / k_wgrad <MR,NR,WM,WN> with <2,2,2,2>, <2,1,2,2>, <1,1,4,1>, <1,2,2,2>, <1,1,2,2>), the
  * split-K factor and the number of workgroups.  For op 2, tile_id + 10 / + 20 means the taps-folded-into-N kernel
- * k_wgrad_tapn<..., 1> / <..., 2> (few big-side / small-side channels).  For profiling / roofline accounting only. */
+ * k_wgrad_tapn<..., 1> / <..., 2> (few big-side / small-side channels); for ops 0/1, + 30 means the row-GEMM +
+ * col2im / tap-gather path.  + 100 (+ 200: power-of-two pixel decode, wgrad) marks the fast buffer-load variant
+ * (k_b2s_fast / k_s2b_fast / k_wgrad_fast) that runs when tensors are 16-byte aligned.  For profiling only. */
 int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups);
 
 /* small[n,p,q,a] = act( sum_{kh,kw,b} big[n, s*p-1+kh, s*q-1+kw, b] * P[kh*4+kw][a][b] + bias[a] )

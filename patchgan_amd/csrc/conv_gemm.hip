@@ -2053,9 +2053,19 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
 int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups) {
     if (!geom_ok(g) || op < 0 || op > 2) return PG_EINVAL;
     Plan p = (op == 0) ? plan_b2s(g) : (op == 1) ? plan_s2b(g) : plan_wgrad(g);
+    // +100: the fast (buffer-load) variant would run for 16-byte-aligned contiguous tensors; +200: its power-of-two
+    // pixel-decode instantiation (wgrad only)
+    int fastcode = 0;
+    if (!force_generic()) {
+        const bool p2 = ((g->Hs & (g->Hs - 1)) == 0) && ((g->Ws & (g->Ws - 1)) == 0);
+        if (op == 0 && g->Cb % 4 == 0 && g->Cb >= KC) fastcode = 100;
+        if (op == 1 && g->Ca % 4 == 0 && g->Ca >= KC) fastcode = 100;
+        if (op == 2 && wgrad_mode(g) == 0 && g->Ca % 4 == 0 && g->Cb % 4 == 0 && (p2 || (g->Ws >= 16 && g->Hs >= 2)))
+            fastcode = p2 ? 200 : 100;
+    }
     size_t reserved = (op == 2) ? (((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255) : 0;
     clamp_split(p, ws_bytes, reserved);
-    if (tile_id) *tile_id = p.t.id + ((op == 2) ? 10 * wgrad_mode(g) : 0);
+    if (tile_id) *tile_id = p.t.id + ((op == 2) ? 10 * wgrad_mode(g) : 0) + fastcode;
     const Geom gq = to_geom(g);
     if ((op == 0 && b2s_tapn_ok(gq) && ws_bytes >= b2s_tapn_ws(gq)) || (op == 1 && s2b_tapn_ok(gq) && ws_bytes >= s2b_tapn_ws(gq))) {
         const long M1 = (op == 0) ? (long)g->N * g->Hb * g->Wb : (long)g->N * g->Hs * g->Ws;

@@ -159,12 +159,21 @@ class ConvOp:
             t, s, w = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_long(0)
             L.check(L.load().pg_conv_describe(ctypes.byref(self.g), opcode, max(self.ws_bytes, 1 << 20), ctypes.byref(t),
                                               ctypes.byref(s), ctypes.byref(w)), 'pg_conv_describe')
-            tid, mode = t.value % 10, t.value // 10
-            name = LaunchProfiler.OP_NAMES[opcode] + LaunchProfiler.TILE_NAMES[tid]
+            fast, rest = t.value // 100, t.value % 100
+            tid, mode = rest % 10, rest // 10
+            tn = LaunchProfiler.TILE_NAMES[tid]
             if mode == 3:
-                name = 'k_b2s_fast' + LaunchProfiler.TILE_NAMES[tid][:-1] + ',true>+' + ('gather' if opcode == 0 else 'col2im')
+                name = 'k_b2s_fast' + tn[:-1] + ',true>+' + ('k_gather_big2small' if opcode == 0 else 'k_col2im_small2big')
             elif mode:
-                name = 'k_wgrad_tapn' + LaunchProfiler.TILE_NAMES[tid][:-1] + f',{mode}>'
+                name = 'k_wgrad_tapn' + tn[:-1] + f',{mode}>'
+            elif fast and opcode == 0:
+                name = 'k_b2s_fast' + tn[:-1] + ',false>'
+            elif fast and opcode == 1:
+                name = 'k_s2b_fast' + tn
+            elif fast:
+                name = 'k_wgrad_fast' + tn[:-1] + (',true>' if fast == 2 else ',false>')
+            else:
+                name = LaunchProfiler.OP_NAMES[opcode] + tn
             self._desc[opcode] = (name, s.value)
         return self._desc[opcode]
 
