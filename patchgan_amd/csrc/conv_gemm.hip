@@ -1216,227 +1216,6 @@ __global__ __launch_bounds__(256) void k_s2b_fast(const float* __restrict__ smal
     }
 }
 
-template <int MR, int NR, int WM, int WN>
-__global__ __launch_bounds__(256) void k_s2b_fastn(const float* __restrict__ small, int ld_small,
-                                                  const float* __restrict__ P, float* __restrict__ out, int ld_out,
-                                                  long slab_stride, Geom g, int chunks_per_slice,
-                                                  const float* __restrict__ bias, int act, int small_bytes,
-                                                  int p_bytes) {
-    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
-    constexpr int AI = BM / 32;
-    constexpr int LDB = BN + 4;
-    constexpr int BQ = BN / 4;          // float4 per B row (a row = one k, BN consecutive b)
-    constexpr int BROWS = 256 / BQ;     // B rows per pass
-    constexpr int NQ = KC / BROWS;      // passes (k rows per thread per chunk)
-    __shared__ __attribute__((aligned(16))) float smem[BM * LDK + KC * LDB];
-    float* As = smem;
-    float* Bs = smem + BM * LDK;
-    const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)small, 0, small_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, p_bytes, 0x00020000);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int lrow = lane & 31, lh = lane >> 5;
-
-    const int ncls = (g.s == 2) ? 4 : 1;
-    const int cls = blockIdx.z % ncls, slice = blockIdx.z / ncls;
-    const int ah = (g.s == 2) ? (cls >> 1) : 0, aw = (g.s == 2) ? (cls & 1) : 0;
-    const int T = (g.s == 2) ? 2 : 4, Tsh = (g.s == 2) ? 1 : 2;
-    const int Hc = (g.s == 2) ? (g.Hb - ah + 1) / 2 : g.Hb;
-    const int Wc = (g.s == 2) ? (g.Wb - aw + 1) / 2 : g.Wb;
-    const int kh0 = (g.s == 2) ? (1 - ah) : 0, kw0 = (g.s == 2) ? (1 - aw) : 0;
-    const int Mc = g.N * Hc * Wc, K = T * T * g.Ca;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    if (m0 >= Mc) return;
-    const int nchunks = (K + KC - 1) / KC;
-    const int c_begin = slice * chunks_per_slice;
-    const int c_end = min(nchunks, c_begin + chunks_per_slice);
-
-    const int kq = tid & 7, r0 = tid >> 3;
-    int a_off[AI], a_mask[AI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int m = m0 + r0 + 32 * i;
-        const int mm = min(m, Mc - 1);
-        const int n = mm / (Hc * Wc);
-        const int rem = mm - n * (Hc * Wc);
-        const int ii = rem / Wc, jj = rem - ii * Wc;
-        const int ib = (g.s == 2) ? ii + ah : ii + 1, jb = (g.s == 2) ? jj + aw : jj + 1;
-        a_off[i] = ((n * g.Hs + ib) * g.Ws + jb) * ld_small;
-        int wv = 0, mask = 0;          // local tap (th, tw) reads small pixel (ib - th, jb - tw)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) wv |= (t < T && (unsigned)(jb - t) < (unsigned)g.Ws) ? (1 << t) : 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) mask |= (t < T && (unsigned)(ib - t) < (unsigned)g.Hs) ? (wv << (T * t)) : 0;
-        a_mask[i] = (m < Mc) ? mask : 0;
-    }
-    const int bq = tid % BQ, brow0 = tid / BQ;
-    const int ncol = n0 + bq * 4;
-    const int ncol_off = (ncol < g.Cb) ? ncol : 0x10000000;      // Cb % 4 == 0: a float4 is all in or all out
-    const int CaCb = g.Ca * g.Cb;
-
-    // incremental (tloc, a) per k-quad: A float4 (index 0) and the NQ quads of B (1..NQ); Ca >= KC: <= 1 wrap
-    int q_tl[NQ + 1], q_a[NQ + 1];
-    {
-        const int k = c_begin * KC + kq * 4;
-        q_tl[0] = k / g.Ca;
-        q_a[0] = k - q_tl[0] * g.Ca;
-    }
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        const int k = c_begin * KC + brow0 + BROWS * i;
-        q_tl[i + 1] = k / g.Ca;
-        q_a[i + 1] = k - q_tl[i + 1] * g.Ca;
-    }
-    auto quad = [&](int qi, int& tl, int& a) {   // returns (tloc, a) of quad qi for the chunk being loaded
-        tl = q_tl[qi];
-        a = q_a[qi];
-        const int na = a + KC;
-        const bool wrap = na >= g.Ca;
-        q_a[qi] = wrap ? na - g.Ca : na;
-        q_tl[qi] = wrap ? tl + 1 : tl;
-    };
-
-    f32x4 ra[AI], rb[NQ];
-    int a_tl = 0, a_koff = OOB;
-    auto next_a = [&](int c) {
-        const int k = c * KC + kq * 4;
-        int tl, a;
-        quad(0, tl, a);
-        a_tl = tl;
-        const int th = tl >> Tsh, tw = tl & (T - 1);
-        a_koff = (k < K) ? (a - (th * g.Ws + tw) * ld_small) : 0x20000000;
-    };
-    auto load_a = [&](int i, bool on) {
-        const bool ok = on && ((a_mask[i] >> a_tl) & 1) && (a_koff < 0x10000000);
-        ra[i] = bload4(rsm, voff(a_off[i] + a_koff, ok));
-    };
-    auto load_b = [&](int i, int c, bool on) {
-        const int kb = c * KC + brow0 + BROWS * i;
-        int tl, a;
-        quad(i + 1, tl, a);
-        const int th = tl >> Tsh, tw = tl & (T - 1);
-        const int tap = (kh0 + g.s * th) * 4 + (kw0 + g.s * tw);
-        const bool ok = on && kb < K;
-        rb[i] = bload4(rP, voff(tap * CaCb + a * g.Cb + ncol_off, ok));
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow0 + BROWS * i) * LDB + bq * 4]) = rb[i];
-    };
-
-    f32x16 acc[MR][NR];
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < NR; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    if (c_begin < c_end) {
-        next_a(c_begin);
-#pragma unroll
-        for (int i = 0; i < AI; ++i) load_a(i, true);
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) load_b(i, c_begin, true);
-        store_chunk();
-    }
-    __syncthreads();
-    for (int c = c_begin; c < c_end; ++c) {
-        const bool more = (c + 1 < c_end);
-        next_a(c + 1);
-#pragma unroll
-        for (int kk = 0; kk < KC / 8; ++kk) {
-            f32x4 af[MR];
-            float bf[NR][4];
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MR + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
-#pragma unroll
-            for (int j = 0; j < NR; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bf[j][e] = Bs[(kk * 8 + lh * 4 + e) * LDB + (wn * NR + j) * 32 + lrow];
-            if (kk < AI) load_a(kk, more);
-            if (kk < NQ) load_b(kk, c + 1, more);
-            PIN_VMEM();
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < MR; ++i)
-#pragma unroll
-                    for (int j = 0; j < NR; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-        if (more) {
-            store_chunk();
-            __syncthreads();
-        }
-    }
-
-    const bool fin = (slab_stride == 0);
-    float* o = out + (long)slice * slab_stride;
-    const int ldo = fin ? ld_out : g.Cb;
-    float bv[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        const int col = n0 + (wn * NR + j) * 32 + lrow;
-        bv[j] = (fin && bias != nullptr && col < g.Cb) ? bias[col] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < MR; ++i) {
-        // decode the lane's first row with two divisions, then walk the other 15 (at most 28 rows further) with a
-        // carry chain: 64 divisions per thread in the epilogue cost as much as several K-chunks
-        const int mb = m0 + (wm * MR + i) * 32 + 4 * lh;
-        const int mbc = min(mb, Mc - 1);
-        const int nb0 = mbc / (Hc * Wc);
-        const int remb = mbc - nb0 * (Hc * Wc);
-        const int ib0 = remb / Wc, jb0 = remb - ib0 * Wc;
-        const bool chain = Wc >= 16 && Hc >= 2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int m = m0 + (wm * MR + i) * 32 + row;
-            if (m < Mc) {
-                int n, ii, jj;
-                if (chain) {
-                    const int d = (r & 3) + 8 * (r >> 2);      // 0..27 rows past the decoded one
-                    jj = jb0 + d;
-                    ii = ib0;
-                    n = nb0;
-                    bool w1 = jj >= Wc;
-                    jj = w1 ? jj - Wc : jj;
-                    ii = w1 ? ii + 1 : ii;
-                    w1 = jj >= Wc;
-                    jj = w1 ? jj - Wc : jj;
-                    ii = w1 ? ii + 1 : ii;
-                    w1 = ii >= Hc;
-                    ii = w1 ? ii - Hc : ii;
-                    n = w1 ? n + 1 : n;
-                } else {
-                    n = m / (Hc * Wc);
-                    const int rem = m - n * (Hc * Wc);
-                    ii = rem / Wc;
-                    jj = rem - ii * Wc;
-                }
-                const int h = (g.s == 2) ? 2 * ii + ah : ii, w = (g.s == 2) ? 2 * jj + aw : jj;
-                float* orow = o + (long)((n * g.Hb + h) * g.Wb + w) * ldo;
-#pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    const int col = n0 + (wn * NR + j) * 32 + lrow;
-                    if (col < g.Cb) {
-                        float v = acc[i][j][r];
-                        if (fin) v = pg_act_epi(v + bv[j], act);
-                        orow[col] = v;
-                    }
-                }
-            }
-        }
-    }
-}
-
 template <int MR, int NR, int WM, int WN, bool POW2>
 __global__ __launch_bounds__(256) void k_wgrad_fast(const float* __restrict__ small, int ld_small,
                                                     const float* __restrict__ big, int ld_big,
@@ -2187,13 +1966,8 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
     dim3 grid(p.tiles_m, p.tiles_n, p.ncls * p.split);
     const long small_bytes = tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca), p_bytes = 16L * g.Ca * g.Cb * 4;
     const bool fast = veck && g.Ca >= KC && small_bytes < FAST_LIMIT && p_bytes < FAST_LIMIT && !force_generic();
-    static const bool ncontig = getenv("PATCHGAN_S2B_NCONTIG") != nullptr;
-    const bool fastn = fast && ncontig && (g.Cb % 4 == 0) && aligned16(P);
     if (p.split == 1) {
-        if (fastn) {
-            PG_DISPATCH_TILE(k_s2b_fastn, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, bias, act,
-                             (int)small_bytes, (int)p_bytes);
-        } else if (fast) {
+        if (fast) {
             PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, bias, act,
                              (int)small_bytes, (int)p_bytes);
         } else {
@@ -2203,10 +1977,7 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     float* slabs = (float*)ws;
-    if (fastn) {
-        PG_DISPATCH_TILE(k_s2b_fastn, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
-                         (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes);
-    } else if (fast) {
+    if (fast) {
         PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
                          (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes);
     } else {
