@@ -163,13 +163,13 @@ def main():
         value = images / elapsed
         summ = prof.summary() if args.events != 'none' else wsum
         # dominant kernel = the conv kernel symbol with the most device time (found in the profiled warm-up step)
-        (sym, split), d = max(summ.items(), key=lambda kv: kv[1]['ms'])
+        sym, d = max(summ.items(), key=lambda kv: kv[1]['ms'])
         if args.events == 'none':
             d = dict(d, launches=d['launches'] * args.steps, ms=d['ms'] * args.steps, flops=d['flops'] * args.steps)
         per_step_all = wsum                      # every conv kernel, from the profiled warm-up step
         conv_ms = sum(v['ms'] for v in per_step_all.values()) * args.steps
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
-        roofline = {'bound': 'mfma', 'kernel': sym + (f' (split-K {split} + reduce)' if split > 1 else ''),
+        roofline = {'bound': 'mfma', 'kernel': sym,
                     'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(sym),
                     'launches_per_step': d['launches'] / args.steps,
@@ -194,7 +194,7 @@ def main():
         elif world == 1:
             out['cpu_baseline'] = None
         out['conv_kernels_note'] = 'per-kernel table from one fully instrumented warm-up step; roofline from the timed region'
-        kernels = {f'{k[0]}/split{k[1]}': {'launches_per_step': v['launches'], 'ms_per_step': round(v['ms'], 4),
+        kernels = {k: {'launches_per_step': v['launches'], 'ms_per_step': round(v['ms'], 4),
                                             'TFLOPs': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)}
                    for k, v in sorted(per_step_all.items(), key=lambda kv: -kv[1]['ms'])}
         out['conv_kernels'] = kernels

@@ -22,7 +22,7 @@
  *     never allocate, never synchronise; the caller owns all memory including
  *     the workspace.  Return 0 on success or a negative PG_E* code; nothing is
  *     launched when an error is returned.
- *   - thread-compatible: no global mutable state.
+ *   - thread-compatible: no global mutable state (pg_conv_time_next keeps two thread-local event handles).
  */
 #ifndef PATCHGAN_HIP_H
 #define PATCHGAN_HIP_H
@@ -74,6 +74,12 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);
  * col2im / tap-gather path.  + 100 (+ 200: power-of-two pixel decode, wgrad) marks the fast buffer-load variant
  * (k_b2s_fast / k_s2b_fast / k_wgrad_fast) that runs when tensors are 16-byte aligned.  For profiling only. */
 int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups);
+
+/* Arms per-launch timing: the NEXT pg_conv4x4_* call on this thread records the caller-owned hipEvent_t `ev_start`
+ * immediately before and `ev_stop` immediately after its main GEMM kernel on the launch stream (the split-K reduce, the
+ * bias column sums and the col2im / gather pass are outside the pair), then disarms itself.  Thread-local state; the
+ * default (never armed) adds nothing to a launch.  Used by bench.py's roofline leg. */
+int pg_conv_time_next(void* ev_start, void* ev_stop);
 
 /* small[n,p,q,a] = act( sum_{kh,kw,b} big[n, s*p-1+kh, s*q-1+kw, b] * P[kh*4+kw][a][b] + bias[a] )
  * Replaces: nn.Conv2d forward (unet.py:19; disc.py:19,27,37,45) with (a,b) = (Cout,Cin), and the

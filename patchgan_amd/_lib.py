@@ -42,6 +42,7 @@ SIGNATURES = {
     'pg_version': (_i, []),
     'pg_conv_workspace_bytes': (_sz, [_G, _i]),
     'pg_conv_describe': (_i, [_G, _i, _sz, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_l)]),
+    'pg_conv_time_next': (_i, [_p, _p]),
     'pg_conv4x4_big2small': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p]),
     'pg_conv4x4_small2big': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p]),
     'pg_conv4x4_wgrad': (_i, [_p, _i, _p, _i, _p, _p, _G, _i, _p, _sz, _p]),

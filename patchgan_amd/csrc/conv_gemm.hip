@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <alloca.h>
+#include <new>
 #include "patchgan_hip.h"
 #include "pg_common.h"
 
@@ -1600,6 +1602,23 @@ __global__ void k_wgrad_direct(const float* __restrict__ small, int ld_small, co
 // ------------------------------------------------------------------------------------------------
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Optional per-launch timing (bench.py's roofline leg): pg_conv_time_next() arms two caller-owned events; the next conv
+// entry point on this thread records them immediately before and after its main GEMM kernel (not the split-K reduce,
+// not the bias column-sum), then disarms.  Thread-local; no effect unless armed.
+thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
+struct TimedLaunch {
+    hipStream_t st;
+    hipEvent_t e1;
+    explicit TimedLaunch(hipStream_t s) : st(s), e1(t_ev1) {
+        if (t_ev0) (void)hipEventRecord(t_ev0, st);
+        t_ev0 = nullptr;
+        t_ev1 = nullptr;
+    }
+    ~TimedLaunch() {
+        if (e1) (void)hipEventRecord(e1, st);
+    }
+};
+
 // bytes spanned by a [pixels][C] view with pixel stride ld (what the buffer descriptor of the fast kernels covers)
 inline long tensor_bytes(long pixels, int ld, int C) { return ((pixels - 1) * (long)ld + C) * 4; }
 constexpr long FAST_LIMIT = 0x60000000L;   // 1.5 GiB: keeps every 32-bit byte offset, incl. the +0x40000000 sentinel, < 2^32
@@ -1829,6 +1848,12 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
     return (bytes + 255) & ~(size_t)255;
 }
 
+int pg_conv_time_next(void* ev_start, void* ev_stop) {
+    t_ev0 = (hipEvent_t)ev_start;
+    t_ev1 = (hipEvent_t)ev_stop;
+    return PG_OK;
+}
+
 int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups) {
     if (!geom_ok(g) || op < 0 || op > 2) return PG_EINVAL;
     Plan p = (op == 0) ? plan_b2s(g) : (op == 1) ? plan_s2b(g) : plan_wgrad(g);
@@ -1884,8 +1909,11 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
         Geom g1{g.N, g.Hb, g.Wb, g.Hb, g.Wb, Nc, g.Cb, 1};
         Tile t = pick_tile(Mb, Nc);
         dim3 grid((unsigned)((Mb + t.bm - 1) / t.bm), (Nc + t.bn - 1) / t.bn, 1);
-        PG_DISPATCH_B2SF(true, t.id, grid, st, big, ld_big, P, D, Nc, 0L, g1, g.Cb / KC, (const float*)nullptr, 0,
-                         (int)tensor_bytes(Mb, ld_big, g.Cb), (int)(16L * g.Ca * g.Cb * 4));
+        {
+            TimedLaunch timed(st);
+            PG_DISPATCH_B2SF(true, t.id, grid, st, big, ld_big, P, D, Nc, 0L, g1, g.Cb / KC, (const float*)nullptr, 0,
+                             (int)tensor_bytes(Mb, ld_big, g.Cb), (int)(16L * g.Ca * g.Cb * 4));
+        }
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         const long total = (long)g.N * g.Hs * g.Ws * g.Ca;
         hipLaunchKernelGGL(k_gather_big2small, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, D, bias,
@@ -1899,6 +1927,7 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
     const long big_bytes = tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb), p_bytes = 16L * g.Ca * g.Cb * 4;
     const bool fast = veck && g.Cb >= KC && big_bytes < FAST_LIMIT && p_bytes < FAST_LIMIT && !force_generic();
     if (p.split == 1) {
+        TimedLaunch timed(st);
         if (fast) {
             PG_DISPATCH_B2SF(false, p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, bias, act,
                              (int)big_bytes, (int)p_bytes);
@@ -1909,12 +1938,15 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     float* slabs = (float*)ws;
-    if (fast) {
-        PG_DISPATCH_B2SF(false, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps,
-                         (const float*)nullptr, 0, (int)big_bytes, (int)p_bytes);
-    } else {
-        PG_DISPATCH_TILE(k_big2small, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps, veck,
-                         (const float*)nullptr, 0);
+    {
+        TimedLaunch timed(st);
+        if (fast) {
+            PG_DISPATCH_B2SF(false, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps,
+                             (const float*)nullptr, 0, (int)big_bytes, (int)p_bytes);
+        } else {
+            PG_DISPATCH_TILE(k_big2small, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps, veck,
+                             (const float*)nullptr, 0);
+        }
     }
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     return launch_reduce(slabs, p.out_elems, p.split, small, ld_small, (long)g.N * g.Hs * g.Ws, g.Ca, bias, act, st);
@@ -1951,8 +1983,11 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
         Geom g1{g.N, g.Hs, g.Ws, g.Hs, g.Ws, Nc, g.Ca, 1};
         Tile t = pick_tile(Ms, Nc);
         dim3 grid((unsigned)((Ms + t.bm - 1) / t.bm), (Nc + t.bn - 1) / t.bn, 1);
-        PG_DISPATCH_B2SF(true, t.id, grid, st, small, ld_small, W, D, Nc, 0L, g1, g.Ca / KC, (const float*)nullptr, 0,
-                         (int)tensor_bytes(Ms, ld_small, g.Ca), (int)((long)Nc * g.Ca * 4));
+        {
+            TimedLaunch timed(st);
+            PG_DISPATCH_B2SF(true, t.id, grid, st, small, ld_small, W, D, Nc, 0L, g1, g.Ca / KC, (const float*)nullptr, 0,
+                             (int)tensor_bytes(Ms, ld_small, g.Ca), (int)((long)Nc * g.Ca * 4));
+        }
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
         hipLaunchKernelGGL(k_col2im_small2big, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, D, bias,
@@ -1967,6 +2002,7 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
     const long small_bytes = tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca), p_bytes = 16L * g.Ca * g.Cb * 4;
     const bool fast = veck && g.Ca >= KC && small_bytes < FAST_LIMIT && p_bytes < FAST_LIMIT && !force_generic();
     if (p.split == 1) {
+        TimedLaunch timed(st);
         if (fast) {
             PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, bias, act,
                              (int)small_bytes, (int)p_bytes);
@@ -1977,12 +2013,15 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     float* slabs = (float*)ws;
-    if (fast) {
-        PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
-                         (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes);
-    } else {
-        PG_DISPATCH_TILE(k_small2big, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps, veck,
-                         vecn, (const float*)nullptr, 0);
+    {
+        TimedLaunch timed(st);
+        if (fast) {
+            PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
+                             (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes);
+        } else {
+            PG_DISPATCH_TILE(k_small2big, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps, veck,
+                             vecn, (const float*)nullptr, 0);
+        }
     }
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     return launch_reduce(slabs, p.out_elems, p.split, big, ld_big, (long)g.N * g.Hb * g.Wb, g.Cb, bias, act, st);
@@ -2029,6 +2068,7 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
     const int vecn = (g.Cb % 4 == 0) && (ld_big % 4 == 0) && aligned16(big);
     const int mode = wgrad_mode(gg);
     float* dst = p.split == 1 ? dP : (float*)((char*)ws + reserved);
+    TimedLaunch* timed = new (alloca(sizeof(TimedLaunch))) TimedLaunch(st);
     if (mode == 0) {
         dim3 grid(p.tiles_m * p.tiles_n, 16, p.split);
         const long small_bytes = tensor_bytes(Kp, ld_small, g.Ca);
@@ -2053,6 +2093,7 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
         dim3 grid(p.tiles_m * p.tiles_n, 1, p.split);
         PG_DISPATCH_TAPN(2, p.t.id, grid, st, big, ld_big, small, ld_small, dst, p.out_elems, g, p.cps, p.tiles_n, vecn);
     }
+    timed->~TimedLaunch();
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     if (p.split == 1) return PG_OK;
     return launch_reduce(dst, p.out_elems, p.split, dP, g.Cb, 16L * g.Ca, g.Cb, nullptr, 0, st);

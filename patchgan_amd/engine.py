@@ -101,26 +101,32 @@ class LaunchProfiler:
 
     def __init__(self, only=None):
         self.records = []   # (symbol, split, flops, start_event, end_event)
-        self.only = only    # (symbol, split): time only this kernel's launches
+        self.only = only    # symbol: time only this kernel's launches
 
     def launch(self, op, opcode, fn):
         if op.algo == L.ALGO_DIRECT:
             return fn()
         sym, split = op.describe(opcode)
-        if self.only is not None and (sym, split) != self.only:
+        if self.only is not None and sym != self.only:
             return fn()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0, e1 = self._event(), self._event()
+        # the C ABI records the pair tightly around the main GEMM kernel of this call (not its split-K reduce)
+        L.check(L.load().pg_conv_time_next(e0.cuda_event, e1.cuda_event), 'pg_conv_time_next')
         fn()
-        e1.record()
         self.records.append((sym, split, op.flops, e0, e1))
 
+    @staticmethod
+    def _event():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()          # torch creates the hipEvent_t lazily: force it, the C side re-records it
+        return e
+
     def summary(self):
-        """{(symbol, split): dict(launches, ms_total, flops_total)} -- call after a device synchronize."""
+        """{symbol: dict(launches, ms_total, flops_total)} over every launch of that kernel symbol (all split-K factors,
+        like a rocprofv3 --stats row) -- call after a device synchronize."""
         out = {}
         for sym, split, flops, e0, e1 in self.records:
-            d = out.setdefault((sym, split), dict(launches=0, ms=0.0, flops=0.0))
+            d = out.setdefault(sym, dict(launches=0, ms=0.0, flops=0.0))
             d['launches'] += 1
             d['ms'] += e0.elapsed_time(e1)
             d['flops'] += flops

@@ -207,3 +207,45 @@ def test_train_driver_vs_golden(tmp_path):
     np.testing.assert_allclose(G2, z['resume_G_loss_ep'], rtol=1e-4)
     np.testing.assert_allclose(D2, z['resume_D_loss_ep'], rtol=1e-4)
     np.testing.assert_allclose([t2.gen_lr, t2.dsc_lr], z['resume_lr'], rtol=1e-12)
+
+
+def test_input_size_errors_match_reference():
+    """64x64 reaches a 1x1 InstanceNorm (ValueError in torch); sizes that are not multiples of 128
+    break a skip concatenation (RuntimeError in torch)."""
+    import patchgan_amd as pg
+    g = pg.UNet(3, 1, 4, activation='relu', final_act='sigmoid').cuda()
+    with pytest.raises(ValueError):
+        g(torch.rand(1, 3, 64, 64).cuda())
+    with pytest.raises(RuntimeError):
+        g(torch.rand(1, 3, 320, 320).cuda())
+    d = pg.Discriminator(4, 4, n_layers=5).cuda()
+    with pytest.raises(RuntimeError):
+        d(torch.rand(1, 4, 32, 32).cuda())          # kernel larger than the padded input
+
+
+def test_dropout_training_and_eval(tmp_path):
+    """use_dropout=True (the CLI default, train.py:92): active in train(), off in eval(); a fresh mask every step."""
+    import patchgan_amd as pg
+    gold = Golden('a_lrelu_tversky')
+    x, y = gold.inputs()
+    g = pg.UNet(3, 1, 4, use_dropout=True, activation='leakyrelu', final_act='sigmoid')
+    g.load_state_dict(gold.weights('g0'))
+    g.cuda()
+    xc = x.cuda()
+    g.eval()
+    with torch.no_grad():
+        e1, e2 = g(xc), g(xc)
+    assert torch.equal(e1, e2)
+    want = O.unet_forward(gold.weights('g0'), x, 'leakyrelu', 'sigmoid')
+    assert _rel(e1.cpu(), want) < FWD_RTOL          # eval = no dropout = the oracle without masks
+    g.train()
+    with torch.no_grad():
+        t1, t2 = g(xc), g(xc)
+    assert not torch.equal(t1, t2) and not torch.equal(t1, e1)
+    d = pg.Discriminator(4, 4, n_layers=3)
+    d.load_state_dict(gold.weights('d0'))
+    t = pg.Trainer(g, d.cuda(), str(tmp_path / 'c'))
+    t.setup_optimizers()
+    d.train()
+    l = [t.batch(x, y, train=True)['gen'] for _ in range(3)]
+    assert all(np.isfinite(l))
