@@ -381,6 +381,9 @@ class GeneratorEngine:
                 op = ConvOp(N, h, w, l.a, l.b, 2, self.algo)
                 enc_ops.append(op)
                 h, w = op.Hs, op.Ws
+                if h * w <= 1:     # torch raises from this block's InstanceNorm before the next conv is reached
+                    raise ValueError(f"Expected more than 1 spatial element when training, got input size "
+                                     f"torch.Size([{N}, {l.a}, {h}, {w}])")
             sizes = [(op.Hs, op.Ws) for op in enc_ops]   # enc i output extent
             for i, l in enumerate(self.dec):
                 # convT: small = input (h, w), big = output (2h, 2w)
