@@ -11,6 +11,10 @@ Parity status: PINNED.  The reference has no tests or golden vectors of its own
 container by importing the reference itself (``tests/golden/make_golden.py``
 -> ``tests/golden/*.npz``) and checked by ``tests/test_oracle_golden.py``.
 
+A second, independent statement of the bottom-level arithmetic (conv 4x4, conv-transpose 4x4, InstanceNorm, conv
+weight gradient) lives in ``oracle/conv_ref.c`` (plain C loops, double accumulation; built by ``make -C oracle``) and
+is held against this file by ``tests/test_oracle_c_cpu.py``.
+
 Where the arithmetic lives: third-party PyTorch (reference ``setup.py:35``,
 ``torch>=1.13.0``, unpinned; this image has torch 2.10.0).  The reference's call
 sites are cited per function below as ``file:line`` into /root/reference.
