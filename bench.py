@@ -25,16 +25,31 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-GFLOP_PER_IMAGE = 85.98                  # useful conv FLOPs of one G+D step per image (cfg2)
-BATCH_PER_GPU = 16
-SIZE = 256
+# workloads.  cfg2 is the one BASELINE.json's metric is quoted on and the default; the others are the
+# parity-test / "next" configurations, runnable here for reference only.
+CONFIGS = {
+    'cfg2': dict(size=256, batch=16, out_nc=1, nf=64, ndf=64, n_layers=3, activation='leakyrelu', final_act='sigmoid',
+                 loss_type='tversky', gflop_per_image=85.98,
+                 desc='cfg2: 256x256x3->1 masks, bs 16/GPU, UNet nf=64 leakyrelu/sigmoid + PatchGAN ndf=64 n_layers=3, '
+                      'focal-Tversky*200 + BCE, Adam 1e-3'),
+    'cfg4': dict(size=512, batch=8, out_nc=4, nf=64, ndf=64, n_layers=3, activation='leakyrelu', final_act='softmax',
+                 loss_type='weighted_bce', gflop_per_image=352.99,
+                 desc='cfg4 (fp32 here; its bf16 path is a "next" row): 512x512x3->4-class masks, bs 8/GPU, nf=ndf=64'),
+    'cfg1': dict(size=256, batch=4, out_nc=7, nf=32, ndf=16, n_layers=5, activation='relu', final_act='sigmoid',
+                 loss_type='weighted_bce', gflop_per_image=12.2,
+                 desc='cfg1: COCO-yaml hyper-parameters (nf=32, ndf=16, n_layers=5, relu, 7 classes, weighted BCE), 256x256 bs 4'),
+}
+CFG = CONFIGS['cfg2']
+GFLOP_PER_IMAGE = CFG['gflop_per_image']
+BATCH_PER_GPU = CFG['batch']
+SIZE = CFG['size']
 
 
 def make_inputs(batch, rank):
     import torch
     g = torch.Generator().manual_seed(7 + rank)
     x = torch.rand(batch, 3, SIZE, SIZE, generator=g)
-    y = (torch.rand(batch, 1, SIZE, SIZE, generator=g) > 0.7).float()
+    y = (torch.rand(batch, CFG['out_nc'], SIZE, SIZE, generator=g) > 0.7).float()
     return x, y
 
 
@@ -72,10 +87,10 @@ def cpu_baseline(max_seconds=25.0):
     cores = usable_cpus()
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
-    gw = O.default_init(O.unet_weight_shapes(3, 1, 64))
-    dw = O.default_init(O.disc_weight_shapes(4, 64, 3, False))
-    ot = O.OracleTrainer(gw, dw, activation='leakyrelu', final_act='sigmoid', n_layers=3, norm=False,
-                         loss_type='tversky', seg_alpha=200)
+    gw = O.default_init(O.unet_weight_shapes(3, CFG['out_nc'], CFG['nf']))
+    dw = O.default_init(O.disc_weight_shapes(3 + CFG['out_nc'], CFG['ndf'], CFG['n_layers'], False))
+    ot = O.OracleTrainer(gw, dw, activation=CFG['activation'], final_act=CFG['final_act'], n_layers=CFG['n_layers'],
+                         norm=False, loss_type=CFG['loss_type'], seg_alpha=200)
     x, y = make_inputs(BATCH_PER_GPU, 0)
     ot.batch(x, y, train=True)                       # warm-up (oneDNN primitive creation)
     t0 = time.perf_counter()
@@ -87,7 +102,7 @@ def cpu_baseline(max_seconds=25.0):
             break
     dt = time.perf_counter() - t0
     return {'value': round(BATCH_PER_GPU * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} G+D steps of cfg2 (bs 16, 256x256, nf=ndf=64) after 1 warm-up step; {dt / n:.2f} s/step'}
+            'sample': f'{n} G+D steps of the same workload (bs {BATCH_PER_GPU}, {SIZE}x{SIZE}) after 1 warm-up step; {dt / n:.2f} s/step'}
 
 
 def main():
@@ -97,9 +112,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dropout', action='store_true', help='nn.Dropout(0.2) in the generator (CLI default of the reference)')
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg2', help='workload (default: the BASELINE metric config)')
     ap.add_argument('--events', choices=['dominant', 'all', 'none'], default='dominant',
                     help='which conv launches get HIP events in the timed region (roofline leg)')
     args = ap.parse_args()
+    global CFG, GFLOP_PER_IMAGE, BATCH_PER_GPU, SIZE
+    CFG = CONFIGS[args.config]
+    GFLOP_PER_IMAGE, BATCH_PER_GPU, SIZE = CFG['gflop_per_image'], CFG['batch'], CFG['size']
 
     import torch
     import torch.distributed as dist
@@ -118,10 +137,11 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     torch.manual_seed(1234)
-    G = pg.UNet(3, 1, 64, use_dropout=args.dropout, activation='leakyrelu', final_act='sigmoid').to(dev)
-    D = pg.Discriminator(4, 64, n_layers=3, norm=False).to(dev)
+    G = pg.UNet(3, CFG['out_nc'], CFG['nf'], use_dropout=args.dropout, activation=CFG['activation'],
+                final_act=CFG['final_act']).to(dev)
+    D = pg.Discriminator(3 + CFG['out_nc'], CFG['ndf'], n_layers=CFG['n_layers'], norm=False).to(dev)
     t = pg.Trainer(G, D, tempfile.mkdtemp(prefix='pgbench_'))
-    t.loss_type, t.seg_alpha = 'tversky', 200
+    t.loss_type, t.seg_alpha = CFG['loss_type'], 200
     t.setup_optimizers(1e-3, 1e-3)
     G.train()
     D.train()
@@ -179,12 +199,11 @@ def main():
                     'all_conv_share_of_step': round(conv_ms / args.steps / (elapsed / args.steps * 1e3), 4),
                     'step_frac_of_fp32_roofline': round(value / world * GFLOP_PER_IMAGE / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
         out = {
-            'metric': 'train images/sec (G+D step) at 256x256 bs=16 per GPU', 'value': round(value, 2),
+            'metric': f'train images/sec (G+D step) at {SIZE}x{SIZE} bs={BATCH_PER_GPU} per GPU', 'value': round(value, 2),
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'cfg2: 256x256x3->1 masks, bs 16/GPU, UNet nf=64 leakyrelu/sigmoid + PatchGAN ndf=64 '
-                                   'n_layers=3, focal-Tversky*200 + BCE, Adam 1e-3, dropout ' + ('on' if args.dropout else 'off'),
+            'config': {'workload': CFG['desc'] + ', dropout ' + ('on' if args.dropout else 'off'),
                        'global_batch': BATCH_PER_GPU * world, 'parallelism': f'dp{world}'},
             'last_losses': {k: round(v, 5) for k, v in last.items()},
             'roofline': roofline,

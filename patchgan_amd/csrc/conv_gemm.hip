@@ -821,6 +821,14 @@ constexpr int OOB = 0x7fffffff;
 #define PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
 // element offset -> byte offset without signed overflow (sentinel offsets exceed INT_MAX/4 on purpose)
 __device__ __forceinline__ int b4(int elem_off) { return (int)((unsigned)elem_off << 2); }
+// XCD-aware tile order (cdna_hip_programming.md T1): workgroups b and b+8 share an XCD (round-robin dispatch), so hand each
+// XCD a CONTIGUOUS run of M-tiles -- neighbouring tiles read overlapping input rows (conv halo) and the same weight
+// slice, which then hit that XCD's private L2 instead of going to the fabric.  Bijective for any grid size; speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // byte offset of a gather element, forced out of range (bit 31 set: >= 2 GiB > any descriptor here) when !ok.
 // Written as an OR so the offset arithmetic stays unconditional: with `ok ? off : OOB` hipcc sinks the arithmetic into
 // an exec-masked region per load, which splits the MFMA loop into many scheduling regions.
@@ -864,7 +872,7 @@ __global__ __launch_bounds__(256) void k_b2s_fast(const float* __restrict__ big,
     const int lrow = lane & 31, lh = lane >> 5;
     const int M = ONE ? g.N * g.Hb * g.Wb : g.N * g.Hs * g.Ws;
     const int K = ONE ? g.Cb : 16 * g.Cb;               // K % 32 == 0 (Cb % 4 == 0; ONE requires Cb % 32 == 0)
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
     const int nchunks = K / KC;
     const int c_begin = blockIdx.z * chunks_per_slice;
     const int c_end = min(nchunks, c_begin + chunks_per_slice);
@@ -1021,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_s2b_fast(const float* __restrict__ smal
     const int Wc = (g.s == 2) ? (g.Wb - aw + 1) / 2 : g.Wb;
     const int kh0 = (g.s == 2) ? (1 - ah) : 0, kw0 = (g.s == 2) ? (1 - aw) : 0;
     const int Mc = g.N * Hc * Wc, K = T * T * g.Ca;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
     if (m0 >= Mc) return;
     const int nchunks = (K + KC - 1) / KC;
     const int c_begin = slice * chunks_per_slice;
