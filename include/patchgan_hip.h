@@ -50,6 +50,8 @@ extern "C" {
 #define PG_ALGO_AUTO 0
 #define PG_ALGO_DIRECT 1 /* one-thread-per-output reference-quality kernels (any channel count) */
 #define PG_ALGO_MFMA 2   /* LDS-tiled implicit GEMM on v_mfma_f32_32x32x2_f32 (channels % 4 == 0) */
+#define PG_ALGO_BF16 3   /* same kernels with operand tiles rounded to bf16 in LDS and v_mfma_f32_32x32x16_bf16 (fp32
+                            tensors, fp32 accumulate); layers the fast path does not cover fall back to fp32 */
 
 typedef struct pg_conv_geom {
     int N;        /* batch */

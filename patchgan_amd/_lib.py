@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'libpatchgan_hip.so')
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 ACT_CODES = {None: ACT_NONE, 'none': ACT_NONE, 'leakyrelu': ACT_LEAKY, 'relu': ACT_RELU, 'tanh': ACT_TANH,
              'sigmoid': ACT_SIGMOID}
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_BF16 = 0, 1, 2, 3
 LOSS_TVERSKY, LOSS_WBCE, LOSS_MAE, LOSS_BCE = 0, 1, 2, 3
 OP_BIG2SMALL, OP_SMALL2BIG, OP_WGRAD = 0, 1, 2
 

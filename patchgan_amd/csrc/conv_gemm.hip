@@ -1373,6 +1373,546 @@ __global__ __launch_bounds__(256) void k_wgrad_fast(const float* __restrict__ sm
         }
 }
 
+// ================================================================================================
+// bf16 variants (PG_ALGO_BF16; the "next" row f2, BASELINE config 4): tensors stay fp32 in HBM and in the C ABI -- fp32
+// master weights, fp32 InstanceNorm statistics, fp32 accumulation -- but operand tiles are rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) as they are staged into LDS and multiplied on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate),
+// which moves these kernels from MFMA-bound to load-bound.  Same tiling, gathers and split-K as the fast fp32 kernels.
+// LDS rows are 32 bf16 + 8 pad = 80 B: conflict-free ds_read_b128 of a lane's 8 consecutive k.
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDKH = KC + 8;
+__device__ __forceinline__ bf16x4 to_bf16(f32x4 v) {
+    bf16x4 r;
+    r[0] = (__bf16)v[0];
+    r[1] = (__bf16)v[1];
+    r[2] = (__bf16)v[2];
+    r[3] = (__bf16)v[3];
+    return r;
+}
+
+template <int MR, int NR, int WM, int WN, bool ONE>
+__global__ __launch_bounds__(256) void k_b2s_bf16(const float* __restrict__ big, int ld_big,
+                                                  const float* __restrict__ P, float* __restrict__ out, int ld_out,
+                                                  long slab_stride, Geom g, int chunks_per_slice,
+                                                  const float* __restrict__ bias, int act, int big_bytes, int p_bytes) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[(BM + BN) * LDKH];
+    __bf16* As = smem;
+    __bf16* Bs = smem + BM * LDKH;
+    const __amdgpu_buffer_rsrc_t rbig = __builtin_amdgcn_make_buffer_rsrc((void*)big, 0, big_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, p_bytes, 0x00020000);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int M = ONE ? g.N * g.Hb * g.Wb : g.N * g.Hs * g.Ws;
+    const int K = ONE ? g.Cb : 16 * g.Cb;               // K % 32 == 0 (Cb % 4 == 0; ONE requires Cb % 32 == 0)
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
+    const int nchunks = K / KC;
+    const int c_begin = blockIdx.z * chunks_per_slice;
+    const int c_end = min(nchunks, c_begin + chunks_per_slice);
+
+    const int kq = tid & 7, r0 = tid >> 3;
+    int a_off[AI], a_mask[AI], b_off[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const int mm = min(m, M - 1);
+        if (ONE) {
+            a_off[i] = mm * ld_big;
+            a_mask[i] = (m < M) ? 1 : 0;
+            continue;
+        }
+        const int n = mm / (g.Hs * g.Ws);
+        const int rem = mm - n * (g.Hs * g.Ws);
+        const int p = rem / g.Ws, q = rem - p * g.Ws;
+        const int h0 = g.s * p - 1, w0 = g.s * q - 1;
+        a_off[i] = ((n * g.Hb + h0) * g.Wb + w0) * ld_big;
+        int wv = 0, mask = 0;          // tap (kh, kw) is inside the image iff row kh and column kw both are
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wv |= ((unsigned)(w0 + t) < (unsigned)g.Wb) ? (1 << t) : 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mask |= ((unsigned)(h0 + t) < (unsigned)g.Hb) ? (wv << (4 * t)) : 0;
+        a_mask[i] = (m < M) ? mask : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int a = n0 + r0 + 32 * i;
+        b_off[i] = (a < g.Ca) ? a * g.Cb : 0x10000000;
+    }
+    const int CaCb = g.Ca * g.Cb;
+    int cur_tap = (c_begin * KC + kq * 4) / g.Cb;
+    int cur_b = (c_begin * KC + kq * 4) - cur_tap * g.Cb;
+
+    f32x4 ra[AI], rb[BI];
+    int tapoff = 0, pboff = 0, ctap = 0;
+    auto next_tap = [&]() {   // (tap, b) of the next chunk for this thread's float4; Cb >= KC: at most one wrap
+        const int tap = cur_tap, b = cur_b;
+        cur_b += KC;
+        const bool wrap = cur_b >= g.Cb;
+        cur_b = wrap ? cur_b - g.Cb : cur_b;
+        cur_tap = wrap ? cur_tap + 1 : cur_tap;
+        ctap = tap;
+        tapoff = ((tap >> 2) * g.Wb + (tap & 3)) * ld_big + b;
+        pboff = tap * CaCb + b;
+    };
+    auto load_a = [&](int i, bool on) {
+        const bool ok = on && ((a_mask[i] >> ctap) & 1);
+        ra[i] = bload4(rbig, voff(a_off[i] + tapoff, ok));
+    };
+    auto load_b = [&](int i, bool on) { rb[i] = bload4(rP, voff(b_off[i] + pboff, on)); };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<bf16x4*>(&As[(r0 + 32 * i) * LDKH + kq * 4]) = to_bf16(ra[i]);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<bf16x4*>(&Bs[(r0 + 32 * i) * LDKH + kq * 4]) = to_bf16(rb[i]);
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        next_tap();
+#pragma unroll
+        for (int i = 0; i < AI; ++i) load_a(i, true);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) load_b(i, true);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
+        next_tap();
+#pragma unroll
+        for (int i = 0; i < AI; ++i) load_a(i, more);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) load_b(i, more);
+        PIN_VMEM();
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            bf16x8 af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(&As[((wm * MR + i) * 32 + lrow) * LDKH + ks * 16 + lh * 8]);
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                bf[j] = *reinterpret_cast<const bf16x8*>(&Bs[((wn * NR + j) * 32 + lrow) * LDKH + ks * 16 + lh * 8]);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    float* o = out + (long)blockIdx.z * slab_stride;
+    const bool fin = (slab_stride == 0);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + lrow;
+            const float bv = (fin && bias != nullptr && col < g.Ca) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + (wm * MR + i) * 32 + row;
+                if (m < M && col < g.Ca) {
+                    float v = acc[i][j][r];
+                    if (fin) v = pg_act_epi(v + bv, act);
+                    o[(long)m * ld_out + col] = v;
+                }
+            }
+        }
+}
+
+template <int MR, int NR, int WM, int WN>
+__global__ __launch_bounds__(256) void k_s2b_bf16(const float* __restrict__ small, int ld_small,
+                                                  const float* __restrict__ P, float* __restrict__ out, int ld_out,
+                                                  long slab_stride, Geom g, int chunks_per_slice,
+                                                  const float* __restrict__ bias, int act, int small_bytes,
+                                                  int p_bytes) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+    constexpr int AI = BM / 32;
+    constexpr int BG = 256 / BN;        // thread groups along k
+    constexpr int NQ = 8 / BG;          // k-quads per thread per chunk
+    __shared__ __attribute__((aligned(16))) __bf16 smem[(BM + BN) * LDKH];
+    __bf16* As = smem;
+    __bf16* Bs = smem + BM * LDKH;
+    const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)small, 0, small_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, p_bytes, 0x00020000);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    const int ncls = (g.s == 2) ? 4 : 1;
+    const int cls = blockIdx.z % ncls, slice = blockIdx.z / ncls;
+    const int ah = (g.s == 2) ? (cls >> 1) : 0, aw = (g.s == 2) ? (cls & 1) : 0;
+    const int T = (g.s == 2) ? 2 : 4, Tsh = (g.s == 2) ? 1 : 2;
+    const int Hc = (g.s == 2) ? (g.Hb - ah + 1) / 2 : g.Hb;
+    const int Wc = (g.s == 2) ? (g.Wb - aw + 1) / 2 : g.Wb;
+    const int kh0 = (g.s == 2) ? (1 - ah) : 0, kw0 = (g.s == 2) ? (1 - aw) : 0;
+    const int Mc = g.N * Hc * Wc, K = T * T * g.Ca;
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
+    if (m0 >= Mc) return;
+    const int nchunks = (K + KC - 1) / KC;
+    const int c_begin = slice * chunks_per_slice;
+    const int c_end = min(nchunks, c_begin + chunks_per_slice);
+
+    const int kq = tid & 7, r0 = tid >> 3;
+    int a_off[AI], a_mask[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const int mm = min(m, Mc - 1);
+        const int n = mm / (Hc * Wc);
+        const int rem = mm - n * (Hc * Wc);
+        const int ii = rem / Wc, jj = rem - ii * Wc;
+        const int ib = (g.s == 2) ? ii + ah : ii + 1, jb = (g.s == 2) ? jj + aw : jj + 1;
+        a_off[i] = ((n * g.Hs + ib) * g.Ws + jb) * ld_small;
+        int wv = 0, mask = 0;          // local tap (th, tw) reads small pixel (ib - th, jb - tw)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wv |= (t < T && (unsigned)(jb - t) < (unsigned)g.Ws) ? (1 << t) : 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mask |= (t < T && (unsigned)(ib - t) < (unsigned)g.Hs) ? (wv << (T * t)) : 0;
+        a_mask[i] = (m < Mc) ? mask : 0;
+    }
+    const int bn = tid % BN, bg = tid / BN;
+    const int ncol = n0 + bn;
+    const int ncol_off = (ncol < g.Cb) ? ncol : 0x10000000;
+    const int CaCb = g.Ca * g.Cb;
+
+    // incremental (tloc, a) per k-quad: A float4 (index 0) and the NQ quads of B (1..NQ); Ca >= KC: <= 1 wrap
+    int q_tl[NQ + 1], q_a[NQ + 1];
+    {
+        const int k = c_begin * KC + kq * 4;
+        q_tl[0] = k / g.Ca;
+        q_a[0] = k - q_tl[0] * g.Ca;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int k = c_begin * KC + 4 * (bg + BG * i);
+        q_tl[i + 1] = k / g.Ca;
+        q_a[i + 1] = k - q_tl[i + 1] * g.Ca;
+    }
+    auto quad = [&](int qi, int& tl, int& a) {   // returns (tloc, a) of quad qi for the chunk being loaded
+        tl = q_tl[qi];
+        a = q_a[qi];
+        const int na = a + KC;
+        const bool wrap = na >= g.Ca;
+        q_a[qi] = wrap ? na - g.Ca : na;
+        q_tl[qi] = wrap ? tl + 1 : tl;
+    };
+
+    f32x4 ra[AI], rb[NQ];
+    int a_tl = 0, a_koff = OOB;
+    auto next_a = [&](int c) {
+        const int k = c * KC + kq * 4;
+        int tl, a;
+        quad(0, tl, a);
+        a_tl = tl;
+        const int th = tl >> Tsh, tw = tl & (T - 1);
+        a_koff = (k < K) ? (a - (th * g.Ws + tw) * ld_small) : 0x20000000;
+    };
+    auto load_a = [&](int i, bool on) {
+        const bool ok = on && ((a_mask[i] >> a_tl) & 1) && (a_koff < 0x10000000);
+        ra[i] = bload4(rsm, voff(a_off[i] + a_koff, ok));
+    };
+    auto load_b = [&](int i, int c, bool on) {
+        const int kb = c * KC + 4 * (bg + BG * i);
+        int tl, a;
+        quad(i + 1, tl, a);
+        if (BN >= 64) {   // a wave shares one k-quad (bg = tid / BN is wave-uniform): keep its decode on the scalar unit
+            tl = __builtin_amdgcn_readfirstlane(tl);
+            a = __builtin_amdgcn_readfirstlane(a);
+        }
+        const int th = tl >> Tsh, tw = tl & (T - 1);
+        const int tap = (kh0 + g.s * th) * 4 + (kw0 + g.s * tw);
+        const bool ok = on && kb < K;
+        const int rowoff = tap * CaCb + a * g.Cb;
+        const int base = voff(rowoff + ncol_off, ok);
+        const int st = g.Cb * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rb[i][e] = bload1(rP, base + e * st);
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<bf16x4*>(&As[(r0 + 32 * i) * LDKH + kq * 4]) = to_bf16(ra[i]);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) *reinterpret_cast<bf16x4*>(&Bs[bn * LDKH + 4 * (bg + BG * i)]) = to_bf16(rb[i]);
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        next_a(c_begin);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) load_a(i, true);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) load_b(i, c_begin, true);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
+        next_a(c + 1);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) load_a(i, more);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) load_b(i, c + 1, more);
+        PIN_VMEM();
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            bf16x8 af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(&As[((wm * MR + i) * 32 + lrow) * LDKH + ks * 16 + lh * 8]);
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                bf[j] = *reinterpret_cast<const bf16x8*>(&Bs[((wn * NR + j) * 32 + lrow) * LDKH + ks * 16 + lh * 8]);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    const bool fin = (slab_stride == 0);
+    float* o = out + (long)slice * slab_stride;
+    const int ldo = fin ? ld_out : g.Cb;
+    float bv[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int col = n0 + (wn * NR + j) * 32 + lrow;
+        bv[j] = (fin && bias != nullptr && col < g.Cb) ? bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        // decode the lane's first row with two divisions, then walk the other 15 (at most 28 rows further) with a
+        // carry chain: 64 divisions per thread in the epilogue cost as much as several K-chunks
+        const int mb = m0 + (wm * MR + i) * 32 + 4 * lh;
+        const int mbc = min(mb, Mc - 1);
+        const int nb0 = mbc / (Hc * Wc);
+        const int remb = mbc - nb0 * (Hc * Wc);
+        const int ib0 = remb / Wc, jb0 = remb - ib0 * Wc;
+        const bool chain = Wc >= 16 && Hc >= 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int m = m0 + (wm * MR + i) * 32 + row;
+            if (m < Mc) {
+                int n, ii, jj;
+                if (chain) {
+                    const int d = (r & 3) + 8 * (r >> 2);      // 0..27 rows past the decoded one
+                    jj = jb0 + d;
+                    ii = ib0;
+                    n = nb0;
+                    bool w1 = jj >= Wc;
+                    jj = w1 ? jj - Wc : jj;
+                    ii = w1 ? ii + 1 : ii;
+                    w1 = jj >= Wc;
+                    jj = w1 ? jj - Wc : jj;
+                    ii = w1 ? ii + 1 : ii;
+                    w1 = ii >= Hc;
+                    ii = w1 ? ii - Hc : ii;
+                    n = w1 ? n + 1 : n;
+                } else {
+                    n = m / (Hc * Wc);
+                    const int rem = m - n * (Hc * Wc);
+                    ii = rem / Wc;
+                    jj = rem - ii * Wc;
+                }
+                const int h = (g.s == 2) ? 2 * ii + ah : ii, w = (g.s == 2) ? 2 * jj + aw : jj;
+                float* orow = o + (long)((n * g.Hb + h) * g.Wb + w) * ldo;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int col = n0 + (wn * NR + j) * 32 + lrow;
+                    if (col < g.Cb) {
+                        float v = acc[i][j][r];
+                        if (fin) v = pg_act_epi(v + bv[j], act);
+                        orow[col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MR, int NR, int WM, int WN, bool POW2>
+__global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ small, int ld_small,
+                                                    const float* __restrict__ big, int ld_big,
+                                                    float* __restrict__ out, long slab_stride, Geom g,
+                                                    int chunks_per_slice, int tilesB, int small_bytes, int big_bytes) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+    constexpr int LDA = BM + 8, LDB = BN + 8;     // bf16 elements; rows stay 8-byte aligned
+    constexpr int AQ = BM / 4, AROWS = 256 / AQ, AI = KC / AROWS;
+    constexpr int BQ = BN / 4, BROWS = 256 / BQ, BI = KC / BROWS;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[KC * LDA + KC * LDB];
+    __bf16* As = smem;
+    __bf16* Bs = smem + KC * LDA;
+    const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)small, 0, small_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbig = __builtin_amdgcn_make_buffer_rsrc((void*)big, 0, big_bytes, 0x00020000);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int tile_a = blockIdx.x / tilesB, tile_b = blockIdx.x % tilesB;
+    const int m0 = tile_a * BM, n0 = tile_b * BN;
+    const int tap = blockIdx.y, kh = tap >> 2, kw = tap & 3;
+    const int Kp = g.N * g.Hs * g.Ws;
+    const int nchunks = (Kp + KC - 1) / KC;
+    const int c_begin = blockIdx.z * chunks_per_slice;
+    const int c_end = min(nchunks, c_begin + chunks_per_slice);
+
+    const int aq = tid % AQ, arow0 = tid / AQ;
+    const int bq = tid % BQ, brow0 = tid / BQ;
+    const int a_col = (m0 + aq * 4 < g.Ca) ? m0 + aq * 4 : 0x10000000;      // small rows beyond Kp are out of range by
+    const int b_col = (n0 + bq * 4 < g.Cb) ? n0 + bq * 4 : 0x10000000;      // construction of small_bytes
+    // pixel -> (img, p, q): shifts when Hs, Ws are powers of two (every UNet layer), else a branch-free carry chain
+    // (needs Ws >= 16 and Hs >= 2: a step of KC = 32 pixels wraps q at most twice and p at most once)
+    const int lgW = 31 - __builtin_clz(g.Ws), lgH = 31 - __builtin_clz(g.Hs);
+    int r_n[BI], r_p[BI], r_q[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int pix = c_begin * KC + brow0 + BROWS * i;
+        r_n[i] = pix / (g.Hs * g.Ws);
+        const int rem = pix - r_n[i] * (g.Hs * g.Ws);
+        r_p[i] = rem / g.Ws;
+        r_q[i] = rem - r_p[i] * g.Ws;
+    }
+
+    f32x4 ra[AI], rb[BI];
+    auto load_a = [&](int i, int c, bool on) {
+        const int pix = c * KC + arow0 + AROWS * i;
+        const bool ok = on && pix < Kp;
+        ra[i] = bload4(rsm, voff(pix * ld_small + a_col, ok));
+    };
+    auto load_b = [&](int i, int c, bool on) {
+        const int pix = c * KC + brow0 + BROWS * i;
+        int n, p, q;
+        if (POW2) {
+            q = pix & (g.Ws - 1);
+            p = (pix >> lgW) & (g.Hs - 1);
+            n = pix >> (lgW + lgH);
+        } else {
+            n = r_n[i];
+            p = r_p[i];
+            q = r_q[i];
+            int nq = q + KC, np = p, nn = n;
+            bool w = nq >= g.Ws;
+            nq = w ? nq - g.Ws : nq;
+            np = w ? np + 1 : np;
+            w = nq >= g.Ws;
+            nq = w ? nq - g.Ws : nq;
+            np = w ? np + 1 : np;
+            w = np >= g.Hs;
+            np = w ? np - g.Hs : np;
+            nn = w ? nn + 1 : nn;
+            r_q[i] = nq;
+            r_p[i] = np;
+            r_n[i] = nn;
+        }
+        const int h = g.s * p - 1 + kh, w = g.s * q - 1 + kw;
+        const bool ok = on && pix < Kp && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
+        rb[i] = bload4(rbig, voff(((n * g.Hb + h) * g.Wb + w) * ld_big + b_col, ok));
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<bf16x4*>(&As[(arow0 + AROWS * i) * LDA + aq * 4]) = to_bf16(ra[i]);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<bf16x4*>(&Bs[(brow0 + BROWS * i) * LDB + bq * 4]) = to_bf16(rb[i]);
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) load_a(i, c_begin, true);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) load_b(i, c_begin, true);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) load_a(i, c + 1, more);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) load_b(i, c + 1, more);
+        PIN_VMEM();
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            // tiles are [k][m]: a lane's 8 consecutive k of its column are 8 ds_read_u16 (K is the pixel axis here and
+            // both operands are contiguous along channels in memory, so there is no K-contiguous image to stage)
+            bf16x8 af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) af[i][e] = As[(ks * 16 + lh * 8 + e) * LDA + (wm * MR + i) * 32 + lrow];
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bf[j][e] = Bs[(ks * 16 + lh * 8 + e) * LDB + (wn * NR + j) * 32 + lrow];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    float* o = out + (long)blockIdx.z * slab_stride + (long)tap * g.Ca * g.Cb;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int a = m0 + (wm * MR + i) * 32 + row;
+                if (a < g.Ca && col < g.Cb) o[(long)a * g.Cb + col] = acc[i][j][r];
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Second halves of the taps-folded-into-N forward paths.  D is the row GEMM's output:
 //   small2big:  D[small pixel][(tap, b)]  ->  big[n,h,w,b] = act(sum over the taps that reach (h,w) + bias[b])
@@ -1829,6 +2369,23 @@ inline size_t b2s_tapn_ws(const Geom& g) { return (size_t)g.N * g.Hb * g.Wb * 16
         default: hipLaunchKernelGGL((k_b2s_fast<1, 1, 2, 2, ONE>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
     }
 
+#define PG_DISPATCH_B2SH(tile_id, grid, st, ...)                                                                    \
+    switch (tile_id) {                                                                                             \
+        case 0: hipLaunchKernelGGL((k_b2s_bf16<2, 2, 2, 2, false>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 1: hipLaunchKernelGGL((k_b2s_bf16<2, 1, 2, 2, false>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 2: hipLaunchKernelGGL((k_b2s_bf16<1, 1, 4, 1, false>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 3: hipLaunchKernelGGL((k_b2s_bf16<1, 2, 2, 2, false>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        default: hipLaunchKernelGGL((k_b2s_bf16<1, 1, 2, 2, false>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+    }
+#define PG_DISPATCH_WGH(POW2, tile_id, grid, st, ...)                                                              \
+    switch (tile_id) {                                                                                            \
+        case 0: hipLaunchKernelGGL((k_wgrad_bf16<2, 2, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        case 1: hipLaunchKernelGGL((k_wgrad_bf16<2, 1, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        case 2: hipLaunchKernelGGL((k_wgrad_bf16<1, 1, 4, 1, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        case 3: hipLaunchKernelGGL((k_wgrad_bf16<1, 2, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL((k_wgrad_bf16<1, 1, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
+    }
+
 #define PG_DISPATCH_WGF(POW2, tile_id, grid, st, ...)                                                              \
     switch (tile_id) {                                                                                            \
         case 0: hipLaunchKernelGGL((k_wgrad_fast<2, 2, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
@@ -1936,7 +2493,10 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
     const bool fast = veck && g.Cb >= KC && big_bytes < FAST_LIMIT && p_bytes < FAST_LIMIT && !force_generic();
     if (p.split == 1) {
         TimedLaunch timed(st);
-        if (fast) {
+        if (fast && algo == PG_ALGO_BF16) {
+            PG_DISPATCH_B2SH(p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, bias, act, (int)big_bytes,
+                             (int)p_bytes);
+        } else if (fast) {
             PG_DISPATCH_B2SF(false, p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, bias, act,
                              (int)big_bytes, (int)p_bytes);
         } else {
@@ -1948,7 +2508,10 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
     float* slabs = (float*)ws;
     {
         TimedLaunch timed(st);
-        if (fast) {
+        if (fast && algo == PG_ALGO_BF16) {
+            PG_DISPATCH_B2SH(p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps, (const float*)nullptr, 0,
+                             (int)big_bytes, (int)p_bytes);
+        } else if (fast) {
             PG_DISPATCH_B2SF(false, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps,
                              (const float*)nullptr, 0, (int)big_bytes, (int)p_bytes);
         } else {
@@ -2011,7 +2574,10 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
     const bool fast = veck && g.Ca >= KC && small_bytes < FAST_LIMIT && p_bytes < FAST_LIMIT && !force_generic();
     if (p.split == 1) {
         TimedLaunch timed(st);
-        if (fast) {
+        if (fast && algo == PG_ALGO_BF16) {
+            PG_DISPATCH_TILE(k_s2b_bf16, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, bias, act,
+                             (int)small_bytes, (int)p_bytes);
+        } else if (fast) {
             PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, bias, act,
                              (int)small_bytes, (int)p_bytes);
         } else {
@@ -2023,7 +2589,10 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
     float* slabs = (float*)ws;
     {
         TimedLaunch timed(st);
-        if (fast) {
+        if (fast && algo == PG_ALGO_BF16) {
+            PG_DISPATCH_TILE(k_s2b_bf16, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
+                             (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes);
+        } else if (fast) {
             PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
                              (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes);
         } else {
@@ -2084,7 +2653,13 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
         const bool pow2 = ((g.Hs & (g.Hs - 1)) == 0) && ((g.Ws & (g.Ws - 1)) == 0);
         const bool fast = vecm && vecn && small_bytes < FAST_LIMIT && big_bytes < FAST_LIMIT && !force_generic() &&
                           (pow2 || (g.Ws >= 16 && g.Hs >= 2));
-        if (fast && pow2) {
+        if (fast && algo == PG_ALGO_BF16 && pow2) {
+            PG_DISPATCH_WGH(true, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
+                            (int)small_bytes, (int)big_bytes);
+        } else if (fast && algo == PG_ALGO_BF16) {
+            PG_DISPATCH_WGH(false, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
+                            (int)small_bytes, (int)big_bytes);
+        } else if (fast && pow2) {
             PG_DISPATCH_WGF(true, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
                             (int)small_bytes, (int)big_bytes);
         } else if (fast) {

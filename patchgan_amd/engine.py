@@ -23,8 +23,9 @@ import torch
 from . import _lib as L
 
 _MASK64 = (1 << 64) - 1
-# PATCHGAN_ALGO=direct forces the one-thread-per-output kernels everywhere (debugging aid); default = MFMA path
-DEFAULT_ALGO = {'direct': L.ALGO_DIRECT, 'mfma': L.ALGO_MFMA}.get(__import__('os').environ.get('PATCHGAN_ALGO', ''), L.ALGO_AUTO)
+# PATCHGAN_ALGO=direct forces the one-thread-per-output kernels everywhere (debugging aid); =bf16 selects the bf16
+# MFMA variants (fp32 tensors, bf16 multiply, fp32 accumulate); default = the fp32 MFMA path
+DEFAULT_ALGO = {'direct': L.ALGO_DIRECT, 'mfma': L.ALGO_MFMA, 'bf16': L.ALGO_BF16}.get(__import__('os').environ.get('PATCHGAN_ALGO', ''), L.ALGO_AUTO)
 
 
 def _stream():
@@ -180,6 +181,8 @@ class ConvOp:
                 name = 'k_wgrad_fast' + tn[:-1] + (',true>' if fast == 2 else ',false>')
             else:
                 name = LaunchProfiler.OP_NAMES[opcode] + tn
+            if self.algo == L.ALGO_BF16 and fast and not mode:
+                name = name.replace('_fast', '_bf16')
             self._desc[opcode] = (name, s.value)
         return self._desc[opcode]
 

@@ -46,7 +46,7 @@ def _mk(N, Hb, Wb, Ca, Cb, s, seed=0):
     return big, small, Wt, Hs, Ws
 
 
-@pytest.mark.parametrize('algo', [1, 2], ids=['direct', 'mfma'])
+@pytest.mark.parametrize('algo', [1, 2, 3], ids=['direct', 'mfma', 'bf16'])
 @pytest.mark.parametrize('geom', GEOMS, ids=lambda g: 'x'.join(map(str, g)))
 def test_big2small(geom, algo):
     from patchgan_amd import engine as E
@@ -63,10 +63,10 @@ def test_big2small(geom, algo):
         want = O.apply_act(F.conv2d(big, Wt, bias, stride=s, padding=1), act)
         got = vs.to_nchw()
         torch.cuda.synchronize()
-        assert rel_err(got, want) < 2e-5, (geom, act)
+        assert rel_err(got, want) < (2e-2 if algo == 3 else 2e-5), (geom, act)
 
 
-@pytest.mark.parametrize('algo', [1, 2], ids=['direct', 'mfma'])
+@pytest.mark.parametrize('algo', [1, 2, 3], ids=['direct', 'mfma', 'bf16'])
 @pytest.mark.parametrize('geom', GEOMS, ids=lambda g: 'x'.join(map(str, g)))
 def test_small2big(geom, algo):
     from patchgan_amd import engine as E
@@ -85,10 +85,10 @@ def test_small2big(geom, algo):
         want = O.apply_act(want, act)
         got = vb.to_nchw()
         torch.cuda.synchronize()
-        assert rel_err(got, want) < 2e-5, (geom, act)
+        assert rel_err(got, want) < (2e-2 if algo == 3 else 2e-5), (geom, act)
 
 
-@pytest.mark.parametrize('algo', [1, 2], ids=['direct', 'mfma'])
+@pytest.mark.parametrize('algo', [1, 2, 3], ids=['direct', 'mfma', 'bf16'])
 @pytest.mark.parametrize('geom', GEOMS, ids=lambda g: 'x'.join(map(str, g)))
 def test_wgrad(geom, algo):
     from patchgan_amd import engine as E
@@ -103,7 +103,7 @@ def test_wgrad(geom, algo):
     db = torch.full((Ca + 4,), float('nan'), device=DEV)
     op.wgrad(to_view(small, ld=Ca + 4, off=4), to_view(big, ld=Cb + 8, off=4), dP, 0, db, 0)
     torch.cuda.synchronize()
-    assert rel_err(unpack(dP, Ca, Cb), Wr.grad) < 3e-5, geom
+    assert rel_err(unpack(dP, Ca, Cb), Wr.grad) < (2e-2 if algo == 3 else 3e-5), geom
     assert rel_err(db[:Ca], br.grad) < 3e-5, geom
 
 
