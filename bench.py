@@ -113,6 +113,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dropout', action='store_true', help='nn.Dropout(0.2) in the generator (CLI default of the reference)')
     ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg2', help='workload (default: the BASELINE metric config)')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help="f32 = the parity path the metric is quoted on; bf16 = bf16-multiply / fp32-accumulate conv kernels ('next' row f2)")
     ap.add_argument('--events', choices=['dominant', 'all', 'none'], default='dominant',
                     help='which conv launches get HIP events in the timed region (roofline leg)')
     args = ap.parse_args()
@@ -140,6 +142,9 @@ def main():
     G = pg.UNet(3, CFG['out_nc'], CFG['nf'], use_dropout=args.dropout, activation=CFG['activation'],
                 final_act=CFG['final_act']).to(dev)
     D = pg.Discriminator(3 + CFG['out_nc'], CFG['ndf'], n_layers=CFG['n_layers'], norm=False).to(dev)
+    if args.dtype == 'bf16':
+        G.set_precision('bf16')
+        D.set_precision('bf16')
     t = pg.Trainer(G, D, tempfile.mkdtemp(prefix='pgbench_'))
     t.loss_type, t.seg_alpha = CFG['loss_type'], 200
     t.setup_optimizers(1e-3, 1e-3)
@@ -189,20 +194,21 @@ def main():
         per_step_all = wsum                      # every conv kernel, from the profiled warm-up step
         conv_ms = sum(v['ms'] for v in per_step_all.values()) * args.steps
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == 'f32' else 2500.0     # dense MFMA peak of the multiply dtype
         roofline = {'bound': 'mfma', 'kernel': sym,
-                    'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(sym),
+                    'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(achieved / peak, 4), 'traffic': pmc_traffic(sym),
                     'launches_per_step': d['launches'] / args.steps,
                     'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                     'kernel_share_of_step': round(d['ms'] / args.steps / (elapsed / args.steps * 1e3), 4),
                     'all_conv_kernels_TFLOPs': round(sum(v['flops'] for v in per_step_all.values()) * args.steps / (conv_ms * 1e-3) / 1e12, 2),
                     'all_conv_share_of_step': round(conv_ms / args.steps / (elapsed / args.steps * 1e3), 4),
-                    'step_frac_of_fp32_roofline': round(value / world * GFLOP_PER_IMAGE / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                    'step_frac_of_mfma_roofline': round(value / world * GFLOP_PER_IMAGE / 1e3 / peak, 4)}
         out = {
             'metric': f'train images/sec (G+D step) at {SIZE}x{SIZE} bs={BATCH_PER_GPU} per GPU', 'value': round(value, 2),
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': CFG['desc'] + ', dropout ' + ('on' if args.dropout else 'off'),
                        'global_batch': BATCH_PER_GPU * world, 'parallelism': f'dp{world}'},
             'last_losses': {k: round(v, 5) for k, v in last.items()},

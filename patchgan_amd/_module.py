@@ -46,6 +46,16 @@ class FlatParamModule(nn.Module):
             p.grad = None
         return self
 
+    def set_precision(self, precision):
+        """'fp32' (default: exact fp32 MFMA, the parity path) or 'bf16' (operand tiles rounded to bf16 in LDS, bf16
+        MFMA, fp32 accumulation; weights, activations, InstanceNorm statistics and Adam stay fp32).  Returns self."""
+        from . import _lib as L
+        algo = {'fp32': L.ALGO_AUTO, 'bf16': L.ALGO_BF16}[precision]
+        self.engine.algo = algo
+        self.engine._ops = {}
+        self.precision = precision
+        return self
+
     def ensure_grad_flat(self):
         """Flat gradient buffer in the packed layout; every parameter's .grad is a view of it."""
         if self.grad_flat is None or self.grad_flat.device != self.flat.device:

@@ -285,3 +285,21 @@ def test_tiled_inference_matches_direct_forward():
     m = build_mask(masks, 256, (512, 512), 0.5, 0.9)
     mo = O.build_mask(want.numpy(), 256, (512, 512), 0.5, 0.9)
     assert m.shape == (512, 512) and (m != mo).mean() < 1e-3     # threshold flips only where |p - 0.5| ~ 1e-6
+
+
+def test_bf16_precision_tracks_fp32(tmp_path):
+    """f2: bf16-multiply / fp32-accumulate convolutions.  Stated tolerance: every loss scalar of the first 5 steps within
+    3e-2 relative of the fp32 golden curve (bf16 has an 8-bit significand; products are rounded once, sums stay fp32)."""
+    gold = Golden('a_lrelu_tversky')
+    g, d, t = build(gold, tmp_path)
+    g.set_precision('bf16')
+    d.set_precision('bf16')
+    x, y = gold.inputs()
+    g.train()
+    d.train()
+    curve = np.array([[t.batch(x, y, train=True)[k] for k in LOSS_KEYS] for _ in range(5)])
+    want = gold.z['losses'][:5]
+    err = np.abs(curve - want) / np.maximum(np.abs(want), 1e-6)
+    print('bf16 vs fp32 golden, max rel err per step', err.max(axis=1))
+    assert err.max() < 3e-2
+    assert err.max() > 1e-7          # it really is a different arithmetic

@@ -32,7 +32,7 @@ tot = {0: 0.0, 1: 0.0, 2: 0.0}
 for name, N, Hb, Wb, Ca, Cb, s, _ in layers:
     if only and not any(name.startswith(o) for o in only):
         continue
-    op = E.ConvOp(N, Hb, Wb, Ca, Cb, s)
+    op = E.ConvOp(N, Hb, Wb, Ca, Cb, s, E.DEFAULT_ALGO)
     big = E.View.alloc(N, Hb, Wb, Cb, dev); big.t.normal_()
     small = E.View.alloc(N, op.Hs, op.Ws, Ca, dev); small.t.normal_()
     P = torch.randn(16 * Ca * Cb, device=dev) * 0.05
