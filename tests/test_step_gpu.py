@@ -289,7 +289,8 @@ def test_tiled_inference_matches_direct_forward():
 
 def test_bf16_precision_tracks_fp32(tmp_path):
     """f2: bf16-multiply / fp32-accumulate convolutions.  Stated tolerance: every loss scalar of the first 5 steps within
-    3e-2 relative of the fp32 golden curve (bf16 has an 8-bit significand; products are rounded once, sums stay fp32)."""
+    2e-3 relative of the fp32 golden curve (bf16 has an 8-bit significand; products are rounded once, sums stay fp32;
+    measured 2e-5 on this configuration)."""
     gold = Golden('a_lrelu_tversky')
     g, d, t = build(gold, tmp_path)
     g.set_precision('bf16')
@@ -297,9 +298,13 @@ def test_bf16_precision_tracks_fp32(tmp_path):
     x, y = gold.inputs()
     g.train()
     d.train()
-    curve = np.array([[t.batch(x, y, train=True)[k] for k in LOSS_KEYS] for _ in range(5)])
+    curve = []
+    for _ in range(5):
+        l = t.batch(x, y, train=True)
+        curve.append([l[k] for k in LOSS_KEYS])
+    curve = np.array(curve)
     want = gold.z['losses'][:5]
     err = np.abs(curve - want) / np.maximum(np.abs(want), 1e-6)
     print('bf16 vs fp32 golden, max rel err per step', err.max(axis=1))
-    assert err.max() < 3e-2
+    assert err.max() < 2e-3
     assert err.max() > 1e-7          # it really is a different arithmetic
