@@ -132,11 +132,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks (launch with torch.distributed.run); WORLD_SIZE={world}")
+    # PATCHGAN_DIST_BACKEND=gloo + PATCHGAN_SHARE_GPU=1 rehearse the multi-rank path on a single-GPU box (all ranks on
+    # device 0, collectives through gloo); the real run is one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get('PATCHGAN_DIST_BACKEND', 'nccl')
+    if os.environ.get('PATCHGAN_SHARE_GPU') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     torch.manual_seed(1234)
     G = pg.UNet(3, CFG['out_nc'], CFG['nf'], use_dropout=args.dropout, activation=CFG['activation'],
