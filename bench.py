@@ -169,13 +169,15 @@ def main():
     # warm-up; the last warm-up step is profiled launch by launch to find the dominant conv kernel symbol, so that the
     # timed region only carries events around THAT kernel's launches (2 event records per launch are not free)
     wprof = E.LaunchProfiler()
-    for i in range(max(args.warmup, 1)):
-        E.PROFILER = wprof if i == max(args.warmup, 1) - 1 else None
+    for i in range(args.warmup):
+        E.PROFILER = wprof if i == args.warmup - 1 else None
         t.batch(x, y, train=True)
     E.PROFILER = None
     torch.cuda.synchronize()
     wsum = wprof.summary()
-    dominant = max(wsum.items(), key=lambda kv: kv[1]['ms'])[0]
+    if not wsum:                       # --warmup 0: nothing to pick the dominant kernel from: instrument every launch
+        args.events = 'all'
+    dominant = max(wsum.items(), key=lambda kv: kv[1]['ms'])[0] if wsum else None
     prof = E.LaunchProfiler(only=None if args.events == 'all' else dominant)
     E.PROFILER = prof if args.events != 'none' else None
     sync()
@@ -200,6 +202,9 @@ def main():
         if args.events == 'none':
             d = dict(d, launches=d['launches'] * args.steps, ms=d['ms'] * args.steps, flops=d['flops'] * args.steps)
         per_step_all = wsum                      # every conv kernel, from the profiled warm-up step
+        if not per_step_all:
+            per_step_all = {k: dict(launches=v['launches'] / args.steps, ms=v['ms'] / args.steps, flops=v['flops'] / args.steps)
+                            for k, v in summ.items()}
         conv_ms = sum(v['ms'] for v in per_step_all.values()) * args.steps
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
         peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == 'f32' else 2500.0     # dense MFMA peak of the multiply dtype
