@@ -621,7 +621,7 @@ template <int MR, int NR, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256) void k_wgrad_tapn(const float* __restrict__ X, int ld_x,
                                                     const float* __restrict__ Y, int ld_y, float* __restrict__ out,
                                                     long slab_stride, Geom g, int chunks_per_slice, int tilesN,
-                                                    int vecm) {
+                                                    int vecm, int vecy) {
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int AQ = BM / 4, AROWS = 256 / AQ, AI = KC / AROWS;
@@ -713,6 +713,13 @@ __global__ __launch_bounds__(256) void k_wgrad_tapn(const float* __restrict__ X,
                 const int rem = pix - img * (Hx * Wx);
                 r = rem / Wx;
                 cc = rem - r * Wx;
+            }
+            if (MODE == 1 && vecy) {
+                // Cb == 4: this thread's four columns are the four channels of ONE tap: one 16-byte load
+                const int h = g.s * r - 1 + e_kh[0], w = g.s * cc - 1 + e_kw[0];
+                const bool ok = pok && e_ok[0] && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
+                rb[i] = ld4(ok ? Y + (long)((img * g.Hb + h) * g.Wb + w) * ld_y : Y, ok);
+                continue;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -2293,6 +2300,15 @@ Plan plan_wgrad(const pg_conv_geom* g) {
     }
     p.nchunks = (int)((Kp + KC - 1) / KC);
     p.split = pick_split((long)p.tiles_m * p.tiles_n * p.ncls, p.nchunks, 8);
+    if (mode != 0) {
+        // the taps-in-N kernels stream a huge K (every pixel) into one or two tiles: latency-bound per workgroup, so they
+        // want far more, shorter slices than the MFMA-bound kernels (measured 83 us at 512 slices vs 187 us at 128)
+        static const int tt = getenv("PATCHGAN_TAPN_SPLIT") ? atoi(getenv("PATCHGAN_TAPN_SPLIT")) : 1024;
+        long want = tt / ((long)p.tiles_m * p.tiles_n);
+        long smax = p.nchunks / 4;
+        if (want > smax) want = smax;
+        p.split = want < 1 ? 1 : (int)want;
+    }
     p.out_elems = 16L * g->Ca * g->Cb;
     return p;
 }
@@ -2671,10 +2687,12 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
         }
     } else if (mode == 1) {
         dim3 grid(p.tiles_m * p.tiles_n, 1, p.split);
-        PG_DISPATCH_TAPN(1, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n, vecm);
+        const int vecy = (g.Cb == 4) && (ld_big % 4 == 0) && aligned16(big);
+        PG_DISPATCH_TAPN(1, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n, vecm,
+                         vecy);
     } else {
         dim3 grid(p.tiles_m * p.tiles_n, 1, p.split);
-        PG_DISPATCH_TAPN(2, p.t.id, grid, st, big, ld_big, small, ld_small, dst, p.out_elems, g, p.cps, p.tiles_n, vecn);
+        PG_DISPATCH_TAPN(2, p.t.id, grid, st, big, ld_big, small, ld_small, dst, p.out_elems, g, p.cps, p.tiles_n, vecn, 0);
     }
     timed->~TimedLaunch();
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
