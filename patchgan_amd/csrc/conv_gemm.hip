@@ -2177,6 +2177,7 @@ struct TimedLaunch {
 // bytes spanned by a [pixels][C] view with pixel stride ld (what the buffer descriptor of the fast kernels covers)
 inline long tensor_bytes(long pixels, int ld, int C) { return ((pixels - 1) * (long)ld + C) * 4; }
 constexpr long FAST_LIMIT = 0x60000000L;   // 1.5 GiB: keeps every 32-bit byte offset, incl. the +0x40000000 sentinel, < 2^32
+constexpr long FAST_P_LIMIT = 0x40000000L; // packed weights: the invalid-row sentinel (+1 GiB) must land beyond the block
 inline bool force_generic() {
     static const bool v = getenv("PATCHGAN_GENERIC_KERNELS") != nullptr;   // debugging aid: disable the fast variants
     return v;
@@ -2506,7 +2507,7 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
     const int veck = (g.Cb % 4 == 0) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P);
     dim3 grid(p.tiles_m, p.tiles_n, p.split);
     const long big_bytes = tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb), p_bytes = 16L * g.Ca * g.Cb * 4;
-    const bool fast = veck && g.Cb >= KC && big_bytes < FAST_LIMIT && p_bytes < FAST_LIMIT && !force_generic();
+    const bool fast = veck && g.Cb >= KC && big_bytes < FAST_LIMIT && p_bytes < FAST_P_LIMIT && !force_generic();
     if (p.split == 1) {
         TimedLaunch timed(st);
         if (fast && algo == PG_ALGO_BF16) {
@@ -2587,7 +2588,7 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
     const int vecn = (g.Cb % 4 == 0) && aligned16(P);
     dim3 grid(p.tiles_m, p.tiles_n, p.ncls * p.split);
     const long small_bytes = tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca), p_bytes = 16L * g.Ca * g.Cb * 4;
-    const bool fast = veck && g.Ca >= KC && small_bytes < FAST_LIMIT && p_bytes < FAST_LIMIT && !force_generic();
+    const bool fast = veck && g.Ca >= KC && small_bytes < FAST_LIMIT && p_bytes < FAST_P_LIMIT && !force_generic();
     if (p.split == 1) {
         TimedLaunch timed(st);
         if (fast && algo == PG_ALGO_BF16) {
