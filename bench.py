@@ -185,6 +185,7 @@ def main():
     last = None
     for _ in range(args.steps):
         last = t.batch(x, y, train=True)
+    t.flush()                      # the last step's (deferred, data-parallel) discriminator update belongs to the timed work
     sync()
     elapsed = time.perf_counter() - t0
     E.PROFILER = None

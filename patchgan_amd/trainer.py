@@ -61,6 +61,7 @@ class Trainer:
         self._adam = None          # (gm, gv, dm, dv) flat moment buffers
         self._t_g = self._t_d = 0  # Adam step counts
         self._step = 0
+        self._pending_d = None
         self.bucket_bytes = 32 << 20   # all-reduce bucket size under data parallelism (parallel.GradReducer)
 
     # -------------------------------------------------------------------------------------- optimizers
@@ -110,6 +111,7 @@ class Trainer:
         # ---- generator step
         seed = E._mix_seed(G._seed_base, self._step) if G.training else 0
         gc = ge.forward(G.flat, xin, gen, G.training, seed)                                   # trainer.py:63
+        self.flush()          # D's deferred all-reduce + Adam from the previous step ran under this G forward
         dc = de.forward(D.flat, fake)                                                         # trainer.py:66
         gseg = E.View.alloc(N, H, W, Cout, dev) if train else None
         E.loss_value_and_grad(gen, yv, 0.0, _LOSS_MODES[self.loss_type], float(self.seg_alpha), gseg, losses, 0,
@@ -146,8 +148,11 @@ class Trainer:
             if g_reducer is not None:
                 g_reducer.finish()                 # G's buckets have been in flight since the generator backward
                 self._adam_step('g')
-                dist.all_reduce(dflat)             # 11 MB at ndf=64: one bucket
-            self._adam_step('d')                                                              # trainer.py:107
+                # D's gradient (11 MB at ndf=64) is all-reduced asynchronously and applied by flush() at the first use of
+                # D's weights -- after the NEXT step's generator forward, which does not read them (trainer.py:63-66)
+                self._pending_d = dist.all_reduce(dflat, async_op=True)
+            else:
+                self._adam_step('d')                                                          # trainer.py:107
 
         if dist.on:
             # seg loss: tversky is already global; the BCE/MAE terms are per-rank partial means
@@ -165,6 +170,15 @@ class Trainer:
         keys = ['gen', 'gen_loss', 'gdisc', 'discr', 'discf', 'disc']
         vals = [float(gen_loss), float(gen_loss), float(gdisc), float(loss_real), float(loss_fake), float(disc_loss)]
         return dict(zip(keys, vals))
+
+    def flush(self):
+        """Apply a discriminator update whose gradient all-reduce is still in flight (data parallelism only).  Called
+        before anything reads the discriminator's weights: the next step's D forward, save(), load(), the end of train()."""
+        h = getattr(self, '_pending_d', None)
+        if h is not None:
+            self._pending_d = None
+            h.wait()
+            self._adam_step('d')
 
     def _adam_step(self, which):
         if which == 'g':
@@ -254,11 +268,13 @@ class Trainer:
 
             if epoch % save_freq == 0:
                 self.save(epoch)
+        self.flush()
         return G_loss_ep, D_loss_ep
 
     # -------------------------------------------------------------------------------------- checkpoints
     def save(self, epoch):
         """generator_ep_%03d.pth / discriminator_ep_%03d.pth holding torch-layout state_dicts (trainer.py:281-287)."""
+        self.flush()
         if _Dist().rank != 0:
             return
         gen_savefile = f'{self.savefolder}/generator_ep_{epoch:03d}.pth'
@@ -282,6 +298,7 @@ class Trainer:
             print("Checkpoints not loaded")
 
     def load(self, generator_save, discriminator_save):
+        self.flush()
         print(generator_save, discriminator_save)
         dev = self.generator.flat.device
         self.generator.load_state_dict(torch.load(generator_save, map_location=dev))

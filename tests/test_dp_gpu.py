@@ -41,6 +41,7 @@ def _worker(rank, world, port, q, name, nsteps):
     for s in range(nsteps):
         l = t.batch(xs, ys, train=True)
         curve.append([l[k] for k in LOSS_KEYS])
+    t.flush()          # D's last update is applied lazily under data parallelism
     torch.cuda.synchronize()
     q.put((rank, np.array(curve), g.flat.cpu().numpy(), d.flat.cpu().numpy()))
     dist.destroy_process_group()
