@@ -6,8 +6,10 @@ Per-step schedule (reference trainer.py:50-115):
    x, y -> NHWC slices of ONE discriminator-input buffer din[2N] (real half = x|y, fake half = x|G(x)):
    G fwd (dec6 writes straight into the fake half) -> D fwd(fake) -> seg loss + BCE(D(fake),1) ->
    dgrad through D (its weight grads are skipped: the reference zeroes them at trainer.py:93-94) ->
-   G bwd -> [all-reduce G grads] -> Adam(G) -> D fwd over din[2N] (real and detached fake in one batch) ->
-   BCE halves -> D bwd -> [all-reduce D grads] -> Adam(D) -> one device->host copy of the loss scalars.
+   G bwd -> Adam(G) -> D fwd over din[2N] (real and detached fake in one batch) -> BCE halves -> D bwd -> Adam(D) ->
+   one device->host copy of the loss scalars.
+   Under data parallelism: G's gradient buckets are all-reduced asynchronously from inside G bwd and Adam(G) moves behind
+   the D backward; D's gradient is all-reduced asynchronously and Adam(D) moves behind the next step's G forward (flush()).
 
 Data parallelism: one process per GPU (torch.distributed, backend "nccl" = RCCL).  InstanceNorm is per sample,
 so the only exchanges are the SUM all-reduce of the flat gradient buffers and of two loss-normalisation terms
