@@ -308,3 +308,33 @@ def test_bf16_precision_tracks_fp32(tmp_path):
     print('bf16 vs fp32 golden, max rel err per step', err.max(axis=1))
     assert err.max() < 2e-3
     assert err.max() > 1e-7          # it really is a different arithmetic
+
+
+def test_full_size_cfg2_matches_oracle(tmp_path):
+    """Parity at the BENCHMARK size (cfg2: nf = ndf = 64, B = 4 here to keep the CPU oracle to a few seconds per step,
+    256x256): every fast kernel variant, every split-K plan and the taps-in-N paths of the real layer shapes, against the
+    CPU oracle for 2 training steps.  Tolerance 1e-4 relative on the six loss scalars, 2e-4 on the generator output."""
+    import patchgan_amd as pg
+    torch.manual_seed(1234)
+    g = pg.UNet(3, 1, 64, use_dropout=False, activation='leakyrelu', final_act='sigmoid')
+    d = pg.Discriminator(4, 64, n_layers=3)
+    gw = {k: v.clone() for k, v in g.state_dict().items()}
+    dw = {k: v.clone() for k, v in d.state_dict().items()}
+    gen = torch.Generator().manual_seed(7)
+    x = torch.rand(4, 3, 256, 256, generator=gen)
+    y = (torch.rand(4, 1, 256, 256, generator=gen) > 0.7).float()
+    ot = O.OracleTrainer(gw, dw, activation='leakyrelu', final_act='sigmoid', n_layers=3, norm=False, loss_type='tversky')
+    t = pg.Trainer(g.cuda(), d.cuda(), str(tmp_path / 'c'))
+    t.setup_optimizers(1e-3, 1e-3)
+    g.train()
+    d.train()
+    for step in range(2):
+        got = t.batch(x, y, train=True)
+        want = ot.batch(x, y, train=True)
+        for k in LOSS_KEYS:
+            assert abs(got[k] - want[k]) <= 1e-4 * max(abs(want[k]), 1e-3), (step, k, got[k], want[k])
+    with torch.no_grad():
+        g.eval()
+        out = g(x.cuda()).cpu()
+        ref = O.unet_forward(ot.gw, x, 'leakyrelu', 'sigmoid')
+    assert _rel(out, ref.detach()) < 2e-4
