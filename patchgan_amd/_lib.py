@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpatchgan_hip.so')
+# PATCHGAN_LIB points at an alternative build of the same C ABI (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get('PATCHGAN_LIB') or os.path.join(_HERE, 'libpatchgan_hip.so')
 
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 ACT_CODES = {None: ACT_NONE, 'none': ACT_NONE, 'leakyrelu': ACT_LEAKY, 'relu': ACT_RELU, 'tanh': ACT_TANH,
