@@ -20,6 +20,7 @@
 #include <new>
 #include "patchgan_hip.h"
 #include "pg_common.h"
+#include "conv_wino.h"
 
 namespace {
 
@@ -2412,6 +2413,17 @@ inline size_t b2s_tapn_ws(const Geom& g) { return (size_t)g.N * g.Hb * g.Wb * 16
         default: hipLaunchKernelGGL((k_wgrad_fast<1, 1, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
     }
 
+inline bool wino_enabled() {
+    static const bool off = [] {
+        const char* e = getenv("PATCHGAN_NO_WINOGRAD");
+        return e && e[0] == '1';
+    }();
+    return !off && !force_generic();
+}
+// stride-1 layers only: forward is a pad-1 correlation big -> small, the data gradient a pad-2 correlation small -> big
+inline bool wino_b2s_ok(const Geom& g) { return g.s == 1 && wino_enabled() && pg_wino_geom_ok(g.N, g.Hs, g.Ws, g.Cb, g.Ca); }
+inline bool wino_s2b_ok(const Geom& g) { return g.s == 1 && wino_enabled() && pg_wino_geom_ok(g.N, g.Hb, g.Wb, g.Ca, g.Cb); }
+
 }  // namespace
 
 extern "C" {
@@ -2427,6 +2439,8 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
     const Geom gq = to_geom(g);
     if (op == 0 && b2s_tapn_ok(gq)) bytes = std::max(bytes, b2s_tapn_ws(gq));
     if (op == 1 && s2b_tapn_ok(gq)) bytes = std::max(bytes, s2b_tapn_ws(gq) + 256);
+    if (op == 0 && wino_b2s_ok(gq)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca));
+    if (op == 1 && wino_s2b_ok(gq)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb));
     return (bytes + 255) & ~(size_t)255;
 }
 
@@ -2462,6 +2476,12 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         if (workgroups) *workgroups = ((M1 + t.bm - 1) / t.bm) * ((Nc + t.bn - 1) / t.bn);
         return PG_OK;
     }
+    // +40: under PG_ALGO_AUTO this stride-1 layer runs Winograd F(2x2, 4x4) (k_wino_gemm, no split-K); the tile / split
+    // reported are those of the implicit-GEMM kernel the other algos use
+    if ((op == 0 && wino_b2s_ok(gq) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca)) ||
+        (op == 1 && wino_s2b_ok(gq) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb))) {
+        if (tile_id) *tile_id += 40;
+    }
     if (split) *split = p.split;
     if (workgroups) *workgroups = (long)p.tiles_m * p.tiles_n * p.ncls * p.split;
     return PG_OK;
@@ -2482,6 +2502,14 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     if (!ws) ws_bytes = 0;
+    if (algo == PG_ALGO_AUTO && wino_b2s_ok(g) && aligned16(P) && aligned16(ws) &&
+        ws_bytes >= pg_wino_ws_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca) &&
+        pg_wino_eligible(g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, ld_big, big)) {
+        int rc = pg_wino_prepare(big, ld_big, P, 0, g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, 1, ws, st);
+        if (rc != PG_OK) return rc;
+        TimedLaunch timed(st);
+        return pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st);
+    }
     if (b2s_tapn_ok(g) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= b2s_tapn_ws(g) && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT) {
         // D[big pixel][(tap, a)] = big . P^T (row GEMM over the pixels), then gather the 16 taps per output pixel
@@ -2555,6 +2583,14 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     if (!ws) ws_bytes = 0;
+    if (algo == PG_ALGO_AUTO && wino_s2b_ok(g) && aligned16(P) && aligned16(ws) &&
+        ws_bytes >= pg_wino_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb) &&
+        pg_wino_eligible(g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, ld_small, small)) {
+        int rc = pg_wino_prepare(small, ld_small, P, 1, g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, 2, ws, st);
+        if (rc != PG_OK) return rc;
+        TimedLaunch timed(st);
+        return pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st);
+    }
     if (s2b_tapn_ok(g) && (ld_small % 4 == 0) && aligned16(small) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= s2b_tapn_ws(g) && tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT) {
         // D[small pixel][(tap, b)] = small . W' (row GEMM), then col2im: each big pixel sums the taps that reach it

@@ -1,0 +1,17 @@
+// conv_wino.h -- internal interface of the Winograd F(2x2, 4x4) path (conv_wino.hip), used by the C-ABI entry points in
+// conv_gemm.hip for stride-1 layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+// geometry + alignment gate; (in, out) = (big, small) forward, (small, big) data gradient
+bool pg_wino_eligible(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ld_in, const void* in);
+bool pg_wino_geom_ok(int N, int Hout, int Wout, int Cin, int Cout);
+// U (25*Cout*Cin floats) followed by V (25*tiles*Cin floats), each 256-byte aligned
+size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout);
+// weight transform + input transform into ws
+int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N, int Hin, int Win, int Cin, int Hout,
+                    int Wout, int Cout, int pad, void* ws, hipStream_t st);
+// the batched GEMM with fused output transform, bias and activation
+int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
+                 void* ws, hipStream_t st);

@@ -169,7 +169,11 @@ class ConvOp:
             fast, rest = t.value // 100, t.value % 100
             tid, mode = rest % 10, rest // 10
             tn = LaunchProfiler.TILE_NAMES[tid]
-            if mode == 3:
+            if mode == 4 and self.algo != L.ALGO_AUTO:
+                mode = 0
+            if mode == 4:
+                name, s.value = 'k_wino_gemm<2,1,2,2>', 1
+            elif mode == 3:
                 name = 'k_b2s_fast' + tn[:-1] + ',true>+' + ('k_gather_big2small' if opcode == 0 else 'k_col2im_small2big')
             elif mode:
                 name = 'k_wgrad_tapn' + tn[:-1] + f',{mode}>'

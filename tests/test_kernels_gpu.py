@@ -107,6 +107,43 @@ def test_wgrad(geom, algo):
     assert rel_err(db[:Ca], br.grad) < 3e-5, geom
 
 
+# stride-1 layers wide enough for the Winograd F(2x2, 4x4) path that PG_ALGO_AUTO selects (>= 2048 tiles, channels >= 64,
+# Cin % 32 == 0): odd / even extents (ragged last tile row and column), ragged channel tile, both directions
+WINO_GEOMS = [(9, 32, 32, 128, 64, 1), (3, 55, 58, 96, 64, 1), (10, 31, 31, 64, 160, 1)]
+
+
+@pytest.mark.parametrize('geom', WINO_GEOMS, ids=lambda g: 'x'.join(map(str, g)))
+def test_winograd_stride1(geom):
+    """AUTO (Winograd) against the fp32 CPU convolution and against the implicit-GEMM kernel of the same library."""
+    from patchgan_amd import engine as E
+    from tests.gpu_util import to_view, empty_view, pack, rel_err
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    auto, mfma = E.ConvOp(*geom, 0), E.ConvOp(*geom, 2)
+    assert auto.describe(0)[0].startswith('k_wino_gemm') and auto.describe(1)[0].startswith('k_wino_gemm')
+    assert not mfma.describe(0)[0].startswith('k_wino_gemm')
+    bias_a, bias_b = torch.randn(Ca), torch.randn(Cb)
+    P = pack(Wt)
+    # forward: bias + LeakyReLU fused, strided output view
+    want = O.apply_act(F.conv2d(big, Wt, bias_a, stride=1, padding=1), 'leakyrelu')
+    outs = []
+    for op in (auto, mfma):
+        vs = empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=4)
+        op.big2small(to_view(big, ld=Cb + 4, off=0), P, 0, bias_a.cuda(), 0, vs, ACTS['leakyrelu'])
+        outs.append(vs.to_nchw())
+    torch.cuda.synchronize()
+    assert rel_err(outs[0], want) < 1e-5 and rel_err(outs[1], want) < 1e-5 and rel_err(outs[0], outs[1]) < 1e-5
+    # data gradient (transposed convolution)
+    want = F.conv_transpose2d(small, Wt, bias_b, stride=1, padding=1)
+    outs = []
+    for op in (auto, mfma):
+        vb = empty_view(N, Hb, Wb, Cb, ld=Cb + 8, off=4)
+        op.small2big(to_view(small, ld=Ca + 4, off=4), P, 0, bias_b.cuda(), 0, vb)
+        outs.append(vb.to_nchw())
+    torch.cuda.synchronize()
+    assert rel_err(outs[0], want) < 1e-5 and rel_err(outs[1], want) < 1e-5 and rel_err(outs[0], outs[1]) < 1e-5
+
+
 def test_mfma_matches_direct_bitwise_shapes():
     """The two algorithms must agree closely on a cfg2-like layer (enc2 at reduced batch)."""
     from patchgan_amd import engine as E
