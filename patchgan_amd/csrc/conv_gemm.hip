@@ -863,7 +863,7 @@ __device__ __forceinline__ float pg_act_epi(float v, int act) {
 // the N*Hb*Wb pixels of `big`): the first half of the taps-folded-into-N path for layers with <= 8 channels on the
 // output side, whose second half is a col2im / tap-gather pass (k_col2im_small2big, k_gather_big2small).
 template <int MR, int NR, int WM, int WN, bool ONE>
-__global__ __launch_bounds__(256) void k_b2s_fast(const float* __restrict__ big, int ld_big,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_b2s_fast(const float* __restrict__ big, int ld_big,
                                                   const float* __restrict__ P, float* __restrict__ out, int ld_out,
                                                   long slab_stride, Geom g, int chunks_per_slice,
                                                   const float* __restrict__ bias, int act, int big_bytes, int p_bytes) {
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_b2s_fast(const float* __restrict__ big,
 }
 
 template <int MR, int NR, int WM, int WN>
-__global__ __launch_bounds__(256) void k_s2b_fast(const float* __restrict__ small, int ld_small,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_s2b_fast(const float* __restrict__ small, int ld_small,
                                                   const float* __restrict__ P, float* __restrict__ out, int ld_out,
                                                   long slab_stride, Geom g, int chunks_per_slice,
                                                   const float* __restrict__ bias, int act, int small_bytes,

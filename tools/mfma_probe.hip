@@ -1,0 +1,141 @@
+// mfma_probe.hip -- where does the fp32 MFMA pipe lose time in an LDS-tiled GEMM loop on gfx950?
+// Stand-alone probe (not part of the library): a 128x128x32-chunk row GEMM main loop with parts switched off.
+//   mode 0: full loop (buffer loads -> registers -> LDS -> ds_read_b128 -> v_mfma_f32_32x32x2_f32)
+//   mode 1: no global loads (the staged registers are loop constants)
+//   mode 2: no LDS stores and no barriers (ds_read + MFMA only, stale tile)
+//   mode 3: MFMA only (fragments are loop constants)
+// build: hipcc -O3 --offload-arch=gfx950 tools/mfma_probe.hip -o tools/mfma_probe ; run: tools/mfma_probe [wgs] [chunks]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int KC = 32, LDK = 36;
+
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+template <int MODE, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_probe(const float* A, const float* B,
+                                                                                              float* out, int K, int nch,
+                                                                                              int bytes) {
+    __shared__ __attribute__((aligned(16))) float smem[256 * LDK];
+    float* As = smem;
+    float* Bs = smem + 128 * LDK;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lh = lane >> 5, kq = tid & 7, r0 = tid >> 3;
+    const int m0 = (blockIdx.x % 64) * 128;
+    int aoff[4], boff[4];
+    for (int i = 0; i < 4; ++i) {
+        aoff[i] = ((m0 + r0 + 32 * i) * K + kq * 4) * 4;
+        boff[i] = ((r0 + 32 * i) * K + kq * 4) * 4;
+    }
+    f32x4 ra[4], rb[4];
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = bload4(rA, aoff[i]);
+        rb[i] = bload4(rB, boff[i]);
+    }
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
+        *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDK + kq * 4]) = rb[i];
+    }
+    __syncthreads();
+    f32x4 af[2], bf[2];
+    for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * 2 + i) * 32 + lrow) * LDK + lh * 4]);
+        bf[i] = *reinterpret_cast<const f32x4*>(&Bs[((wn * 2 + i) * 32 + lrow) * LDK + lh * 4]);
+    }
+    for (int c = 0; c < nch; ++c) {
+        if (MODE == 0) {
+            const int ko = ((c + 1) % (K / KC)) * KC * 4;
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = bload4(rA, aoff[i] + ko);
+                rb[i] = bload4(rB, boff[i] + ko);
+            }
+            __builtin_amdgcn_sched_barrier(0x386);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            if (MODE <= 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * 2 + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+                    bf[i] = *reinterpret_cast<const f32x4*>(&Bs[((wn * 2 + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (MODE <= 1) {
+            __syncthreads();
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
+                *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDK + kq * 4]) = rb[i];
+            }
+            __syncthreads();
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int MODE, int WPE>
+void run(const char* name, const float* A, const float* B, float* out, int K, int nch, int wgs, int bytes) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_probe<MODE, WPE>), dim3(wgs), dim3(256), 0, 0, A, B, out, K, nch, bytes);
+    hipEventRecord(e0, 0);
+    const int reps = 5;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((k_probe<MODE, WPE>), dim3(wgs), dim3(256), 0, 0, A, B, out, K, nch, bytes);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    const double flop = 2.0 * 128 * 128 * 32 * (double)nch * wgs;
+    printf("%-34s waves/SIMD %d  wgs %5d  %8.1f us  %7.1f TFLOP/s\n", name, WPE, wgs, ms * 1e3, flop / ms / 1e9);
+}
+
+int main(int argc, char** argv) {
+    const int wgs = argc > 1 ? atoi(argv[1]) : 512, nch = argc > 2 ? atoi(argv[2]) : 512;
+    const int K = 1024, rows = 64 * 128;
+    const size_t bytes = (size_t)rows * K * 4;
+    float *A, *B, *out;
+    hipMalloc(&A, bytes);
+    hipMalloc(&B, bytes);
+    hipMalloc(&out, (size_t)wgs * 256 * 4);
+    const bool zeros = argc > 3 && atoi(argv[3]) == 0;      // zeros draw less power: the clock stays higher
+    float* h = (float*)malloc(bytes);
+    unsigned s = 12345u;
+    for (size_t i = 0; i < bytes / 4; ++i) {
+        s = s * 1664525u + 1013904223u;
+        h[i] = zeros ? 0.f : ((int)(s >> 8) - (1 << 23)) * (1.0f / (1 << 23));
+    }
+    hipMemcpy(A, h, bytes, hipMemcpyHostToDevice);
+    hipMemcpy(B, h, bytes, hipMemcpyHostToDevice);
+    printf("operands: %s\n", zeros ? "zeros" : "uniform(-1, 1)");
+    run<0, 2>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
+    run<1, 2>("1 no global loads", A, B, out, K, nch, wgs, (int)bytes);
+    run<2, 2>("2 ds_read + mfma", A, B, out, K, nch, wgs, (int)bytes);
+    run<3, 2>("3 mfma only", A, B, out, K, nch, wgs, (int)bytes);
+    run<0, 1>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
+    run<0, 3>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
+    return 0;
+}
