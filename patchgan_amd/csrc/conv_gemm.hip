@@ -2476,11 +2476,13 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         if (workgroups) *workgroups = ((M1 + t.bm - 1) / t.bm) * ((Nc + t.bn - 1) / t.bn);
         return PG_OK;
     }
-    // +40: under PG_ALGO_AUTO this stride-1 layer runs Winograd F(2x2, 4x4) (k_wino_gemm, no split-K); the tile / split
+    // +40 / +50: under PG_ALGO_AUTO this stride-1 layer runs Winograd F(2x2, 4x4) (k_wino_gemm<2,1,2,2> / <1,1,2,2>, no
+    // split-K); the tile / split
     // reported are those of the implicit-GEMM kernel the other algos use
     if ((op == 0 && wino_b2s_ok(gq) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca)) ||
         (op == 1 && wino_s2b_ok(gq) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb))) {
-        if (tile_id) *tile_id += 40;
+        const bool st = (op == 0) ? pg_wino_small_tile(gq.N, gq.Hs, gq.Ws, gq.Ca) : pg_wino_small_tile(gq.N, gq.Hb, gq.Wb, gq.Cb);
+        if (tile_id) *tile_id += st ? 50 : 40;
     }
     if (split) *split = p.split;
     if (workgroups) *workgroups = (long)p.tiles_m * p.tiles_n * p.ncls * p.split;

@@ -290,6 +290,17 @@ bool pg_wino_eligible(int N, int Hin, int Win, int Cin, int Hout, int Wout, int 
     return pg_wino_geom_ok(N, Hout, Wout, Cin, Cout) && ld_in % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
 }
 
+// 128-tile rows unless that leaves the 256 CUs short of two workgroups each
+bool pg_wino_small_tile(int N, int Hout, int Wout, int Cout) {
+    static const int forced = [] {
+        const char* e = getenv("PATCHGAN_WINO_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    const long T = (long)N * ((Hout + 1) / 2) * ((Wout + 1) / 2);
+    const long wg128 = ((T + 127) / 128) * ((Cout + 63) / 64);
+    return forced ? forced == 1 : wg128 < 400;
+}
+
 size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout) {
     const long T = (long)N * ((Hout + 1) / 2) * ((Wout + 1) / 2);
     return align256((size_t)25 * Cout * Cin * 4) + align256((size_t)25 * T * Cin * 4);
@@ -314,13 +325,7 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
     const long T = (long)N * TH * TW;
     const float* U = (const float*)ws;
     const float* V = (const float*)((const char*)ws + align256((size_t)25 * Cout * Cin * 4));
-    // 128-tile rows unless that leaves the 256 CUs short of one workgroup each
-    static const int forced = [] {
-        const char* e = getenv("PATCHGAN_WINO_TILE");
-        return e ? atoi(e) : 0;
-    }();
-    const long wg128 = ((T + 127) / 128) * ((Cout + 63) / 64);
-    const bool small_tile = forced ? forced == 1 : wg128 < 200;
+    const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cout);
     const int v_bytes = (int)(25L * T * Cin * 4), u_bytes = (int)(25L * Cout * Cin * 4);
     if (small_tile) {
         dim3 grid((unsigned)((T + 63) / 64), (Cout + 63) / 64, 1);

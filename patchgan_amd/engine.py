@@ -169,10 +169,10 @@ class ConvOp:
             fast, rest = t.value // 100, t.value % 100
             tid, mode = rest % 10, rest // 10
             tn = LaunchProfiler.TILE_NAMES[tid]
-            if mode == 4 and self.algo != L.ALGO_AUTO:
+            if mode in (4, 5) and self.algo != L.ALGO_AUTO:
                 mode = 0
-            if mode == 4:
-                name, s.value = 'k_wino_gemm<2,1,2,2>', 1
+            if mode in (4, 5):
+                name, s.value = ('k_wino_gemm<2,1,2,2>' if mode == 4 else 'k_wino_gemm<1,1,2,2>'), 1
             elif mode == 3:
                 name = 'k_b2s_fast' + tn[:-1] + ',true>+' + ('k_gather_big2small' if opcode == 0 else 'k_col2im_small2big')
             elif mode:
