@@ -75,7 +75,10 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);
  * split-K factor and the number of workgroups.  For op 2, tile_id + 10 / + 20 means the taps-folded-into-N kernel
  * k_wgrad_tapn<..., 1> / <..., 2> (few big-side / small-side channels); for ops 0/1, + 30 means the row-GEMM +
  * col2im / tap-gather path.  + 100 (+ 200: power-of-two pixel decode, wgrad) marks the fast buffer-load variant
- * (k_b2s_fast / k_s2b_fast / k_wgrad_fast) that runs when tensors are 16-byte aligned.  For profiling only. */
+ * (k_b2s_fast / k_s2b_fast / k_wgrad_fast) that runs when tensors are 16-byte aligned.  `op` may carry the algorithm as
+ * op + 16 * PG_ALGO_*; for PG_ALGO_AUTO (op < 16) wide stride-1 layers report the Winograd kernels instead: + 40 / + 50 =
+ * k_wino_gemm<2,1,2,2> / <1,1,2,2> (ops 0/1; tile / split of the implicit-GEMM plan otherwise unchanged), 60 =
+ * k_wino_wgrad_gemm<2,2,2,2> with split = its K slices (op 2).  For profiling only. */
 int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups);
 
 /* Arms per-launch timing: the NEXT pg_conv4x4_* call on this thread records the caller-owned hipEvent_t `ev_start`

@@ -2422,6 +2422,13 @@ inline bool wino_enabled() {
 }
 // stride-1 layers only: forward is a pad-1 correlation big -> small, the data gradient a pad-2 correlation small -> big
 inline bool wino_b2s_ok(const Geom& g) { return g.s == 1 && wino_enabled() && pg_wino_geom_ok(g.N, g.Hs, g.Ws, g.Cb, g.Ca); }
+inline bool wino_wgrad_ok(const Geom& g) {
+    static const bool off = [] {
+        const char* e = getenv("PATCHGAN_NO_WINOGRAD_WGRAD");
+        return e && e[0] == '1';
+    }();
+    return g.s == 1 && !off && wino_enabled() && pg_wino_wgrad_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb);
+}
 inline bool wino_s2b_ok(const Geom& g) { return g.s == 1 && wino_enabled() && pg_wino_geom_ok(g.N, g.Hb, g.Wb, g.Ca, g.Cb); }
 
 }  // namespace
@@ -2441,6 +2448,9 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
     if (op == 1 && s2b_tapn_ok(gq)) bytes = std::max(bytes, s2b_tapn_ws(gq) + 256);
     if (op == 0 && wino_b2s_ok(gq)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca));
     if (op == 1 && wino_s2b_ok(gq)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb));
+    if (op == 2 && wino_wgrad_ok(gq))
+        bytes = std::max(bytes, pg_wino_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb) +
+                                    (((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255));
     return (bytes + 255) & ~(size_t)255;
 }
 
@@ -2451,7 +2461,9 @@ int pg_conv_time_next(void* ev_start, void* ev_stop) {
 }
 
 int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups) {
-    if (!geom_ok(g) || op < 0 || op > 2) return PG_EINVAL;
+    const int algo = op >> 4;      // op = opcode + 16 * PG_ALGO_*: the Winograd codes are reported for PG_ALGO_AUTO only
+    op &= 15;
+    if (!geom_ok(g) || op < 0 || op > 2 || algo < PG_ALGO_AUTO || algo > PG_ALGO_BF16) return PG_EINVAL;
     Plan p = (op == 0) ? plan_b2s(g) : (op == 1) ? plan_s2b(g) : plan_wgrad(g);
     // +100: the fast (buffer-load) variant would run for 16-byte-aligned contiguous tensors; +200: its power-of-two
     // pixel-decode instantiation (wgrad only)
@@ -2479,10 +2491,18 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
     // +40 / +50: under PG_ALGO_AUTO this stride-1 layer runs Winograd F(2x2, 4x4) (k_wino_gemm<2,1,2,2> / <1,1,2,2>, no
     // split-K); the tile / split
     // reported are those of the implicit-GEMM kernel the other algos use
-    if ((op == 0 && wino_b2s_ok(gq) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca)) ||
-        (op == 1 && wino_s2b_ok(gq) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb))) {
+    if (algo == PG_ALGO_AUTO &&
+        ((op == 0 && wino_b2s_ok(gq) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca)) ||
+         (op == 1 && wino_s2b_ok(gq) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb)))) {
         const bool st = (op == 0) ? pg_wino_small_tile(gq.N, gq.Hs, gq.Ws, gq.Ca) : pg_wino_small_tile(gq.N, gq.Hb, gq.Wb, gq.Cb);
         if (tile_id) *tile_id += st ? 50 : 40;
+    }
+    // +60: Winograd F(4x4, 2x2) weight gradient (k_wino_wgrad_gemm<2,2,2,2>); split = its K slices
+    if (algo == PG_ALGO_AUTO && op == 2 && wino_wgrad_ok(gq) && ws_bytes >= reserved + pg_wino_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
+        if (tile_id) *tile_id = 60;
+        if (split) *split = pg_wino_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb);
+        if (workgroups) *workgroups = 25L * ((g->Ca + 127) / 128) * ((g->Cb + 127) / 128) * pg_wino_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb);
+        return PG_OK;
     }
     if (split) *split = p.split;
     if (workgroups) *workgroups = (long)p.tiles_m * p.tiles_n * p.ncls * p.split;
@@ -2693,6 +2713,14 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         if (slices == 1) return PG_OK;
         return launch_reduce(dst, per, slices, dP, g.Cb, 16L * g.Ca, g.Cb, nullptr, 0, st);
+    }
+    if (algo == PG_ALGO_AUTO && wino_wgrad_ok(g) && (ld_small % 4 == 0) && (ld_big % 4 == 0) && aligned16(small) &&
+        aligned16(big) && aligned16(ws) && ws_bytes >= reserved + pg_wino_wgrad_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) {
+        hipEvent_t e0 = t_ev0, e1 = t_ev1;
+        t_ev0 = nullptr;
+        t_ev1 = nullptr;
+        return pg_wino_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, (char*)ws + reserved, st,
+                             e0, e1);
     }
     Plan p = plan_wgrad(gg);
     clamp_split(p, ws_bytes, reserved);

@@ -17,3 +17,11 @@ int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N,
 // the batched GEMM with fused output transform, bias and activation
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
                  void* ws, hipStream_t st);
+
+// weight gradient of the same layers, F(4x4, 2x2): V (25*tiles*Cb) | DY (25*tiles*Ca) | S (slices*25*Ca*Cb) in ws
+bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
+int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb);
+size_t pg_wino_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
+// ev0 / ev1 (optional) are recorded around the GEMM kernel
+int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
+                  int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);

@@ -272,6 +272,181 @@ __global__ __launch_bounds__(256) void k_wino_gemm(const float* __restrict__ V, 
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layer, F(4x4, 2x2):  dW[kh][kw][a][b] = sum_pix dy[pix][a] * x[pix + (kh-1, kw-1)][b]  is, per
+// 2x2 tile of dy and its 5x5 window of x, the 4x4 correlation of the window with the tile:
+//        dW = A4^T [ sum_tiles (G2 dy G2^T) (.) (B^T x B) ] A4        (same points, same B^T as above)
+//   k_wino_dy          DY[xi][tile][a] = (G2 dy G2^T)[xi]            (zero beyond the last row / column)
+//   k_wino_v           V[xi][tile][b]                                 (the forward's input transform)
+//   k_wino_wgrad_gemm  S[slice][xi][a][b] = sum_{tile in slice} DY[xi][tile][a] * V[xi][tile][b]     (MFMA, split over tiles)
+//   k_wino_wgrad_out   dP[kh*4+kw][a][b] = sum_slice sum_xi A4T[kh][xi_i] A4T[kw][xi_j] S[slice][xi][a][b]   (fixed order)
+__device__ __constant__ float c_G2[5][2] = {{0.5f, 0.f}, {-0.5f, -0.5f}, {-1.f / 6, 1.f / 6}, {1.f / 6, 1.f / 3}, {0.f, 1.f}};
+__device__ __constant__ float c_A4T[4][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 2, 0}, {0, 1, 1, 4, 0}, {0, 1, -1, 8, 1}};
+
+__global__ __launch_bounds__(256) void k_wino_dy(const float* __restrict__ dy, int ld, float* __restrict__ DY, int N, int Hs,
+                                                 int Ws, int Ca, int TH, int TW) {
+    const int cq = Ca >> 2;
+    const long T = (long)N * TH * TW;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= T * cq) return;
+    const int c0 = (int)(idx % cq) << 2;
+    const long tile = idx / cq;
+    const int n = (int)(tile / (TH * TW));
+    const int rem = (int)(tile - (long)n * TH * TW);
+    const int ti = rem / TW, tj = rem - ti * TW;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 d[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int y = 2 * ti + u, x = 2 * tj + v;
+            d[u][v] = (y < Hs && x < Ws) ? *reinterpret_cast<const f32x4*>(dy + ((long)(n * Hs + y) * Ws + x) * ld + c0) : z;
+        }
+    f32x4 t[5][2];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) t[a][v] = c_G2[a][0] * d[0][v] + c_G2[a][1] * d[1][v];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b)
+            *reinterpret_cast<f32x4*>(DY + ((long)(a * 5 + b) * T + tile) * Ca + c0) = t[a][0] * c_G2[b][0] + t[a][1] * c_G2[b][1];
+}
+
+// grid (tilesA * tilesB, 25, slices); both operands are K-major (K = tiles): rows of Ca resp. Cb floats
+template <int MR, int NR, int WM, int WN>
+__global__ __launch_bounds__(256) void k_wino_wgrad_gemm(const float* __restrict__ DY, const float* __restrict__ V,
+                                                         float* __restrict__ S, int T, int Ca, int Cb, int chunks_per_slice,
+                                                         int tilesB, int dy_bytes, int v_bytes) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int AQ = BM / 4, AROWS = 256 / AQ, AI = KC / AROWS;
+    constexpr int BQ = BN / 4, BROWS = 256 / BQ, BI = KC / BROWS;
+    __shared__ __attribute__((aligned(16))) float smem[KC * LDA + KC * LDB];
+    float* As = smem;
+    float* Bs = smem + KC * LDA;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)DY, 0, dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, v_bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int tile_a = blockIdx.x / tilesB, tile_b = blockIdx.x % tilesB;
+    const int m0 = tile_a * BM, n0 = tile_b * BN;
+    const int xi = blockIdx.y;
+    const int nchunks = (T + KC - 1) / KC;
+    const int c_begin = blockIdx.z * chunks_per_slice;
+    const int c_end = min(nchunks, c_begin + chunks_per_slice);
+    const int aq = tid % AQ, arow0 = tid / AQ;
+    const int bq = tid % BQ, brow0 = tid / BQ;
+    const bool a_in = m0 + aq * 4 < Ca, b_in = n0 + bq * 4 < Cb;
+    const int a_base = xi * T * Ca + m0 + aq * 4, b_base = xi * T * Cb + n0 + bq * 4;
+
+    f32x4 ra[AI], rb[BI];
+    auto issue_loads = [&](int c, bool on) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int k = c * KC + arow0 + AROWS * i;
+            ra[i] = bload4(rA, voff(a_base + k * Ca, on && a_in && k < T));
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int k = c * KC + brow0 + BROWS * i;
+            rb[i] = bload4(rB, voff(b_base + k * Cb, on && b_in && k < T));
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(arow0 + AROWS * i) * LDA + aq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow0 + BROWS * i) * LDB + bq * 4]) = rb[i];
+    };
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (c_begin < c_end) {
+        issue_loads(c_begin, true);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = (c + 1 < c_end);
+        issue_loads(c + 1, more);
+        __builtin_amdgcn_sched_barrier(0x386);
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) {
+            float af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) af[i] = As[(kk * 2 + lh) * LDA + (wm * MR + i) * 32 + lrow];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) bf[j] = Bs[(kk * 2 + lh) * LDB + (wn * NR + j) * 32 + lrow];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+    float* o = S + ((long)blockIdx.z * 25 + xi) * Ca * Cb;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int a = m0 + (wm * MR + i) * 32 + row;
+                if (a < Ca && col < Cb) o[(long)a * Cb + col] = acc[i][j][r];
+            }
+        }
+}
+
+// one thread per (a, b): sums the slices in order, then the 25 -> 16 output transform
+__global__ void k_wino_wgrad_out(const float* __restrict__ S, int slices, float* __restrict__ dP, int Ca, int Cb) {
+    const long ab = (long)Ca * Cb;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= ab) return;
+    float m[5][5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float v = 0.f;
+            for (int s = 0; s < slices; ++s) v += S[((long)s * 25 + i * 5 + j) * ab + idx];
+            m[i][j] = v;
+        }
+    float t[4][5];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) v += c_A4T[k][i] * m[i][j];
+            t[k][j] = v;
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) v += t[k][j] * c_A4T[l][j];
+            dP[(long)(k * 4 + l) * ab + idx] = v;
+        }
+}
+
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -336,5 +511,55 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
         hipLaunchKernelGGL((k_wino_gemm<2, 1, 2, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
                            TW, Hout, Wout, act, v_bytes, u_bytes);
     }
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+}
+
+// ---- weight gradient ----
+bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb) {
+    if (Ca % 4 != 0 || Cb % 4 != 0 || Ca < 64 || Cb < 64) return false;
+    const long T = (long)N * ((Hs + 1) / 2) * ((Ws + 1) / 2);
+    if (T < 2048) return false;
+    if (25.0 * T * Ca * 4 >= 1.5e9 || 25.0 * T * Cb * 4 >= 1.5e9) return false;
+    return true;
+}
+
+int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb) {
+    const long T = (long)N * ((Hs + 1) / 2) * ((Ws + 1) / 2);
+    const long wgs = 25L * ((Ca + 127) / 128) * ((Cb + 127) / 128);
+    long s = (768 + wgs - 1) / wgs;                 // three workgroups per CU
+    const long nchunks = (T + KC - 1) / KC;
+    if (s > nchunks / 16) s = nchunks / 16;          // at least 16 chunks per slice
+    return (int)(s < 1 ? 1 : s);
+}
+
+size_t pg_wino_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb) {
+    const long T = (long)N * ((Hs + 1) / 2) * ((Ws + 1) / 2);
+    return align256((size_t)25 * T * Cb * 4) + align256((size_t)25 * T * Ca * 4) +
+           align256((size_t)pg_wino_wgrad_slices(N, Hs, Ws, Ca, Cb) * 25 * Ca * Cb * 4);
+}
+
+int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
+                  int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    const int TH = (Hs + 1) / 2, TW = (Ws + 1) / 2;
+    const long T = (long)N * TH * TW;
+    float* V = (float*)ws;
+    float* DY = (float*)((char*)ws + align256((size_t)25 * T * Cb * 4));
+    float* S = (float*)((char*)DY + align256((size_t)25 * T * Ca * 4));
+    hipLaunchKernelGGL(k_wino_v, dim3((unsigned)((T * (Cb / 4) + 255) / 256)), dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb,
+                       TH, TW, 1);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    hipLaunchKernelGGL(k_wino_dy, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, small, ld_small, DY, N, Hs, Ws,
+                       Ca, TH, TW);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    const int slices = pg_wino_wgrad_slices(N, Hs, Ws, Ca, Cb);
+    const int nchunks = (int)((T + KC - 1) / KC);
+    const int cps = (nchunks + slices - 1) / slices;
+    const int tilesA = (Ca + 127) / 128, tilesB = (Cb + 127) / 128;
+    if (ev0) (void)hipEventRecord(ev0, st);
+    hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB, 25, slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                       Cb, cps, tilesB, (int)(25L * T * Ca * 4), (int)(25L * T * Cb * 4));
+    if (ev1) (void)hipEventRecord(ev1, st);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    hipLaunchKernelGGL(k_wino_wgrad_out, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, S, slices, dP, Ca, Cb);
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }

@@ -164,13 +164,14 @@ class ConvOp:
     def describe(self, opcode):
         if opcode not in self._desc:
             t, s, w = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_long(0)
-            L.check(L.load().pg_conv_describe(ctypes.byref(self.g), opcode, max(self.ws_bytes, 1 << 20), ctypes.byref(t),
+            L.check(L.load().pg_conv_describe(ctypes.byref(self.g), opcode + 16 * self.algo, max(self.ws_bytes, 1 << 20), ctypes.byref(t),
                                               ctypes.byref(s), ctypes.byref(w)), 'pg_conv_describe')
             fast, rest = t.value // 100, t.value % 100
             tid, mode = rest % 10, rest // 10
             tn = LaunchProfiler.TILE_NAMES[tid]
-            if mode in (4, 5) and self.algo != L.ALGO_AUTO:
-                mode = 0
+            if mode == 6:
+                self._desc[opcode] = ('k_wino_wgrad_gemm<2,2,2,2>', s.value)
+                return self._desc[opcode]
             if mode in (4, 5):
                 name, s.value = ('k_wino_gemm<2,1,2,2>' if mode == 4 else 'k_wino_gemm<1,1,2,2>'), 1
             elif mode == 3:

@@ -142,6 +142,21 @@ def test_winograd_stride1(geom):
         outs.append(vb.to_nchw())
     torch.cuda.synchronize()
     assert rel_err(outs[0], want) < 1e-5 and rel_err(outs[1], want) < 1e-5 and rel_err(outs[0], outs[1]) < 1e-5
+    # weight (+ bias) gradient: F(4x4, 2x2)
+    from tests.gpu_util import unpack, DEV
+    assert auto.describe(2)[0].startswith('k_wino_wgrad_gemm') and not mfma.describe(2)[0].startswith('k_wino')
+    Wr = Wt.clone().requires_grad_(True)
+    br = torch.zeros(Ca, requires_grad=True)
+    F.conv2d(big, Wr, br, stride=1, padding=1).backward(small)
+    outs = []
+    for op in (auto, mfma):
+        dP = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+        db = torch.full((Ca,), float('nan'), device=DEV)
+        op.wgrad(to_view(small, ld=Ca + 4, off=4), to_view(big, ld=Cb + 8, off=4), dP, 0, db, 0)
+        torch.cuda.synchronize()
+        assert rel_err(db, br.grad) < 3e-5
+        outs.append(unpack(dP, Ca, Cb))
+    assert rel_err(outs[0], Wr.grad) < 3e-5 and rel_err(outs[1], Wr.grad) < 3e-5, (rel_err(outs[0], Wr.grad), rel_err(outs[1], Wr.grad))
 
 
 def test_mfma_matches_direct_bitwise_shapes():
