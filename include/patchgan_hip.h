@@ -200,6 +200,20 @@ int pg_nhwc_to_nchw(const float* src, int ld_src, float* dst, int N, int C, int 
 int pg_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, long npix, int C, void* stream);
 int pg_fill(float* dst, long n, float value, void* stream);
 
+/* ---- tiled inference (infer.py:14-68: n_crop / build_mask around the generator forward) -----------
+ * Tile k of an axis of `extent` pixels starts at k*eff - max(k*eff + size - extent, 0), eff = int(overlap*size),
+ * k < pg_tiles_count(extent, size, eff) = ceil(extent / eff) (0 if extent < size: the reference cannot tile such an image).
+ * Tiles are numbered row-major over (y tile, x tile) -- the reference's j*ncropsy + i on the square images it supports. */
+int pg_tiles_count(int extent, int size, int eff);
+/* n_crop (infer.py:14-35): image [C,H,W] (CHW, the dataset item layout) -> tiles [ny*nx, size, size, ld] NHWC, the batch
+ * the generator kernels read */
+int pg_tiles_gather(const float* image, int C, int H, int W, int size, int eff, float* tiles, int ld, void* stream);
+/* build_mask (infer.py:38-68): predicted tiles [ny*nx, size, size, ld] NHWC -> overlap average in double, in tile order
+ * (bit-identical to the reference's `mask += tile.double(); mask / count`), `>= threshold` -> {0,1} when threshold > 0.
+ * mask: [C,H,W] doubles or NULL; argmax: [H,W] int64 class index (first maximum, numpy.argmax) or NULL. */
+int pg_tiles_blend(const float* tiles, int ld, int C, int size, int eff, int H, int W, double threshold, double* mask,
+                   long long* argmax, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

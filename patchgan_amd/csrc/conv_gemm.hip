@@ -2067,6 +2067,36 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     if (rl == 0 && c < C) partial[(long)blockIdx.x * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
+// float4 variant (C % 4 == 0, 16-byte aligned rows): 256 threads = 16 channel quads x 16 row lanes, four independent
+// loads in flight per lane; fixed-order combine.
+__global__ __launch_bounds__(256) void k_colsum_partial4(const float* __restrict__ x, int ld, long rows, int C,
+                                                         long rows_per_chunk, float* __restrict__ partial) {
+    __shared__ f32x4 red[16][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cl * 4;
+    const long r_begin = blockIdx.x * rows_per_chunk;
+    const long r_end = min(rows, r_begin + rows_per_chunk);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (c < C) {
+        long r = r_begin + rl;
+        for (; r + 48 < r_end; r += 64) {
+            s0 += *reinterpret_cast<const f32x4*>(x + r * ld + c);
+            s1 += *reinterpret_cast<const f32x4*>(x + (r + 16) * ld + c);
+            s2 += *reinterpret_cast<const f32x4*>(x + (r + 32) * ld + c);
+            s3 += *reinterpret_cast<const f32x4*>(x + (r + 48) * ld + c);
+        }
+        for (; r < r_end; r += 16) s0 += *reinterpret_cast<const f32x4*>(x + r * ld + c);
+    }
+    red[rl][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        f32x4 t = red[0][cl];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) t += red[i][cl];
+        *reinterpret_cast<f32x4*>(partial + (long)blockIdx.x * C + c) = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // direct kernels: one thread per output element, no LDS, no MFMA.  Any channel count / alignment.
 // ------------------------------------------------------------------------------------------------
@@ -2694,8 +2724,12 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
         int chunks = (int)std::min<long>(COLSUM_CHUNKS, Kp);
         long rpc = (Kp + chunks - 1) / chunks;
         chunks = (int)((Kp + rpc - 1) / rpc);
-        hipLaunchKernelGGL(k_colsum_partial, dim3(chunks, (g.Ca + 63) / 64), dim3(256), 0, st, small, ld_small, Kp, g.Ca,
-                           rpc, part);
+        if ((g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned16(small) && aligned16(part))
+            hipLaunchKernelGGL(k_colsum_partial4, dim3(chunks, (g.Ca + 63) / 64), dim3(256), 0, st, small, ld_small, Kp, g.Ca,
+                               rpc, part);
+        else
+            hipLaunchKernelGGL(k_colsum_partial, dim3(chunks, (g.Ca + 63) / 64), dim3(256), 0, st, small, ld_small, Kp, g.Ca,
+                               rpc, part);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         int rc = launch_reduce(part, g.Ca, chunks, dbias, g.Ca, 1, g.Ca, nullptr, 0, st);
         if (rc != PG_OK) return rc;

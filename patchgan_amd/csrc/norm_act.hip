@@ -9,6 +9,7 @@
 // Reductions are fixed-order LDS trees: bit-reproducible run to run.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "patchgan_hip.h"
 #include "pg_common.h"
 
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void k_instnorm_bwd(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Chunked path for large planes (HW >= 2048): the single-workgroup-per-(n, channel group) kernels above either
+// Chunked path for large planes (HW >= 512, PATCHGAN_IN_CHUNK_MIN): the single-workgroup-per-(n, channel group) kernels above either
 // run too few workgroups or (G = 1) touch 16 B of every 128-B line per lane.  Here a workgroup owns (n, pixel
 // chunk, channel group) with G as wide as the channel count allows (full-line reads), partial sums go to a
 // workspace in fp64, a tiny merge kernel finishes the statistics in fixed order, and the apply pass is a flat
@@ -474,7 +475,7 @@ int pick_group(int N, int units) {
 }
 
 // chunked InstanceNorm plan: channel-group width G (as wide as the channels allow, <= 64 units), pixel chunks so
-// that the grid has >= ~2048 workgroups; planes under 2048 pixels keep the single-workgroup kernels
+// that the grid has >= ~2048 workgroups; planes under 512 pixels keep the single-workgroup kernels
 struct ChunkPlan {
     int G, groups, nchunk, ppc;
     size_t part_bytes, coef_bytes;
@@ -487,7 +488,11 @@ ChunkPlan chunk_plan(int N, int HW, int C, int vecw) {
     p.G = G;
     p.groups = (units + G - 1) / G;
     int nchunk = 1;
-    if (HW >= 2048) {
+    static const int chunk_min = [] {
+        const char* e = getenv("PATCHGAN_IN_CHUNK_MIN");
+        return e ? atoi(e) : 512;
+    }();
+    if (HW >= chunk_min) {
         const int PL = 256 / G;
         long want = (1024 + (long)N * p.groups - 1) / ((long)N * p.groups);
         long maxc = HW / (PL * 2);            // at least two pixels per lane per chunk

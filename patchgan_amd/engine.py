@@ -269,6 +269,42 @@ def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
                                   eps, bc1, math.sqrt(bc2), _stream()), 'pg_adam_step')
 
 
+def tiles_gather(image, size, overlap):
+    """reference infer.py:14-35 (n_crop): device image [C, H, W] -> View of the ny*nx overlapping size x size tiles in the
+    NHWC batch layout the generator kernels read."""
+    C, H, W = image.shape
+    eff = int(overlap * size)
+    lib = L.load()
+    ny, nx = lib.pg_tiles_count(H, size, eff), lib.pg_tiles_count(W, size, eff)
+    if ny <= 0 or nx <= 0:
+        raise ValueError(f"cannot cut {size}x{size} tiles with overlap {overlap} from a {H}x{W} image")
+    image = image.to(dtype=torch.float32).contiguous()
+    tiles = View.alloc(ny * nx, size, size, C, image.device)
+    L.check(lib.pg_tiles_gather(image.data_ptr(), C, H, W, size, eff, tiles.ptr(), tiles.ld, _stream()), 'pg_tiles_gather')
+    return tiles
+
+
+def tiles_blend(tiles, image_size, threshold, overlap):
+    """reference infer.py:38-68 (build_mask): View of predicted tiles -> overlap-averaged mask on the device: float64
+    [H, W] for one class, int64 class index [H, W] for several (same values / dtypes as the reference returns)."""
+    H, W = image_size
+    size = tiles.H
+    eff = int(overlap * size)
+    lib = L.load()
+    if lib.pg_tiles_count(H, size, eff) * lib.pg_tiles_count(W, size, eff) != tiles.N or tiles.W != size:
+        raise ValueError(f"{tiles.N} tiles of {tiles.H}x{tiles.W} do not tile a {H}x{W} image with overlap {overlap}")
+    dev = tiles.t.device
+    if tiles.C > 1:
+        out = torch.empty(H, W, dtype=torch.int64, device=dev)
+        mask_p, arg_p = None, out.data_ptr()
+    else:
+        out = torch.empty(H, W, dtype=torch.float64, device=dev)
+        mask_p, arg_p = out.data_ptr(), None
+    L.check(lib.pg_tiles_blend(tiles.ptr(), tiles.ld, tiles.C, size, eff, H, W, float(threshold), mask_p, arg_p, _stream()),
+            'pg_tiles_blend')
+    return out
+
+
 def _mix_seed(base, *vals):
     h = (base * 0x9E3779B97F4A7C15 + 0x1234567) & _MASK64
     for v in vals:

@@ -1,9 +1,11 @@
 """``patchgan_infer`` -- tiled inference (reference patchgan/infer.py:14-174) with the generator forward on the HIP path.
 
-``n_crop`` cuts an image into overlapping size x size tiles and ``build_mask`` overlap-averages the predicted tiles back
-(float64, optional threshold, argmax for multi-class), both on the device.  The reference indexes tiles with
-``j * ncropsy + i`` (infer.py:32,57), which is only correct for square images (it overwrites / skips tiles otherwise);
-here the row-major index ``j * ncropsx + i`` is used, identical for square images and correct for the rest.
+``predict_image`` is what ``patchgan_infer`` runs per image: ``pg_tiles_gather`` (image -> NHWC tile batch), the generator
+forward, ``pg_tiles_blend`` (overlap average in float64, optional threshold, class argmax) -- three stages of HIP kernels
+with no layout conversion in between.  ``n_crop`` / ``build_mask`` keep the reference's function signatures (NCHW tensors in
+and out, any device) for user code that calls them directly.  The reference indexes tiles with ``j * ncropsy + i``
+(infer.py:32,57), which is only correct for square images (it overwrites / skips tiles otherwise); here the row-major
+index ``j * ncropsx + i`` is used, identical for square images and correct for the rest.
 """
 import argparse
 import os
@@ -59,6 +61,17 @@ def build_mask(masks, crop_size, image_size, threshold, overlap):
     if c > 1:
         return np.argmax(mask, axis=0)
     return mask[0]
+
+
+def predict_image(generator, image, size, overlap, threshold):
+    """One image [C, H, W] (device tensor) -> mask as numpy: float64 [H, W] for a single-class generator, class index
+    [H, W] otherwise -- reference infer.py:155-163 (n_crop -> generator -> build_mask) on the HIP path end to end."""
+    from . import engine as E
+    eng = generator.engine
+    tiles = E.tiles_gather(image, size, overlap)
+    pred = E.View.alloc(tiles.N, size, size, eng.output_nc, image.device)
+    eng.forward(generator.flat, tiles, pred, False, 0)
+    return E.tiles_blend(pred, tuple(image.shape[1:]), threshold, overlap).cpu().numpy()
 
 
 def patchgan_infer(argv=None):
@@ -124,11 +137,8 @@ def patchgan_infer(argv=None):
 
     for i, data in enumerate(tqdm.tqdm(datagen, desc='Predicting', dynamic_ncols=True, ascii=True)):
         data = torch.as_tensor(data).to(device)
-        imgs = n_crop(data, size, overlap)
         out_fname, _ = os.path.splitext(datagen.get_filename(i))
-        with torch.no_grad():
-            masks = generator(imgs)
-        mask = build_mask(masks, size, data.shape[1:], threshold, overlap)
+        mask = predict_image(generator, data, size, overlap, threshold)
         Dataset.save_mask(mask, output_path, out_fname)
 
 

@@ -287,6 +287,66 @@ def test_tiled_inference_matches_direct_forward():
     assert m.shape == (512, 512) and (m != mo).mean() < 1e-3     # threshold flips only where |p - 0.5| ~ 1e-6
 
 
+@pytest.mark.parametrize('tag', ['sq1024', 'sq600', 'sq300_1c'])
+def test_tile_kernels_match_reference_goldens(tag):
+    """f1: pg_tiles_gather / pg_tiles_blend against vectors produced by the reference's own n_crop / build_mask (bit-exact:
+    same double accumulation in the same tile order) and against the oracle restatement."""
+    import os
+    from patchgan_amd import engine as E
+    from tests.golden_util import GOLDEN_DIR, probe
+    z = np.load(os.path.join(GOLDEN_DIR, 'infer_tiles.npz'))
+    gen = torch.Generator().manual_seed(3)
+    for t in ['sq1024', 'sq600', 'sq300_1c']:     # replay the generator stream of make_golden.run_infer_tiles
+        c, h, w, size, overlap, thr = z[f'{t}/params']
+        c, h, w, size = int(c), int(h), int(w), int(size)
+        img = torch.rand(c, h, w, generator=gen)
+        masks = torch.rand(int(z[f'{t}/ncrops'][0]), c, size, size, generator=gen)
+        if t == tag:
+            break
+    tiles = E.tiles_gather(img.cuda(), size, overlap)
+    crops = tiles.to_nchw().cpu()
+    assert tuple(crops.shape) == tuple(z[f'{tag}/ncrops'])
+    np.testing.assert_allclose(probe(crops), z[f'{tag}/crop_probe'], rtol=1e-7)
+    assert torch.equal(crops, O.n_crop(img, size, overlap))
+    pv = E.View.alloc(masks.shape[0], size, size, c + 1, 'cuda').channels(1, c).from_nchw(masks.cuda())   # strided view
+    m = E.tiles_blend(pv, (h, w), thr, overlap).cpu().numpy()
+    assert tuple(m.shape) == tuple(z[f'{tag}/mask_shape'])
+    np.testing.assert_allclose(probe(torch.as_tensor(np.ascontiguousarray(m))), z[f'{tag}/mask_probe'], rtol=1e-12)
+    want = O.build_mask(masks.numpy(), size, (h, w), thr, overlap)
+    assert m.dtype == want.dtype
+    np.testing.assert_array_equal(m, want)
+
+
+def test_tile_kernels_non_square_and_errors():
+    from patchgan_amd import engine as E
+    img = torch.rand(2, 600, 1024, generator=torch.Generator().manual_seed(9))
+    tiles = E.tiles_gather(img.cuda(), 256, 0.9)
+    assert tiles.N == 3 * 5
+    back = E.tiles_blend(tiles, (600, 1024), 0, 0.9).cpu().numpy()    # identity "prediction": channel argmax of the image
+    np.testing.assert_array_equal(back, np.argmax(img.numpy(), axis=0))
+    with pytest.raises(ValueError):
+        E.tiles_gather(torch.rand(3, 200, 300).cuda(), 256, 0.9)      # smaller than one tile (the reference fails too)
+    with pytest.raises(ValueError):
+        E.tiles_blend(tiles, (512, 512), 0, 0.9)
+
+
+def test_predict_image_equals_ncrop_forward_build_mask():
+    """patchgan_infer's per-image path (gather -> generator -> blend, NHWC throughout) equals the reference-shaped
+    n_crop -> generator(NCHW) -> build_mask composition bit for bit."""
+    import patchgan_amd as pg
+    from patchgan_amd.infer import n_crop, build_mask, predict_image
+    for out_nc, final_act, thr in ((1, 'sigmoid', 0.5), (3, 'softmax', 0.0)):
+        torch.manual_seed(11)
+        g = pg.UNet(3, out_nc, 4, activation='leakyrelu', final_act=final_act).cuda().eval()
+        img = torch.rand(3, 600, 600, generator=torch.Generator().manual_seed(5)).cuda()
+        got = predict_image(g, img, 256, 0.9, thr)
+        with torch.no_grad():
+            masks = g(n_crop(img, 256, 0.9))
+        want = build_mask(masks, 256, (600, 600), thr, 0.9)
+        assert got.dtype == want.dtype and got.shape == want.shape
+        np.testing.assert_array_equal(got, want)
+
+
 def test_bf16_precision_tracks_fp32(tmp_path):
     """f2: bf16-multiply / fp32-accumulate convolutions.  Stated tolerance: every loss scalar of the first 5 steps within
     2e-3 relative of the fp32 golden curve (bf16 has an 8-bit significand; products are rounded once, sums stay fp32;
