@@ -200,6 +200,15 @@ int pg_nhwc_to_nchw(const float* src, int ld_src, float* dst, int N, int C, int 
 int pg_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, long npix, int C, void* stream);
 int pg_fill(float* dst, long n, float value, void* stream);
 
+/* ---- input pipeline on the device (io.py:42-56: the dataset's `/ 255.` and one-hot mask) ----------------
+ * dst[pix*ld_dst + c] = (float)src[pix*C + c] / div : decoded image bytes [npix][C] (HWC) into an NHWC channel slice */
+int pg_u8_to_f32(const unsigned char* src, float* dst, int ld_dst, long npix, int C, float div, void* stream);
+/* dst[pix*ld_dst + i] = ((unsigned char)(src[pix] + add) == labels[i]) ? 1 : 0 for i < nlabels <= PG_MAX_LABELS; `labels` is
+ * a HOST array (copied into the launch); add = 1 reproduces the reference's uint8 `read_image(mask) + 1` incl. 255 -> 0 */
+#define PG_MAX_LABELS 32
+int pg_labels_to_onehot(const unsigned char* src, float* dst, int ld_dst, long npix, const int* labels, int nlabels, int add,
+                        void* stream);
+
 /* ---- tiled inference (infer.py:14-68: n_crop / build_mask around the generator forward) -----------
  * Tile k of an axis of `extent` pixels starts at k*eff - max(k*eff + size - extent, 0), eff = int(overlap*size),
  * k < pg_tiles_count(extent, size, eff) = ceil(extent / eff) (0 if extent < size: the reference cannot tile such an image).

@@ -60,6 +60,30 @@ __global__ void k_nhwc_to_nchw(const float* __restrict__ src, int ld_src, float*
     }
 }
 
+// decoded image bytes [npix][C] (HWC, what a JPEG decoder hands over) -> float NHWC slice: value / 255.f, the reference's
+// `read_image(...) / 255.` (io.py:42) computed on the device
+__global__ void k_u8_to_f32(const uint8_t* __restrict__ src, float* __restrict__ dst, int ld_dst, long npix, int C, float div) {
+    const long total = npix * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        dst[pix * ld_dst + c] = (float)src[i] / div;
+    }
+}
+
+// label map bytes [npix] -> one-hot float NHWC slice of nl channels: dst[pix][i] = ((uint8)(src + add) == labels[i])
+// (io.py:43,53-56: `read_image(mask, GRAY) + 1` is uint8 arithmetic -- 255 wraps to 0 -- then `mask[i, labels == label] = 1`)
+struct LabelSet {
+    int v[PG_MAX_LABELS];
+};
+__global__ void k_labels_onehot(const uint8_t* __restrict__ src, float* __restrict__ dst, int ld_dst, long npix, LabelSet ls,
+                                int nl, int add) {
+    for (long pix = blockIdx.x * (long)blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+        const int v = (uint8_t)(src[pix] + add);
+        for (int i = 0; i < nl; ++i) dst[pix * ld_dst + i] = (v == ls.v[i]) ? 1.f : 0.f;
+    }
+}
+
 __global__ void k_copy_channels(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
                                 long npix, int C) {
     const long total = npix * C;
@@ -117,6 +141,23 @@ int pg_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, long 
     if (!src || !dst || npix <= 0 || C <= 0 || ld_src < C || ld_dst < C) return PG_EINVAL;
     hipLaunchKernelGGL(k_copy_channels, dim3(blocks_for(npix * C)), dim3(256), 0, (hipStream_t)stream, src, ld_src, dst,
                        ld_dst, npix, C);
+    return pg_launch_status();
+}
+
+int pg_u8_to_f32(const unsigned char* src, float* dst, int ld_dst, long npix, int C, float div, void* stream) {
+    if (!src || !dst || npix <= 0 || C <= 0 || ld_dst < C || div == 0.f) return PG_EINVAL;
+    hipLaunchKernelGGL(k_u8_to_f32, dim3(blocks_for(npix * C)), dim3(256), 0, (hipStream_t)stream, src, dst, ld_dst, npix, C,
+                       div);
+    return pg_launch_status();
+}
+
+int pg_labels_to_onehot(const unsigned char* src, float* dst, int ld_dst, long npix, const int* labels, int nlabels, int add,
+                        void* stream) {
+    if (!src || !dst || !labels || npix <= 0 || nlabels <= 0 || nlabels > PG_MAX_LABELS || ld_dst < nlabels) return PG_EINVAL;
+    LabelSet ls;
+    for (int i = 0; i < PG_MAX_LABELS; ++i) ls.v[i] = i < nlabels ? labels[i] : -1;
+    hipLaunchKernelGGL(k_labels_onehot, dim3(blocks_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, ld_dst, npix, ls,
+                       nlabels, add);
     return pg_launch_status();
 }
 

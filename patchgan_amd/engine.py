@@ -78,6 +78,24 @@ class View:
                                          _stream()), 'pg_nchw_to_nhwc')
         return self
 
+    def from_u8(self, src, div=255.0):
+        """Fill from decoded image bytes: uint8 device tensor [N, H, W, C] -> value / div (reference io.py:42)."""
+        assert src.dtype == torch.uint8 and tuple(src.shape) == (self.N, self.H, self.W, self.C), tuple(src.shape)
+        src = src.contiguous()
+        L.check(L.load().pg_u8_to_f32(src.data_ptr(), self.ptr(), self.ld, self.npix, self.C, div, _stream()), 'pg_u8_to_f32')
+        return self
+
+    def from_labels(self, src, labels, add=1):
+        """Fill with the one-hot mask of a uint8 label map [N, H, W]: channel i = ((uint8)(src + add) == labels[i])
+        (reference io.py:43,53-56)."""
+        assert src.dtype == torch.uint8 and tuple(src.shape) == (self.N, self.H, self.W), tuple(src.shape)
+        assert len(labels) == self.C, (len(labels), self.C)
+        src = src.contiguous()
+        arr = (ctypes.c_int * len(labels))(*[int(v) for v in labels])
+        L.check(L.load().pg_labels_to_onehot(src.data_ptr(), self.ptr(), self.ld, self.npix, arr, len(labels), add, _stream()),
+                'pg_labels_to_onehot')
+        return self
+
 
 # ------------------------------------------------------------------------------------------------
 # workspace (split-K slabs): one growing buffer per device; all launches are stream-ordered

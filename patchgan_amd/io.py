@@ -7,6 +7,10 @@ inference (items: ``[C,H,W]`` tensors, plus ``get_filename(i)`` and a static ``s
 
 torchvision is not a dependency here: images are decoded with Pillow and resized with torch.nn.functional.interpolate
 (bilinear, no antialias -- what ``transforms.Resize(antialias=None)`` does on tensors).
+
+``device_pipeline=True`` (an extension) makes the dataset hand over the decoded bytes -- image uint8 [S,S,3]
+and label map uint8 [S,S] -- and leaves ``/ 255.`` and the one-hot mask to the GPU (``Trainer.batch`` with uint8 input,
+``pg_u8_to_f32`` / ``pg_labels_to_onehot``): a quarter of the H2D bytes and no per-pixel Python work in the loader.
 """
 import glob
 import os
@@ -28,7 +32,7 @@ def _read_image(path, mode):
 class COCOStuffDataset(Dataset):
     augmentation = None
 
-    def __init__(self, imgfolder, maskfolder, labels=[1], size=256, augmentation='resize'):
+    def __init__(self, imgfolder, maskfolder, labels=[1], size=256, augmentation='resize', device_pipeline=False):
         self.images = np.asarray(sorted(glob.glob(os.path.join(imgfolder, "*.jpg"))))
         self.masks = np.asarray(sorted(glob.glob(os.path.join(maskfolder, "*.png"))))
         self.size = size
@@ -38,6 +42,9 @@ class COCOStuffDataset(Dataset):
         assert np.all(self.image_ids == self.mask_ids), "Image IDs and Mask IDs do not match!"
         self.flip = 0.25 if augmentation == 'randomcrop+flip' else 0.0
         self.augmentation = augmentation if augmentation in ('randomcrop', 'randomcrop+flip') else None
+        self.device_pipeline = bool(device_pipeline)
+        if self.device_pipeline and self.augmentation is not None:
+            raise NotImplementedError("device_pipeline hands over undecoded-size bytes: use augmentation='resize' (none)")
         print(f"Loaded {len(self)} images")
 
     def __len__(self):
@@ -56,8 +63,11 @@ class COCOStuffDataset(Dataset):
         return s
 
     def __getitem__(self, index):
+        if self.device_pipeline:
+            return (_read_image(self.images[index], 'RGB').permute(1, 2, 0).contiguous(),
+                    _read_image(self.masks[index], 'L')[0].contiguous())
         img = _read_image(self.images[index], 'RGB').float() / 255.
-        labels = _read_image(self.masks[index], 'L').float() + 1
+        labels = (_read_image(self.masks[index], 'L') + 1).float()      # uint8 + 1 like read_image(...) + 1: 255 wraps to 0
         stacked = self._augment(torch.cat((img, labels), dim=0))
         img, labels = stacked[:3], stacked[3]
         mask = torch.zeros((len(self.labels), labels.shape[0], labels.shape[1]))

@@ -12,6 +12,7 @@ takes a distinct shard of every epoch (DistributedSampler) and gradients are all
 import argparse
 import os
 
+import numpy as np
 import torch
 import yaml
 from torch.utils.data import DataLoader, random_split
@@ -88,6 +89,8 @@ def patchgan_train(argv=None):
         labels = dataset_params.get('labels', [1])
         out_channels = len(labels)
         dataset_kwargs['labels'] = labels
+        if dataset_params.get('device_pipeline', False):      # extension: `/255.` + one-hot on the GPU (io.py docstring)
+            dataset_kwargs['device_pipeline'] = True
     else:
         Dataset = load_plugin_dataset(dataset_params['type'])
         in_channels = dataset_params.get('in_channels', 3)
@@ -128,6 +131,8 @@ def patchgan_train(argv=None):
 
     checkpoint_path = config.get('checkpoint_path', './checkpoints/')
     trainer = Trainer(generator, discriminator, savefolder=checkpoint_path)
+    if dataset_kwargs.get('device_pipeline', False):
+        trainer.label_values = [int(v) for v in np.sort(dataset_kwargs['labels'])]
     if config.get('load_last_checkpoint', False):
         trainer.load_last_checkpoint()
     elif config.get('transfer_learn', {}).get('generator_checkpoint', None) is not None:

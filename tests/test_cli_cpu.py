@@ -131,6 +131,27 @@ def test_coco_dataset_and_plugin_loader(tmp_path):
         load_plugin_dataset('Toy', str(tmp_path / 'nope.py'))
 
 
+def test_coco_dataset_device_pipeline_bytes(tmp_path):
+    """f3: device_pipeline=True hands over the decoded bytes; converting them the way the reference's __getitem__ does
+    (io.py:42-56: / 255., uint8 + 1 with 255 -> 0, one-hot) gives exactly the float item of the default mode."""
+    from PIL import Image
+    from patchgan_amd.io import COCOStuffDataset
+    rng = np.random.default_rng(1)
+    lab = rng.integers(0, 4, (32, 32), dtype=np.uint8)
+    lab[0, :5] = 255                                              # COCO-stuff "unlabeled": + 1 wraps to 0
+    Image.fromarray(rng.integers(0, 255, (32, 32, 3), dtype=np.uint8)).save(tmp_path / '000001.jpg')
+    Image.fromarray(lab).save(tmp_path / '000001.png')
+    kw = dict(labels=[0, 1, 3], size=32, augmentation='resize')
+    img_f, mask_f = COCOStuffDataset(str(tmp_path), str(tmp_path), **kw)[0]
+    img_b, lab_b = COCOStuffDataset(str(tmp_path), str(tmp_path), device_pipeline=True, **kw)[0]
+    assert img_b.dtype == torch.uint8 and img_b.shape == (32, 32, 3) and lab_b.dtype == torch.uint8 and lab_b.shape == (32, 32)
+    assert torch.equal(img_b.permute(2, 0, 1).float() / 255., img_f)
+    assert torch.equal(torch.stack([((lab_b + 1) == v).float() for v in (0, 1, 3)]), mask_f)
+    assert mask_f[0, 0, :5].sum() == 5                            # label 0 selects the wrapped 255s, as in the reference
+    with pytest.raises(NotImplementedError):
+        COCOStuffDataset(str(tmp_path), str(tmp_path), labels=[1], size=32, augmentation='randomcrop', device_pipeline=True)
+
+
 def test_losses_module_matches_oracle():
     from patchgan_amd import losses
     g = torch.Generator().manual_seed(0)

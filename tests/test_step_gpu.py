@@ -347,6 +347,44 @@ def test_predict_image_equals_ncrop_forward_build_mask():
         np.testing.assert_array_equal(got, want)
 
 
+def test_device_input_pipeline_equals_float_path(tmp_path):
+    """f3: Trainer.batch on decoded bytes (uint8 NHWC image + uint8 label map; / 255. and one-hot on the GPU) equals the
+    float NCHW path fed with the reference dataset's arithmetic (io.py:42-56), bit for bit."""
+    from patchgan_amd import engine as E
+    gen = torch.Generator().manual_seed(4)
+    img = torch.randint(0, 256, (2, 256, 256, 3), dtype=torch.uint8, generator=gen)
+    lab = torch.randint(0, 6, (2, 256, 256), dtype=torch.uint8, generator=gen)
+    lab[0, 0, :7] = 255
+    labels = [0, 2, 5]
+    # kernels alone (strided destination views)
+    buf = E.View.alloc(2, 256, 256, 8, 'cuda', zero=True)
+    buf.channels(1, 3).from_u8(img.cuda())
+    buf.channels(5, 3).from_labels(lab.cuda(), labels)
+    x = img.permute(0, 3, 1, 2).float() / 255.
+    y = torch.stack([((lab + 1) == v).float() for v in labels], 1)
+    assert torch.equal(buf.channels(1, 3).to_nchw().cpu(), x) and torch.equal(buf.channels(5, 3).to_nchw().cpu(), y)
+    assert y[0, 0, 0, :7].sum() == 7                      # 255 + 1 wraps to 0 (uint8), like read_image(...) + 1
+    assert float(buf.t.view(-1, 8)[:, [0, 4]].abs().sum()) == 0
+    # whole step
+    import patchgan_amd as pg
+    curves = []
+    for mode in ('float', 'u8'):
+        torch.manual_seed(3)
+        g = pg.UNet(3, 3, 4, activation='leakyrelu', final_act='sigmoid').cuda()
+        d = pg.Discriminator(6, 4, n_layers=2).cuda()
+        t = pg.Trainer(g, d, str(tmp_path / mode))
+        t.loss_type = 'weighted_bce'
+        if mode == 'u8':
+            t.label_values = labels
+            curves.append([t.batch(img, lab, train=True) for _ in range(3)])
+        else:
+            curves.append([t.batch(x, y, train=True) for _ in range(3)])
+    assert curves[0] == curves[1]
+    t.label_values = None
+    with pytest.raises(RuntimeError):
+        t.batch(img, lab, train=False)
+
+
 def test_bf16_precision_tracks_fp32(tmp_path):
     """f2: bf16-multiply / fp32-accumulate convolutions.  Stated tolerance: every loss scalar of the first 5 steps within
     2e-3 relative of the fp32 golden curve (bf16 has an 8-bit significand; products are rounded once, sums stay fp32;
