@@ -413,6 +413,54 @@ def E_views(flat, module):
     return E.torch_views(flat, module.engine.layers)
 
 
+def test_cfg2_loss_curve_10_steps_vs_oracle(tmp_path):
+    """The north-star parity statement at the BENCHMARK configuration itself (cfg2: bs 16, 256x256, nf = ndf = 64, every
+    kernel the bench runs incl. the Winograd stride-1 layer): 10 training steps against the fp32 CPU oracle on the same
+    inputs and initial weights.
+
+    At this size the G/D dynamics amplify fp32 rounding quickly (gdisc swings between 4 and 0.005 within these steps):
+    the CPU oracle itself is 6e-5..8e-5 away from its own float64 run by steps 3-5.  Stated tolerance, as for the small
+    configurations: each of the 6 loss scalars of each step within max(1e-4, 10 x E_s) relative of the fp32 CPU oracle,
+    E_s = running max of the CPU oracle's fp32-vs-fp64 gap; and the HIP path no further from the float64 run than
+    max(1e-4, 4 x E_s).  The float64 run is the same oracle code on torch's GPU double ops (minutes per step on the CPU)."""
+    import patchgan_amd as pg
+    B, steps = 16, 10
+    torch.manual_seed(1234)
+    g = pg.UNet(3, 1, 64, use_dropout=False, activation='leakyrelu', final_act='sigmoid')
+    d = pg.Discriminator(4, 64, n_layers=3)
+    gw = {k: v.clone() for k, v in g.state_dict().items()}
+    dw = {k: v.clone() for k, v in d.state_dict().items()}
+    gen = torch.Generator().manual_seed(7)
+    x = torch.rand(B, 3, 256, 256, generator=gen)
+    y = (torch.rand(B, 1, 256, 256, generator=gen) > 0.7).float()
+    kw = dict(activation='leakyrelu', final_act='sigmoid', n_layers=3, norm=False, loss_type='tversky')
+
+    def run(trainer, xx, yy):
+        rows = []
+        for _ in range(steps):
+            l = trainer.batch(xx, yy, train=True)
+            rows.append([float(l[k]) for k in LOSS_KEYS])
+        return np.array(rows)
+
+    c64 = run(O.OracleTrainer({k: v.cuda() for k, v in gw.items()}, {k: v.cuda() for k, v in dw.items()}, dtype=torch.float64,
+                              **kw), x.cuda(), y.cuda())
+    c32 = run(O.OracleTrainer(gw, dw, **kw), x, y)
+    t = pg.Trainer(g.cuda(), d.cuda(), str(tmp_path / 'c'))
+    t.setup_optimizers(1e-3, 1e-3)
+    g.train()
+    d.train()
+    got = run(t, x, y)
+
+    def rel(a, b):
+        return (np.abs(a - b) / np.maximum(np.abs(b), 1e-3)).max(axis=1)
+
+    env = np.maximum.accumulate(rel(c32, c64))
+    err, err64 = rel(got, c32), rel(got, c64)
+    print('cfg2 bs16 per step: HIP vs fp32 CPU oracle', err, 'HIP vs fp64', err64, 'fp32 CPU oracle vs fp64 (running max)', env)
+    assert (err <= np.maximum(LOSS_RTOL, 10 * env)).all(), (err, env)
+    assert (err64 <= np.maximum(LOSS_RTOL, 4 * env)).all(), (err64, env)
+
+
 def test_full_size_cfg2_matches_oracle(tmp_path):
     """Parity at the BENCHMARK size (cfg2: nf = ndf = 64, B = 4 here to keep the CPU oracle to a few seconds per step,
     256x256): every fast kernel variant, every split-K plan and the taps-in-N paths of the real layer shapes, against the
