@@ -2452,6 +2452,29 @@ inline bool wino_enabled() {
 }
 // stride-1 layers only: forward is a pad-1 correlation big -> small, the data gradient a pad-2 correlation small -> big
 inline bool wino_b2s_ok(const Geom& g) { return g.s == 1 && wino_enabled() && pg_wino_geom_ok(g.N, g.Hs, g.Ws, g.Cb, g.Ca); }
+// stride-2 big -> small polyphase Winograd: PATCHGAN_WINO2 = 0 off, 1 wherever the geometry allows, default: where the
+// channel counts are large against the tile count (measured per layer of cfg2, tools/layer_bench.py)
+inline bool wino2_b2s_ok(const Geom& g) {
+    static const int mode = [] {
+        const char* e = getenv("PATCHGAN_WINO2");
+        return e ? atoi(e) : 2;
+    }();
+    if (g.s != 2 || mode == 0 || !wino_enabled() || !pg_wino2_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) return false;
+    if (mode == 1) return true;
+    // measured on the cfg2 layers (F(3x3,2x2)): 128->256 ch -31 %, 256->512 on 16x16 -11 %, 256->1024 -25 %, 128->512 -35 %,
+    // 64->256 -18 %; 64->128 +-0; 512->512 on 8x8 and smaller maps slower (weight transform dominates)
+    return pg_wino2_tiles_b2s(g.N, g.Hs, g.Ws) >= 512 && g.Cb >= 64 && g.Ca >= 256;
+}
+inline bool wino2_s2b_ok(const Geom& g) {
+    static const int mode = [] {
+        const char* e = getenv("PATCHGAN_WINO2");
+        return e ? atoi(e) : 2;
+    }();
+    if (g.s != 2 || mode == 0 || !wino_enabled() || !pg_wino2c_geom_ok(g.N, g.Hb, g.Wb, g.Ca, g.Cb)) return false;
+    if (mode == 1) return true;
+    // measured: 256->128 ch -13 %, 512->256 -18 %, 1024->256 -16 %, 512->128 -22 %; 64 output channels or fewer: slower
+    return pg_wino2_tiles_s2b(g.N, g.Hb, g.Wb) >= 512 && g.Cb >= 128 && g.Ca >= 256;
+}
 inline bool wino_wgrad_ok(const Geom& g) {
     static const bool off = [] {
         const char* e = getenv("PATCHGAN_NO_WINOGRAD_WGRAD");
@@ -2478,6 +2501,8 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
     if (op == 1 && s2b_tapn_ok(gq)) bytes = std::max(bytes, s2b_tapn_ws(gq) + 256);
     if (op == 0 && wino_b2s_ok(gq)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca));
     if (op == 1 && wino_s2b_ok(gq)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb));
+    if (op == 0 && wino2_b2s_ok(gq)) bytes = std::max(bytes, pg_wino2_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb));
+    if (op == 1 && wino2_s2b_ok(gq)) bytes = std::max(bytes, pg_wino2c_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb));
     if (op == 2 && wino_wgrad_ok(gq))
         bytes = std::max(bytes, pg_wino_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb) +
                                     (((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255));
@@ -2527,6 +2552,21 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         const bool st = (op == 0) ? pg_wino_small_tile(gq.N, gq.Hs, gq.Ws, gq.Ca) : pg_wino_small_tile(gq.N, gq.Hb, gq.Wb, gq.Cb);
         if (tile_id) *tile_id += st ? 50 : 40;
     }
+    // 70 / 71: polyphase Winograd of a stride-2 layer (k_wino_bgemm<2,2,2,2> / <1,2,2,2>)
+    if (algo == PG_ALGO_AUTO && op == 0 && wino2_b2s_ok(gq) && ws_bytes >= pg_wino2_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
+        const long T = pg_wino2_tiles_b2s(g->N, g->Hs, g->Ws), X = (long)(pg_wino2_mo() + 1) * (pg_wino2_mo() + 1);
+        if (tile_id) *tile_id = T >= 1024 ? 70 : 71;
+        if (split) *split = 1;
+        if (workgroups) *workgroups = X * ((T + (T >= 1024 ? 127 : 63)) / (T >= 1024 ? 128 : 64)) * ((g->Ca + 127) / 128);
+        return PG_OK;
+    }
+    if (algo == PG_ALGO_AUTO && op == 1 && wino2_s2b_ok(gq) && ws_bytes >= pg_wino2c_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb)) {
+        const long T = pg_wino2_tiles_s2b(g->N, g->Hb, g->Wb), X = 4L * (pg_wino2_mo() + 1) * (pg_wino2_mo() + 1);
+        if (tile_id) *tile_id = T >= 1024 ? 70 : 71;
+        if (split) *split = 1;
+        if (workgroups) *workgroups = X * ((T + (T >= 1024 ? 127 : 63)) / (T >= 1024 ? 128 : 64)) * ((g->Cb + 127) / 128);
+        return PG_OK;
+    }
     // +60: Winograd F(4x4, 2x2) weight gradient (k_wino_wgrad_gemm<2,2,2,2>); split = its K slices
     if (algo == PG_ALGO_AUTO && op == 2 && wino_wgrad_ok(gq) && ws_bytes >= reserved + pg_wino_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
         if (tile_id) *tile_id = 60;
@@ -2561,6 +2601,14 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
         if (rc != PG_OK) return rc;
         TimedLaunch timed(st);
         return pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st);
+    }
+    if (algo == PG_ALGO_AUTO && wino2_b2s_ok(g) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
+        aligned16(small) && aligned16(ws) && (!bias || aligned16(bias)) &&
+        ws_bytes >= pg_wino2_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) {
+        hipEvent_t e0 = t_ev0, e1 = t_ev1;
+        t_ev0 = nullptr;
+        t_ev1 = nullptr;
+        return pg_wino2_b2s(big, ld_big, P, bias, small, ld_small, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1);
     }
     if (b2s_tapn_ok(g) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= b2s_tapn_ws(g) && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT) {
@@ -2642,6 +2690,14 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
         if (rc != PG_OK) return rc;
         TimedLaunch timed(st);
         return pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st);
+    }
+    if (algo == PG_ALGO_AUTO && wino2_s2b_ok(g) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
+        aligned16(small) && aligned16(ws) && (!bias || aligned16(bias)) &&
+        ws_bytes >= pg_wino2c_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb)) {
+        hipEvent_t e0 = t_ev0, e1 = t_ev1;
+        t_ev0 = nullptr;
+        t_ev1 = nullptr;
+        return pg_wino2_s2b(small, ld_small, P, bias, big, ld_big, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1);
     }
     if (s2b_tapn_ok(g) && (ld_small % 4 == 0) && aligned16(small) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= s2b_tapn_ws(g) && tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT) {

@@ -25,3 +25,19 @@ size_t pg_wino_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
 // ev0 / ev1 (optional) are recorded around the GEMM kernel
 int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
                   int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+
+// stride-2 layers, polyphase F(MO x MO, 2x2), MO = pg_wino2_mo() (3, or 4 with PATCHGAN_WINO2_TILE=4), X = (MO+1)^2:
+// big -> small: U (X*Ca*4Cb) | V (X*tiles*4Cb) | M (X*tiles*Ca) in ws
+int pg_wino2_mo();
+long pg_wino2_tiles_b2s(int N, int Hs, int Ws);
+long pg_wino2_tiles_s2b(int N, int Hb, int Wb);
+bool pg_wino2_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
+size_t pg_wino2_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
+int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N, int Hb,
+                 int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+
+// small -> big, four parity classes: U (4X*Cb*Ca) | V (4X*tiles*Ca) | M (4X*tiles*Cb) in ws
+bool pg_wino2c_geom_ok(int N, int Hb, int Wb, int Ca, int Cb);
+size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb);
+int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N, int Hb,
+                 int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);

@@ -447,6 +447,336 @@ __global__ void k_wino_wgrad_out(const float* __restrict__ S, int slices, float*
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Stride-2 layers, polyphase Winograd F(MO x MO, 2x2), MO = 3 (points 0, 1, -1, inf: 16 instead of 36 multiplies per tile,
+// phase and channel pair; error ~3e-6, the level of the stride-1 path) or MO = 4 (the 5 points above: 25 instead of 64,
+// error ~1e-5; opt-in).
+//
+// big -> small (Conv2d forward, ConvTranspose2d data gradient):
+//   small[p][q] = sum_{r,s in {0,1}} sum_{u,v in {0,1}} X_rs[p+u][q+v] * w[2u+r][2v+s],   X_rs[i][j] = big[2i+r-1][2j+s-1]
+// -- four 2x2-kernel stride-1 correlations over the four parity phases of the input, one GEMM with K = 4*Cb:
+//   k_wino2_u    U[xi][a][ph*Cb + b] = (G g_ph G^T)[xi]
+//   k_wino2_v    V[xi][tile][ph*Cb + b] = (B^T X_ph B)[xi]
+//   k_wino_bgemm M[xi][tile][a] = sum_k V[xi][tile][k] U[xi][a][k]          (NP^2 row GEMMs, grid.z = xi)
+//   k_wino2_out  small[MO*ti+al][MO*tj+be][a] = act(bias + sum_xi AT[al][xi_i] AT[be][xi_j] M[xi][tile][a])
+// small -> big (ConvTranspose2d forward, Conv2d data gradient): each output parity class (r, s) of `big` is a 2x2-kernel
+// stride-1 correlation of `small`:
+//   big[2i+r][2j+s] = sum_{t,t' in {0,1}} small[i+r-1+t][j+s-1+t'] * w[kh(r,t)][kw(s,t')],  kh(0,t) = 3-2t, kh(1,t) = 2-2t
+// the classes see windows shifted by one pixel, so each has its own transformed input; batches z = xi*4 + class:
+//   k_wino2c_u   U[z][b][a] = (G g_class G^T)[xi]          k_wino2c_v   V[z][tile][a] = (B^T d_class B)[xi]
+//   k_wino_bgemm M[z][tile][b] = sum_a V[z][tile][a] U[z][b][a]
+//   k_wino2c_out big[2(MO*ti+al)+r][2(MO*tj+be)+s][b] = act(bias + sum_xi AT[al][xi_i] AT[be][xi_j] M[xi*4+class][tile][b])
+// Pays where the channel counts are large against the tile count (the transformed tensors make a round trip through HBM).
+__device__ __constant__ float c_BT3[4][4] = {{-1, 0, 1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, -1, 0, 1}};
+__device__ __constant__ float c_G3[4][2] = {{-1.f, 0.f}, {0.5f, 0.5f}, {0.5f, -0.5f}, {0.f, 1.f}};
+__device__ __constant__ float c_A3T[3][4] = {{1, 1, 1, 0}, {0, 1, -1, 0}, {0, 1, 1, 1}};
+template <int MO> __device__ __forceinline__ float w_bt(int a, int i) { return MO == 4 ? c_BT[a][i] : c_BT3[a][i]; }
+template <int MO> __device__ __forceinline__ float w_g(int a, int u) { return MO == 4 ? c_G2[a][u] : c_G3[a][u]; }
+template <int MO> __device__ __forceinline__ float w_at(int k, int i) { return MO == 4 ? c_A4T[k][i] : c_A3T[k][i]; }
+
+template <int MO>
+__global__ void k_wino2_u(const float* __restrict__ P, float* __restrict__ U, int Ca, int Cb) {
+    constexpr int NP = MO + 1;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)Ca * Cb) return;
+    const int b = (int)(idx % Cb), a = (int)(idx / Cb);
+    float w[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) w[k][l] = P[((long)(k * 4 + l) * Ca + a) * Cb + b];
+    const int K = 4 * Cb;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int sph = 0; sph < 2; ++sph) {
+            float t[NP][2];
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) t[i][v] = w_g<MO>(i, 0) * w[r][2 * v + sph] + w_g<MO>(i, 1) * w[2 + r][2 * v + sph];
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+                    U[((long)(i * NP + j) * Ca + a) * K + (r * 2 + sph) * Cb + b] = t[i][0] * w_g<MO>(j, 0) + t[i][1] * w_g<MO>(j, 1);
+        }
+}
+
+// shared by both directions: window origin (oy, ox) + step `st` pixels between window entries; writes V[(xi*nb + bi)][tile][c]
+template <int MO>
+__device__ __forceinline__ void wino2_v_tile(const float* __restrict__ src, int ld, int n, int H, int W, int oy, int ox, int st,
+                                             int c0, float* __restrict__ V, long zstride, long vbase) {
+    constexpr int NP = MO + 1;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 d[NP][NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int y = oy + st * i, x = ox + st * j;
+            const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            d[i][j] = ok ? *reinterpret_cast<const f32x4*>(src + ((long)(n * H + y) * W + x) * ld + c0) : z;
+        }
+    f32x4 t[NP][NP];
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            f32x4 v = z;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) v += w_bt<MO>(a, i) * d[i][j];
+            t[a][j] = v;
+        }
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+        for (int b = 0; b < NP; ++b) {
+            f32x4 v = z;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) v += t[a][j] * w_bt<MO>(b, j);
+            *reinterpret_cast<f32x4*>(V + (long)(a * NP + b) * zstride + vbase) = v;
+        }
+}
+
+template <int MO>
+__global__ __launch_bounds__(256) void k_wino2_v(const float* __restrict__ big, int ld, float* __restrict__ V, int N, int Hb,
+                                                 int Wb, int Cb, int TH, int TW) {
+    const int cq = Cb >> 2;
+    const long T = (long)N * TH * TW;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= T * 4 * cq) return;
+    const int c0 = (int)(idx % cq) << 2;
+    long rr = idx / cq;
+    const int ph = (int)(rr & 3);
+    const long tile = rr >> 2;
+    const int n = (int)(tile / (TH * TW));
+    const int rem = (int)(tile - (long)n * TH * TW);
+    const int ti = rem / TW, tj = rem - ti * TW;
+    const long K = 4L * Cb;
+    // X_ph[MO*ti + i][MO*tj + j] = big[2*(MO*ti + i) + r - 1][2*(MO*tj + j) + s - 1]
+    wino2_v_tile<MO>(big, ld, n, Hb, Wb, 2 * MO * ti + (ph >> 1) - 1, 2 * MO * tj + (ph & 1) - 1, 2, c0, V, T * K,
+                     tile * K + ph * Cb + c0);
+}
+
+// NZ independent row GEMMs: C[z][m][n] = sum_k A[z][m][k] * B[z][n][k]; rows of A and B are K contiguous floats (K % 32 == 0)
+template <int MR, int NR, int WM, int WN>
+__global__ __launch_bounds__(256) void k_wino_bgemm(const float* __restrict__ A, const float* __restrict__ B,
+                                                    float* __restrict__ C, int Mrows, int Ncols, int K, int a_bytes,
+                                                    int b_bytes) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32, AI = BM / 32, BI = BN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    float* As = smem;
+    float* Bs = smem + BM * LDK;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+    const int nch = K / KC;
+    const int kq = tid & 7, r0 = tid >> 3;
+    int a_off[AI], b_off[BI];
+    bool a_ok[AI], b_ok[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        a_ok[i] = m < Mrows;
+        a_off[i] = (z * Mrows + min(m, Mrows - 1)) * K + kq * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        b_ok[i] = n < Ncols;
+        b_off[i] = (z * Ncols + min(n, Ncols - 1)) * K + kq * 4;
+    }
+    f32x4 ra[AI], rb[BI];
+    auto issue_loads = [&](int c, bool on) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) ra[i] = bload4(rA, voff(a_off[i] + c * KC, on && a_ok[i]));
+#pragma unroll
+        for (int i = 0; i < BI; ++i) rb[i] = bload4(rB, voff(b_off[i] + c * KC, on && b_ok[i]));
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDK + kq * 4]) = rb[i];
+    };
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    issue_loads(0, true);
+    store_chunk();
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const bool more = c + 1 < nch;
+        issue_loads(c + 1, more);
+        __builtin_amdgcn_sched_barrier(0x386);
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            f32x4 af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MR + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NR + j) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+    float* o = C + (long)z * Mrows * Ncols;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + (wm * MR + i) * 32 + row;
+                if (m < Mrows && col < Ncols) o[(long)m * Ncols + col] = acc[i][j][r];
+            }
+        }
+}
+
+// shared output transform: M values at M[xi*zstride + mbase], outputs at (oy + st*k, ox + st*l) of an H x W image
+template <int MO>
+__device__ __forceinline__ void wino2_out_tile(const float* __restrict__ M, long zstride, long mbase, const float* __restrict__ bias,
+                                               float* __restrict__ out, int ld_out, int n, int H, int W, int oy, int ox, int st,
+                                               int c0, int act) {
+    constexpr int NP = MO + 1;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 t[MO][NP];
+#pragma unroll
+    for (int k = 0; k < MO; ++k)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) t[k][j] = z;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(M + (long)(i * NP + j) * zstride + mbase);
+#pragma unroll
+            for (int k = 0; k < MO; ++k) t[k][j] += w_at<MO>(k, i) * m;
+        }
+    f32x4 bv = z;
+    if (bias != nullptr) bv = *reinterpret_cast<const f32x4*>(bias + c0);
+#pragma unroll
+    for (int k = 0; k < MO; ++k)
+#pragma unroll
+        for (int l = 0; l < MO; ++l) {
+            const int y = oy + st * k, x = ox + st * l;
+            if (y >= H || x >= W) continue;
+            f32x4 v = bv;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) v += t[k][j] * w_at<MO>(l, j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_epi(v[e], act);
+            *reinterpret_cast<f32x4*>(out + ((long)(n * H + y) * W + x) * ld_out + c0) = v;
+        }
+}
+
+template <int MO>
+__global__ __launch_bounds__(256) void k_wino2_out(const float* __restrict__ M, const float* __restrict__ bias,
+                                                   float* __restrict__ out, int ld_out, int N, int Hs, int Ws, int Ca, int TH,
+                                                   int TW, int act) {
+    const int cq = Ca >> 2;
+    const long T = (long)N * TH * TW;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= T * cq) return;
+    const int c0 = (int)(idx % cq) << 2;
+    const long tile = idx / cq;
+    const int n = (int)(tile / (TH * TW));
+    const int rem = (int)(tile - (long)n * TH * TW);
+    const int ti = rem / TW, tj = rem - ti * TW;
+    wino2_out_tile<MO>(M, T * Ca, tile * Ca + c0, bias, out, ld_out, n, Hs, Ws, MO * ti, MO * tj, 1, c0, act);
+}
+
+template <int MO>
+__global__ void k_wino2c_u(const float* __restrict__ P, float* __restrict__ U, int Ca, int Cb) {
+    constexpr int NP = MO + 1;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)Ca * Cb) return;
+    const int a = (int)(idx % Ca), b = (int)(idx / Ca);
+    float w[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) w[k][l] = P[((long)(k * 4 + l) * Ca + a) * Cb + b];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc) {
+            float t[NP][2];      // g[t][t'] = w[kh(r,t)][kw(sc,t')]
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int kw = (sc == 0) ? 3 - 2 * v : 2 - 2 * v;
+                    const float g0 = w[(r == 0) ? 3 : 2][kw], g1 = w[(r == 0) ? 1 : 0][kw];
+                    t[i][v] = w_g<MO>(i, 0) * g0 + w_g<MO>(i, 1) * g1;
+                }
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+                    U[(((long)(i * NP + j) * 4 + r * 2 + sc) * Cb + b) * Ca + a] = t[i][0] * w_g<MO>(j, 0) + t[i][1] * w_g<MO>(j, 1);
+        }
+}
+
+template <int MO>
+__global__ __launch_bounds__(256) void k_wino2c_v(const float* __restrict__ small, int ld, float* __restrict__ V, int N, int Hs,
+                                                  int Ws, int Ca, int TH, int TW) {
+    const int cq = Ca >> 2;
+    const long T = (long)N * TH * TW;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= T * 4 * cq) return;
+    const int c0 = (int)(idx % cq) << 2;
+    long rr = idx / cq;
+    const int cls = (int)(rr & 3);
+    const long tile = rr >> 2;
+    const int n = (int)(tile / (TH * TW));
+    const int rem = (int)(tile - (long)n * TH * TW);
+    const int ti = rem / TW, tj = rem - ti * TW;
+    wino2_v_tile<MO>(small, ld, n, Hs, Ws, MO * ti + (cls >> 1) - 1, MO * tj + (cls & 1) - 1, 1, c0, V, 4L * T * Ca,
+                     ((long)cls * T + tile) * Ca + c0);
+}
+
+template <int MO>
+__global__ __launch_bounds__(256) void k_wino2c_out(const float* __restrict__ M, const float* __restrict__ bias,
+                                                    float* __restrict__ out, int ld_out, int N, int Hb, int Wb, int Cb, int TH,
+                                                    int TW, int act) {
+    const int cq = Cb >> 2;
+    const long T = (long)N * TH * TW;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= T * 4 * cq) return;
+    const int c0 = (int)(idx % cq) << 2;
+    long rr = idx / cq;
+    const int cls = (int)(rr & 3);
+    const long tile = rr >> 2;
+    const int n = (int)(tile / (TH * TW));
+    const int rem = (int)(tile - (long)n * TH * TW);
+    const int ti = rem / TW, tj = rem - ti * TW;
+    wino2_out_tile<MO>(M, 4L * T * Cb, ((long)cls * T + tile) * Cb + c0, bias, out, ld_out, n, Hb, Wb, 2 * MO * ti + (cls >> 1),
+                       2 * MO * tj + (cls & 1), 2, c0, act);
+}
+
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -562,4 +892,121 @@ int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     hipLaunchKernelGGL(k_wino_wgrad_out, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, S, slices, dP, Ca, Cb);
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+}
+
+// ---- stride-2 layers (polyphase / parity classes) ----
+int pg_wino2_mo() {     // output tile edge: 3 (default) or 4 (PATCHGAN_WINO2_TILE=4)
+    static const int mo = [] {
+        const char* e = getenv("PATCHGAN_WINO2_TILE");
+        return (e && atoi(e) == 4) ? 4 : 3;
+    }();
+    return mo;
+}
+static long wino2_tiles(int N, int H, int W) {
+    const int mo = pg_wino2_mo();
+    return (long)N * ((H + mo - 1) / mo) * ((W + mo - 1) / mo);
+}
+static long wino2_nxi() { return (long)(pg_wino2_mo() + 1) * (pg_wino2_mo() + 1); }
+
+long pg_wino2_tiles_b2s(int N, int Hs, int Ws) { return wino2_tiles(N, Hs, Ws); }
+long pg_wino2_tiles_s2b(int N, int Hb, int Wb) { return wino2_tiles(N, (Hb + 1) / 2, (Wb + 1) / 2); }
+
+bool pg_wino2_geom_ok(int N, int Hs, int Ws, int Ca, int Cb) {
+    if (Cb % 8 != 0 || Ca % 4 != 0 || Cb < 32 || Ca < 64) return false;
+    const long T = wino2_tiles(N, Hs, Ws), X = wino2_nxi();
+    if (T < 64) return false;
+    if ((double)X * T * 4 * Cb * 4 >= 1.5e9 || (double)X * Ca * 4 * Cb * 4 >= 1.5e9 || (double)X * T * Ca * 4 >= 1.5e9) return false;
+    return true;
+}
+
+size_t pg_wino2_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb) {
+    const long T = wino2_tiles(N, Hs, Ws), X = wino2_nxi();
+    return align256((size_t)X * Ca * 4 * Cb * 4) + align256((size_t)X * T * 4 * Cb * 4) + align256((size_t)X * T * Ca * 4);
+}
+
+template <int MO>
+static int wino2_b2s_run(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N,
+                         int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0,
+                         hipEvent_t ev1) {
+    constexpr int X = (MO + 1) * (MO + 1);
+    const int TH = (Hs + MO - 1) / MO, TW = (Ws + MO - 1) / MO, K = 4 * Cb;
+    const long T = (long)N * TH * TW;
+    float* U = (float*)ws;
+    float* V = (float*)((char*)U + align256((size_t)X * Ca * K * 4));
+    float* M = (float*)((char*)V + align256((size_t)X * T * K * 4));
+    hipLaunchKernelGGL(k_wino2_u<MO>, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, P, U, Ca, Cb);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    hipLaunchKernelGGL(k_wino2_v<MO>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb, TH,
+                       TW);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    if (ev0) (void)hipEventRecord(ev0, st);
+    const int a_bytes = (int)((long)X * T * K * 4), b_bytes = (int)((long)X * Ca * K * 4);
+    if (T >= 1024)
+        hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (Ca + 127) / 128, X), dim3(256), 0, st, V, U,
+                           M, (int)T, Ca, K, a_bytes, b_bytes);
+    else
+        hipLaunchKernelGGL((k_wino_bgemm<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (Ca + 127) / 128, X), dim3(256), 0, st, V, U,
+                           M, (int)T, Ca, K, a_bytes, b_bytes);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    hipLaunchKernelGGL(k_wino2_out<MO>, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, M, bias, small, ld_small, N,
+                       Hs, Ws, Ca, TH, TW, act);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+}
+
+int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N, int Hb,
+                 int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    if (pg_wino2_mo() == 4)
+        return wino2_b2s_run<4>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1);
+    return wino2_b2s_run<3>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1);
+}
+
+bool pg_wino2c_geom_ok(int N, int Hb, int Wb, int Ca, int Cb) {
+    if (Ca % 32 != 0 || Cb % 4 != 0 || Ca < 64 || Cb < 32) return false;
+    const long T = pg_wino2_tiles_s2b(N, Hb, Wb), X = 4 * wino2_nxi();
+    if (T < 64) return false;
+    if ((double)X * T * Ca * 4 >= 1.5e9 || (double)X * Ca * Cb * 4 >= 1.5e9 || (double)X * T * Cb * 4 >= 1.5e9) return false;
+    return true;
+}
+
+size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb) {
+    const long T = pg_wino2_tiles_s2b(N, Hb, Wb), X = 4 * wino2_nxi();
+    return align256((size_t)X * Ca * Cb * 4) + align256((size_t)X * T * Ca * 4) + align256((size_t)X * T * Cb * 4);
+}
+
+template <int MO>
+static int wino2_s2b_run(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N,
+                         int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0,
+                         hipEvent_t ev1) {
+    constexpr int X = 4 * (MO + 1) * (MO + 1);
+    const int TH = ((Hb + 1) / 2 + MO - 1) / MO, TW = ((Wb + 1) / 2 + MO - 1) / MO;
+    const long T = (long)N * TH * TW;
+    float* U = (float*)ws;
+    float* V = (float*)((char*)U + align256((size_t)X * Ca * Cb * 4));
+    float* M = (float*)((char*)V + align256((size_t)X * T * Ca * 4));
+    hipLaunchKernelGGL(k_wino2c_u<MO>, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, P, U, Ca, Cb);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    hipLaunchKernelGGL(k_wino2c_v<MO>, dim3((unsigned)((T * Ca + 255) / 256)), dim3(256), 0, st, small, ld_small, V, N, Hs, Ws, Ca,
+                       TH, TW);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    if (ev0) (void)hipEventRecord(ev0, st);
+    const int a_bytes = (int)((long)X * T * Ca * 4), b_bytes = (int)((long)X * Cb * Ca * 4);
+    if (T >= 1024)
+        hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (Cb + 127) / 128, X), dim3(256), 0, st, V, U,
+                           M, (int)T, Cb, Ca, a_bytes, b_bytes);
+    else
+        hipLaunchKernelGGL((k_wino_bgemm<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (Cb + 127) / 128, X), dim3(256), 0, st, V, U,
+                           M, (int)T, Cb, Ca, a_bytes, b_bytes);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    hipLaunchKernelGGL(k_wino2c_out<MO>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, M, bias, big, ld_big, N, Hb, Wb,
+                       Cb, TH, TW, act);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+}
+
+int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N, int Hb,
+                 int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    if (pg_wino2_mo() == 4)
+        return wino2_s2b_run<4>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1);
+    return wino2_s2b_run<3>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1);
 }

@@ -190,6 +190,9 @@ class ConvOp:
             if mode == 6:
                 self._desc[opcode] = ('k_wino_wgrad_gemm<2,2,2,2>', s.value)
                 return self._desc[opcode]
+            if mode == 7:
+                self._desc[opcode] = ('k_wino_bgemm<2,2,2,2>' if tid == 0 else 'k_wino_bgemm<1,2,2,2>', 1)
+                return self._desc[opcode]
             if mode in (4, 5):
                 name, s.value = ('k_wino_gemm<2,1,2,2>' if mode == 4 else 'k_wino_gemm<1,1,2,2>'), 1
             elif mode == 3:

@@ -159,6 +159,45 @@ def test_winograd_stride1(geom):
     assert rel_err(outs[0], Wr.grad) < 3e-5 and rel_err(outs[1], Wr.grad) < 3e-5, (rel_err(outs[0], Wr.grad), rel_err(outs[1], Wr.grad))
 
 
+# stride-2 layers for the polyphase Winograd path: the last two pass the default size heuristic (channel-heavy layers), the
+# others run when the suite is started with PATCHGAN_WINO2=1 (forces the path wherever the geometry allows; also with
+# PATCHGAN_WINO2_TILE=4): odd tile counts, ragged extents, both GEMM tile variants
+WINO2_GEOMS = [(4, 32, 32, 128, 64, 2), (2, 64, 64, 64, 32, 2), (3, 36, 44, 96, 40, 2), (16, 16, 16, 256, 128, 2), (9, 64, 64, 160, 64, 2),
+               (3, 35, 41, 64, 64, 2), (6, 62, 58, 256, 128, 2), (16, 32, 32, 288, 160, 2)]
+
+
+@pytest.mark.parametrize('geom', WINO2_GEOMS, ids=lambda g: 'x'.join(map(str, g)))
+def test_winograd_stride2_big2small(geom, monkeypatch):
+    from patchgan_amd import engine as E
+    from tests.gpu_util import to_view, empty_view, pack, rel_err
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    auto, mfma = E.ConvOp(*geom, 0), E.ConvOp(*geom, 2)
+    if not (auto.describe(0)[0].startswith('k_wino_bgemm') and auto.describe(1)[0].startswith('k_wino_bgemm')):
+        pytest.skip('below the default size heuristic: covered when the suite runs with PATCHGAN_WINO2=1')
+    bias = torch.randn(Ca)
+    P = pack(Wt)
+    want = O.apply_act(F.conv2d(big, Wt, bias, stride=2, padding=1), 'leakyrelu')
+    outs = []
+    for op in (auto, mfma):
+        vs = empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=4)
+        op.big2small(to_view(big, ld=Cb + 4, off=0), P, 0, bias.cuda(), 0, vs, ACTS['leakyrelu'])
+        outs.append(vs.to_nchw())
+    torch.cuda.synchronize()
+    assert rel_err(outs[0], want) < 2e-5 and rel_err(outs[1], want) < 2e-5, (rel_err(outs[0], want), rel_err(outs[1], want))
+    # transposed direction (four parity classes)
+    bias_b = torch.randn(Cb)
+    want = O.apply_act(F.conv_transpose2d(small, Wt, bias_b, stride=2, padding=1,
+                                          output_padding=(Hb - ((Hs - 1) * 2 + 2), Wb - ((Ws - 1) * 2 + 2))), 'tanh')
+    outs = []
+    for op in (auto, mfma):
+        vb = empty_view(N, Hb, Wb, Cb, ld=Cb + 8, off=4)
+        op.small2big(to_view(small, ld=Ca + 4, off=4), P, 0, bias_b.cuda(), 0, vb, ACTS['tanh'])
+        outs.append(vb.to_nchw())
+    torch.cuda.synchronize()
+    assert rel_err(outs[0], want) < 2e-5 and rel_err(outs[1], want) < 2e-5, (rel_err(outs[0], want), rel_err(outs[1], want))
+
+
 def test_mfma_matches_direct_bitwise_shapes():
     """The two algorithms must agree closely on a cfg2-like layer (enc2 at reduced batch)."""
     from patchgan_amd import engine as E
