@@ -2475,6 +2475,18 @@ inline bool wino2_s2b_ok(const Geom& g) {
     // measured: 256->128 ch -13 %, 512->256 -18 %, 1024->256 -16 %, 512->128 -22 %; 64 output channels or fewer: slower
     return pg_wino2_tiles_s2b(g.N, g.Hb, g.Wb) >= 512 && g.Cb >= 128 && g.Ca >= 256;
 }
+inline bool wino2_wgrad_ok(const Geom& g) {
+    static const int mode = [] {
+        const char* e = getenv("PATCHGAN_WINO2_WGRAD");
+        return e ? atoi(e) : 2;
+    }();
+    if (g.s != 2 || mode == 0 || !wino_enabled() || !pg_wino2_wgrad_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) return false;
+    if (mode == 1) return true;
+    // measured on the cfg2 layers: 1024x256 on 16x16 -13 %, 512x128 on 32x32 -22 %; everything with fewer small-side channels
+    // is slower than the implicit GEMM (many K slices of little work each, 6.25x transformed operands)
+    const long T = (long)g.N * ((g.Hs + 2) / 3) * ((g.Ws + 2) / 3);
+    return g.Ca >= 512 && g.Cb >= 128 && (g.Ca >= 1024 || T >= 1024);
+}
 inline bool wino_wgrad_ok(const Geom& g) {
     static const bool off = [] {
         const char* e = getenv("PATCHGAN_NO_WINOGRAD_WGRAD");
@@ -2505,6 +2517,9 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
     if (op == 1 && wino2_s2b_ok(gq)) bytes = std::max(bytes, pg_wino2c_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb));
     if (op == 2 && wino_wgrad_ok(gq))
         bytes = std::max(bytes, pg_wino_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb) +
+                                    (((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255));
+    if (op == 2 && wino2_wgrad_ok(gq))
+        bytes = std::max(bytes, pg_wino2_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb) +
                                     (((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255));
     return (bytes + 255) & ~(size_t)255;
 }
@@ -2565,6 +2580,15 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         if (tile_id) *tile_id = T >= 1024 ? 70 : 71;
         if (split) *split = 1;
         if (workgroups) *workgroups = X * ((T + (T >= 1024 ? 127 : 63)) / (T >= 1024 ? 128 : 64)) * ((g->Cb + 127) / 128);
+        return PG_OK;
+    }
+    // 61: polyphase F(2x2, 3x3) weight gradient of a stride-2 layer (k_wino_wgrad_gemm<2,2,2,2>)
+    if (algo == PG_ALGO_AUTO && op == 2 && wino2_wgrad_ok(gq) &&
+        ws_bytes >= reserved + pg_wino2_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
+        const int sl = pg_wino2_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb);
+        if (tile_id) *tile_id = 61;
+        if (split) *split = sl;
+        if (workgroups) *workgroups = 16L * ((g->Ca + 127) / 128) * ((4 * g->Cb + 127) / 128) * sl;
         return PG_OK;
     }
     // +60: Winograd F(4x4, 2x2) weight gradient (k_wino_wgrad_gemm<2,2,2,2>); split = its K slices
@@ -2811,6 +2835,14 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
         t_ev1 = nullptr;
         return pg_wino_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, (char*)ws + reserved, st,
                              e0, e1);
+    }
+    if (algo == PG_ALGO_AUTO && wino2_wgrad_ok(g) && (ld_small % 4 == 0) && (ld_big % 4 == 0) && aligned16(small) &&
+        aligned16(big) && aligned16(ws) && ws_bytes >= reserved + pg_wino2_wgrad_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) {
+        hipEvent_t e0 = t_ev0, e1 = t_ev1;
+        t_ev0 = nullptr;
+        t_ev1 = nullptr;
+        return pg_wino2_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, (char*)ws + reserved, st,
+                              e0, e1);
     }
     Plan p = plan_wgrad(gg);
     clamp_split(p, ws_bytes, reserved);

@@ -41,3 +41,10 @@ bool pg_wino2c_geom_ok(int N, int Hb, int Wb, int Ca, int Cb);
 size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb);
 int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+
+// weight gradient of the stride-2 layers, polyphase F(2x2, 3x3): V (16*tiles*4Cb) | DY (16*tiles*Ca) | S (slices*16*Ca*4Cb)
+bool pg_wino2_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
+int pg_wino2_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb);
+size_t pg_wino2_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
+int pg_wino2_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
+                   int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);

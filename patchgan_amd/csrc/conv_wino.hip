@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void k_wino_wgrad_gemm(const float* __restrict
             __syncthreads();
         }
     }
-    float* o = S + ((long)blockIdx.z * 25 + xi) * Ca * Cb;
+    float* o = S + ((long)blockIdx.z * gridDim.y + xi) * Ca * Cb;
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -777,6 +777,83 @@ __global__ __launch_bounds__(256) void k_wino2c_out(const float* __restrict__ M,
                        2 * MO * tj + (cls & 1), 2, c0, act);
 }
 
+// Weight gradient of the stride-2 layers, polyphase F(2x2, 3x3): per phase (r, s) the taps (2u+r, 2v+s), u, v in {0,1}, are
+//   dW[2u+r][2v+s][a][b] = sum_pix dy[p][q][a] * X_rs[p+u][q+v][b]
+// -- per 3x3 tile of dy and its 4x4 window of the phase (the forward's window: V is the forward's k_wino2_v<3>) a 2x2
+// correlation with a 3x3 "kernel" dy: 16 instead of 36 multiplies.
+//   k_wino2_dy         DY[xi][tile][a] = (G23 dy G23^T)[xi]
+//   k_wino_wgrad_gemm  S[slice][xi][a][ph*Cb + b] = sum_{tile in slice} DY[xi][tile][a] * V[xi][tile][ph*Cb + b]
+//   k_wino2_wgrad_out  dP[(2u+r)*4 + 2v+s][a][b] = sum_slice sum_xi A2T[u][xi_i] A2T[v][xi_j] S[slice][xi][a][ph*Cb + b]
+__device__ __constant__ float c_G23[4][3] = {{-1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+__device__ __constant__ float c_A2T[2][4] = {{1, 1, 1, 0}, {0, 1, -1, 1}};
+
+__global__ __launch_bounds__(256) void k_wino2_dy(const float* __restrict__ dy, int ld, float* __restrict__ DY, int N, int Hs,
+                                                  int Ws, int Ca, int TH, int TW) {
+    const int cq = Ca >> 2;
+    const long T = (long)N * TH * TW;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= T * cq) return;
+    const int c0 = (int)(idx % cq) << 2;
+    const long tile = idx / cq;
+    const int n = (int)(tile / (TH * TW));
+    const int rem = (int)(tile - (long)n * TH * TW);
+    const int ti = rem / TW, tj = rem - ti * TW;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 d[3][3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int y = 3 * ti + u, x = 3 * tj + v;
+            d[u][v] = (y < Hs && x < Ws) ? *reinterpret_cast<const f32x4*>(dy + ((long)(n * Hs + y) * Ws + x) * ld + c0) : z;
+        }
+    f32x4 t[4][3];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) t[a][v] = c_G23[a][0] * d[0][v] + c_G23[a][1] * d[1][v] + c_G23[a][2] * d[2][v];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            *reinterpret_cast<f32x4*>(DY + ((long)(a * 4 + b) * T + tile) * Ca + c0) =
+                t[a][0] * c_G23[b][0] + t[a][1] * c_G23[b][1] + t[a][2] * c_G23[b][2];
+}
+
+// one thread per (a, b)
+__global__ void k_wino2_wgrad_out(const float* __restrict__ S, int slices, float* __restrict__ dP, int Ca, int Cb) {
+    const long ab = (long)Ca * Cb;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= ab) return;
+    const int b = (int)(idx % Cb), a = (int)(idx / Cb);
+    const long K = 4L * Cb, slab = (long)Ca * K;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        float m[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = 0.f;
+                for (int s = 0; s < slices; ++s) v += S[((long)s * 16 + i * 4 + j) * slab + (long)a * K + ph * Cb + b];
+                m[i][j] = v;
+            }
+        float t[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[u][j] = c_A2T[u][0] * m[0][j] + c_A2T[u][1] * m[1][j] + c_A2T[u][2] * m[2][j] + c_A2T[u][3] * m[3][j];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const float w = t[u][0] * c_A2T[v][0] + t[u][1] * c_A2T[v][1] + t[u][2] * c_A2T[v][2] + t[u][3] * c_A2T[v][3];
+                const int kh = 2 * u + (ph >> 1), kw = 2 * v + (ph & 1);
+                dP[(long)(kh * 4 + kw) * ab + idx] = w;
+            }
+    }
+}
+
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -1009,4 +1086,55 @@ int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* 
     if (pg_wino2_mo() == 4)
         return wino2_s2b_run<4>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1);
     return wino2_s2b_run<3>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1);
+}
+
+// ---- weight gradient of the stride-2 layers (polyphase F(2x2, 3x3)) ----
+static long wino2w_tiles(int N, int Hs, int Ws) { return (long)N * ((Hs + 2) / 3) * ((Ws + 2) / 3); }
+
+bool pg_wino2_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb) {
+    if (Ca % 4 != 0 || Cb % 4 != 0 || Ca < 64 || Cb < 32) return false;
+    const long T = wino2w_tiles(N, Hs, Ws);
+    if (T < 512) return false;
+    if (16.0 * T * Ca * 4 >= 1.5e9 || 16.0 * T * 4 * Cb * 4 >= 1.5e9) return false;
+    return true;
+}
+
+int pg_wino2_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb) {
+    const long T = wino2w_tiles(N, Hs, Ws);
+    const long wgs = 16L * ((Ca + 127) / 128) * ((4 * Cb + 127) / 128);
+    long s = (768 + wgs - 1) / wgs;
+    const long nchunks = (T + KC - 1) / KC;
+    if (s > nchunks / 8) s = nchunks / 8;
+    return (int)(s < 1 ? 1 : s);
+}
+
+size_t pg_wino2_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb) {
+    const long T = wino2w_tiles(N, Hs, Ws);
+    return align256((size_t)16 * T * 4 * Cb * 4) + align256((size_t)16 * T * Ca * 4) +
+           align256((size_t)pg_wino2_wgrad_slices(N, Hs, Ws, Ca, Cb) * 16 * Ca * 4 * Cb * 4);
+}
+
+int pg_wino2_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
+                   int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    const int TH = (Hs + 2) / 3, TW = (Ws + 2) / 3, K = 4 * Cb;
+    const long T = (long)N * TH * TW;
+    float* V = (float*)ws;
+    float* DY = (float*)((char*)ws + align256((size_t)16 * T * K * 4));
+    float* S = (float*)((char*)DY + align256((size_t)16 * T * Ca * 4));
+    hipLaunchKernelGGL(k_wino2_v<3>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb, TH, TW);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    hipLaunchKernelGGL(k_wino2_dy, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, small, ld_small, DY, N, Hs, Ws,
+                       Ca, TH, TW);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    const int slices = pg_wino2_wgrad_slices(N, Hs, Ws, Ca, Cb);
+    const int nchunks = (int)((T + KC - 1) / KC);
+    const int cps = (nchunks + slices - 1) / slices;
+    const int tilesA = (Ca + 127) / 128, tilesB = (K + 127) / 128;
+    if (ev0) (void)hipEventRecord(ev0, st);
+    hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB, 16, slices), dim3(256), 0, st, DY, V, S, (int)T, Ca, K,
+                       cps, tilesB, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
+    if (ev1) (void)hipEventRecord(ev1, st);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    hipLaunchKernelGGL(k_wino2_wgrad_out, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, S, slices, dP, Ca, Cb);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }

@@ -198,6 +198,30 @@ def test_winograd_stride2_big2small(geom, monkeypatch):
     assert rel_err(outs[0], want) < 2e-5 and rel_err(outs[1], want) < 2e-5, (rel_err(outs[0], want), rel_err(outs[1], want))
 
 
+@pytest.mark.parametrize('geom', [(6, 62, 58, 256, 128, 2), (16, 32, 32, 288, 160, 2), (5, 64, 64, 64, 32, 2), (3, 70, 74, 96, 36, 2),
+                                  (9, 64, 64, 512, 128, 2)],
+                         ids=lambda g: 'x'.join(map(str, g)))
+def test_winograd_stride2_wgrad(geom):
+    """Polyphase F(2x2, 3x3) weight gradient (PATCHGAN_WINO2_WGRAD=1 forces it wherever the geometry allows)."""
+    from patchgan_amd import engine as E
+    from tests.gpu_util import to_view, unpack, rel_err, DEV
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    auto, mfma = E.ConvOp(*geom, 0), E.ConvOp(*geom, 2)
+    if not auto.describe(2)[0].startswith('k_wino_wgrad_gemm'):
+        pytest.skip('below the default size heuristic: covered when the suite runs with PATCHGAN_WINO2_WGRAD=1')
+    Wr = Wt.clone().requires_grad_(True)
+    br = torch.zeros(Ca, requires_grad=True)
+    F.conv2d(big, Wr, br, stride=2, padding=1).backward(small)
+    for op in (auto, mfma):
+        dP = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+        db = torch.full((Ca,), float('nan'), device=DEV)
+        op.wgrad(to_view(small, ld=Ca + 4, off=4), to_view(big, ld=Cb + 8, off=4), dP, 0, db, 0)
+        torch.cuda.synchronize()
+        assert rel_err(db, br.grad) < 3e-5
+        assert rel_err(unpack(dP, Ca, Cb), Wr.grad) < 3e-5, rel_err(unpack(dP, Ca, Cb), Wr.grad)
+
+
 def test_mfma_matches_direct_bitwise_shapes():
     """The two algorithms must agree closely on a cfg2-like layer (enc2 at reduced batch)."""
     from patchgan_amd import engine as E
