@@ -16,6 +16,7 @@ Nothing here touches autograd; `patchgan_amd.unet` / `.disc` wrap the engines in
 `patchgan_amd.trainer` drives them directly.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -132,7 +133,7 @@ class LaunchProfiler:
         # the C ABI records the pair tightly around the main GEMM kernel of this call (not its split-K reduce)
         L.check(L.load().pg_conv_time_next(e0.cuda_event, e1.cuda_event), 'pg_conv_time_next')
         fn()
-        self.records.append((sym, split, op.flops, e0, e1))
+        self.records.append((sym, split, op.flops, op.kernel_flops(opcode), e0, e1))
 
     @staticmethod
     def _event():
@@ -141,14 +142,16 @@ class LaunchProfiler:
         return e
 
     def summary(self):
-        """{symbol: dict(launches, ms_total, flops_total)} over every launch of that kernel symbol (all split-K factors,
-        like a rocprofv3 --stats row) -- call after a device synchronize."""
+        """{symbol: dict(launches, ms, flops, kflops)} over every launch of that kernel symbol (all split-K factors, like a
+        rocprofv3 --stats row): flops = algorithmic (direct-convolution) FLOPs of the layers, kflops = FLOPs the kernel
+        executed (fewer for Winograd kernels) -- call after a device synchronize."""
         out = {}
-        for sym, split, flops, e0, e1 in self.records:
-            d = out.setdefault(sym, dict(launches=0, ms=0.0, flops=0.0))
+        for sym, split, flops, kflops, e0, e1 in self.records:
+            d = out.setdefault(sym, dict(launches=0, ms=0.0, flops=0.0, kflops=0.0))
             d['launches'] += 1
             d['ms'] += e0.elapsed_time(e1)
             d['flops'] += flops
+            d['kflops'] += kflops
         return out
 
 
@@ -178,6 +181,25 @@ class ConvOp:
     def flops(self):
         """Algorithmic FLOPs of any of the three kernels on this geometry: 2 * N*Hs*Ws * 16 * Ca * Cb."""
         return 2.0 * self.N * self.Hs * self.Ws * 16 * self.Ca * self.Cb
+
+    def kernel_flops(self, opcode):
+        """FLOPs the main GEMM kernel of this call really executes on the MFMA pipe: the algorithmic count for the implicit
+        GEMM kernels, 2.25-2.56x fewer for the Winograd kernels (their tile counts include the ragged-edge padding)."""
+        sym = self.describe(opcode)[0]
+        cd = lambda a, b: -(-a // b)
+        if sym.startswith('k_wino_gemm'):            # stride 1, F(2x2, 4x4): 25 GEMMs of tiles x Cin x Cout
+            ho, wo = (self.Hs, self.Ws) if opcode == 0 else (self.Hb, self.Wb)
+            return 2.0 * 25 * self.N * cd(ho, 2) * cd(wo, 2) * self.Ca * self.Cb
+        if sym.startswith('k_wino_wgrad_gemm'):
+            if self.stride == 1:
+                return 2.0 * 25 * self.N * cd(self.Hs, 2) * cd(self.Ws, 2) * self.Ca * self.Cb
+            return 2.0 * 16 * self.N * cd(self.Hs, 3) * cd(self.Ws, 3) * self.Ca * 4 * self.Cb
+        if sym.startswith('k_wino_bgemm'):
+            mo = 4 if os.environ.get('PATCHGAN_WINO2_TILE', '') == '4' else 3
+            if opcode == 0:
+                return 2.0 * (mo + 1) ** 2 * self.N * cd(self.Hs, mo) * cd(self.Ws, mo) * 4 * self.Cb * self.Ca
+            return 2.0 * 4 * (mo + 1) ** 2 * self.N * cd(cd(self.Hb, 2), mo) * cd(cd(self.Wb, 2), mo) * self.Ca * self.Cb
+        return self.flops
 
     def describe(self, opcode):
         if opcode not in self._desc:
