@@ -1381,6 +1381,86 @@ __global__ __launch_bounds__(256) void k_wgrad_fast(const float* __restrict__ sm
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// big2small for image-facing layers with 1..3 big-side channels (enc0 forward, dec6 data gradient): the whole
+// contraction K = 16*CB <= 48 fits one LDS tile, so the kernel is one shot -- gather 128 pixels x K and 64 x K weights,
+// one barrier, K/2 MFMAs per 32x32 tile, bias + activation, store -- and is bound by the HBM write of its output.
+// ------------------------------------------------------------------------------------------------
+template <int CB>
+__global__ __launch_bounds__(256) void k_b2s_tapk(const float* __restrict__ big, int ld_big, const float* __restrict__ P,
+                                                  float* __restrict__ out, int ld_out, Geom g, const float* __restrict__ bias,
+                                                  int act, int vec4) {
+    constexpr int K = 16 * CB, LDT = K + 4;
+    __shared__ __attribute__((aligned(16))) float smem[(128 + 64) * LDT];
+    float* As = smem;
+    float* Bs = smem + 128 * LDT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int M = g.N * g.Hs * g.Ws;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64;
+    // A: 128 pixels x 16 taps, one (pixel, tap) item = CB consecutive floats; a thread owns one pixel and 8 taps
+    {
+        const int r = tid & 127, t0 = (tid >> 7) * 8;
+        const int m = m0 + r;
+        const int mm = min(m, M - 1);
+        const int n = mm / (g.Hs * g.Ws);
+        const int rem = mm - n * (g.Hs * g.Ws);
+        const int p = rem / g.Ws, q = rem - p * g.Ws;
+        const int h0 = g.s * p - 1, w0 = g.s * q - 1;
+        const float* base = big + ((long)(n * g.Hb + h0) * g.Wb + w0) * ld_big;
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            const int tap = t0 + tt, kh = tap >> 2, kw = tap & 3;
+            const bool ok = m < M && (unsigned)(h0 + kh) < (unsigned)g.Hb && (unsigned)(w0 + kw) < (unsigned)g.Wb;
+            const float* src = base + ((long)kh * g.Wb + kw) * ld_big;
+            float* dst = &As[r * LDT + tap * CB];
+            if (CB == 4 && vec4) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(dst) = ok ? *reinterpret_cast<const f32x4*>(src) : z;
+            } else {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) dst[c] = ok ? src[c] : 0.f;
+            }
+        }
+    }
+    // B: 64 output channels x K, Bs[a][tap*CB + c] = P[(tap*Ca + a)*CB + c]
+    for (int item = tid; item < 64 * 16; item += 256) {
+        const int a = item & 63, tap = item >> 6;
+        const bool ok = n0 + a < g.Ca;
+#pragma unroll
+        for (int c = 0; c < CB; ++c) Bs[a * LDT + tap * CB + c] = ok ? P[((long)tap * g.Ca + n0 + a) * CB + c] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < K / 8; ++kk) {
+        f32x4 af[2], bf;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * 2 + i) * 32 + lrow) * LDT + kk * 8 + lh * 4]);
+        bf = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 + lrow) * LDT + kk * 8 + lh * 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[e], acc[i], 0, 0, 0);
+    }
+    const int col = n0 + wn * 32 + lrow;
+    const float bv = (bias != nullptr && col < g.Ca) ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int m = m0 + (wm * 2 + i) * 32 + row;
+            if (m < M && col < g.Ca) out[(long)m * ld_out + col] = pg_act_epi(acc[i][r] + bv, act);
+        }
+}
+
 // ================================================================================================
 // bf16 variants (PG_ALGO_BF16; the "next" row f2, BASELINE config 4): tensors stay fp32 in HBM and in the C ABI -- fp32
 // master weights, fp32 InstanceNorm statistics, fp32 accumulation -- but operand tiles are rounded to bf16 (RNE,
@@ -2443,6 +2523,13 @@ inline size_t b2s_tapn_ws(const Geom& g) { return (size_t)g.N * g.Hb * g.Wb * 16
         default: hipLaunchKernelGGL((k_wgrad_fast<1, 1, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
     }
 
+inline bool tapk_enabled() {
+    static const bool off = [] {
+        const char* e = getenv("PATCHGAN_NO_TAPK");
+        return e && e[0] == '1';
+    }();
+    return !off;
+}
 inline bool wino_enabled() {
     static const bool off = [] {
         const char* e = getenv("PATCHGAN_NO_WINOGRAD");
@@ -2567,6 +2654,14 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         const bool st = (op == 0) ? pg_wino_small_tile(gq.N, gq.Hs, gq.Ws, gq.Ca) : pg_wino_small_tile(gq.N, gq.Hb, gq.Wb, gq.Cb);
         if (tile_id) *tile_id += st ? 50 : 40;
     }
+    // 81..83: one-shot k_b2s_tapk<Cb> for 1..3 big-side channels
+    if (op == 0 && g->Cb <= 3 && algo != PG_ALGO_BF16 && !force_generic() && tapk_enabled() &&
+        !(b2s_tapn_ok(gq) && ws_bytes >= b2s_tapn_ws(gq))) {
+        if (tile_id) *tile_id = 80 + g->Cb;
+        if (split) *split = 1;
+        if (workgroups) *workgroups = (((long)g->N * g->Hs * g->Ws + 127) / 128) * ((g->Ca + 63) / 64);
+        return PG_OK;
+    }
     // 70 / 71: polyphase Winograd of a stride-2 layer (k_wino_bgemm<2,2,2,2> / <1,2,2,2>)
     if (algo == PG_ALGO_AUTO && op == 0 && wino2_b2s_ok(gq) && ws_bytes >= pg_wino2_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
         const long T = pg_wino2_tiles_b2s(g->N, g->Hs, g->Ws), X = (long)(pg_wino2_mo() + 1) * (pg_wino2_mo() + 1);
@@ -2652,6 +2747,19 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
         const long total = (long)g.N * g.Hs * g.Ws * g.Ca;
         hipLaunchKernelGGL(k_gather_big2small, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, D, bias,
                            small, ld_small, g, act);
+        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+    }
+    if (g.Cb <= 3 && algo != PG_ALGO_BF16 && !force_generic() && tapk_enabled()) {
+        // K = 16*Cb <= 48: one-shot kernel (with 4 channels the pipelined generic kernel is as fast: 46 TFLOP/s both)
+        const int vec4 = (g.Cb == 4) && (ld_big % 4 == 0) && aligned16(big);
+        dim3 grid((unsigned)(((long)g.N * g.Hs * g.Ws + 127) / 128), (g.Ca + 63) / 64, 1);
+        TimedLaunch timed(st);
+        switch (g.Cb) {
+            case 1: hipLaunchKernelGGL(k_b2s_tapk<1>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4); break;
+            case 2: hipLaunchKernelGGL(k_b2s_tapk<2>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4); break;
+            case 3: hipLaunchKernelGGL(k_b2s_tapk<3>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4); break;
+            default: hipLaunchKernelGGL(k_b2s_tapk<4>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4); break;
+        }
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     Plan p = plan_b2s(gg);

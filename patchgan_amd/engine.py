@@ -212,6 +212,9 @@ class ConvOp:
             if mode == 6:
                 self._desc[opcode] = ('k_wino_wgrad_gemm<2,2,2,2>', s.value)
                 return self._desc[opcode]
+            if mode == 8:
+                self._desc[opcode] = (f'k_b2s_tapk<{tid}>', 1)
+                return self._desc[opcode]
             if mode == 7:
                 self._desc[opcode] = ('k_wino_bgemm<2,2,2,2>' if tid == 0 else 'k_wino_bgemm<1,2,2,2>', 1)
                 return self._desc[opcode]
