@@ -2559,8 +2559,9 @@ inline bool wino2_s2b_ok(const Geom& g) {
     }();
     if (g.s != 2 || mode == 0 || !wino_enabled() || !pg_wino2c_geom_ok(g.N, g.Hb, g.Wb, g.Ca, g.Cb)) return false;
     if (mode == 1) return true;
-    // measured: 256->128 ch -13 %, 512->256 -18 %, 1024->256 -16 %, 512->128 -22 %; 64 output channels or fewer: slower
-    return pg_wino2_tiles_s2b(g.N, g.Hb, g.Wb) >= 512 && g.Cb >= 128 && g.Ca >= 256;
+    // measured on the cfg2 layers (F(3x3,2x2), shared windows): 128->64 ch -16..-18 %, 256->128 -23..-27 %, 512->256 -22 %,
+    // 1024->256 -28 %, 512->128 -38 %, 256->64 -27 %; 8x8 maps and smaller: no gain (weight transform dominates)
+    return pg_wino2_tiles_s2b(g.N, g.Hb, g.Wb) >= 512 && g.Cb >= 64 && g.Ca >= 128;
 }
 inline bool wino2_wgrad_ok(const Geom& g) {
     static const int mode = [] {
@@ -2671,10 +2672,10 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         return PG_OK;
     }
     if (algo == PG_ALGO_AUTO && op == 1 && wino2_s2b_ok(gq) && ws_bytes >= pg_wino2c_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb)) {
-        const long T = pg_wino2_tiles_s2b(g->N, g->Hb, g->Wb), X = 4L * (pg_wino2_mo() + 1) * (pg_wino2_mo() + 1);
+        const long T = pg_wino2_tiles_s2b(g->N, g->Hb, g->Wb), X = (long)(pg_wino2_mo() + 1) * (pg_wino2_mo() + 1);
         if (tile_id) *tile_id = T >= 1024 ? 70 : 71;
         if (split) *split = 1;
-        if (workgroups) *workgroups = X * ((T + (T >= 1024 ? 127 : 63)) / (T >= 1024 ? 128 : 64)) * ((g->Cb + 127) / 128);
+        if (workgroups) *workgroups = X * ((T + (T >= 1024 ? 127 : 63)) / (T >= 1024 ? 128 : 64)) * ((4 * g->Cb + 127) / 128);
         return PG_OK;
     }
     // 61: polyphase F(2x2, 3x3) weight gradient of a stride-2 layer (k_wino_wgrad_gemm<2,2,2,2>)

@@ -36,7 +36,7 @@ size_t pg_wino2_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
 int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 
-// small -> big, four parity classes: U (4X*Cb*Ca) | V (4X*tiles*Ca) | M (4X*tiles*Cb) in ws
+// small -> big, four parity classes as column blocks: U (X*4Cb*Ca) | V (X*tiles*Ca) | M (X*tiles*4Cb) in ws
 bool pg_wino2c_geom_ok(int N, int Hb, int Wb, int Ca, int Cb);
 size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb);
 int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N, int Hb,

@@ -462,10 +462,12 @@ __global__ void k_wino_wgrad_out(const float* __restrict__ S, int slices, float*
 // small -> big (ConvTranspose2d forward, Conv2d data gradient): each output parity class (r, s) of `big` is a 2x2-kernel
 // stride-1 correlation of `small`:
 //   big[2i+r][2j+s] = sum_{t,t' in {0,1}} small[i+r-1+t][j+s-1+t'] * w[kh(r,t)][kw(s,t')],  kh(0,t) = 3-2t, kh(1,t) = 2-2t
-// the classes see windows shifted by one pixel, so each has its own transformed input; batches z = xi*4 + class:
-//   k_wino2c_u   U[z][b][a] = (G g_class G^T)[xi]          k_wino2c_v   V[z][tile][a] = (B^T d_class B)[xi]
-//   k_wino_bgemm M[z][tile][b] = sum_a V[z][tile][a] U[z][b][a]
-//   k_wino2c_out big[2(MO*ti+al)+r][2(MO*tj+be)+s][b] = act(bias + sum_xi AT[al][xi_i] AT[be][xi_j] M[xi*4+class][tile][b])
+// class r needs the window small[i+r-1 .. ]: with windows starting at MO*t - 1 all four classes share ONE transformed
+// input per tile -- class r then produces the outputs i = MO*t - r + al, i.e. the classes' output tiles are staggered by
+// one pixel instead of their windows -- and the four classes are the column blocks of one GEMM with N = 4*Cb:
+//   k_wino2c_u   U[xi][cls*Cb + b][a] = (G g_class G^T)[xi]        k_wino2c_v   V[xi][tile][a] = (B^T d B)[xi]
+//   k_wino_bgemm M[xi][tile][cls*Cb + b] = sum_a V[xi][tile][a] U[xi][cls*Cb + b][a]
+//   k_wino2c_out big[2(MO*ti-r+al)+r][2(MO*tj-s+be)+s][b] = act(bias + sum_xi AT[al][xi_i] AT[be][xi_j] M[xi][tile][cls*Cb+b])
 // Pays where the channel counts are large against the tile count (the transformed tensors make a round trip through HBM).
 __device__ __constant__ float c_BT3[4][4] = {{-1, 0, 1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, -1, 0, 1}};
 __device__ __constant__ float c_G3[4][2] = {{-1.f, 0.f}, {0.5f, 0.5f}, {0.5f, -0.5f}, {0.f, 1.f}};
@@ -682,7 +684,7 @@ __device__ __forceinline__ void wino2_out_tile(const float* __restrict__ M, long
 #pragma unroll
         for (int l = 0; l < MO; ++l) {
             const int y = oy + st * k, x = ox + st * l;
-            if (y >= H || x >= W) continue;
+            if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) continue;
             f32x4 v = bv;
 #pragma unroll
             for (int j = 0; j < NP; ++j) v += t[k][j] * w_at<MO>(l, j);
@@ -746,16 +748,13 @@ __global__ __launch_bounds__(256) void k_wino2c_v(const float* __restrict__ smal
     const int cq = Ca >> 2;
     const long T = (long)N * TH * TW;
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (idx >= T * 4 * cq) return;
+    if (idx >= T * cq) return;
     const int c0 = (int)(idx % cq) << 2;
-    long rr = idx / cq;
-    const int cls = (int)(rr & 3);
-    const long tile = rr >> 2;
+    const long tile = idx / cq;
     const int n = (int)(tile / (TH * TW));
     const int rem = (int)(tile - (long)n * TH * TW);
     const int ti = rem / TW, tj = rem - ti * TW;
-    wino2_v_tile<MO>(small, ld, n, Hs, Ws, MO * ti + (cls >> 1) - 1, MO * tj + (cls & 1) - 1, 1, c0, V, 4L * T * Ca,
-                     ((long)cls * T + tile) * Ca + c0);
+    wino2_v_tile<MO>(small, ld, n, Hs, Ws, MO * ti - 1, MO * tj - 1, 1, c0, V, T * Ca, tile * Ca + c0);
 }
 
 template <int MO>
@@ -770,11 +769,13 @@ __global__ __launch_bounds__(256) void k_wino2c_out(const float* __restrict__ M,
     long rr = idx / cq;
     const int cls = (int)(rr & 3);
     const long tile = rr >> 2;
+    const int r = cls >> 1, sc = cls & 1;
     const int n = (int)(tile / (TH * TW));
     const int rem = (int)(tile - (long)n * TH * TW);
     const int ti = rem / TW, tj = rem - ti * TW;
-    wino2_out_tile<MO>(M, 4L * T * Cb, ((long)cls * T + tile) * Cb + c0, bias, out, ld_out, n, Hb, Wb, 2 * MO * ti + (cls >> 1),
-                       2 * MO * tj + (cls & 1), 2, c0, act);
+    // class plane index i = MO*ti - r + al  ->  big row 2*i + r = 2*MO*ti - r + 2*al
+    wino2_out_tile<MO>(M, 4L * T * Cb, tile * 4L * Cb + cls * Cb + c0, bias, out, ld_out, n, Hb, Wb, 2 * MO * ti - r,
+                       2 * MO * tj - sc, 2, c0, act);
 }
 
 // Weight gradient of the stride-2 layers, polyphase F(2x2, 3x3): per phase (r, s) the taps (2u+r, 2v+s), u, v in {0,1}, are
@@ -986,7 +987,7 @@ static long wino2_tiles(int N, int H, int W) {
 static long wino2_nxi() { return (long)(pg_wino2_mo() + 1) * (pg_wino2_mo() + 1); }
 
 long pg_wino2_tiles_b2s(int N, int Hs, int Ws) { return wino2_tiles(N, Hs, Ws); }
-long pg_wino2_tiles_s2b(int N, int Hb, int Wb) { return wino2_tiles(N, (Hb + 1) / 2, (Wb + 1) / 2); }
+long pg_wino2_tiles_s2b(int N, int Hb, int Wb) { return wino2_tiles(N, (Hb + 1) / 2 + 1, (Wb + 1) / 2 + 1); }
 
 bool pg_wino2_geom_ok(int N, int Hs, int Ws, int Ca, int Cb) {
     if (Cb % 8 != 0 || Ca % 4 != 0 || Cb < 32 || Ca < 64) return false;
@@ -1040,40 +1041,40 @@ int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias
 
 bool pg_wino2c_geom_ok(int N, int Hb, int Wb, int Ca, int Cb) {
     if (Ca % 32 != 0 || Cb % 4 != 0 || Ca < 64 || Cb < 32) return false;
-    const long T = pg_wino2_tiles_s2b(N, Hb, Wb), X = 4 * wino2_nxi();
+    const long T = pg_wino2_tiles_s2b(N, Hb, Wb), X = wino2_nxi();
     if (T < 64) return false;
-    if ((double)X * T * Ca * 4 >= 1.5e9 || (double)X * Ca * Cb * 4 >= 1.5e9 || (double)X * T * Cb * 4 >= 1.5e9) return false;
+    if ((double)X * T * Ca * 4 >= 1.5e9 || (double)X * Ca * 4 * Cb * 4 >= 1.5e9 || (double)X * T * 4 * Cb * 4 >= 1.5e9) return false;
     return true;
 }
 
 size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb) {
-    const long T = pg_wino2_tiles_s2b(N, Hb, Wb), X = 4 * wino2_nxi();
-    return align256((size_t)X * Ca * Cb * 4) + align256((size_t)X * T * Ca * 4) + align256((size_t)X * T * Cb * 4);
+    const long T = pg_wino2_tiles_s2b(N, Hb, Wb), X = wino2_nxi();
+    return align256((size_t)X * Ca * 4 * Cb * 4) + align256((size_t)X * T * Ca * 4) + align256((size_t)X * T * 4 * Cb * 4);
 }
 
 template <int MO>
 static int wino2_s2b_run(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N,
                          int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0,
                          hipEvent_t ev1) {
-    constexpr int X = 4 * (MO + 1) * (MO + 1);
-    const int TH = ((Hb + 1) / 2 + MO - 1) / MO, TW = ((Wb + 1) / 2 + MO - 1) / MO;
+    constexpr int X = (MO + 1) * (MO + 1);
+    const int TH = ((Hb + 1) / 2 + 1 + MO - 1) / MO, TW = ((Wb + 1) / 2 + 1 + MO - 1) / MO, NC = 4 * Cb;
     const long T = (long)N * TH * TW;
     float* U = (float*)ws;
-    float* V = (float*)((char*)U + align256((size_t)X * Ca * Cb * 4));
+    float* V = (float*)((char*)U + align256((size_t)X * Ca * NC * 4));
     float* M = (float*)((char*)V + align256((size_t)X * T * Ca * 4));
     hipLaunchKernelGGL(k_wino2c_u<MO>, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, P, U, Ca, Cb);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
-    hipLaunchKernelGGL(k_wino2c_v<MO>, dim3((unsigned)((T * Ca + 255) / 256)), dim3(256), 0, st, small, ld_small, V, N, Hs, Ws, Ca,
-                       TH, TW);
+    hipLaunchKernelGGL(k_wino2c_v<MO>, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, small, ld_small, V, N, Hs, Ws,
+                       Ca, TH, TW);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     if (ev0) (void)hipEventRecord(ev0, st);
-    const int a_bytes = (int)((long)X * T * Ca * 4), b_bytes = (int)((long)X * Cb * Ca * 4);
+    const int a_bytes = (int)((long)X * T * Ca * 4), b_bytes = (int)((long)X * NC * Ca * 4);
     if (T >= 1024)
-        hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (Cb + 127) / 128, X), dim3(256), 0, st, V, U,
-                           M, (int)T, Cb, Ca, a_bytes, b_bytes);
+        hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (NC + 127) / 128, X), dim3(256), 0, st, V, U,
+                           M, (int)T, NC, Ca, a_bytes, b_bytes);
     else
-        hipLaunchKernelGGL((k_wino_bgemm<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (Cb + 127) / 128, X), dim3(256), 0, st, V, U,
-                           M, (int)T, Cb, Ca, a_bytes, b_bytes);
+        hipLaunchKernelGGL((k_wino_bgemm<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (NC + 127) / 128, X), dim3(256), 0, st, V, U,
+                           M, (int)T, NC, Ca, a_bytes, b_bytes);
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     hipLaunchKernelGGL(k_wino2c_out<MO>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, M, bias, big, ld_big, N, Hb, Wb,

@@ -198,7 +198,7 @@ class ConvOp:
             mo = 4 if os.environ.get('PATCHGAN_WINO2_TILE', '') == '4' else 3
             if opcode == 0:
                 return 2.0 * (mo + 1) ** 2 * self.N * cd(self.Hs, mo) * cd(self.Ws, mo) * 4 * self.Cb * self.Ca
-            return 2.0 * 4 * (mo + 1) ** 2 * self.N * cd(cd(self.Hb, 2), mo) * cd(cd(self.Wb, 2), mo) * self.Ca * self.Cb
+            return 2.0 * 4 * (mo + 1) ** 2 * self.N * cd(cd(self.Hb, 2) + 1, mo) * cd(cd(self.Wb, 2) + 1, mo) * self.Ca * self.Cb
         return self.flops
 
     def describe(self, opcode):

@@ -168,8 +168,10 @@ WINO2_GEOMS = [(4, 32, 32, 128, 64, 2), (2, 64, 64, 64, 32, 2), (3, 36, 44, 96, 
 
 @pytest.mark.parametrize('geom', WINO2_GEOMS, ids=lambda g: 'x'.join(map(str, g)))
 def test_winograd_stride2_big2small(geom, monkeypatch):
+    import os
     from patchgan_amd import engine as E
     from tests.gpu_util import to_view, empty_view, pack, rel_err
+    tol = 5e-5 if os.environ.get('PATCHGAN_WINO2_TILE') == '4' else 2e-5     # F(4x4,2x2) (opt-in) is 4x less accurate
     N, Hb, Wb, Ca, Cb, s = geom
     big, small, Wt, Hs, Ws = _mk(*geom)
     auto, mfma = E.ConvOp(*geom, 0), E.ConvOp(*geom, 2)
@@ -184,7 +186,7 @@ def test_winograd_stride2_big2small(geom, monkeypatch):
         op.big2small(to_view(big, ld=Cb + 4, off=0), P, 0, bias.cuda(), 0, vs, ACTS['leakyrelu'])
         outs.append(vs.to_nchw())
     torch.cuda.synchronize()
-    assert rel_err(outs[0], want) < 2e-5 and rel_err(outs[1], want) < 2e-5, (rel_err(outs[0], want), rel_err(outs[1], want))
+    assert rel_err(outs[0], want) < tol and rel_err(outs[1], want) < 2e-5, (rel_err(outs[0], want), rel_err(outs[1], want))
     # transposed direction (four parity classes)
     bias_b = torch.randn(Cb)
     want = O.apply_act(F.conv_transpose2d(small, Wt, bias_b, stride=2, padding=1,
@@ -195,7 +197,7 @@ def test_winograd_stride2_big2small(geom, monkeypatch):
         op.small2big(to_view(small, ld=Ca + 4, off=4), P, 0, bias_b.cuda(), 0, vb, ACTS['tanh'])
         outs.append(vb.to_nchw())
     torch.cuda.synchronize()
-    assert rel_err(outs[0], want) < 2e-5 and rel_err(outs[1], want) < 2e-5, (rel_err(outs[0], want), rel_err(outs[1], want))
+    assert rel_err(outs[0], want) < tol and rel_err(outs[1], want) < 2e-5, (rel_err(outs[0], want), rel_err(outs[1], want))
 
 
 @pytest.mark.parametrize('geom', [(6, 62, 58, 256, 128, 2), (16, 32, 32, 288, 160, 2), (5, 64, 64, 64, 32, 2), (3, 70, 74, 96, 36, 2),
