@@ -657,6 +657,117 @@ __global__ __launch_bounds__(256) void k_wino_bgemm(const float* __restrict__ A,
         }
 }
 
+// Multi-batch variant: a workgroup owns one (m, n) tile position and runs `zb` consecutive batches z through ONE flattened (z, chunk) loop: the
+// loads of the next batch's first chunk are in flight during the last MFMAs of the current one and the tile stores are
+// fire-and-forget, so the short K loops of these layers (4..32 chunks) do not pay a prologue and an epilogue each.
+template <int MR, int NR, int WM, int WN>
+__global__ __launch_bounds__(256) void k_wino_bgemm_mz(const float* __restrict__ A, const float* __restrict__ B,
+                                                       float* __restrict__ C, int Mrows, int Ncols, int K, int zb, int a_bytes,
+                                                    int b_bytes) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32, AI = BM / 32, BI = BN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    float* As = smem;
+    float* Bs = smem + BM * LDK;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z0 = blockIdx.z * zb;
+    const int nch = K / KC, total = zb * nch;
+    const int kq = tid & 7, r0 = tid >> 3;
+    int a_off[AI], b_off[BI];
+    bool a_ok[AI], b_ok[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        a_ok[i] = m < Mrows;
+        a_off[i] = (z0 * Mrows + min(m, Mrows - 1)) * K + kq * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        b_ok[i] = n < Ncols;
+        b_off[i] = (z0 * Ncols + min(n, Ncols - 1)) * K + kq * 4;
+    }
+    const int a_zs = Mrows * K, b_zs = Ncols * K;       // elements per batch
+    f32x4 ra[AI], rb[BI];
+    int ld_z = 0, ld_c = 0;                             // (batch, chunk) of the NEXT load
+    auto issue_loads = [&](bool on) {
+        const int ao = ld_z * a_zs + ld_c * KC, bo = ld_z * b_zs + ld_c * KC;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) ra[i] = bload4(rA, voff(a_off[i] + ao, on && a_ok[i]));
+#pragma unroll
+        for (int i = 0; i < BI; ++i) rb[i] = bload4(rB, voff(b_off[i] + bo, on && b_ok[i]));
+        const bool wrap = ld_c + 1 >= nch;
+        ld_c = wrap ? 0 : ld_c + 1;
+        ld_z = wrap ? ld_z + 1 : ld_z;
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDK + kq * 4]) = rb[i];
+    };
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    issue_loads(true);
+    store_chunk();
+    __syncthreads();
+    int z = 0, c = 0;
+    for (int it = 0; it < total; ++it) {
+        const bool more = it + 1 < total;
+        issue_loads(more);
+        __builtin_amdgcn_sched_barrier(0x386);
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            f32x4 af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MR + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NR + j) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (c == nch - 1) {      // batch z0 + z is complete: store its tile, start the next from zero
+            float* o = C + (long)(z0 + z) * Mrows * Ncols;
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int col = n0 + (wn * NR + j) * 32 + lrow;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int m = m0 + (wm * MR + i) * 32 + row;
+                        if (m < Mrows && col < Ncols) o[(long)m * Ncols + col] = acc[i][j][r];
+                        acc[i][j][r] = 0.f;
+                    }
+                }
+        }
+        const bool wrap = c + 1 >= nch;
+        c = wrap ? 0 : c + 1;
+        z = wrap ? z + 1 : z;
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+}
+
 // shared output transform: M values at M[xi*zstride + mbase], outputs at (oy + st*k, ox + st*l) of an H x W image
 template <int MO>
 __device__ __forceinline__ void wino2_out_tile(const float* __restrict__ M, long zstride, long mbase, const float* __restrict__ bias,
@@ -972,6 +1083,19 @@ int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
 
+// batches per workgroup of k_wino_bgemm_mz (1 -> the single-batch kernel; PATCHGAN_BGEMM_MZ=0 forces that): the largest divisor of X that still leaves >= 768 workgroups (3 per CU)
+static int bgemm_zb(long tiles_mn, int X) {
+    static const bool off = [] {
+        const char* e = getenv("PATCHGAN_BGEMM_MZ");
+        return e && e[0] == '0';
+    }();
+    if (off) return 1;
+    int zb = 1;
+    for (int d = 2; d <= X; ++d)
+        if (X % d == 0 && tiles_mn * (X / d) >= 768) zb = d;
+    return zb;
+}
+
 // ---- stride-2 layers (polyphase / parity classes) ----
 int pg_wino2_mo() {     // output tile edge: 3 (default) or 4 (PATCHGAN_WINO2_TILE=4)
     static const int mo = [] {
@@ -1019,12 +1143,23 @@ static int wino2_b2s_run(const float* big, int ld_big, const float* P, const flo
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     if (ev0) (void)hipEventRecord(ev0, st);
     const int a_bytes = (int)((long)X * T * K * 4), b_bytes = (int)((long)X * Ca * K * 4);
-    if (T >= 1024)
-        hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (Ca + 127) / 128, X), dim3(256), 0, st, V, U,
-                           M, (int)T, Ca, K, a_bytes, b_bytes);
-    else
-        hipLaunchKernelGGL((k_wino_bgemm<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (Ca + 127) / 128, X), dim3(256), 0, st, V, U,
-                           M, (int)T, Ca, K, a_bytes, b_bytes);
+    if (T >= 1024) {
+        const int zb = bgemm_zb(((T + 127) / 128) * ((Ca + 127) / 128), X);
+        if (zb > 1)
+            hipLaunchKernelGGL((k_wino_bgemm_mz<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (Ca + 127) / 128, X / zb), dim3(256),
+                               0, st, V, U, M, (int)T, Ca, K, zb, a_bytes, b_bytes);
+        else
+            hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (Ca + 127) / 128, X), dim3(256), 0, st,
+                               V, U, M, (int)T, Ca, K, a_bytes, b_bytes);
+    } else {
+        const int zb = bgemm_zb(((T + 63) / 64) * ((Ca + 127) / 128), X);
+        if (zb > 1)
+            hipLaunchKernelGGL((k_wino_bgemm_mz<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (Ca + 127) / 128, X / zb), dim3(256), 0,
+                               st, V, U, M, (int)T, Ca, K, zb, a_bytes, b_bytes);
+        else
+            hipLaunchKernelGGL((k_wino_bgemm<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (Ca + 127) / 128, X), dim3(256), 0, st, V,
+                               U, M, (int)T, Ca, K, a_bytes, b_bytes);
+    }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     hipLaunchKernelGGL(k_wino2_out<MO>, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, M, bias, small, ld_small, N,
@@ -1069,12 +1204,23 @@ static int wino2_s2b_run(const float* small, int ld_small, const float* P, const
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     if (ev0) (void)hipEventRecord(ev0, st);
     const int a_bytes = (int)((long)X * T * Ca * 4), b_bytes = (int)((long)X * NC * Ca * 4);
-    if (T >= 1024)
-        hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (NC + 127) / 128, X), dim3(256), 0, st, V, U,
-                           M, (int)T, NC, Ca, a_bytes, b_bytes);
-    else
-        hipLaunchKernelGGL((k_wino_bgemm<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (NC + 127) / 128, X), dim3(256), 0, st, V, U,
-                           M, (int)T, NC, Ca, a_bytes, b_bytes);
+    if (T >= 1024) {
+        const int zb = bgemm_zb(((T + 127) / 128) * ((NC + 127) / 128), X);
+        if (zb > 1)
+            hipLaunchKernelGGL((k_wino_bgemm_mz<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (NC + 127) / 128, X / zb), dim3(256),
+                               0, st, V, U, M, (int)T, NC, Ca, zb, a_bytes, b_bytes);
+        else
+            hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (NC + 127) / 128, X), dim3(256), 0, st,
+                               V, U, M, (int)T, NC, Ca, a_bytes, b_bytes);
+    } else {
+        const int zb = bgemm_zb(((T + 63) / 64) * ((NC + 127) / 128), X);
+        if (zb > 1)
+            hipLaunchKernelGGL((k_wino_bgemm_mz<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (NC + 127) / 128, X / zb), dim3(256), 0,
+                               st, V, U, M, (int)T, NC, Ca, zb, a_bytes, b_bytes);
+        else
+            hipLaunchKernelGGL((k_wino_bgemm<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (NC + 127) / 128, X), dim3(256), 0, st, V,
+                               U, M, (int)T, NC, Ca, a_bytes, b_bytes);
+    }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     hipLaunchKernelGGL(k_wino2c_out<MO>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, M, bias, big, ld_big, N, Hb, Wb,
