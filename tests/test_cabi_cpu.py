@@ -43,6 +43,35 @@ def test_workspace_query_and_arg_validation():
     assert lib.pg_instnorm_act_fwd(None, 4, None, 4, None, 1, 4, 4, 0, 1e-5, 0.0, 0, None, 0, None) == -1
 
 
+def test_kernel_plan_of_the_benchmark_layers():
+    """pg_conv_describe is host-only: which kernel family PG_ALGO_AUTO / PG_ALGO_MFMA pick for the cfg2 layer shapes
+    (bs 16), and that the workspace query covers the Winograd paths."""
+    import ctypes
+    from patchgan_amd import engine as E, _lib
+    if os.environ.get('PATCHGAN_WINO2') or os.environ.get('PATCHGAN_NO_WINOGRAD'):
+        pytest.skip('kernel-selection switches set in the environment')
+    want = {   # (N, Hb, Wb, Ca, Cb, stride): (big2small, small2big, wgrad) kernel families under PG_ALGO_AUTO
+        (16, 256, 256, 64, 3, 2): ('k_b2s_tapk', 'k_b2s_fast<2,1,2,2,true>+k_col2im', 'k_wgrad_tapn'),     # enc0
+        (16, 128, 128, 128, 64, 2): ('k_b2s_fast', 'k_wino_bgemm', 'k_wgrad_fast'),                          # enc1
+        (16, 64, 64, 256, 128, 2): ('k_wino_bgemm', 'k_wino_bgemm', 'k_wgrad_fast'),                          # enc2
+        (16, 16, 16, 512, 512, 2): ('k_b2s_fast', 'k_s2b_fast', 'k_wgrad_fast'),                              # enc4: too few tiles
+        (16, 64, 64, 512, 128, 2): ('k_wino_bgemm', 'k_wino_bgemm', 'k_wino_wgrad_gemm'),                     # dec4
+        (32, 32, 32, 512, 256, 1): ('k_wino_gemm', 'k_wino_gemm', 'k_wino_wgrad_gemm'),                       # d3 at 2N
+        (32, 31, 31, 1, 512, 1): ('k_b2s_fast<1,1,4,1,true>+k_gather', 'k_small2big', 'k_wgrad_tapn'),        # D head
+    }
+    for geom, fams in want.items():
+        auto, mfma = E.ConvOp(*geom, _lib.ALGO_AUTO), E.ConvOp(*geom, _lib.ALGO_MFMA)
+        for oc, fam in enumerate(fams):
+            sym = auto.describe(oc)[0]
+            assert sym.startswith(fam), (geom, oc, sym)
+            assert 'wino' not in mfma.describe(oc)[0], (geom, oc)
+            assert auto.kernel_flops(oc) <= auto.flops * 1.3       # Winograd executes fewer (ragged tiles may add a little)
+            if 'wino' in sym:
+                assert auto.kernel_flops(oc) < 0.6 * auto.flops
+        g = _lib.ConvGeom(geom[0], geom[1], geom[2], auto.Hs, auto.Ws, geom[3], geom[4], geom[5])
+        assert auto.ws_bytes == max(_lib.load().pg_conv_workspace_bytes(ctypes.byref(g), oc) for oc in range(3))
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from patchgan_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)
