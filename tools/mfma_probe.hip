@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, bytes, 0x00020000);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int lrow = lane & 31, lh = lane >> 5, kq = tid & 7, r0 = tid >> 3;
-    const int m0 = (blockIdx.x % 64) * 128;
+    const int m0 = (blockIdx.x % (bytes / (K * 512))) * 128;     // rows = bytes / (4*K): each workgroup its own rows if there are enough
     int aoff[4], boff[4];
     for (int i = 0; i < 4; ++i) {
         aoff[i] = ((m0 + r0 + 32 * i) * K + kq * 4) * 4;
@@ -95,6 +95,89 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     out[blockIdx.x * 256 + tid] = s;
 }
 
+// mode 4: the full loop with a TWO-chunk-deep register prefetch (two staging register sets, loop unrolled by two): the loads
+// of chunk c+2 are issued before the MFMAs of chunk c, the set holding chunk c+1 is written to LDS after the barrier
+template <int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_probe2(const float* A, const float* B,
+                                                                                               float* out, int K, int nch,
+                                                                                               int bytes) {
+    __shared__ __attribute__((aligned(16))) float smem[256 * LDK];
+    float* As = smem;
+    float* Bs = smem + 128 * LDK;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lh = lane >> 5, kq = tid & 7, r0 = tid >> 3;
+    const int m0 = (blockIdx.x % (bytes / (K * 512))) * 128;
+    int aoff[4], boff[4];
+    for (int i = 0; i < 4; ++i) {
+        aoff[i] = ((m0 + r0 + 32 * i) * K + kq * 4) * 4;
+        boff[i] = ((r0 + 32 * i) * K + kq * 4) * 4;
+    }
+    f32x4 ra[2][4], rb[2][4];
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = K / KC;
+    auto loads = [&](int s, int c) {
+        const int ko = (c % nk) * KC * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[s][i] = bload4(rA, aoff[i] + ko);
+            rb[s][i] = bload4(rB, boff[i] + ko);
+        }
+    };
+    auto stores = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[s][i];
+            *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDK + kq * 4]) = rb[s][i];
+        }
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            f32x4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * 2 + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+                bf[i] = *reinterpret_cast<const f32x4*>(&Bs[((wn * 2 + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+    loads(0, 0);
+    stores(0);
+    loads(1, 1);          // chunk 1 in flight
+    __syncthreads();
+    for (int c = 0; c < nch; c += 2) {
+        loads(0, c + 2);  // chunk c+2 -> set 0
+        __builtin_amdgcn_sched_barrier(0x386);
+        mfmas();          // chunk c from LDS
+        __syncthreads();
+        stores(1);        // chunk c+1 (set 1): waits only for its own loads
+        __syncthreads();
+        loads(1, c + 3);  // chunk c+3 -> set 1
+        __builtin_amdgcn_sched_barrier(0x386);
+        mfmas();          // chunk c+1
+        __syncthreads();
+        stores(0);        // chunk c+2
+        __syncthreads();
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
 template <int MODE, int WPE>
 void run(const char* name, const float* A, const float* B, float* out, int K, int nch, int wgs, int bytes) {
     hipEvent_t e0, e1;
@@ -113,10 +196,31 @@ void run(const char* name, const float* A, const float* B, float* out, int K, in
     printf("%-34s waves/SIMD %d  wgs %5d  %8.1f us  %7.1f TFLOP/s\n", name, WPE, wgs, ms * 1e3, flop / ms / 1e9);
 }
 
+template <int WPE>
+void run2(const char* name, const float* A, const float* B, float* out, int K, int nch, int wgs, int bytes) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_probe2<WPE>), dim3(wgs), dim3(256), 0, 0, A, B, out, K, nch, bytes);
+    hipEventRecord(e0, 0);
+    const int reps = 5;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((k_probe2<WPE>), dim3(wgs), dim3(256), 0, 0, A, B, out, K, nch, bytes);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    const double flop = 2.0 * 128 * 128 * 32 * (double)nch * wgs;
+    printf("%-34s waves/SIMD %d  wgs %5d  %8.1f us  %7.1f TFLOP/s\n", name, WPE, wgs, ms * 1e3, flop / ms / 1e9);
+}
+
 int main(int argc, char** argv) {
     const int wgs = argc > 1 ? atoi(argv[1]) : 512, nch = argc > 2 ? atoi(argv[2]) : 512;
-    const int K = 1024, rows = 64 * 128;
+    // argv[4] = K (row length; default 1024), argv[5] = rows (default 64*128: 33 MB of A, L2 / Infinity-Cache resident;
+    // wgs*128 rows with K = 4096 stream ~1 GB from HBM per launch)
+    const int K = argc > 4 ? atoi(argv[4]) : 1024, rows = argc > 5 ? atoi(argv[5]) : 64 * 128;
     const size_t bytes = (size_t)rows * K * 4;
+    if (bytes >= (1ull << 31)) { printf("A too large for 32-bit offsets\n"); return 1; }
     float *A, *B, *out;
     hipMalloc(&A, bytes);
     hipMalloc(&B, bytes);
@@ -135,6 +239,8 @@ int main(int argc, char** argv) {
     run<1, 2>("1 no global loads", A, B, out, K, nch, wgs, (int)bytes);
     run<2, 2>("2 ds_read + mfma", A, B, out, K, nch, wgs, (int)bytes);
     run<3, 2>("3 mfma only", A, B, out, K, nch, wgs, (int)bytes);
+    run2<2>("4 full loop, 2-deep prefetch", A, B, out, K, nch, wgs, (int)bytes);
+    run2<3>("4 full loop, 2-deep prefetch", A, B, out, K, nch, wgs, (int)bytes);
     run<0, 1>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
     run<0, 3>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
     return 0;
