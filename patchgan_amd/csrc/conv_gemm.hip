@@ -2663,17 +2663,17 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         if (workgroups) *workgroups = (((long)g->N * g->Hs * g->Ws + 127) / 128) * ((g->Ca + 63) / 64);
         return PG_OK;
     }
-    // 70 / 71: polyphase Winograd of a stride-2 layer (k_wino_bgemm<2,2,2,2> / <1,2,2,2>)
+    // 70 / 71: polyphase Winograd of a stride-2 layer (k_wino_bgemm<2,2,2,2> / <1,2,2,2>); 72 / 73: k_wino_bgemm_mz
     if (algo == PG_ALGO_AUTO && op == 0 && wino2_b2s_ok(gq) && ws_bytes >= pg_wino2_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
         const long T = pg_wino2_tiles_b2s(g->N, g->Hs, g->Ws), X = (long)(pg_wino2_mo() + 1) * (pg_wino2_mo() + 1);
-        if (tile_id) *tile_id = T >= 1024 ? 70 : 71;
+        if (tile_id) *tile_id = (T >= 1024 ? 70 : 71) + (pg_wino2_b2s_zb(g->N, g->Hs, g->Ws, g->Ca) > 1 ? 2 : 0);
         if (split) *split = 1;
         if (workgroups) *workgroups = X * ((T + (T >= 1024 ? 127 : 63)) / (T >= 1024 ? 128 : 64)) * ((g->Ca + 127) / 128);
         return PG_OK;
     }
     if (algo == PG_ALGO_AUTO && op == 1 && wino2_s2b_ok(gq) && ws_bytes >= pg_wino2c_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb)) {
         const long T = pg_wino2_tiles_s2b(g->N, g->Hb, g->Wb), X = (long)(pg_wino2_mo() + 1) * (pg_wino2_mo() + 1);
-        if (tile_id) *tile_id = T >= 1024 ? 70 : 71;
+        if (tile_id) *tile_id = (T >= 1024 ? 70 : 71) + (pg_wino2_s2b_zb(g->N, g->Hb, g->Wb, g->Cb) > 1 ? 2 : 0);
         if (split) *split = 1;
         if (workgroups) *workgroups = X * ((T + (T >= 1024 ? 127 : 63)) / (T >= 1024 ? 128 : 64)) * ((4 * g->Cb + 127) / 128);
         return PG_OK;

@@ -31,6 +31,8 @@ int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big
 int pg_wino2_mo();
 long pg_wino2_tiles_b2s(int N, int Hs, int Ws);
 long pg_wino2_tiles_s2b(int N, int Hb, int Wb);
+int pg_wino2_b2s_zb(int N, int Hs, int Ws, int Ca);   // batches per workgroup (> 1: k_wino_bgemm_mz)
+int pg_wino2_s2b_zb(int N, int Hb, int Wb, int Cb);
 bool pg_wino2_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
 size_t pg_wino2_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
 int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N, int Hb,

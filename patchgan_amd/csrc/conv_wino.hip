@@ -1285,3 +1285,15 @@ int pg_wino2_wgrad(const float* small, int ld_small, const float* big, int ld_bi
     hipLaunchKernelGGL(k_wino2_wgrad_out, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, S, slices, dP, Ca, Cb);
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
+
+// batches per workgroup the two stride-2 paths would use (> 1: k_wino_bgemm_mz); for pg_conv_describe
+int pg_wino2_b2s_zb(int N, int Hs, int Ws, int Ca) {
+    const long T = wino2_tiles(N, Hs, Ws);
+    const long tm = (T >= 1024) ? (T + 127) / 128 : (T + 63) / 64;
+    return bgemm_zb(tm * ((Ca + 127) / 128), (int)wino2_nxi());
+}
+int pg_wino2_s2b_zb(int N, int Hb, int Wb, int Cb) {
+    const long T = pg_wino2_tiles_s2b(N, Hb, Wb);
+    const long tm = (T >= 1024) ? (T + 127) / 128 : (T + 63) / 64;
+    return bgemm_zb(tm * ((4 * Cb + 127) / 128), (int)wino2_nxi());
+}

@@ -216,7 +216,8 @@ class ConvOp:
                 self._desc[opcode] = (f'k_b2s_tapk<{tid}>', 1)
                 return self._desc[opcode]
             if mode == 7:
-                self._desc[opcode] = ('k_wino_bgemm<2,2,2,2>' if tid == 0 else 'k_wino_bgemm<1,2,2,2>', 1)
+                self._desc[opcode] = ({0: 'k_wino_bgemm<2,2,2,2>', 1: 'k_wino_bgemm<1,2,2,2>', 2: 'k_wino_bgemm_mz<2,2,2,2>',
+                                       3: 'k_wino_bgemm_mz<1,2,2,2>'}[tid], 1)
                 return self._desc[opcode]
             if mode in (4, 5):
                 name, s.value = ('k_wino_gemm<2,1,2,2>' if mode == 4 else 'k_wino_gemm<1,1,2,2>'), 1
