@@ -10,17 +10,21 @@ from oracle import patchgan_oracle as O
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+# optional: image size, output classes (> 1: softmax head + weighted BCE, BASELINE config 4), e.g. `... 5 4 512 4`
+SIZE = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+COUT = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+FINAL, LOSS = ('sigmoid', 'tversky') if COUT == 1 else ('softmax', 'weighted_bce')
 KEYS = ['gen', 'gen_loss', 'gdisc', 'discr', 'discf', 'disc']
 torch.set_num_threads(16)
 torch.manual_seed(1234)
-g = pg.UNet(3, 1, 64, use_dropout=False, activation='leakyrelu', final_act='sigmoid')
-d = pg.Discriminator(4, 64, n_layers=3)
+g = pg.UNet(3, COUT, 64, use_dropout=False, activation='leakyrelu', final_act=FINAL)
+d = pg.Discriminator(3 + COUT, 64, n_layers=3)
 gw = {k: v.clone() for k, v in g.state_dict().items()}
 dw = {k: v.clone() for k, v in d.state_dict().items()}
 gen = torch.Generator().manual_seed(7)
-x = torch.rand(B, 3, 256, 256, generator=gen)
-y = (torch.rand(B, 1, 256, 256, generator=gen) > 0.7).float()
-kw = dict(activation='leakyrelu', final_act='sigmoid', n_layers=3, norm=False, loss_type='tversky')
+x = torch.rand(B, 3, SIZE, SIZE, generator=gen)
+y = (torch.rand(B, COUT, SIZE, SIZE, generator=gen) > 0.7).float()
+kw = dict(activation='leakyrelu', final_act=FINAL, n_layers=3, norm=False, loss_type=LOSS)
 
 
 def run(tr, xx, yy):
@@ -39,6 +43,7 @@ print('fp32 oracle on the GPU (torch / MIOpen float)', flush=True)
 g32 = run(O.OracleTrainer({k: v.cuda() for k, v in gw.items()}, {k: v.cuda() for k, v in dw.items()}, **kw), x.cuda(), y.cuda())
 print('HIP path', flush=True)
 t = pg.Trainer(g.cuda(), d.cuda(), tempfile.mkdtemp())
+t.loss_type = LOSS
 t.setup_optimizers(1e-3, 1e-3)
 g.train(); d.train()
 hip = run(t, x, y)
