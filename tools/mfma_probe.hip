@@ -178,6 +178,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     out[blockIdx.x * 256 + tid] = s;
 }
 
+// mode 5: LDS-DMA staging (buffer_load_dwordx4 ... lds: no staging registers, no ds_write), two LDS stages of 32 KB, ONE raw
+// barrier per chunk; rows are 128 B linear with the 16-byte slot index XOR-swizzled by (row >> 1) & 7 on the SOURCE address
+// (the DMA destination is wave-uniform base + lane * 16), so ds_read_b128 fragments stay conflict-free without padding
+template <int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_probe5(const float* A, const float* B,
+                                                                                               float* out, int K, int nch,
+                                                                                               int bytes) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 256 * 32];
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int m0 = (blockIdx.x % (bytes / (K * 512))) * 128;
+    const int nk = K / KC;
+    // DMA pieces of this wave: 8 per stage, piece j covers 8 rows; waves 0,1 stage A, waves 2,3 stage B
+    const bool isA = wave < 2;
+    int voffs[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int R0 = ((wave & 1) * 8 + jj) * 8, row = R0 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((row >> 1) & 7);
+        voffs[jj] = ((isA ? m0 + row : row) * K) * 4 + slot * 16;
+    }
+    auto dma = [&](int stage, int c) {
+        const int ko = (c % nk) * KC * 4;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int R0 = ((wave & 1) * 8 + jj) * 8;
+            float* dst = smem + stage * (256 * 32) + (isA ? 0 : 128 * 32) + R0 * 32;
+            if (isA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, dst, 16, voffs[jj] + ko, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, dst, 16, voffs[jj] + ko, 0, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    dma(0, 0);
+    for (int c = 0; c < nch; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c + 1 < nch) dma((c + 1) & 1, c + 1);
+        const float* As = smem + (c & 1) * (256 * 32);
+        const float* Bs = As + 128 * 32;
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            f32x4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra_ = (wm * 2 + i) * 32 + lrow, rb_ = (wn * 2 + i) * 32 + lrow;
+                af[i] = *reinterpret_cast<const f32x4*>(&As[ra_ * 32 + (((kk * 2 + lh) ^ ((ra_ >> 1) & 7)) << 2)]);
+                bf[i] = *reinterpret_cast<const f32x4*>(&Bs[rb_ * 32 + (((kk * 2 + lh) ^ ((rb_ >> 1) & 7)) << 2)]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
 template <int MODE, int WPE>
 void run(const char* name, const float* A, const float* B, float* out, int K, int nch, int wgs, int bytes) {
     hipEvent_t e0, e1;
@@ -214,6 +285,24 @@ void run2(const char* name, const float* A, const float* B, float* out, int K, i
     printf("%-34s waves/SIMD %d  wgs %5d  %8.1f us  %7.1f TFLOP/s\n", name, WPE, wgs, ms * 1e3, flop / ms / 1e9);
 }
 
+template <int WPE>
+void run5(const char* name, const float* A, const float* B, float* out, int K, int nch, int wgs, int bytes) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_probe5<WPE>), dim3(wgs), dim3(256), 0, 0, A, B, out, K, nch, bytes);
+    hipEventRecord(e0, 0);
+    const int reps = 5;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((k_probe5<WPE>), dim3(wgs), dim3(256), 0, 0, A, B, out, K, nch, bytes);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    const double flop = 2.0 * 128 * 128 * 32 * (double)nch * wgs;
+    printf("%-34s waves/SIMD %d  wgs %5d  %8.1f us  %7.1f TFLOP/s\n", name, WPE, wgs, ms * 1e3, flop / ms / 1e9);
+}
+
 int main(int argc, char** argv) {
     const int wgs = argc > 1 ? atoi(argv[1]) : 512, nch = argc > 2 ? atoi(argv[2]) : 512;
     // argv[4] = K (row length; default 1024), argv[5] = rows (default 64*128: 33 MB of A, L2 / Infinity-Cache resident;
@@ -241,6 +330,7 @@ int main(int argc, char** argv) {
     run<3, 2>("3 mfma only", A, B, out, K, nch, wgs, (int)bytes);
     run2<2>("4 full loop, 2-deep prefetch", A, B, out, K, nch, wgs, (int)bytes);
     run2<3>("4 full loop, 2-deep prefetch", A, B, out, K, nch, wgs, (int)bytes);
+    run5<2>("5 LDS-DMA, 2 stages, 1 barrier", A, B, out, K, nch, wgs, (int)bytes);
     run<0, 1>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
     run<0, 3>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
     return 0;
