@@ -1235,7 +1235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 template <int MR, int NR, int WM, int WN, bool POW2>
-__global__ __launch_bounds__(256) void k_wgrad_fast(const float* __restrict__ small, int ld_small,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wgrad_fast(const float* __restrict__ small, int ld_small,
                                                     const float* __restrict__ big, int ld_big,
                                                     float* __restrict__ out, long slab_stride, Geom g,
                                                     int chunks_per_slice, int tilesB, int small_bytes, int big_bytes) {

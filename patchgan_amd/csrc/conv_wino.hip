@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_wino_dy(const float* __restrict__ dy, i
 
 // grid (tilesA * tilesB, 25, slices); both operands are K-major (K = tiles): rows of Ca resp. Cb floats
 template <int MR, int NR, int WM, int WN>
-__global__ __launch_bounds__(256) void k_wino_wgrad_gemm(const float* __restrict__ DY, const float* __restrict__ V,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wino_wgrad_gemm(const float* __restrict__ DY, const float* __restrict__ V,
                                                          float* __restrict__ S, int T, int Ca, int Cb, int chunks_per_slice,
                                                          int tilesB, int dy_bytes, int v_bytes) {
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void k_wino2_v(const float* __restrict__ big, 
 
 // NZ independent row GEMMs: C[z][m][n] = sum_k A[z][m][k] * B[z][n][k]; rows of A and B are K contiguous floats (K % 32 == 0)
 template <int MR, int NR, int WM, int WN>
-__global__ __launch_bounds__(256) void k_wino_bgemm(const float* __restrict__ A, const float* __restrict__ B,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wino_bgemm(const float* __restrict__ A, const float* __restrict__ B,
                                                     float* __restrict__ C, int Mrows, int Ncols, int K, int a_bytes,
                                                     int b_bytes) {
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32, AI = BM / 32, BI = BN / 32;

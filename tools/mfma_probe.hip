@@ -333,5 +333,6 @@ int main(int argc, char** argv) {
     run5<2>("5 LDS-DMA, 2 stages, 1 barrier", A, B, out, K, nch, wgs, (int)bytes);
     run<0, 1>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
     run<0, 3>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
+    run<0, 4>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
     return 0;
 }
