@@ -2646,7 +2646,7 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         if (workgroups) *workgroups = ((M1 + t.bm - 1) / t.bm) * ((Nc + t.bn - 1) / t.bn);
         return PG_OK;
     }
-    // +40 / +50: under PG_ALGO_AUTO this stride-1 layer runs Winograd F(2x2, 4x4) (k_wino_gemm<2,1,2,2> / <1,1,2,2>, no
+    // +40 / +50: under PG_ALGO_AUTO this stride-1 layer runs Winograd F(2x2, 4x4) (k_wino_gemm<2,1,2,2,2> / <1,1,2,2,4>, no
     // split-K); the tile / split
     // reported are those of the implicit-GEMM kernel the other algos use
     if (algo == PG_ALGO_AUTO &&

@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void k_wino_v(const float* __restrict__ in, in
 
 // 25 row GEMMs + fused output transform.  Workgroup = 4 waves (2 x 2), tile = 128 Winograd tiles x 64 output channels,
 // each wave 64 x 32 (two 32x32 MFMA tiles).  Requires Ci % 32 == 0.
-template <int MR, int NR, int WM, int WN>
-__global__ __launch_bounds__(256) void k_wino_gemm(const float* __restrict__ V, const float* __restrict__ U,
+template <int MR, int NR, int WM, int WN, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_gemm(const float* __restrict__ V, const float* __restrict__ U,
                                                    const float* __restrict__ bias, float* __restrict__ out, int ld_out,
                                                    int T, int Ci, int Co, int TH, int TW, int Hout, int Wout, int act,
                                                    int v_bytes, int u_bytes) {
@@ -1023,11 +1023,11 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
     const int v_bytes = (int)(25L * T * Cin * 4), u_bytes = (int)(25L * Cout * Cin * 4);
     if (small_tile) {
         dim3 grid((unsigned)((T + 63) / 64), (Cout + 63) / 64, 1);
-        hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
+        hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 4>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
                            TW, Hout, Wout, act, v_bytes, u_bytes);
     } else {
         dim3 grid((unsigned)((T + 127) / 128), (Cout + 63) / 64, 1);
-        hipLaunchKernelGGL((k_wino_gemm<2, 1, 2, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
+        hipLaunchKernelGGL((k_wino_gemm<2, 1, 2, 2, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
                            TW, Hout, Wout, act, v_bytes, u_bytes);
     }
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;

@@ -220,7 +220,7 @@ class ConvOp:
                                        3: 'k_wino_bgemm_mz<1,2,2,2>'}[tid], 1)
                 return self._desc[opcode]
             if mode in (4, 5):
-                name, s.value = ('k_wino_gemm<2,1,2,2>' if mode == 4 else 'k_wino_gemm<1,1,2,2>'), 1
+                name, s.value = ('k_wino_gemm<2,1,2,2,2>' if mode == 4 else 'k_wino_gemm<1,1,2,2,4>'), 1
             elif mode == 3:
                 name = 'k_b2s_fast' + tn[:-1] + ',true>+' + ('k_gather_big2small' if opcode == 0 else 'k_col2im_small2big')
             elif mode:
