@@ -2570,10 +2570,10 @@ inline bool wino2_wgrad_ok(const Geom& g) {
     }();
     if (g.s != 2 || mode == 0 || !wino_enabled() || !pg_wino2_wgrad_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) return false;
     if (mode == 1) return true;
-    // measured on the cfg2 layers: 1024x256 on 16x16 -13 %, 512x128 on 32x32 -22 %; everything with fewer small-side channels
-    // is slower than the implicit GEMM (many K slices of little work each, 6.25x transformed operands)
+    // measured on the cfg2 layers (64x64 output tiles unless 128x128 ones alone fill the chip): 256x128 ch -16 %, 512x256 -20 %,
+    // 512x128 -17 %, 256x64 -15 %, 1024x256 +-0; 128 small-side channels: slower than the implicit GEMM (+35 %)
     const long T = (long)g.N * ((g.Hs + 2) / 3) * ((g.Ws + 2) / 3);
-    return g.Ca >= 512 && g.Cb >= 128 && (g.Ca >= 1024 || T >= 1024);
+    return T >= 512 && g.Ca >= 256 && g.Cb >= 64;
 }
 inline bool wino_wgrad_ok(const Geom& g) {
     static const bool off = [] {
@@ -2678,11 +2678,11 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         if (workgroups) *workgroups = X * ((T + (T >= 1024 ? 127 : 63)) / (T >= 1024 ? 128 : 64)) * ((4 * g->Cb + 127) / 128);
         return PG_OK;
     }
-    // 61: polyphase F(2x2, 3x3) weight gradient of a stride-2 layer (k_wino_wgrad_gemm<2,2,2,2>)
+    // 61 / 62: polyphase F(2x2, 3x3) weight gradient of a stride-2 layer (k_wino_wgrad_gemm<2,2,2,2> / <1,1,2,2>)
     if (algo == PG_ALGO_AUTO && op == 2 && wino2_wgrad_ok(gq) &&
         ws_bytes >= reserved + pg_wino2_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
         const int sl = pg_wino2_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb);
-        if (tile_id) *tile_id = 61;
+        if (tile_id) *tile_id = pg_wino2_wgrad_tile64(gq.Ca, gq.Cb) ? 62 : 61;
         if (split) *split = sl;
         if (workgroups) *workgroups = 16L * ((g->Ca + 127) / 128) * ((4 * g->Cb + 127) / 128) * sl;
         return PG_OK;

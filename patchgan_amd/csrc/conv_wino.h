@@ -47,6 +47,7 @@ int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* 
 // weight gradient of the stride-2 layers, polyphase F(2x2, 3x3): V (16*tiles*4Cb) | DY (16*tiles*Ca) | S (slices*16*Ca*4Cb)
 bool pg_wino2_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
 int pg_wino2_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb);
+bool pg_wino2_wgrad_tile64(int Ca, int Cb);     // k_wino_wgrad_gemm<1,1,2,2> (64x64 output tiles) instead of <2,2,2,2>
 size_t pg_wino2_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
 int pg_wino2_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
                    int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);

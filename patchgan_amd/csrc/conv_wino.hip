@@ -1246,9 +1246,20 @@ bool pg_wino2_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb) {
     return true;
 }
 
+// 128x128 output tiles when they alone fill the chip, else 64x64 tiles (4x the workgroups) so that fewer, longer K slices do
+bool pg_wino2_wgrad_tile64(int Ca, int Cb) {
+    static const int forced = [] {
+        const char* e = getenv("PATCHGAN_WINO2W_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced) return forced == 64;
+    return 16L * ((Ca + 127) / 128) * ((4 * Cb + 127) / 128) < 768;
+}
+
 int pg_wino2_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb) {
     const long T = wino2w_tiles(N, Hs, Ws);
-    const long wgs = 16L * ((Ca + 127) / 128) * ((4 * Cb + 127) / 128);
+    const int t = pg_wino2_wgrad_tile64(Ca, Cb) ? 64 : 128;
+    const long wgs = 16L * ((Ca + t - 1) / t) * ((4 * Cb + t - 1) / t);
     long s = (768 + wgs - 1) / wgs;
     const long nchunks = (T + KC - 1) / KC;
     if (s > nchunks / 8) s = nchunks / 8;
@@ -1276,10 +1287,16 @@ int pg_wino2_wgrad(const float* small, int ld_small, const float* big, int ld_bi
     const int slices = pg_wino2_wgrad_slices(N, Hs, Ws, Ca, Cb);
     const int nchunks = (int)((T + KC - 1) / KC);
     const int cps = (nchunks + slices - 1) / slices;
-    const int tilesA = (Ca + 127) / 128, tilesB = (K + 127) / 128;
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB, 16, slices), dim3(256), 0, st, DY, V, S, (int)T, Ca, K,
-                       cps, tilesB, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
+    if (pg_wino2_wgrad_tile64(Ca, Cb)) {
+        const int tilesA = (Ca + 63) / 64, tilesB = (K + 63) / 64;
+        hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB, 16, slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                           K, cps, tilesB, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
+    } else {
+        const int tilesA = (Ca + 127) / 128, tilesB = (K + 127) / 128;
+        hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB, 16, slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                           K, cps, tilesB, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
+    }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     hipLaunchKernelGGL(k_wino2_wgrad_out, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, S, slices, dP, Ca, Cb);
