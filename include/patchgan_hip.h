@@ -79,7 +79,7 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);
  * (k_b2s_fast / k_s2b_fast / k_wgrad_fast) that runs when tensors are 16-byte aligned.  `op` may carry the algorithm as
  * op + 16 * PG_ALGO_*; for PG_ALGO_AUTO (op < 16) wide stride-1 layers report the Winograd kernels instead: + 40 / + 50 =
  * k_wino_gemm<2,1,2,2,2> / <1,1,2,2,4> (ops 0/1; tile / split of the implicit-GEMM plan otherwise unchanged), 60 =
- * k_wino_wgrad_gemm<2,2,2,2> with split = its K slices (op 2; 61 / 62: its polyphase stride-2 form with 128x128 / 64x64 tiles), 70 / 71 = k_wino_bgemm<2,2,2,2> / <1,2,2,2>, 72 / 73 = k_wino_bgemm_mz<...> (polyphase
+ * k_wino_wgrad_gemm<2,2,2,2> with split = its K slices (op 2; 63: 64x64 tiles <1,1,2,2>; 61 / 62: its polyphase stride-2 form with 128x128 / 64x64 tiles), 70 / 71 = k_wino_bgemm<2,2,2,2> / <1,2,2,2>, 72 / 73 = k_wino_bgemm_mz<...> (polyphase
  * Winograd of a stride-2 layer, ops 0/1).  For profiling only. */
 int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups);
 

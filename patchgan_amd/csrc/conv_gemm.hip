@@ -2687,11 +2687,13 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         if (workgroups) *workgroups = 16L * ((g->Ca + 127) / 128) * ((4 * g->Cb + 127) / 128) * sl;
         return PG_OK;
     }
-    // +60: Winograd F(4x4, 2x2) weight gradient (k_wino_wgrad_gemm<2,2,2,2>); split = its K slices
+    // 60 / 63: Winograd F(4x4, 2x2) weight gradient (k_wino_wgrad_gemm<2,2,2,2> / <1,1,2,2>); split = its K slices
     if (algo == PG_ALGO_AUTO && op == 2 && wino_wgrad_ok(gq) && ws_bytes >= reserved + pg_wino_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
-        if (tile_id) *tile_id = 60;
+        const bool t64 = pg_wino_wgrad_tile64(gq.Ca, gq.Cb);
+        const int tt = t64 ? 64 : 128;
+        if (tile_id) *tile_id = t64 ? 63 : 60;
         if (split) *split = pg_wino_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb);
-        if (workgroups) *workgroups = 25L * ((g->Ca + 127) / 128) * ((g->Cb + 127) / 128) * pg_wino_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb);
+        if (workgroups) *workgroups = 25L * ((g->Ca + tt - 1) / tt) * ((g->Cb + tt - 1) / tt) * pg_wino_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb);
         return PG_OK;
     }
     if (split) *split = p.split;

@@ -21,6 +21,7 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
 // weight gradient of the same layers, F(4x4, 2x2): V (25*tiles*Cb) | DY (25*tiles*Ca) | S (slices*25*Ca*Cb) in ws
 bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
 int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb);
+bool pg_wino_wgrad_tile64(int Ca, int Cb);      // k_wino_wgrad_gemm<1,1,2,2> instead of <2,2,2,2>
 size_t pg_wino_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
 // ev0 / ev1 (optional) are recorded around the GEMM kernel
 int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,

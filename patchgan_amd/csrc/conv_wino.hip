@@ -1042,9 +1042,19 @@ bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb) {
     return true;
 }
 
+// stride-1 weight gradient: 64x64 output tiles unless 128x128 ones alone give >= 768 workgroups (no K split then)
+bool pg_wino_wgrad_tile64(int Ca, int Cb) {
+    static const int forced = [] {
+        const char* e = getenv("PATCHGAN_WINOW_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced) return forced == 64;
+    return 25L * ((Ca + 127) / 128) * ((Cb + 127) / 128) < 768;
+}
 int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb) {
     const long T = (long)N * ((Hs + 1) / 2) * ((Ws + 1) / 2);
-    const long wgs = 25L * ((Ca + 127) / 128) * ((Cb + 127) / 128);
+    const int tt = pg_wino_wgrad_tile64(Ca, Cb) ? 64 : 128;
+    const long wgs = 25L * ((Ca + tt - 1) / tt) * ((Cb + tt - 1) / tt);
     long s = (768 + wgs - 1) / wgs;                 // three workgroups per CU
     const long nchunks = (T + KC - 1) / KC;
     if (s > nchunks / 16) s = nchunks / 16;          // at least 16 chunks per slice
@@ -1073,10 +1083,16 @@ int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big
     const int slices = pg_wino_wgrad_slices(N, Hs, Ws, Ca, Cb);
     const int nchunks = (int)((T + KC - 1) / KC);
     const int cps = (nchunks + slices - 1) / slices;
-    const int tilesA = (Ca + 127) / 128, tilesB = (Cb + 127) / 128;
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB, 25, slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                       Cb, cps, tilesB, (int)(25L * T * Ca * 4), (int)(25L * T * Cb * 4));
+    if (pg_wino_wgrad_tile64(Ca, Cb)) {
+        const int tilesA = (Ca + 63) / 64, tilesB = (Cb + 63) / 64;
+        hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB, 25, slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                           Cb, cps, tilesB, (int)(25L * T * Ca * 4), (int)(25L * T * Cb * 4));
+    } else {
+        const int tilesA = (Ca + 127) / 128, tilesB = (Cb + 127) / 128;
+        hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB, 25, slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                           Cb, cps, tilesB, (int)(25L * T * Ca * 4), (int)(25L * T * Cb * 4));
+    }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     hipLaunchKernelGGL(k_wino_wgrad_out, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, S, slices, dP, Ca, Cb);

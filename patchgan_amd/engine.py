@@ -210,7 +210,7 @@ class ConvOp:
             tid, mode = rest % 10, rest // 10
             tn = LaunchProfiler.TILE_NAMES[tid]
             if mode == 6:
-                self._desc[opcode] = ('k_wino_wgrad_gemm<1,1,2,2>' if tid == 2 else 'k_wino_wgrad_gemm<2,2,2,2>', s.value)
+                self._desc[opcode] = ('k_wino_wgrad_gemm<1,1,2,2>' if tid in (2, 3) else 'k_wino_wgrad_gemm<2,2,2,2>', s.value)
                 return self._desc[opcode]
             if mode == 8:
                 self._desc[opcode] = (f'k_b2s_tapk<{tid}>', 1)
