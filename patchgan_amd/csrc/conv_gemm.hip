@@ -2549,8 +2549,8 @@ inline bool wino2_b2s_ok(const Geom& g) {
     if (g.s != 2 || mode == 0 || !wino_enabled() || !pg_wino2_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) return false;
     if (mode == 1) return true;
     // measured on the cfg2 layers (F(3x3,2x2)): 128->256 ch -31 %, 256->512 on 16x16 -11 %, 256->1024 -25 %, 128->512 -35 %,
-    // 64->256 -18 %; 64->128 +-0; 512->512 on 8x8 and smaller maps slower (weight transform dominates)
-    return pg_wino2_tiles_b2s(g.N, g.Hs, g.Ws) >= 512 && g.Cb >= 64 && g.Ca >= 256;
+    // 64->256 -18 %, 64->128 -10..-16 %; 512->512 on 8x8 and smaller maps slower (weight transform dominates)
+    return pg_wino2_tiles_b2s(g.N, g.Hs, g.Ws) >= 512 && g.Cb >= 64 && g.Ca >= 128;
 }
 inline bool wino2_s2b_ok(const Geom& g) {
     static const int mode = [] {
