@@ -2948,7 +2948,7 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
                              e0, e1);
     }
     if (algo == PG_ALGO_AUTO && wino2_wgrad_ok(g) && (ld_small % 4 == 0) && (ld_big % 4 == 0) && aligned16(small) &&
-        aligned16(big) && aligned16(ws) && ws_bytes >= reserved + pg_wino2_wgrad_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) {
+        aligned16(big) && aligned16(ws) && aligned16(dP) && ws_bytes >= reserved + pg_wino2_wgrad_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) {
         hipEvent_t e0 = t_ev0, e1 = t_ev1;
         t_ev0 = nullptr;
         t_ev1 = nullptr;

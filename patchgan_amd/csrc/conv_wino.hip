@@ -932,38 +932,41 @@ __global__ __launch_bounds__(256) void k_wino2_dy(const float* __restrict__ dy, 
                 t[a][0] * c_G23[b][0] + t[a][1] * c_G23[b][1] + t[a][2] * c_G23[b][2];
 }
 
-// one thread per (a, b)
-__global__ void k_wino2_wgrad_out(const float* __restrict__ S, int slices, float* __restrict__ dP, int Ca, int Cb) {
+// one thread per (a, phase, 4 consecutive b): 16-byte loads of the slabs, fixed slice order
+__global__ __launch_bounds__(256) void k_wino2_wgrad_out(const float* __restrict__ S, int slices, float* __restrict__ dP,
+                                                         int Ca, int Cb) {
+    const int cq = Cb >> 2;
     const long ab = (long)Ca * Cb;
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (idx >= ab) return;
-    const int b = (int)(idx % Cb), a = (int)(idx / Cb);
+    if (idx >= (long)Ca * 4 * cq) return;
+    const int b = (int)(idx % cq) << 2;
+    const int ph = (int)((idx / cq) & 3);
+    const int a = (int)(idx / (4 * cq));
     const long K = 4L * Cb, slab = (long)Ca * K;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 m[4][4];
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph) {
-        float m[4][4];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = z;
+            for (int s = 0; s < slices; ++s)
+                v += *reinterpret_cast<const f32x4*>(S + ((long)s * 16 + i * 4 + j) * slab + (long)a * K + ph * Cb + b);
+            m[i][j] = v;
+        }
+    f32x4 t[2][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = 0.f;
-                for (int s = 0; s < slices; ++s) v += S[((long)s * 16 + i * 4 + j) * slab + (long)a * K + ph * Cb + b];
-                m[i][j] = v;
-            }
-        float t[2][4];
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int j = 0; j < 4; ++j) t[u][j] = c_A2T[u][0] * m[0][j] + c_A2T[u][1] * m[1][j] + c_A2T[u][2] * m[2][j] + c_A2T[u][3] * m[3][j];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t[u][j] = c_A2T[u][0] * m[0][j] + c_A2T[u][1] * m[1][j] + c_A2T[u][2] * m[2][j] + c_A2T[u][3] * m[3][j];
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const float w = t[u][0] * c_A2T[v][0] + t[u][1] * c_A2T[v][1] + t[u][2] * c_A2T[v][2] + t[u][3] * c_A2T[v][3];
-                const int kh = 2 * u + (ph >> 1), kw = 2 * v + (ph & 1);
-                dP[(long)(kh * 4 + kw) * ab + idx] = w;
-            }
-    }
+        for (int v = 0; v < 2; ++v) {
+            const f32x4 w = t[u][0] * c_A2T[v][0] + t[u][1] * c_A2T[v][1] + t[u][2] * c_A2T[v][2] + t[u][3] * c_A2T[v][3];
+            const int kh = 2 * u + (ph >> 1), kw = 2 * v + (ph & 1);
+            *reinterpret_cast<f32x4*>(dP + (long)(kh * 4 + kw) * ab + (long)a * Cb + b) = w;
+        }
 }
 
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
