@@ -821,17 +821,28 @@ __global__ __launch_bounds__(256) void k_wino2_out(const float* __restrict__ M, 
     wino2_out_tile<MO>(M, T * Ca, tile * Ca + c0, bias, out, ld_out, n, Hs, Ws, MO * ti, MO * tj, 1, c0, act);
 }
 
+// P is [tap][a][b] (b fastest), U is [.][b][a] (a fastest): a block transposes a 32 (a) x 32 (b) tile of the 16 taps through
+// LDS so that both the reads and the writes are 128-byte runs.  grid (ceil(Cb/32), ceil(Ca/32)), 1024 threads.
 template <int MO>
-__global__ void k_wino2c_u(const float* __restrict__ P, float* __restrict__ U, int Ca, int Cb) {
+__global__ __launch_bounds__(1024) void k_wino2c_u(const float* __restrict__ P, float* __restrict__ U, int Ca, int Cb) {
     constexpr int NP = MO + 1;
-    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (idx >= (long)Ca * Cb) return;
-    const int a = (int)(idx % Ca), b = (int)(idx / Ca);
+    __shared__ float tile[16][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int b0 = blockIdx.x * 32, a0 = blockIdx.y * 32;
+    {   // read: b fastest
+        const int a = a0 + ty, b = b0 + tx;
+        const bool ok = a < Ca && b < Cb;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) tile[t][ty][tx] = ok ? P[((long)t * Ca + a) * Cb + b] : 0.f;
+    }
+    __syncthreads();
+    const int a = a0 + tx, b = b0 + ty;     // write: a fastest
+    if (a >= Ca || b >= Cb) return;
     float w[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int l = 0; l < 4; ++l) w[k][l] = P[((long)(k * 4 + l) * Ca + a) * Cb + b];
+        for (int l = 0; l < 4; ++l) w[k][l] = tile[k * 4 + l][tx][ty];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -1216,7 +1227,7 @@ static int wino2_s2b_run(const float* small, int ld_small, const float* P, const
     float* U = (float*)ws;
     float* V = (float*)((char*)U + align256((size_t)X * Ca * NC * 4));
     float* M = (float*)((char*)V + align256((size_t)X * T * Ca * 4));
-    hipLaunchKernelGGL(k_wino2c_u<MO>, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, P, U, Ca, Cb);
+    hipLaunchKernelGGL(k_wino2c_u<MO>, dim3((Cb + 31) / 32, (Ca + 31) / 32), dim3(1024), 0, st, P, U, Ca, Cb);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     hipLaunchKernelGGL(k_wino2c_v<MO>, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, small, ld_small, V, N, Hs, Ws,
                        Ca, TH, TW);
