@@ -48,7 +48,7 @@ extern "C" {
 
 /* algorithm selector for the three conv entry points */
 #define PG_ALGO_AUTO 0   /* fastest fp32 kernel for the geometry: PG_ALGO_MFMA, except Winograd on MFMA (fp32; 1.5e-6 .. 4e-6
-                            relative error instead of 1e-7) for wide stride-1 layers (F(2x2,4x4); weight gradient
+                            relative error instead of 1e-7) for wide stride-1 layers (F(2x2,4x4) / F(3x3,4x4); weight gradient
                             F(4x4,2x2)) and channel-heavy stride-2 layers (polyphase F(3x3,2x2)) */
 #define PG_ALGO_DIRECT 1 /* one-thread-per-output reference-quality kernels (any channel count) */
 #define PG_ALGO_MFMA 2   /* LDS-tiled implicit GEMM on v_mfma_f32_32x32x2_f32 (channels % 4 == 0) */
@@ -78,7 +78,7 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);
  * col2im / tap-gather path.  + 100 (+ 200: power-of-two pixel decode, wgrad) marks the fast buffer-load variant
  * (k_b2s_fast / k_s2b_fast / k_wgrad_fast) that runs when tensors are 16-byte aligned.  `op` may carry the algorithm as
  * op + 16 * PG_ALGO_*; for PG_ALGO_AUTO (op < 16) wide stride-1 layers report the Winograd kernels instead: + 40 / + 50 =
- * k_wino_gemm<2,1,2,2,2> / <1,1,2,2,4> (ops 0/1; tile / split of the implicit-GEMM plan otherwise unchanged), 60 =
+ * k_wino_gemm<2,1,2,2,2,2> / <1,1,2,2,4,2>, + 90 = its F(3x3,4x4) instance <1,1,2,2,2,3> (ops 0/1; tile / split of the implicit-GEMM plan otherwise unchanged), 60 =
  * k_wino_wgrad_gemm<2,2,2,2> with split = its K slices (op 2; 63: 64x64 tiles <1,1,2,2>; 61 / 62: its polyphase stride-2 form with 128x128 / 64x64 tiles), 70 / 71 = k_wino_bgemm<2,2,2,2> / <1,2,2,2>, 72 / 73 = k_wino_bgemm_mz<...> (polyphase
  * Winograd of a stride-2 layer, ops 0/1).  For profiling only. */
 int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups);

@@ -55,9 +55,28 @@ __device__ __forceinline__ float act_epi(float v, int act) {
     return act_slow(v, act);
 }
 
+// F(3x3, 4x4) on the points {0, 1, -1, 1/2, -2, inf}: 36 instead of 144 multiplies per 3x3 output tile and channel pair (4x;
+// F(2x2, 4x4) above: 2.56x) at the same fp32 error in simulation (4.5e-6 vs 4.6e-6: the reciprocal pair 1/2, -2 keeps the
+// transform entries small).  MO = 2 / 3 selects the variant in the three kernels below; NP = MO + 3 points.
+__device__ __constant__ float c_BT6[6][6] = {{1, -1.5f, -2, 1.5f, 1, 0}, {0, -1, 0.5f, 2.5f, 1, 0}, {0, 1, -2.5f, 0.5f, 1, 0},
+                                             {0, -2, -1, 2, 1, 0}, {0, 0.5f, -1, -0.5f, 1, 0}, {0, 1, -1.5f, -2, 1.5f, 1}};
+__device__ __constant__ float c_G34[6][4] = {{1, 0, 0, 0},
+                                             {1.f / 3, 1.f / 3, 1.f / 3, 1.f / 3},
+                                             {-1.f / 3, 1.f / 3, -1.f / 3, 1.f / 3},
+                                             {-16.f / 15, -8.f / 15, -4.f / 15, -2.f / 15},
+                                             {1.f / 15, -2.f / 15, 4.f / 15, -8.f / 15},
+                                             {0, 0, 0, 1}};
+__device__ __constant__ float c_AT34[3][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 0.5f, -2, 0}, {0, 1, 1, 0.25f, 4, 1}};
+__device__ __constant__ float c_AT24[2][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 2, 1}};
+template <int MO> __device__ __forceinline__ float s1_bt(int a, int i) { return MO == 2 ? c_BT[a][i] : c_BT6[a][i]; }
+template <int MO> __device__ __forceinline__ float s1_g(int a, int k) { return MO == 2 ? c_G[a][k] : c_G34[a][k]; }
+template <int MO> __device__ __forceinline__ float s1_at(int k, int i) { return MO == 2 ? c_AT24[k][i] : c_AT34[k][i]; }
+
 // U[xi][co][ci] = sum_{k,l} G[xi_i][k] G[xi_j][l] w(k, l, co, ci);  flip = 0: w = P[(k*4+l)][co][ci] (forward),
 // flip = 1: w = P[((3-k)*4 + (3-l))][ci][co] (data gradient).  One thread per (co, ci).
+template <int MO>
 __global__ void k_wino_u(const float* __restrict__ P, float* __restrict__ U, int Co, int Ci, int flip) {
+    constexpr int NP = MO + 3;
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (idx >= (long)Co * Ci) return;
     const int ci = (int)(idx % Ci), co = (int)(idx / Ci);
@@ -68,31 +87,33 @@ __global__ void k_wino_u(const float* __restrict__ P, float* __restrict__ U, int
         for (int l = 0; l < 4; ++l)
             g[k][l] = flip ? P[((long)((3 - k) * 4 + (3 - l)) * Ci + ci) * Co + co]     // P[tap][a = ci][b = co]
                            : P[((long)(k * 4 + l) * Co + co) * Ci + ci];                // P[tap][a = co][b = ci]
-    float t[5][4];
+    float t[NP][4];
 #pragma unroll
-    for (int a = 0; a < 5; ++a)
+    for (int a = 0; a < NP; ++a)
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s += c_G[a][k] * g[k][l];
+            for (int k = 0; k < 4; ++k) s += s1_g<MO>(a, k) * g[k][l];
             t[a][l] = s;
         }
 #pragma unroll
-    for (int a = 0; a < 5; ++a)
+    for (int a = 0; a < NP; ++a)
 #pragma unroll
-        for (int b = 0; b < 5; ++b) {
+        for (int b = 0; b < NP; ++b) {
             float s = 0.f;
 #pragma unroll
-            for (int l = 0; l < 4; ++l) s += t[a][l] * c_G[b][l];
-            U[((long)(a * 5 + b) * Co + co) * Ci + ci] = s;
+            for (int l = 0; l < 4; ++l) s += t[a][l] * s1_g<MO>(b, l);
+            U[((long)(a * NP + b) * Co + co) * Ci + ci] = s;
         }
 }
 
 // V[xi][tile][ci] = (B^T d B)[xi], d[i][j] = in[n, 2*Ti - pad + i, 2*Tj - pad + j, ci] (0 outside).  One thread per
 // (tile, 4 channels).
+template <int MO>
 __global__ __launch_bounds__(256) void k_wino_v(const float* __restrict__ in, int ld_in, float* __restrict__ V, int N,
                                                 int Hin, int Win, int Ci, int TH, int TW, int pad) {
+    constexpr int NP = MO + 3;
     const int cq = Ci >> 2;
     const long T = (long)N * TH * TW;
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -102,46 +123,47 @@ __global__ __launch_bounds__(256) void k_wino_v(const float* __restrict__ in, in
     const int n = (int)(tile / (TH * TW));
     const int rem = (int)(tile - (long)n * TH * TW);
     const int ti = rem / TW, tj = rem - ti * TW;
-    const int y0 = 2 * ti - pad, x0 = 2 * tj - pad;
-    f32x4 d[5][5];
+    const int y0 = MO * ti - pad, x0 = MO * tj - pad;
+    f32x4 d[NP][NP];
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < NP; ++i)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NP; ++j) {
             const int y = y0 + i, x = x0 + j;
             const bool ok = (unsigned)y < (unsigned)Hin && (unsigned)x < (unsigned)Win;
             d[i][j] = ok ? *reinterpret_cast<const f32x4*>(in + ((long)(n * Hin + y) * Win + x) * ld_in + c0) : z;
         }
-    f32x4 t[5][5];
+    f32x4 t[NP][NP];
 #pragma unroll
-    for (int a = 0; a < 5; ++a)
+    for (int a = 0; a < NP; ++a)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NP; ++j) {
             f32x4 s = z;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) s += c_BT[a][i] * d[i][j];
+            for (int i = 0; i < NP; ++i) s += s1_bt<MO>(a, i) * d[i][j];
             t[a][j] = s;
         }
 #pragma unroll
-    for (int a = 0; a < 5; ++a)
+    for (int a = 0; a < NP; ++a)
 #pragma unroll
-        for (int b = 0; b < 5; ++b) {
+        for (int b = 0; b < NP; ++b) {
             f32x4 s = z;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) s += t[a][j] * c_BT[b][j];
-            *reinterpret_cast<f32x4*>(V + ((long)(a * 5 + b) * T + tile) * Ci + c0) = s;
+            for (int j = 0; j < NP; ++j) s += t[a][j] * s1_bt<MO>(b, j);
+            *reinterpret_cast<f32x4*>(V + ((long)(a * NP + b) * T + tile) * Ci + c0) = s;
         }
 }
 
 // 25 row GEMMs + fused output transform.  Workgroup = 4 waves (2 x 2), tile = 128 Winograd tiles x 64 output channels,
 // each wave 64 x 32 (two 32x32 MFMA tiles).  Requires Ci % 32 == 0.
-template <int MR, int NR, int WM, int WN, int WPE>
+template <int MR, int NR, int WM, int WN, int WPE, int MO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_gemm(const float* __restrict__ V, const float* __restrict__ U,
                                                    const float* __restrict__ bias, float* __restrict__ out, int ld_out,
                                                    int T, int Ci, int Co, int TH, int TW, int Hout, int Wout, int act,
                                                    int v_bytes, int u_bytes) {
     static_assert(NR == 1 && WM * WN == 4, "one 32-column MFMA tile per wave");
+    constexpr int NP = MO + 3, NXI = NP * NP, NY = MO * MO;      // points, products, outputs per tile
     constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN, AI = BM / 32, BI = BN / 32;
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
     float* As = smem;
@@ -153,7 +175,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int nch = Ci / KC, total = 25 * nch;
+    const int nch = Ci / KC, total = NXI * nch;
     const int kq = tid & 7, r0 = tid >> 3;
 
     int a_off[AI], b_off[BI];
@@ -190,14 +212,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDK + kq * 4]) = rb[i];
     };
 
-    f32x16 accm[MR], accy[4][MR];
+    f32x16 accm[MR], accy[NY][MR];
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             accm[i][r] = 0.f;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) accy[p][i][r] = 0.f;
+            for (int p = 0; p < NY; ++p) accy[p][i][r] = 0.f;
         }
 
     issue_loads(true);
@@ -221,22 +243,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 for (int i = 0; i < MR; ++i) accm[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[e], accm[i], 0, 0, 0);
         }
         if (ch == nch - 1) {
-            // fold M_xi into the four outputs: Y[al][be] += AT[al][xi_i] * AT[be][xi_j] * M_xi,
-            // AT = [[1, 1, 1, 1, 0], [0, 1, -1, 2, 1]]
-            const int xa = xi / 5, xb = xi - xa * 5;
-            const float a0 = xa < 4 ? 1.f : 0.f, b0 = xb < 4 ? 1.f : 0.f;
-            const float a1 = xa == 0 ? 0.f : (xa == 2 ? -1.f : (xa == 3 ? 2.f : 1.f));
-            const float b1 = xb == 0 ? 0.f : (xb == 2 ? -1.f : (xb == 3 ? 2.f : 1.f));
-            const float c00 = a0 * b0, c01 = a0 * b1, c10 = a1 * b0, c11 = a1 * b1;
+            // fold M_xi into the outputs: Y[al][be] += AT[al][xi_i] * AT[be][xi_j] * M_xi
+            const int xa = xi / NP, xb = xi - xa * NP;
+            float ca[MO], cb[MO];
+#pragma unroll
+            for (int k = 0; k < MO; ++k) {
+                ca[k] = s1_at<MO>(k, xa);
+                cb[k] = s1_at<MO>(k, xb);
+            }
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float mv = accm[i][r];
-                    accy[0][i][r] += c00 * mv;
-                    accy[1][i][r] += c01 * mv;
-                    accy[2][i][r] += c10 * mv;
-                    accy[3][i][r] += c11 * mv;
+#pragma unroll
+                    for (int al = 0; al < MO; ++al)
+#pragma unroll
+                        for (int be = 0; be < MO; ++be) accy[al * MO + be][i][r] += (ca[al] * cb[be]) * mv;
                     accm[i][r] = 0.f;
                 }
         }
@@ -263,8 +286,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 const int rem = m - n * (TH * TW);
                 const int ti = rem / TW, tj = rem - ti * TW;
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int y = 2 * ti + (p >> 1), x = 2 * tj + (p & 1);
+                for (int p = 0; p < NY; ++p) {
+                    const int y = MO * ti + p / MO, x = MO * tj + p % MO;
                     if (y < Hout && x < Wout)
                         out[((long)(n * Hout + y) * Wout + x) * ld_out + col] = act_epi(accy[p][i][r] + bv, act);
                 }
@@ -984,11 +1007,32 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
 
+// output tile edge of the stride-1 forward / data-gradient path: 2 = F(2x2,4x4), 3 = F(3x3,4x4) (PATCHGAN_WINO1_TILE)
+// F(3x3,4x4) keeps nine output accumulator sets per lane, so its workgroup tile is 64 tiles x 64 channels at 2 waves per SIMD:
+// it is used when that grid still fills the chip (>= 240 workgroups), F(2x2,4x4) otherwise.
+int pg_wino_mo(int N, int Hout, int Wout, int Cout) {
+    static const int forced = [] {
+        const char* e = getenv("PATCHGAN_WINO1_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 2 || forced == 3) return forced;
+    const long T3 = (long)N * ((Hout + 2) / 3) * ((Wout + 2) / 3);
+    return ((T3 + 63) / 64) * ((Cout + 63) / 64) >= 240 ? 3 : 2;
+}
+static long wino1_tiles(int N, int Hout, int Wout, int Cout) {
+    const int mo = pg_wino_mo(N, Hout, Wout, Cout);
+    return (long)N * ((Hout + mo - 1) / mo) * ((Wout + mo - 1) / mo);
+}
+static long wino1_nxi(int N, int Hout, int Wout, int Cout) {
+    const int np = pg_wino_mo(N, Hout, Wout, Cout) + 3;
+    return (long)np * np;
+}
+
 bool pg_wino_geom_ok(int N, int Hout, int Wout, int Cin, int Cout) {
     if (Cin % 32 != 0 || Cin < 64 || Cout < 64) return false;
-    const long T = (long)N * ((Hout + 1) / 2) * ((Wout + 1) / 2);
-    if (T < 2048) return false;                                   // needs enough tiles to fill the chip
-    if (25.0 * T * Cin * 4 >= 1.5e9 || 25.0 * Cout * Cin * 4 >= 1.0e9) return false;   // 32-bit buffer offsets
+    const long T = wino1_tiles(N, Hout, Wout, Cout), X = wino1_nxi(N, Hout, Wout, Cout);
+    if ((long)N * ((Hout + 1) / 2) * ((Wout + 1) / 2) < 2048) return false;       // needs enough tiles to fill the chip
+    if ((double)X * T * Cin * 4 >= 1.5e9 || (double)X * Cout * Cin * 4 >= 1.0e9) return false;   // 32-bit buffer offsets
     return true;
 }
 
@@ -1004,44 +1048,55 @@ bool pg_wino_small_tile(int N, int Hout, int Wout, int Cout) {
         const char* e = getenv("PATCHGAN_WINO_TILE");
         return e ? atoi(e) : 0;
     }();
+    if (pg_wino_mo(N, Hout, Wout, Cout) == 3) return true;          // nine output accumulator sets: 64-tile rows only
     const long T = (long)N * ((Hout + 1) / 2) * ((Wout + 1) / 2);
     const long wg128 = ((T + 127) / 128) * ((Cout + 63) / 64);
     return forced ? forced == 1 : wg128 < 400;
 }
 
 size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout) {
-    const long T = (long)N * ((Hout + 1) / 2) * ((Wout + 1) / 2);
-    return align256((size_t)25 * Cout * Cin * 4) + align256((size_t)25 * T * Cin * 4);
+    const long T = wino1_tiles(N, Hout, Wout, Cout), X = wino1_nxi(N, Hout, Wout, Cout);
+    return align256((size_t)X * Cout * Cin * 4) + align256((size_t)X * T * Cin * 4);
 }
 
 int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N, int Hin, int Win, int Cin, int Hout,
                     int Wout, int Cout, int pad, void* ws, hipStream_t st) {
-    const int TH = (Hout + 1) / 2, TW = (Wout + 1) / 2;
-    const long T = (long)N * TH * TW;
+    const int mo = pg_wino_mo(N, Hout, Wout, Cout), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
+    const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cout);
     float* U = (float*)ws;
-    float* V = (float*)((char*)ws + align256((size_t)25 * Cout * Cin * 4));
-    hipLaunchKernelGGL(k_wino_u, dim3((unsigned)(((long)Cout * Cin + 255) / 256)), dim3(256), 0, st, P, U, Cout, Cin, flip);
+    float* V = (float*)((char*)ws + align256((size_t)X * Cout * Cin * 4));
+    const dim3 gu((unsigned)(((long)Cout * Cin + 255) / 256)), gv((unsigned)((T * (Cin / 4) + 255) / 256));
+    if (mo == 3)
+        hipLaunchKernelGGL(k_wino_u<3>, gu, dim3(256), 0, st, P, U, Cout, Cin, flip);
+    else
+        hipLaunchKernelGGL(k_wino_u<2>, gu, dim3(256), 0, st, P, U, Cout, Cin, flip);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
-    hipLaunchKernelGGL(k_wino_v, dim3((unsigned)((T * (Cin / 4) + 255) / 256)), dim3(256), 0, st, in, ld_in, V, N, Hin, Win,
-                       Cin, TH, TW, pad);
+    if (mo == 3)
+        hipLaunchKernelGGL(k_wino_v<3>, gv, dim3(256), 0, st, in, ld_in, V, N, Hin, Win, Cin, TH, TW, pad);
+    else
+        hipLaunchKernelGGL(k_wino_v<2>, gv, dim3(256), 0, st, in, ld_in, V, N, Hin, Win, Cin, TH, TW, pad);
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
 
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
                  void* ws, hipStream_t st) {
-    const int TH = (Hout + 1) / 2, TW = (Wout + 1) / 2;
-    const long T = (long)N * TH * TW;
+    const int mo = pg_wino_mo(N, Hout, Wout, Cout), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
+    const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cout);
     const float* U = (const float*)ws;
-    const float* V = (const float*)((const char*)ws + align256((size_t)25 * Cout * Cin * 4));
+    const float* V = (const float*)((const char*)ws + align256((size_t)X * Cout * Cin * 4));
     const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cout);
-    const int v_bytes = (int)(25L * T * Cin * 4), u_bytes = (int)(25L * Cout * Cin * 4);
-    if (small_tile) {
+    const int v_bytes = (int)(X * T * Cin * 4), u_bytes = (int)(X * Cout * Cin * 4);
+    if (mo == 3) {
         dim3 grid((unsigned)((T + 63) / 64), (Cout + 63) / 64, 1);
-        hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 4>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
+        hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 2, 3>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
+                           TW, Hout, Wout, act, v_bytes, u_bytes);
+    } else if (small_tile) {
+        dim3 grid((unsigned)((T + 63) / 64), (Cout + 63) / 64, 1);
+        hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 4, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
                            TW, Hout, Wout, act, v_bytes, u_bytes);
     } else {
         dim3 grid((unsigned)((T + 127) / 128), (Cout + 63) / 64, 1);
-        hipLaunchKernelGGL((k_wino_gemm<2, 1, 2, 2, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
+        hipLaunchKernelGGL((k_wino_gemm<2, 1, 2, 2, 2, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
                            TW, Hout, Wout, act, v_bytes, u_bytes);
     }
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
@@ -1088,7 +1143,7 @@ int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big
     float* V = (float*)ws;
     float* DY = (float*)((char*)ws + align256((size_t)25 * T * Cb * 4));
     float* S = (float*)((char*)DY + align256((size_t)25 * T * Ca * 4));
-    hipLaunchKernelGGL(k_wino_v, dim3((unsigned)((T * (Cb / 4) + 255) / 256)), dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb,
+    hipLaunchKernelGGL(k_wino_v<2>, dim3((unsigned)((T * (Cb / 4) + 255) / 256)), dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb,
                        TH, TW, 1);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     hipLaunchKernelGGL(k_wino_dy, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, small, ld_small, DY, N, Hs, Ws,

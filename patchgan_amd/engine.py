@@ -187,9 +187,10 @@ class ConvOp:
         GEMM kernels, 2.25-2.56x fewer for the Winograd kernels (their tile counts include the ragged-edge padding)."""
         sym = self.describe(opcode)[0]
         cd = lambda a, b: -(-a // b)
-        if sym.startswith('k_wino_gemm'):            # stride 1, F(2x2, 4x4): 25 GEMMs of tiles x Cin x Cout
+        if sym.startswith('k_wino_gemm'):            # stride 1, F(2x2, 4x4) / F(3x3, 4x4): 25 / 36 GEMMs of tiles x Cin x Cout
             ho, wo = (self.Hs, self.Ws) if opcode == 0 else (self.Hb, self.Wb)
-            return 2.0 * 25 * self.N * cd(ho, 2) * cd(wo, 2) * self.Ca * self.Cb
+            mo = 3 if sym.endswith(',3>') else 2
+            return 2.0 * (mo + 3) ** 2 * self.N * cd(ho, mo) * cd(wo, mo) * self.Ca * self.Cb
         if sym.startswith('k_wino_wgrad_gemm'):
             if self.stride == 1:
                 return 2.0 * 25 * self.N * cd(self.Hs, 2) * cd(self.Ws, 2) * self.Ca * self.Cb
@@ -219,8 +220,10 @@ class ConvOp:
                 self._desc[opcode] = ({0: 'k_wino_bgemm<2,2,2,2>', 1: 'k_wino_bgemm<1,2,2,2>', 2: 'k_wino_bgemm_mz<2,2,2,2>',
                                        3: 'k_wino_bgemm_mz<1,2,2,2>'}[tid], 1)
                 return self._desc[opcode]
-            if mode in (4, 5):
-                name, s.value = ('k_wino_gemm<2,1,2,2,2>' if mode == 4 else 'k_wino_gemm<1,1,2,2,4>'), 1
+            if mode == 9:
+                name, s.value = 'k_wino_gemm<1,1,2,2,2,3>', 1
+            elif mode in (4, 5):
+                name, s.value = ('k_wino_gemm<2,1,2,2,2,2>' if mode == 4 else 'k_wino_gemm<1,1,2,2,4,2>'), 1
             elif mode == 3:
                 name = 'k_b2s_fast' + tn[:-1] + ',true>+' + ('k_gather_big2small' if opcode == 0 else 'k_col2im_small2big')
             elif mode:
