@@ -472,8 +472,8 @@ __global__ void k_wino_wgrad_out(const float* __restrict__ S, int slices, float*
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Stride-2 layers, polyphase Winograd F(MO x MO, 2x2), MO = 3 (points 0, 1, -1, inf: 16 instead of 36 multiplies per tile,
-// phase and channel pair; error ~3e-6, the level of the stride-1 path) or MO = 4 (the 5 points above: 25 instead of 64,
-// error ~1e-5; opt-in).
+// phase and channel pair; error ~3e-6, the level of the stride-1 path) or MO = 4 (points 0, 1, -1/2, -2, inf: 25 instead
+// of 64, error ~6e-6; experiment switch, the size heuristics are tuned for MO = 3).
 //
 // big -> small (Conv2d forward, ConvTranspose2d data gradient):
 //   small[p][q] = sum_{r,s in {0,1}} sum_{u,v in {0,1}} X_rs[p+u][q+v] * w[2u+r][2v+s],   X_rs[i][j] = big[2i+r-1][2j+s-1]
@@ -495,9 +495,15 @@ __global__ void k_wino_wgrad_out(const float* __restrict__ S, int slices, float*
 __device__ __constant__ float c_BT3[4][4] = {{-1, 0, 1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, -1, 0, 1}};
 __device__ __constant__ float c_G3[4][2] = {{-1.f, 0.f}, {0.5f, 0.5f}, {0.5f, -0.5f}, {0.f, 1.f}};
 __device__ __constant__ float c_A3T[3][4] = {{1, 1, 1, 0}, {0, 1, -1, 0}, {0, 1, 1, 1}};
-template <int MO> __device__ __forceinline__ float w_bt(int a, int i) { return MO == 4 ? c_BT[a][i] : c_BT3[a][i]; }
-template <int MO> __device__ __forceinline__ float w_g(int a, int u) { return MO == 4 ? c_G2[a][u] : c_G3[a][u]; }
-template <int MO> __device__ __forceinline__ float w_at(int k, int i) { return MO == 4 ? c_A4T[k][i] : c_A3T[k][i]; }
+// MO = 4 on the points {0, 1, -1/2, -2, inf}: the most accurate of the 5-point sets drawn from {0, +-1, +-1/2, +-2}
+// (simulated fp32 error 6.4e-6; {0, 1, -1, 2}: 1.1e-5; F(3x3,2x2) on {0, 1, -1}: 2.5e-6)
+__device__ __constant__ float c_BT4p[5][5] = {{-1, -1.5f, 1.5f, 1, 0}, {0, 1, 2.5f, 1, 0}, {0, -2, 1, 1, 0}, {0, -0.5f, -0.5f, 1, 0},
+                                              {0, -1, -1.5f, 1.5f, 1}};
+__device__ __constant__ float c_G2p[5][2] = {{-1.f, 0.f}, {2.f / 9, 2.f / 9}, {8.f / 9, -4.f / 9}, {-1.f / 9, 2.f / 9}, {0.f, 1.f}};
+__device__ __constant__ float c_A4Tp[4][5] = {{1, 1, 1, 1, 0}, {0, 1, -0.5f, -2, 0}, {0, 1, 0.25f, 4, 0}, {0, 1, -0.125f, -8, 1}};
+template <int MO> __device__ __forceinline__ float w_bt(int a, int i) { return MO == 4 ? c_BT4p[a][i] : c_BT3[a][i]; }
+template <int MO> __device__ __forceinline__ float w_g(int a, int u) { return MO == 4 ? c_G2p[a][u] : c_G3[a][u]; }
+template <int MO> __device__ __forceinline__ float w_at(int k, int i) { return MO == 4 ? c_A4Tp[k][i] : c_A3T[k][i]; }
 
 template <int MO>
 __global__ void k_wino2_u(const float* __restrict__ P, float* __restrict__ U, int Ca, int Cb) {
