@@ -2652,8 +2652,8 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
     if (algo == PG_ALGO_AUTO &&
         ((op == 0 && wino_b2s_ok(gq) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca)) ||
          (op == 1 && wino_s2b_ok(gq) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb)))) {
-        const bool st = (op == 0) ? pg_wino_small_tile(gq.N, gq.Hs, gq.Ws, gq.Ca) : pg_wino_small_tile(gq.N, gq.Hb, gq.Wb, gq.Cb);
-        const int mo1 = (op == 0) ? pg_wino_mo(gq.N, gq.Hs, gq.Ws, gq.Ca) : pg_wino_mo(gq.N, gq.Hb, gq.Wb, gq.Cb);
+        const bool st = (op == 0) ? pg_wino_small_tile(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca) : pg_wino_small_tile(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb);
+        const int mo1 = (op == 0) ? pg_wino_mo(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca) : pg_wino_mo(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb);
         if (tile_id) *tile_id += (mo1 == 3) ? 90 : (st ? 50 : 40);     // +90: F(3x3,4x4) variant k_wino_gemm<1,1,2,2,2,3>
     }
     // 81..83: one-shot k_b2s_tapk<Cb> for 1..3 big-side channels

@@ -7,9 +7,9 @@
 // geometry + alignment gate; (in, out) = (big, small) forward, (small, big) data gradient
 bool pg_wino_eligible(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ld_in, const void* in);
 bool pg_wino_geom_ok(int N, int Hout, int Wout, int Cin, int Cout);
-int pg_wino_mo(int N, int Hout, int Wout, int Cout);     // 2: F(2x2,4x4), 3: F(3x3,4x4) where its 64x64 grid fills the chip
+int pg_wino_mo(int N, int Hout, int Wout, int Cin, int Cout);     // 2: F(2x2,4x4), 3: F(3x3,4x4) where its 64x64 grid fills the chip
 // true: k_wino_gemm<1,1,2,2> (64-tile rows), false: <2,1,2,2> (128-tile rows)
-bool pg_wino_small_tile(int N, int Hout, int Wout, int Cout);
+bool pg_wino_small_tile(int N, int Hout, int Wout, int Cin, int Cout);
 // U (25*Cout*Cin floats) followed by V (25*tiles*Cin floats), each 256-byte aligned
 size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout);
 // weight transform + input transform into ws

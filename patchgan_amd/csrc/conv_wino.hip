@@ -164,10 +164,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                                                    int v_bytes, int u_bytes) {
     static_assert(NR == 1 && WM * WN == 4, "one 32-column MFMA tile per wave");
     constexpr int NP = MO + 3, NXI = NP * NP, NY = MO * MO;      // points, products, outputs per tile
-    constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN, AI = BM / 32, BI = BN / 32;
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    // K chunk: 64 floats for the F(3x3,4x4) instance (its workgroup tile is only 64 x 64: twice the MFMAs per barrier pair)
+    constexpr int KCL = (MO == 3) ? 64 : 32, LDL = KCL + 4, QR = KCL / 4, RP = 256 / QR;   // quads per row, rows per pass
+    constexpr int BM = 32 * MR * WM, BN = 32 * NR * WN, AI = BM / RP, BI = BN / RP;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDL];
     float* As = smem;
-    float* Bs = smem + BM * LDK;
+    float* Bs = smem + BM * LDL;
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, v_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, u_bytes, 0x00020000);
 
@@ -175,20 +177,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int nch = Ci / KC, total = NXI * nch;
-    const int kq = tid & 7, r0 = tid >> 3;
+    const int nch = Ci / KCL, total = NXI * nch;
+    const int kq = tid % QR, r0 = tid / QR;
 
     int a_off[AI], b_off[BI];
     bool a_ok[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int m = m0 + r0 + 32 * i;
+        const int m = m0 + r0 + RP * i;
         a_ok[i] = m < T;
         a_off[i] = min(m, T - 1) * Ci + kq * 4;
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-        const int co = n0 + r0 + 32 * i;
+        const int co = n0 + r0 + RP * i;
         b_off[i] = (co < Co) ? co * Ci + kq * 4 : 0x10000000;
     }
     const int v_xi = T * Ci, u_xi = Co * Ci;     // elements per xi slab
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     f32x4 ra[AI], rb[BI];
     int ld_xi = 0, ld_ch = 0;                    // (xi, chunk) of the NEXT load
     auto issue_loads = [&](bool on) {
-        const int av = ld_xi * v_xi + ld_ch * KC, bu = ld_xi * u_xi + ld_ch * KC;
+        const int av = ld_xi * v_xi + ld_ch * KCL, bu = ld_xi * u_xi + ld_ch * KCL;
 #pragma unroll
         for (int i = 0; i < AI; ++i) ra[i] = bload4(rV, voff(a_off[i] + av, on && a_ok[i]));
 #pragma unroll
@@ -207,9 +209,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + RP * i) * LDL + kq * 4]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDK + kq * 4]) = rb[i];
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(r0 + RP * i) * LDL + kq * 4]) = rb[i];
     };
 
     f32x16 accm[MR], accy[NY][MR];
@@ -231,12 +233,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         issue_loads(more);
         __builtin_amdgcn_sched_barrier(0x386);
 #pragma unroll
-        for (int kk = 0; kk < KC / 8; ++kk) {
+        for (int kk = 0; kk < KCL / 8; ++kk) {
             f32x4 af[MR], bf;
 #pragma unroll
             for (int i = 0; i < MR; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MR + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
-            bf = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+                af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MR + i) * 32 + lrow) * LDL + kk * 8 + lh * 4]);
+            bf = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 + lrow) * LDL + kk * 8 + lh * 4]);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1016,27 +1018,28 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // output tile edge of the stride-1 forward / data-gradient path: 2 = F(2x2,4x4), 3 = F(3x3,4x4) (PATCHGAN_WINO1_TILE)
 // F(3x3,4x4) keeps nine output accumulator sets per lane, so its workgroup tile is 64 tiles x 64 channels at 2 waves per SIMD:
 // it is used when that grid still fills the chip (>= 240 workgroups), F(2x2,4x4) otherwise.
-int pg_wino_mo(int N, int Hout, int Wout, int Cout) {
+int pg_wino_mo(int N, int Hout, int Wout, int Cin, int Cout) {
     static const int forced = [] {
         const char* e = getenv("PATCHGAN_WINO1_TILE");
         return e ? atoi(e) : 0;
     }();
+    if (Cin % 64 != 0) return 2;                 // the F(3x3,4x4) instance walks K in chunks of 64
     if (forced == 2 || forced == 3) return forced;
     const long T3 = (long)N * ((Hout + 2) / 3) * ((Wout + 2) / 3);
-    return ((T3 + 63) / 64) * ((Cout + 63) / 64) >= 240 ? 3 : 2;
+    return ((T3 + 63) / 64) * ((Cout + 63) / 64) >= 240 ? 3 : 2;     // (callers fall back to 2 when Cin % 64 != 0)
 }
-static long wino1_tiles(int N, int Hout, int Wout, int Cout) {
-    const int mo = pg_wino_mo(N, Hout, Wout, Cout);
+static long wino1_tiles(int N, int Hout, int Wout, int Cin, int Cout) {
+    const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout);
     return (long)N * ((Hout + mo - 1) / mo) * ((Wout + mo - 1) / mo);
 }
-static long wino1_nxi(int N, int Hout, int Wout, int Cout) {
-    const int np = pg_wino_mo(N, Hout, Wout, Cout) + 3;
+static long wino1_nxi(int N, int Hout, int Wout, int Cin, int Cout) {
+    const int np = pg_wino_mo(N, Hout, Wout, Cin, Cout) + 3;
     return (long)np * np;
 }
 
 bool pg_wino_geom_ok(int N, int Hout, int Wout, int Cin, int Cout) {
     if (Cin % 32 != 0 || Cin < 64 || Cout < 64) return false;
-    const long T = wino1_tiles(N, Hout, Wout, Cout), X = wino1_nxi(N, Hout, Wout, Cout);
+    const long T = wino1_tiles(N, Hout, Wout, Cin, Cout), X = wino1_nxi(N, Hout, Wout, Cin, Cout);
     if ((long)N * ((Hout + 1) / 2) * ((Wout + 1) / 2) < 2048) return false;       // needs enough tiles to fill the chip
     if ((double)X * T * Cin * 4 >= 1.5e9 || (double)X * Cout * Cin * 4 >= 1.0e9) return false;   // 32-bit buffer offsets
     return true;
@@ -1049,26 +1052,26 @@ bool pg_wino_eligible(int N, int Hin, int Win, int Cin, int Hout, int Wout, int 
 }
 
 // 128-tile rows unless that leaves the 256 CUs short of two workgroups each
-bool pg_wino_small_tile(int N, int Hout, int Wout, int Cout) {
+bool pg_wino_small_tile(int N, int Hout, int Wout, int Cin, int Cout) {
     static const int forced = [] {
         const char* e = getenv("PATCHGAN_WINO_TILE");
         return e ? atoi(e) : 0;
     }();
-    if (pg_wino_mo(N, Hout, Wout, Cout) == 3) return true;          // nine output accumulator sets: 64-tile rows only
+    if (pg_wino_mo(N, Hout, Wout, Cin, Cout) == 3) return true;          // nine output accumulator sets: 64-tile rows only
     const long T = (long)N * ((Hout + 1) / 2) * ((Wout + 1) / 2);
     const long wg128 = ((T + 127) / 128) * ((Cout + 63) / 64);
     return forced ? forced == 1 : wg128 < 400;
 }
 
 size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout) {
-    const long T = wino1_tiles(N, Hout, Wout, Cout), X = wino1_nxi(N, Hout, Wout, Cout);
+    const long T = wino1_tiles(N, Hout, Wout, Cin, Cout), X = wino1_nxi(N, Hout, Wout, Cin, Cout);
     return align256((size_t)X * Cout * Cin * 4) + align256((size_t)X * T * Cin * 4);
 }
 
 int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N, int Hin, int Win, int Cin, int Hout,
                     int Wout, int Cout, int pad, void* ws, hipStream_t st) {
-    const int mo = pg_wino_mo(N, Hout, Wout, Cout), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
-    const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cout);
+    const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
+    const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout);
     float* U = (float*)ws;
     float* V = (float*)((char*)ws + align256((size_t)X * Cout * Cin * 4));
     const dim3 gu((unsigned)(((long)Cout * Cin + 255) / 256)), gv((unsigned)((T * (Cin / 4) + 255) / 256));
@@ -1086,11 +1089,11 @@ int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N,
 
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
                  void* ws, hipStream_t st) {
-    const int mo = pg_wino_mo(N, Hout, Wout, Cout), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
-    const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cout);
+    const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
+    const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout);
     const float* U = (const float*)ws;
     const float* V = (const float*)((const char*)ws + align256((size_t)X * Cout * Cin * 4));
-    const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cout);
+    const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cin, Cout);
     const int v_bytes = (int)(X * T * Cin * 4), u_bytes = (int)(X * Cout * Cin * 4);
     if (mo == 3) {
         dim3 grid((unsigned)((T + 63) / 64), (Cout + 63) / 64, 1);
