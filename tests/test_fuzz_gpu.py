@@ -27,7 +27,10 @@ def _geoms(n, seed):
     return out
 
 
-@pytest.mark.parametrize('seed', [0, 1, 2])
+import os
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2] + ([int(v) for v in os.environ['PATCHGAN_FUZZ_SEEDS'].split(',')] if os.environ.get('PATCHGAN_FUZZ_SEEDS') else []))
 def test_auto_matches_direct_on_random_geometries(seed):
     from patchgan_amd import engine as E
     from tests.gpu_util import to_view, empty_view, pack, unpack, rel_err, DEV
