@@ -8,5 +8,5 @@ setup(
     package_data={'patchgan_amd': ['libpatchgan_hip.so', 'csrc/*']},
     entry_points={'console_scripts': ['patchgan_train = patchgan_amd.train:patchgan_train',
                                       'patchgan_infer = patchgan_amd.infer:patchgan_infer']},
-    install_requires=['torch', 'numpy', 'tqdm', 'pyyaml'],
+    install_requires=['torch', 'numpy', 'tqdm', 'pyyaml', 'pillow'],
 )
