@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- train images/sec of one full patchGAN G+D step (Trainer.batch(train=True) semantics) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, one per GPU, over RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W              (the driver's launch: RANK / LOCAL_RANK / WORLD_SIZE from the env)
 
 Workload (BASELINE.json configs[1], "cfg2" of SURVEY.md 8(d)): synthetic 256x256x3 -> 1-channel masks, batch 16
 PER GPU (weak scaling; cfg3 = 8 x 16), UNet nf=64 leakyrelu/sigmoid, Discriminator ndf=64 n_layers=3 norm=False,
@@ -105,6 +105,33 @@ def cpu_baseline(max_seconds=25.0):
             'sample': f'{n} G+D steps of the same workload (bs {BATCH_PER_GPU}, {SIZE}x{SIZE}) after 1 warm-up step; {dt / n:.2f} s/step'}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh worker processes (one rank per GPU) from THIS process,
+    which has not touched the GPU and does not import torch (a process that has initialised HIP must never exec or be
+    replaced), wait for all of them, forward rank 0's JSON line, and fail if any rank failed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cpus() // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -122,16 +149,20 @@ def main():
     CFG = CONFIGS[args.config]
     GFLOP_PER_IMAGE, BATCH_PER_GPU, SIZE = CFG['gflop_per_image'], CFG['batch'], CFG['size']
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])
+
     import torch
     import torch.distributed as dist
     import patchgan_amd as pg
     from patchgan_amd import engine as E
+    from patchgan_amd import parallel
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks (launch with torch.distributed.run); WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # PATCHGAN_DIST_BACKEND=gloo + PATCHGAN_SHARE_GPU=1 rehearse the multi-rank path on a single-GPU box (all ranks on
     # device 0, collectives through gloo); the real run is one rank per GPU over RCCL ("nccl")
     backend = os.environ.get('PATCHGAN_DIST_BACKEND', 'nccl')
@@ -139,12 +170,18 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # PATCHGAN_DP_FORCE=1: run the data-parallel code path (RCCL collectives on the comm stream) even with one rank
+    use_dist = world > 1 or os.environ.get('PATCHGAN_DP_FORCE') == '1'
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {args.gpus}")
 
     torch.manual_seed(1234)
     G = pg.UNet(3, CFG['out_nc'], CFG['nf'], use_dropout=args.dropout, activation=CFG['activation'],
@@ -162,7 +199,7 @@ def main():
     x, y = x.to(dev), y.to(dev)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -180,6 +217,9 @@ def main():
     dominant = max(wsum.items(), key=lambda kv: kv[1]['ms'])[0] if wsum else None
     prof = E.LaunchProfiler(only=None if args.events == 'all' else dominant)
     E.PROFILER = prof if args.events != 'none' else None
+    pd = parallel.current()
+    if pd.on:
+        pd.timing = []             # (start, end, bytes) HIP events on the comm stream around every collective
     sync()
     t0 = time.perf_counter()
     last = None
@@ -189,7 +229,16 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     E.PROFILER = None
-    if world > 1:
+    comm = None
+    if pd.on:
+        recs, pd.timing = pd.timing, None
+        comm = {'backend': dist.get_backend(), 'ranks_in_group': dist.get_world_size(),
+                'collectives_per_step': len(recs) / args.steps,
+                'allreduce_ms_per_step': round(sum(e0.elapsed_time(e1) for e0, e1, _ in recs) / args.steps, 4),
+                'allreduce_MB_per_step': round(sum(b for _, _, b in recs) / args.steps / 1e6, 2),
+                'note': 'HIP events on the second (comm) stream around each gradient / loss-term all-reduce; they run '
+                        'under the backward and discriminator kernels of the compute stream'}
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
@@ -233,6 +282,8 @@ def main():
             'last_losses': {k: round(v, 5) for k, v in last.items()},
             'roofline': roofline,
         }
+        if comm is not None:
+            out['comm'] = comm
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         elif world == 1:
@@ -244,7 +295,7 @@ def main():
                    for k, v in sorted(per_step_all.items(), key=lambda kv: -kv[1]['ms'])}
         out['conv_kernels'] = kernels
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -55,6 +55,19 @@ extern "C" {
 #define PG_ALGO_BF16 3   /* same kernels with operand tiles rounded to bf16 in LDS and v_mfma_f32_32x32x16_bf16 (fp32
                             tensors, fp32 accumulate); layers the fast path does not cover fall back to fp32 */
 
+#define PG_ALGO_MASK 0xF
+/* Per-call tuning bits, OR-ed into the `algo` argument of the three conv entry points (and into pg_conv_describe's op as
+ * op + 16 * (PG_ALGO_* | PG_TUNE_*)).  They override the size heuristics of PG_ALGO_AUTO (and the process-wide PATCHGAN_*
+ * environment defaults that exist for A/B timing); results stay inside the stated per-kernel tolerances either way. */
+#define PG_TUNE_WINO2_ALL 0x010   /* polyphase Winograd forward / data gradient on every stride-2 layer the geometry allows */
+#define PG_TUNE_WINO2_OFF 0x020   /* ... on none */
+#define PG_TUNE_WINO2W_ALL 0x040  /* polyphase Winograd weight gradient on every stride-2 layer the geometry allows */
+#define PG_TUNE_WINO2W_OFF 0x080  /* ... on none */
+#define PG_TUNE_WINO_OFF 0x100    /* no Winograd path at all: the kernels of PG_ALGO_MFMA */
+#define PG_TUNE_WINOW_OFF 0x200   /* stride-1 weight gradient on the implicit GEMM */
+#define PG_TUNE_WINO1_F2 0x400    /* stride-1 forward / data gradient: F(2x2,4x4) tiles */
+#define PG_TUNE_WINO1_F3 0x800    /* ... F(3x3,4x4) tiles (needs Cin % 64 == 0) */
+
 typedef struct pg_conv_geom {
     int N;        /* batch */
     int Hb, Wb;   /* big spatial extent  (conv input  / convT output) */
@@ -67,7 +80,8 @@ typedef struct pg_conv_geom {
 int pg_version(void);
 
 /* Bytes of workspace that lets op (0 = big2small, 1 = small2big, 2 = wgrad) use its preferred
- * split-K factor for geometry g.  A smaller (or NULL) workspace is legal: the split shrinks. */
+ * split-K factor / Winograd path for geometry g under ANY algo / PG_TUNE_* combination.  A smaller (or NULL) workspace is
+ * legal: the split shrinks, the Winograd paths fall back to the implicit GEMM. */
 size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);
 
 /* Reports which kernel the MFMA path of op would launch for g with a workspace of ws_bytes: tile_id
@@ -82,6 +96,13 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);
  * k_wino_wgrad_gemm<2,2,2,2> with split = its K slices (op 2; 63: 64x64 tiles <1,1,2,2>; 61 / 62: its polyphase stride-2 form with 128x128 / 64x64 tiles), 70 / 71 = k_wino_bgemm<2,2,2,2> / <1,2,2,2>, 72 / 73 = k_wino_bgemm_mz<...> (polyphase
  * Winograd of a stride-2 layer, ops 0/1).  For profiling only. */
 int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups);
+
+/* The kernel symbol (as rocprofv3 prints it, without the namespace / argument list) of the main GEMM kernel that op would
+ * launch -- the same decision code as the entry points, so profiles can be attributed without re-deriving the dispatch --
+ * its split-K factor, and the FLOPs that kernel executes on the MFMA pipe (the direct-convolution count 2*N*Hs*Ws*16*Ca*Cb
+ * for the implicit-GEMM kernels, 2.25-4x fewer for the Winograd kernels, ragged tiles included).  `op` as in
+ * pg_conv_describe.  For profiling only. */
+int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, size_t name_len, int* split, double* mfma_flops);
 
 /* Arms per-launch timing: the NEXT pg_conv4x4_* call on this thread records the caller-owned hipEvent_t `ev_start`
  * immediately before and `ev_stop` immediately after its main GEMM kernel on the launch stream (the split-K reduce, the

@@ -14,6 +14,10 @@ ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 ACT_CODES = {None: ACT_NONE, 'none': ACT_NONE, 'leakyrelu': ACT_LEAKY, 'relu': ACT_RELU, 'tanh': ACT_TANH,
              'sigmoid': ACT_SIGMOID}
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_BF16 = 0, 1, 2, 3
+ALGO_MASK = 0xF
+# per-call tuning bits OR-ed into `algo` (include/patchgan_hip.h PG_TUNE_*)
+TUNE_WINO2_ALL, TUNE_WINO2_OFF, TUNE_WINO2W_ALL, TUNE_WINO2W_OFF = 0x010, 0x020, 0x040, 0x080
+TUNE_WINO_OFF, TUNE_WINOW_OFF, TUNE_WINO1_F2, TUNE_WINO1_F3 = 0x100, 0x200, 0x400, 0x800
 LOSS_TVERSKY, LOSS_WBCE, LOSS_MAE, LOSS_BCE = 0, 1, 2, 3
 OP_BIG2SMALL, OP_SMALL2BIG, OP_WGRAD = 0, 1, 2
 
@@ -43,6 +47,7 @@ SIGNATURES = {
     'pg_version': (_i, []),
     'pg_conv_workspace_bytes': (_sz, [_G, _i]),
     'pg_conv_describe': (_i, [_G, _i, _sz, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_l)]),
+    'pg_conv_kernel': (_i, [_G, _i, _sz, ctypes.c_char_p, _sz, ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double)]),
     'pg_conv_time_next': (_i, [_p, _p]),
     'pg_conv4x4_big2small': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p]),
     'pg_conv4x4_small2big': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p]),

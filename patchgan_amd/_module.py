@@ -51,9 +51,18 @@ class FlatParamModule(nn.Module):
         MFMA, fp32 accumulation; weights, activations, InstanceNorm statistics and Adam stay fp32).  Returns self."""
         from . import _lib as L
         algo = {'fp32': L.ALGO_AUTO, 'bf16': L.ALGO_BF16}[precision]
-        self.engine.algo = algo
+        self.engine.algo = algo | (self.engine.algo & ~L.ALGO_MASK)
         self.engine._ops = {}
         self.precision = precision
+        return self
+
+    def set_tuning(self, bits):
+        """Per-call PG_TUNE_* bits (patchgan_amd._lib.TUNE_*) for every convolution of this network: overrides the kernel
+        selection heuristics (e.g. TUNE_WINO2_ALL forces the polyphase Winograd path wherever the geometry allows,
+        TUNE_WINO_OFF gives the exact implicit GEMM everywhere).  Returns self."""
+        from . import _lib as L
+        self.engine.algo = (self.engine.algo & L.ALGO_MASK) | int(bits)
+        self.engine._ops = {}
         return self
 
     def ensure_grad_flat(self):

@@ -14,6 +14,7 @@
 // K-contiguous operands are read from LDS as one ds_read_b128 per lane per 8 k: lane (row, h) takes
 // k = 8*kk + 4*h + j (j = 0..3) for MFMA j, the same permutation of K on both operands.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <alloca.h>
@@ -829,13 +830,7 @@ constexpr int OOB = 0x7fffffff;
 #define PIN_VMEM() __builtin_amdgcn_sched_barrier(0x386)
 // element offset -> byte offset without signed overflow (sentinel offsets exceed INT_MAX/4 on purpose)
 __device__ __forceinline__ int b4(int elem_off) { return (int)((unsigned)elem_off << 2); }
-// XCD-aware tile order (cdna_hip_programming.md T1): workgroups b and b+8 share an XCD (round-robin dispatch), so hand each
-// XCD a CONTIGUOUS run of M-tiles -- neighbouring tiles read overlapping input rows (conv halo) and the same weight
-// slice, which then hit that XCD's private L2 instead of going to the fabric.  Bijective for any grid size; speed only.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) { return pg_xcd_remap(bid, nblk); }   // pg_common.h
 
 // byte offset of a gather element, forced out of range (bit 31 set: >= 2 GiB > any descriptor here) when !ok.
 // Written as an OR so the offset arithmetic stays unconditional: with `ok ? off : OOB` hipcc sinks the arithmetic into
@@ -2530,59 +2525,78 @@ inline bool tapk_enabled() {
     }();
     return !off;
 }
-inline bool wino_enabled() {
-    static const bool off = [] {
-        const char* e = getenv("PATCHGAN_NO_WINOGRAD");
-        return e && e[0] == '1';
-    }();
-    return !off && !force_generic();
+// Per-call tuning: the PG_TUNE_* bits of the `algo` argument over the process-wide defaults (the PATCHGAN_* environment
+// switches, read once: they exist for same-device A/B timing; tests and callers use the bits).
+struct Tune {
+    bool wino;      // any Winograd path
+    bool winow;     // stride-1 Winograd weight gradient
+    int wino2;      // polyphase stride-2 forward / data gradient: 0 off, 1 wherever the geometry allows, 2 size heuristic
+    int wino2w;     // polyphase stride-2 weight gradient: same codes
+    int mo1;        // stride-1 tile edge: 0 heuristic, 2 / 3 pinned
+};
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
-// stride-1 layers only: forward is a pad-1 correlation big -> small, the data gradient a pad-2 correlation small -> big
-inline bool wino_b2s_ok(const Geom& g) { return g.s == 1 && wino_enabled() && pg_wino_geom_ok(g.N, g.Hs, g.Ws, g.Cb, g.Ca); }
-// stride-2 big -> small polyphase Winograd: PATCHGAN_WINO2 = 0 off, 1 wherever the geometry allows, default: where the
-// channel counts are large against the tile count (measured per layer of cfg2, tools/layer_bench.py)
-inline bool wino2_b2s_ok(const Geom& g) {
-    static const int mode = [] {
-        const char* e = getenv("PATCHGAN_WINO2");
-        return e ? atoi(e) : 2;
+inline Tune tune_of(int algo) {
+    static const Tune env = [] {
+        Tune t;
+        t.wino = env_int("PATCHGAN_NO_WINOGRAD", 0) != 1;
+        t.winow = env_int("PATCHGAN_NO_WINOGRAD_WGRAD", 0) != 1;
+        t.wino2 = env_int("PATCHGAN_WINO2", 2);
+        t.wino2w = env_int("PATCHGAN_WINO2_WGRAD", 2);
+        t.mo1 = env_int("PATCHGAN_WINO1_TILE", 0);
+        return t;
     }();
-    if (g.s != 2 || mode == 0 || !wino_enabled() || !pg_wino2_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) return false;
-    if (mode == 1) return true;
+    Tune t = env;
+    if (algo & PG_TUNE_WINO_OFF) t.wino = false;
+    if (algo & PG_TUNE_WINOW_OFF) t.winow = false;
+    if (algo & PG_TUNE_WINO2_ALL) t.wino2 = 1;
+    if (algo & PG_TUNE_WINO2_OFF) t.wino2 = 0;
+    if (algo & PG_TUNE_WINO2W_ALL) t.wino2w = 1;
+    if (algo & PG_TUNE_WINO2W_OFF) t.wino2w = 0;
+    if (algo & PG_TUNE_WINO1_F2) t.mo1 = 2;
+    if (algo & PG_TUNE_WINO1_F3) t.mo1 = 3;
+    if (force_generic()) t.wino = false;
+    return t;
+}
+// every path on, for sizing a workspace that serves any tuning
+inline Tune tune_widest(int mo1) { return Tune{true, true, 1, 1, mo1}; }
+
+// stride-1 layers only: forward is a pad-1 correlation big -> small, the data gradient a pad-2 correlation small -> big
+inline bool wino_b2s_ok(const Geom& g, const Tune& t) {
+    return g.s == 1 && t.wino && pg_wino_geom_ok(g.N, g.Hs, g.Ws, g.Cb, g.Ca, t.mo1);
+}
+inline bool wino_s2b_ok(const Geom& g, const Tune& t) {
+    return g.s == 1 && t.wino && pg_wino_geom_ok(g.N, g.Hb, g.Wb, g.Ca, g.Cb, t.mo1);
+}
+// stride-2 big -> small polyphase Winograd: where the channel counts are large against the tile count (measured per
+// layer of cfg2, tools/layer_bench.py) unless the tuning forces it on / off
+inline bool wino2_b2s_ok(const Geom& g, const Tune& t) {
+    if (g.s != 2 || t.wino2 == 0 || !t.wino || !pg_wino2_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) return false;
+    if (t.wino2 == 1) return true;
     // measured on the cfg2 layers (F(3x3,2x2)): 128->256 ch -31 %, 256->512 on 16x16 -11 %, 256->1024 -25 %, 128->512 -35 %,
     // 64->256 -18 %, 64->128 -10..-16 %; 512->512 on 8x8 and smaller maps slower (weight transform dominates)
     return pg_wino2_tiles_b2s(g.N, g.Hs, g.Ws) >= 512 && g.Cb >= 64 && g.Ca >= 128;
 }
-inline bool wino2_s2b_ok(const Geom& g) {
-    static const int mode = [] {
-        const char* e = getenv("PATCHGAN_WINO2");
-        return e ? atoi(e) : 2;
-    }();
-    if (g.s != 2 || mode == 0 || !wino_enabled() || !pg_wino2c_geom_ok(g.N, g.Hb, g.Wb, g.Ca, g.Cb)) return false;
-    if (mode == 1) return true;
+inline bool wino2_s2b_ok(const Geom& g, const Tune& t) {
+    if (g.s != 2 || t.wino2 == 0 || !t.wino || !pg_wino2c_geom_ok(g.N, g.Hb, g.Wb, g.Ca, g.Cb)) return false;
+    if (t.wino2 == 1) return true;
     // measured on the cfg2 layers (F(3x3,2x2), shared windows): 128->64 ch -16..-18 %, 256->128 -23..-27 %, 512->256 -22 %,
     // 1024->256 -28 %, 512->128 -38 %, 256->64 -27 %; 8x8 maps and smaller: no gain (weight transform dominates)
     return pg_wino2_tiles_s2b(g.N, g.Hb, g.Wb) >= 512 && g.Cb >= 64 && g.Ca >= 128;
 }
-inline bool wino2_wgrad_ok(const Geom& g) {
-    static const int mode = [] {
-        const char* e = getenv("PATCHGAN_WINO2_WGRAD");
-        return e ? atoi(e) : 2;
-    }();
-    if (g.s != 2 || mode == 0 || !wino_enabled() || !pg_wino2_wgrad_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) return false;
-    if (mode == 1) return true;
+inline bool wino2_wgrad_ok(const Geom& g, const Tune& t) {
+    if (g.s != 2 || t.wino2w == 0 || !t.wino || !pg_wino2_wgrad_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) return false;
+    if (t.wino2w == 1) return true;
     // measured on the cfg2 layers (64x64 output tiles unless 128x128 ones alone fill the chip): 256x128 ch -16 %, 512x256 -20 %,
     // 512x128 -17 %, 256x64 -15 %, 1024x256 +-0; 128 small-side channels: slower than the implicit GEMM (+35 %)
     const long T = (long)g.N * ((g.Hs + 2) / 3) * ((g.Ws + 2) / 3);
     return T >= 512 && g.Ca >= 256 && g.Cb >= 64;
 }
-inline bool wino_wgrad_ok(const Geom& g) {
-    static const bool off = [] {
-        const char* e = getenv("PATCHGAN_NO_WINOGRAD_WGRAD");
-        return e && e[0] == '1';
-    }();
-    return g.s == 1 && !off && wino_enabled() && pg_wino_wgrad_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb);
+inline bool wino_wgrad_ok(const Geom& g, const Tune& t) {
+    return g.s == 1 && t.winow && t.wino && pg_wino_wgrad_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb);
 }
-inline bool wino_s2b_ok(const Geom& g) { return g.s == 1 && wino_enabled() && pg_wino_geom_ok(g.N, g.Hb, g.Wb, g.Ca, g.Cb); }
 
 }  // namespace
 
@@ -2599,16 +2613,18 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
     const Geom gq = to_geom(g);
     if (op == 0 && b2s_tapn_ok(gq)) bytes = std::max(bytes, b2s_tapn_ws(gq));
     if (op == 1 && s2b_tapn_ok(gq)) bytes = std::max(bytes, s2b_tapn_ws(gq) + 256);
-    if (op == 0 && wino_b2s_ok(gq)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca));
-    if (op == 1 && wino_s2b_ok(gq)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb));
-    if (op == 0 && wino2_b2s_ok(gq)) bytes = std::max(bytes, pg_wino2_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb));
-    if (op == 1 && wino2_s2b_ok(gq)) bytes = std::max(bytes, pg_wino2c_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb));
-    if (op == 2 && wino_wgrad_ok(gq))
-        bytes = std::max(bytes, pg_wino_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb) +
-                                    (((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255));
-    if (op == 2 && wino2_wgrad_ok(gq))
-        bytes = std::max(bytes, pg_wino2_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb) +
-                                    (((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255));
+    // enough for whichever Winograd path a PG_TUNE_* combination selects
+    for (int mo1 = 2; mo1 <= 3; ++mo1) {
+        const Tune t = tune_widest(mo1);
+        if (op == 0 && wino_b2s_ok(gq, t)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca, mo1));
+        if (op == 1 && wino_s2b_ok(gq, t)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb, mo1));
+    }
+    const Tune tw = tune_widest(0);
+    const size_t colsum = ((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255;
+    if (op == 0 && wino2_b2s_ok(gq, tw)) bytes = std::max(bytes, pg_wino2_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb));
+    if (op == 1 && wino2_s2b_ok(gq, tw)) bytes = std::max(bytes, pg_wino2c_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb));
+    if (op == 2 && wino_wgrad_ok(gq, tw)) bytes = std::max(bytes, pg_wino_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb) + colsum);
+    if (op == 2 && wino2_wgrad_ok(gq, tw)) bytes = std::max(bytes, pg_wino2_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb) + colsum);
     return (bytes + 255) & ~(size_t)255;
 }
 
@@ -2619,7 +2635,9 @@ int pg_conv_time_next(void* ev_start, void* ev_stop) {
 }
 
 int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups) {
-    const int algo = op >> 4;      // op = opcode + 16 * PG_ALGO_*: the Winograd codes are reported for PG_ALGO_AUTO only
+    const int algo_full = op >> 4;      // op = opcode + 16 * (PG_ALGO_* | PG_TUNE_*): the Winograd codes are reported for PG_ALGO_AUTO only
+    const int algo = algo_full & PG_ALGO_MASK;
+    const Tune tune = tune_of(algo_full);
     op &= 15;
     if (!geom_ok(g) || op < 0 || op > 2 || algo < PG_ALGO_AUTO || algo > PG_ALGO_BF16) return PG_EINVAL;
     Plan p = (op == 0) ? plan_b2s(g) : (op == 1) ? plan_s2b(g) : plan_wgrad(g);
@@ -2650,10 +2668,10 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
     // split-K); the tile / split
     // reported are those of the implicit-GEMM kernel the other algos use
     if (algo == PG_ALGO_AUTO &&
-        ((op == 0 && wino_b2s_ok(gq) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca)) ||
-         (op == 1 && wino_s2b_ok(gq) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb)))) {
-        const bool st = (op == 0) ? pg_wino_small_tile(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca) : pg_wino_small_tile(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb);
-        const int mo1 = (op == 0) ? pg_wino_mo(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca) : pg_wino_mo(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb);
+        ((op == 0 && wino_b2s_ok(gq, tune) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca, tune.mo1)) ||
+         (op == 1 && wino_s2b_ok(gq, tune) && ws_bytes >= pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb, tune.mo1)))) {
+        const bool st = (op == 0) ? pg_wino_small_tile(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca, tune.mo1) : pg_wino_small_tile(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb, tune.mo1);
+        const int mo1 = (op == 0) ? pg_wino_mo(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca, tune.mo1) : pg_wino_mo(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb, tune.mo1);
         if (tile_id) *tile_id += (mo1 == 3) ? 90 : (st ? 50 : 40);     // +90: F(3x3,4x4) variant k_wino_gemm<1,1,2,2,2,3>
     }
     // 81..83: one-shot k_b2s_tapk<Cb> for 1..3 big-side channels
@@ -2665,14 +2683,14 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         return PG_OK;
     }
     // 70 / 71: polyphase Winograd of a stride-2 layer (k_wino_bgemm<2,2,2,2> / <1,2,2,2>); 72 / 73: k_wino_bgemm_mz
-    if (algo == PG_ALGO_AUTO && op == 0 && wino2_b2s_ok(gq) && ws_bytes >= pg_wino2_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
+    if (algo == PG_ALGO_AUTO && op == 0 && wino2_b2s_ok(gq, tune) && ws_bytes >= pg_wino2_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
         const long T = pg_wino2_tiles_b2s(g->N, g->Hs, g->Ws), X = (long)(pg_wino2_mo() + 1) * (pg_wino2_mo() + 1);
         if (tile_id) *tile_id = (T >= 1024 ? 70 : 71) + (pg_wino2_b2s_zb(g->N, g->Hs, g->Ws, g->Ca) > 1 ? 2 : 0);
         if (split) *split = 1;
         if (workgroups) *workgroups = X * ((T + (T >= 1024 ? 127 : 63)) / (T >= 1024 ? 128 : 64)) * ((g->Ca + 127) / 128);
         return PG_OK;
     }
-    if (algo == PG_ALGO_AUTO && op == 1 && wino2_s2b_ok(gq) && ws_bytes >= pg_wino2c_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb)) {
+    if (algo == PG_ALGO_AUTO && op == 1 && wino2_s2b_ok(gq, tune) && ws_bytes >= pg_wino2c_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb)) {
         const long T = pg_wino2_tiles_s2b(g->N, g->Hb, g->Wb), X = (long)(pg_wino2_mo() + 1) * (pg_wino2_mo() + 1);
         if (tile_id) *tile_id = (T >= 1024 ? 70 : 71) + (pg_wino2_s2b_zb(g->N, g->Hb, g->Wb, g->Cb) > 1 ? 2 : 0);
         if (split) *split = 1;
@@ -2680,7 +2698,7 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         return PG_OK;
     }
     // 61 / 62: polyphase F(2x2, 3x3) weight gradient of a stride-2 layer (k_wino_wgrad_gemm<2,2,2,2> / <1,1,2,2>)
-    if (algo == PG_ALGO_AUTO && op == 2 && wino2_wgrad_ok(gq) &&
+    if (algo == PG_ALGO_AUTO && op == 2 && wino2_wgrad_ok(gq, tune) &&
         ws_bytes >= reserved + pg_wino2_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
         const int sl = pg_wino2_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb);
         if (tile_id) *tile_id = pg_wino2_wgrad_tile64(gq.Ca, gq.Cb) ? 62 : 61;
@@ -2689,7 +2707,7 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         return PG_OK;
     }
     // 60 / 63: Winograd F(4x4, 2x2) weight gradient (k_wino_wgrad_gemm<2,2,2,2> / <1,1,2,2>); split = its K slices
-    if (algo == PG_ALGO_AUTO && op == 2 && wino_wgrad_ok(gq) && ws_bytes >= reserved + pg_wino_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
+    if (algo == PG_ALGO_AUTO && op == 2 && wino_wgrad_ok(gq, tune) && ws_bytes >= reserved + pg_wino_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
         const bool t64 = pg_wino_wgrad_tile64(gq.Ca, gq.Cb);
         const int tt = t64 ? 64 : 128;
         if (tile_id) *tile_id = t64 ? 63 : 60;
@@ -2702,6 +2720,58 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
     return PG_OK;
 }
 
+int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, size_t name_len, int* split, double* mfma_flops) {
+    int code = 0, sp = 1;
+    long wgs = 0;
+    int rc = pg_conv_describe(g, op, ws_bytes, &code, &sp, &wgs);
+    if (rc != PG_OK) return rc;
+    const int algo_full = op >> 4, algo = algo_full & PG_ALGO_MASK, oc = op & 15;
+    const Tune tune = tune_of(algo_full);
+    static const char* const TILE[5] = {"2,2,2,2", "2,1,2,2", "1,1,4,1", "1,2,2,2", "1,1,2,2"};
+    const int fast = code / 100, rest = code % 100, tid = rest % 10, mode = rest / 10;
+    auto cd = [](long a, long b) { return (a + b - 1) / b; };
+    const double direct = 2.0 * g->N * g->Hs * g->Ws * 16.0 * g->Ca * g->Cb;
+    double fl = direct;
+    char buf[128];
+    if (algo == PG_ALGO_DIRECT) {
+        snprintf(buf, sizeof buf, "%s", oc == 0 ? "k_big2small_direct" : oc == 1 ? "k_small2big_direct" : "k_wgrad_direct");
+    } else if (mode == 6) {          // Winograd weight gradients: 60 / 63 stride 1 (F(4x4,2x2)), 61 / 62 polyphase stride 2
+        snprintf(buf, sizeof buf, "k_wino_wgrad_gemm<%s>", (tid == 2 || tid == 3) ? "1,1,2,2" : "2,2,2,2");
+        fl = (g->stride == 1) ? 2.0 * 25 * g->N * cd(g->Hs, 2) * cd(g->Ws, 2) * g->Ca * g->Cb
+                              : 2.0 * 16 * g->N * cd(g->Hs, 3) * cd(g->Ws, 3) * g->Ca * 4.0 * g->Cb;
+    } else if (mode == 8) {
+        snprintf(buf, sizeof buf, "k_b2s_tapk<%d>", tid);
+        sp = 1;
+    } else if (mode == 7) {          // polyphase Winograd of a stride-2 layer
+        snprintf(buf, sizeof buf, "k_wino_bgemm%s<%s>", tid >= 2 ? "_mz" : "", (tid & 1) ? "1,2,2,2" : "2,2,2,2");
+        const int mo = pg_wino2_mo();
+        fl = (oc == 0) ? 2.0 * (mo + 1) * (mo + 1) * g->N * cd(g->Hs, mo) * cd(g->Ws, mo) * 4.0 * g->Cb * g->Ca
+                       : 2.0 * 4 * (mo + 1) * (mo + 1) * g->N * cd(cd(g->Hb, 2) + 1, mo) * cd(cd(g->Wb, 2) + 1, mo) * (double)g->Ca * g->Cb;
+        sp = 1;
+    } else if (mode == 9 || mode == 4 || mode == 5) {     // stride-1 Winograd forward / data gradient
+        const int mo = mode == 9 ? 3 : 2;
+        snprintf(buf, sizeof buf, "k_wino_gemm<%s>", mode == 9 ? "1,1,2,2,2,3" : mode == 4 ? "2,1,2,2,2,2" : "1,1,2,2,4,2");
+        const int ho = oc == 0 ? g->Hs : g->Hb, wo = oc == 0 ? g->Ws : g->Wb;
+        fl = 2.0 * (mo + 3) * (mo + 3) * g->N * cd(ho, mo) * cd(wo, mo) * (double)g->Ca * g->Cb;
+        sp = 1;
+    } else if (mode == 3) {
+        snprintf(buf, sizeof buf, "k_b2s_fast<%s,true>+%s", TILE[tid], oc == 0 ? "k_gather_big2small" : "k_col2im_small2big");
+    } else if (mode) {
+        snprintf(buf, sizeof buf, "k_wgrad_tapn<%s,%d>", TILE[tid], mode);
+    } else {
+        const bool half = (algo == PG_ALGO_BF16) && fast;
+        if (fast && oc == 0) snprintf(buf, sizeof buf, "%s<%s,false>", half ? "k_b2s_bf16" : "k_b2s_fast", TILE[tid]);
+        else if (fast && oc == 1) snprintf(buf, sizeof buf, "%s<%s>", half ? "k_s2b_bf16" : "k_s2b_fast", TILE[tid]);
+        else if (fast) snprintf(buf, sizeof buf, "%s<%s,%s>", half ? "k_wgrad_bf16" : "k_wgrad_fast", TILE[tid], fast == 2 ? "true" : "false");
+        else snprintf(buf, sizeof buf, "%s<%s>", oc == 0 ? "k_big2small" : oc == 1 ? "k_small2big" : "k_wgrad", TILE[tid]);
+    }
+    (void)tune;
+    if (name && name_len) snprintf(name, name_len, "%s", buf);
+    if (split) *split = sp;
+    if (mfma_flops) *mfma_flops = fl;
+    return PG_OK;
+}
+
 int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const float* bias, float* small,
                          int ld_small, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
                          void* stream) {
@@ -2709,6 +2779,8 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
     if (act < PG_ACT_NONE || act > PG_ACT_SIGMOID) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     Geom g = to_geom(gg);
+    const Tune tune = tune_of(algo);
+    algo &= PG_ALGO_MASK;
     if (algo == PG_ALGO_DIRECT) {
         const long total = (long)g.N * g.Hs * g.Ws * g.Ca;
         int blocks = (int)std::min<long>((total + 255) / 256, 65536);
@@ -2717,15 +2789,15 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     if (!ws) ws_bytes = 0;
-    if (algo == PG_ALGO_AUTO && wino_b2s_ok(g) && aligned16(P) && aligned16(ws) &&
-        ws_bytes >= pg_wino_ws_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca) &&
-        pg_wino_eligible(g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, ld_big, big)) {
-        int rc = pg_wino_prepare(big, ld_big, P, 0, g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, 1, ws, st);
+    if (algo == PG_ALGO_AUTO && wino_b2s_ok(g, tune) && aligned16(P) && aligned16(ws) &&
+        ws_bytes >= pg_wino_ws_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1) &&
+        pg_wino_eligible(g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, ld_big, big, tune.mo1)) {
+        int rc = pg_wino_prepare(big, ld_big, P, 0, g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, 1, ws, st, tune.mo1);
         if (rc != PG_OK) return rc;
         TimedLaunch timed(st);
-        return pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st);
+        return pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st, tune.mo1);
     }
-    if (algo == PG_ALGO_AUTO && wino2_b2s_ok(g) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
+    if (algo == PG_ALGO_AUTO && wino2_b2s_ok(g, tune) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
         aligned16(small) && aligned16(ws) && (!bias || aligned16(bias)) &&
         ws_bytes >= pg_wino2_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) {
         hipEvent_t e0 = t_ev0, e1 = t_ev1;
@@ -2811,6 +2883,8 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
     if (act < PG_ACT_NONE || act > PG_ACT_SIGMOID) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     Geom g = to_geom(gg);
+    const Tune tune = tune_of(algo);
+    algo &= PG_ALGO_MASK;
     if (algo == PG_ALGO_DIRECT) {
         const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
         int blocks = (int)std::min<long>((total + 255) / 256, 65536);
@@ -2819,15 +2893,15 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     if (!ws) ws_bytes = 0;
-    if (algo == PG_ALGO_AUTO && wino_s2b_ok(g) && aligned16(P) && aligned16(ws) &&
-        ws_bytes >= pg_wino_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb) &&
-        pg_wino_eligible(g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, ld_small, small)) {
-        int rc = pg_wino_prepare(small, ld_small, P, 1, g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, 2, ws, st);
+    if (algo == PG_ALGO_AUTO && wino_s2b_ok(g, tune) && aligned16(P) && aligned16(ws) &&
+        ws_bytes >= pg_wino_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1) &&
+        pg_wino_eligible(g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, ld_small, small, tune.mo1)) {
+        int rc = pg_wino_prepare(small, ld_small, P, 1, g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, 2, ws, st, tune.mo1);
         if (rc != PG_OK) return rc;
         TimedLaunch timed(st);
-        return pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st);
+        return pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st, tune.mo1);
     }
-    if (algo == PG_ALGO_AUTO && wino2_s2b_ok(g) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
+    if (algo == PG_ALGO_AUTO && wino2_s2b_ok(g, tune) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
         aligned16(small) && aligned16(ws) && (!bias || aligned16(bias)) &&
         ws_bytes >= pg_wino2c_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb)) {
         hipEvent_t e0 = t_ev0, e1 = t_ev1;
@@ -2906,6 +2980,8 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
     if (!geom_ok(gg) || !big || !dP || !small || ld_big < gg->Cb || ld_small < gg->Ca) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     Geom g = to_geom(gg);
+    const Tune tune = tune_of(algo);
+    algo &= PG_ALGO_MASK;
     if (!ws) ws_bytes = 0;
     const long Kp = (long)g.N * g.Hs * g.Ws;
     size_t reserved = 0;
@@ -2940,7 +3016,7 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
         if (slices == 1) return PG_OK;
         return launch_reduce(dst, per, slices, dP, g.Cb, 16L * g.Ca, g.Cb, nullptr, 0, st);
     }
-    if (algo == PG_ALGO_AUTO && wino_wgrad_ok(g) && (ld_small % 4 == 0) && (ld_big % 4 == 0) && aligned16(small) &&
+    if (algo == PG_ALGO_AUTO && wino_wgrad_ok(g, tune) && (ld_small % 4 == 0) && (ld_big % 4 == 0) && aligned16(small) &&
         aligned16(big) && aligned16(ws) && ws_bytes >= reserved + pg_wino_wgrad_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) {
         hipEvent_t e0 = t_ev0, e1 = t_ev1;
         t_ev0 = nullptr;
@@ -2948,7 +3024,7 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
         return pg_wino_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, (char*)ws + reserved, st,
                              e0, e1);
     }
-    if (algo == PG_ALGO_AUTO && wino2_wgrad_ok(g) && (ld_small % 4 == 0) && (ld_big % 4 == 0) && aligned16(small) &&
+    if (algo == PG_ALGO_AUTO && wino2_wgrad_ok(g, tune) && (ld_small % 4 == 0) && (ld_big % 4 == 0) && aligned16(small) &&
         aligned16(big) && aligned16(ws) && aligned16(dP) && ws_bytes >= reserved + pg_wino2_wgrad_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) {
         hipEvent_t e0 = t_ev0, e1 = t_ev1;
         t_ev0 = nullptr;

@@ -5,19 +5,20 @@
 #include <stddef.h>
 
 // geometry + alignment gate; (in, out) = (big, small) forward, (small, big) data gradient
-bool pg_wino_eligible(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ld_in, const void* in);
-bool pg_wino_geom_ok(int N, int Hout, int Wout, int Cin, int Cout);
-int pg_wino_mo(int N, int Hout, int Wout, int Cin, int Cout);     // 2: F(2x2,4x4), 3: F(3x3,4x4) where its 64x64 grid fills the chip
+// mo_forced: 0 = tile-edge heuristic, 2 / 3 = F(2x2,4x4) / F(3x3,4x4) pinned (PG_TUNE_WINO1_F2 / _F3)
+bool pg_wino_eligible(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ld_in, const void* in, int mo_forced);
+bool pg_wino_geom_ok(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced);
+int pg_wino_mo(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced);     // 2: F(2x2,4x4), 3: F(3x3,4x4) where its 64x64 grid fills the chip
 // true: k_wino_gemm<1,1,2,2> (64-tile rows), false: <2,1,2,2> (128-tile rows)
-bool pg_wino_small_tile(int N, int Hout, int Wout, int Cin, int Cout);
+bool pg_wino_small_tile(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced);
 // U (25*Cout*Cin floats) followed by V (25*tiles*Cin floats), each 256-byte aligned
-size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout);
+size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced);
 // weight transform + input transform into ws
 int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N, int Hin, int Win, int Cin, int Hout,
-                    int Wout, int Cout, int pad, void* ws, hipStream_t st);
+                    int Wout, int Cout, int pad, void* ws, hipStream_t st, int mo_forced);
 // the batched GEMM with fused output transform, bias and activation
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
-                 void* ws, hipStream_t st);
+                 void* ws, hipStream_t st, int mo_forced);
 
 // weight gradient of the same layers, F(4x4, 2x2): V (25*tiles*Cb) | DY (25*tiles*Ca) | S (slices*25*Ca*Cb) in ws
 bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);

@@ -161,7 +161,7 @@ template <int MR, int NR, int WM, int WN, int WPE, int MO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_gemm(const float* __restrict__ V, const float* __restrict__ U,
                                                    const float* __restrict__ bias, float* __restrict__ out, int ld_out,
                                                    int T, int Ci, int Co, int TH, int TW, int Hout, int Wout, int act,
-                                                   int v_bytes, int u_bytes) {
+                                                   int v_bytes, int u_bytes, int tiles_n) {
     static_assert(NR == 1 && WM * WN == 4, "one 32-column MFMA tile per wave");
     constexpr int NP = MO + 3, NXI = NP * NP, NY = MO * MO;      // points, products, outputs per tile
     // K chunk: 64 floats for the F(3x3,4x4) instance (its workgroup tile is only 64 x 64: twice the MFMAs per barrier pair)
@@ -176,7 +176,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // 1-D grid: work index w = tile block * tiles_n + channel block, each XCD a contiguous run of w -- the tiles_n workgroups
+    // that read one slab of V sit next to each other on one XCD (one fabric fetch of V instead of tiles_n), and every XCD walks
+    // xi in step, so the current U[xi] slab (Co*Ci floats) stays in its L2
+    const int w = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (w / tiles_n) * BM, n0 = (w % tiles_n) * BN;
     const int nch = Ci / KCL, total = NXI * nch;
     const int kq = tid % QR, r0 = tid / QR;
 
@@ -341,11 +345,13 @@ __global__ __launch_bounds__(256) void k_wino_dy(const float* __restrict__ dy, i
             *reinterpret_cast<f32x4*>(DY + ((long)(a * 5 + b) * T + tile) * Ca + c0) = t[a][0] * c_G2[b][0] + t[a][1] * c_G2[b][1];
 }
 
-// grid (tilesA * tilesB, 25, slices); both operands are K-major (K = tiles): rows of Ca resp. Cb floats
+// 1-D grid of tilesA * tilesB * NX * slices workgroups; work index = ((slice * NX + xi) * tilesA + tile_a) * tilesB + tile_b,
+// each XCD a contiguous run of it: the tilesA * tilesB workgroups that share the DY[xi] / V[xi] slabs of one K slice run
+// together on one XCD.  Both operands are K-major (K = tiles): rows of Ca resp. Cb floats
 template <int MR, int NR, int WM, int WN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wino_wgrad_gemm(const float* __restrict__ DY, const float* __restrict__ V,
                                                          float* __restrict__ S, int T, int Ca, int Cb, int chunks_per_slice,
-                                                         int tilesB, int dy_bytes, int v_bytes) {
+                                                         int tilesA, int tilesB, int NX, int dy_bytes, int v_bytes) {
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int AQ = BM / 4, AROWS = 256 / AQ, AI = KC / AROWS;
@@ -358,11 +364,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = lane & 31, lh = lane >> 5;
-    const int tile_a = blockIdx.x / tilesB, tile_b = blockIdx.x % tilesB;
+    int w = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_b = w % tilesB;
+    w /= tilesB;
+    const int tile_a = w % tilesA;
+    w /= tilesA;
+    const int xi = w % NX, slice = w / NX;
     const int m0 = tile_a * BM, n0 = tile_b * BN;
-    const int xi = blockIdx.y;
     const int nchunks = (T + KC - 1) / KC;
-    const int c_begin = blockIdx.z * chunks_per_slice;
+    const int c_begin = slice * chunks_per_slice;
     const int c_end = min(nchunks, c_begin + chunks_per_slice);
     const int aq = tid % AQ, arow0 = tid / AQ;
     const int bq = tid % BQ, brow0 = tid / BQ;
@@ -422,7 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             __syncthreads();
         }
     }
-    float* o = S + ((long)blockIdx.z * gridDim.y + xi) * Ca * Cb;
+    float* o = S + ((long)slice * NX + xi) * Ca * Cb;
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -596,7 +606,7 @@ __global__ __launch_bounds__(256) void k_wino2_v(const float* __restrict__ big, 
 template <int MR, int NR, int WM, int WN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wino_bgemm(const float* __restrict__ A, const float* __restrict__ B,
                                                     float* __restrict__ C, int Mrows, int Ncols, int K, int a_bytes,
-                                                    int b_bytes) {
+                                                    int b_bytes, int tiles_m, int tiles_n) {
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32, AI = BM / 32, BI = BN / 32;
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
     float* As = smem;
@@ -606,7 +616,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+    // 1-D grid, work index = (z * tiles_m + tm) * tiles_n + tn, each XCD a contiguous run: the tiles_n workgroups that read
+    // one 128-row slab of A[z] are neighbours on one XCD, and an XCD stays on one batch z (one B[z]) for a long stretch
+    int w = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (w % tiles_n) * BN;
+    w /= tiles_n;
+    const int m0 = (w % tiles_m) * BM, z = w / tiles_m;
     const int nch = K / KC;
     const int kq = tid & 7, r0 = tid >> 3;
     int a_off[AI], b_off[BI];
@@ -694,7 +709,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 template <int MR, int NR, int WM, int WN>
 __global__ __launch_bounds__(256) void k_wino_bgemm_mz(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, int Mrows, int Ncols, int K, int zb, int a_bytes,
-                                                    int b_bytes) {
+                                                       int b_bytes, int tiles_m, int tiles_n) {
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32, AI = BM / 32, BI = BN / 32;
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
     float* As = smem;
@@ -704,7 +719,10 @@ __global__ __launch_bounds__(256) void k_wino_bgemm_mz(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z0 = blockIdx.z * zb;
+    int w = pg_xcd_remap(blockIdx.x, gridDim.x);          // work order as in k_wino_bgemm, z = group of zb batches
+    const int n0 = (w % tiles_n) * BN;
+    w /= tiles_n;
+    const int m0 = (w % tiles_m) * BM, z0 = (w / tiles_m) * zb;
     const int nch = K / KC, total = zb * nch;
     const int kq = tid & 7, r0 = tid >> 3;
     int a_off[AI], b_off[BI];
@@ -1015,63 +1033,60 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
 
-// output tile edge of the stride-1 forward / data-gradient path: 2 = F(2x2,4x4), 3 = F(3x3,4x4) (PATCHGAN_WINO1_TILE)
+// output tile edge of the stride-1 forward / data-gradient path: 2 = F(2x2,4x4), 3 = F(3x3,4x4); `forced` = 2 / 3 pins it
+// (PG_TUNE_WINO1_F2 / _F3, PATCHGAN_WINO1_TILE), 0 = heuristic.
 // F(3x3,4x4) keeps nine output accumulator sets per lane, so its workgroup tile is 64 tiles x 64 channels at 2 waves per SIMD:
 // it is used when that grid still fills the chip (>= 240 workgroups), F(2x2,4x4) otherwise.
-int pg_wino_mo(int N, int Hout, int Wout, int Cin, int Cout) {
-    static const int forced = [] {
-        const char* e = getenv("PATCHGAN_WINO1_TILE");
-        return e ? atoi(e) : 0;
-    }();
+int pg_wino_mo(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
     if (Cin % 64 != 0) return 2;                 // the F(3x3,4x4) instance walks K in chunks of 64
     if (forced == 2 || forced == 3) return forced;
     const long T3 = (long)N * ((Hout + 2) / 3) * ((Wout + 2) / 3);
-    return ((T3 + 63) / 64) * ((Cout + 63) / 64) >= 240 ? 3 : 2;     // (callers fall back to 2 when Cin % 64 != 0)
+    return ((T3 + 63) / 64) * ((Cout + 63) / 64) >= 240 ? 3 : 2;
 }
-static long wino1_tiles(int N, int Hout, int Wout, int Cin, int Cout) {
-    const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout);
+static long wino1_tiles(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
+    const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced);
     return (long)N * ((Hout + mo - 1) / mo) * ((Wout + mo - 1) / mo);
 }
-static long wino1_nxi(int N, int Hout, int Wout, int Cin, int Cout) {
-    const int np = pg_wino_mo(N, Hout, Wout, Cin, Cout) + 3;
+static long wino1_nxi(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
+    const int np = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced) + 3;
     return (long)np * np;
 }
 
-bool pg_wino_geom_ok(int N, int Hout, int Wout, int Cin, int Cout) {
+bool pg_wino_geom_ok(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
     if (Cin % 32 != 0 || Cin < 64 || Cout < 64) return false;
-    const long T = wino1_tiles(N, Hout, Wout, Cin, Cout), X = wino1_nxi(N, Hout, Wout, Cin, Cout);
+    const long T = wino1_tiles(N, Hout, Wout, Cin, Cout, forced), X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
     if ((long)N * ((Hout + 1) / 2) * ((Wout + 1) / 2) < 2048) return false;       // needs enough tiles to fill the chip
     if ((double)X * T * Cin * 4 >= 1.5e9 || (double)X * Cout * Cin * 4 >= 1.0e9) return false;   // 32-bit buffer offsets
     return true;
 }
 
-bool pg_wino_eligible(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ld_in, const void* in) {
+bool pg_wino_eligible(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ld_in, const void* in, int forced) {
     (void)Hin;
     (void)Win;
-    return pg_wino_geom_ok(N, Hout, Wout, Cin, Cout) && ld_in % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    return pg_wino_geom_ok(N, Hout, Wout, Cin, Cout, forced) && ld_in % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
 }
 
 // 128-tile rows unless that leaves the 256 CUs short of two workgroups each
-bool pg_wino_small_tile(int N, int Hout, int Wout, int Cin, int Cout) {
+bool pg_wino_small_tile(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced) {
     static const int forced = [] {
         const char* e = getenv("PATCHGAN_WINO_TILE");
         return e ? atoi(e) : 0;
     }();
-    if (pg_wino_mo(N, Hout, Wout, Cin, Cout) == 3) return true;          // nine output accumulator sets: 64-tile rows only
+    if (pg_wino_mo(N, Hout, Wout, Cin, Cout, mo_forced) == 3) return true;          // nine output accumulator sets: 64-tile rows only
     const long T = (long)N * ((Hout + 1) / 2) * ((Wout + 1) / 2);
     const long wg128 = ((T + 127) / 128) * ((Cout + 63) / 64);
     return forced ? forced == 1 : wg128 < 400;
 }
 
-size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout) {
-    const long T = wino1_tiles(N, Hout, Wout, Cin, Cout), X = wino1_nxi(N, Hout, Wout, Cin, Cout);
+size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
+    const long T = wino1_tiles(N, Hout, Wout, Cin, Cout, forced), X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
     return align256((size_t)X * Cout * Cin * 4) + align256((size_t)X * T * Cin * 4);
 }
 
 int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N, int Hin, int Win, int Cin, int Hout,
-                    int Wout, int Cout, int pad, void* ws, hipStream_t st) {
-    const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
-    const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout);
+                    int Wout, int Cout, int pad, void* ws, hipStream_t st, int forced) {
+    const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
+    const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
     float* U = (float*)ws;
     float* V = (float*)((char*)ws + align256((size_t)X * Cout * Cin * 4));
     const dim3 gu((unsigned)(((long)Cout * Cin + 255) / 256)), gv((unsigned)((T * (Cin / 4) + 255) / 256));
@@ -1088,25 +1103,26 @@ int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N,
 }
 
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
-                 void* ws, hipStream_t st) {
-    const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
-    const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout);
+                 void* ws, hipStream_t st, int forced) {
+    const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
+    const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
     const float* U = (const float*)ws;
     const float* V = (const float*)((const char*)ws + align256((size_t)X * Cout * Cin * 4));
-    const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cin, Cout);
+    const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cin, Cout, forced);
     const int v_bytes = (int)(X * T * Cin * 4), u_bytes = (int)(X * Cout * Cin * 4);
+    const int tn = (Cout + 63) / 64;
     if (mo == 3) {
-        dim3 grid((unsigned)((T + 63) / 64), (Cout + 63) / 64, 1);
+        dim3 grid((unsigned)(((T + 63) / 64) * tn));
         hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 2, 3>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
-                           TW, Hout, Wout, act, v_bytes, u_bytes);
+                           TW, Hout, Wout, act, v_bytes, u_bytes, tn);
     } else if (small_tile) {
-        dim3 grid((unsigned)((T + 63) / 64), (Cout + 63) / 64, 1);
+        dim3 grid((unsigned)(((T + 63) / 64) * tn));
         hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 4, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
-                           TW, Hout, Wout, act, v_bytes, u_bytes);
+                           TW, Hout, Wout, act, v_bytes, u_bytes, tn);
     } else {
-        dim3 grid((unsigned)((T + 127) / 128), (Cout + 63) / 64, 1);
+        dim3 grid((unsigned)(((T + 127) / 128) * tn));
         hipLaunchKernelGGL((k_wino_gemm<2, 1, 2, 2, 2, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
-                           TW, Hout, Wout, act, v_bytes, u_bytes);
+                           TW, Hout, Wout, act, v_bytes, u_bytes, tn);
     }
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
@@ -1164,12 +1180,12 @@ int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big
     if (ev0) (void)hipEventRecord(ev0, st);
     if (pg_wino_wgrad_tile64(Ca, Cb)) {
         const int tilesA = (Ca + 63) / 64, tilesB = (Cb + 63) / 64;
-        hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB, 25, slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                           Cb, cps, tilesB, (int)(25L * T * Ca * 4), (int)(25L * T * Cb * 4));
+        hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB * 25 * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                           Cb, cps, tilesA, tilesB, 25, (int)(25L * T * Ca * 4), (int)(25L * T * Cb * 4));
     } else {
         const int tilesA = (Ca + 127) / 128, tilesB = (Cb + 127) / 128;
-        hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB, 25, slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                           Cb, cps, tilesB, (int)(25L * T * Ca * 4), (int)(25L * T * Cb * 4));
+        hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB * 25 * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                           Cb, cps, tilesA, tilesB, 25, (int)(25L * T * Ca * 4), (int)(25L * T * Cb * 4));
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
@@ -1237,22 +1253,19 @@ static int wino2_b2s_run(const float* big, int ld_big, const float* P, const flo
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     if (ev0) (void)hipEventRecord(ev0, st);
     const int a_bytes = (int)((long)X * T * K * 4), b_bytes = (int)((long)X * Ca * K * 4);
-    if (T >= 1024) {
-        const int zb = bgemm_zb(((T + 127) / 128) * ((Ca + 127) / 128), X);
-        if (zb > 1)
-            hipLaunchKernelGGL((k_wino_bgemm_mz<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (Ca + 127) / 128, X / zb), dim3(256),
-                               0, st, V, U, M, (int)T, Ca, K, zb, a_bytes, b_bytes);
+    {
+        const int big_rows = T >= 1024;
+        const int tm = (int)(big_rows ? (T + 127) / 128 : (T + 63) / 64), tn = (Ca + 127) / 128;
+        const int zb = bgemm_zb((long)tm * tn, X);
+        const dim3 grid((unsigned)(tm * tn * (X / zb)));
+        if (big_rows && zb > 1)
+            hipLaunchKernelGGL((k_wino_bgemm_mz<2, 2, 2, 2>), grid, dim3(256), 0, st, V, U, M, (int)T, Ca, K, zb, a_bytes, b_bytes, tm, tn);
+        else if (big_rows)
+            hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), grid, dim3(256), 0, st, V, U, M, (int)T, Ca, K, a_bytes, b_bytes, tm, tn);
+        else if (zb > 1)
+            hipLaunchKernelGGL((k_wino_bgemm_mz<1, 2, 2, 2>), grid, dim3(256), 0, st, V, U, M, (int)T, Ca, K, zb, a_bytes, b_bytes, tm, tn);
         else
-            hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (Ca + 127) / 128, X), dim3(256), 0, st,
-                               V, U, M, (int)T, Ca, K, a_bytes, b_bytes);
-    } else {
-        const int zb = bgemm_zb(((T + 63) / 64) * ((Ca + 127) / 128), X);
-        if (zb > 1)
-            hipLaunchKernelGGL((k_wino_bgemm_mz<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (Ca + 127) / 128, X / zb), dim3(256), 0,
-                               st, V, U, M, (int)T, Ca, K, zb, a_bytes, b_bytes);
-        else
-            hipLaunchKernelGGL((k_wino_bgemm<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (Ca + 127) / 128, X), dim3(256), 0, st, V,
-                               U, M, (int)T, Ca, K, a_bytes, b_bytes);
+            hipLaunchKernelGGL((k_wino_bgemm<1, 2, 2, 2>), grid, dim3(256), 0, st, V, U, M, (int)T, Ca, K, a_bytes, b_bytes, tm, tn);
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
@@ -1298,22 +1311,19 @@ static int wino2_s2b_run(const float* small, int ld_small, const float* P, const
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     if (ev0) (void)hipEventRecord(ev0, st);
     const int a_bytes = (int)((long)X * T * Ca * 4), b_bytes = (int)((long)X * NC * Ca * 4);
-    if (T >= 1024) {
-        const int zb = bgemm_zb(((T + 127) / 128) * ((NC + 127) / 128), X);
-        if (zb > 1)
-            hipLaunchKernelGGL((k_wino_bgemm_mz<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (NC + 127) / 128, X / zb), dim3(256),
-                               0, st, V, U, M, (int)T, NC, Ca, zb, a_bytes, b_bytes);
+    {
+        const int big_rows = T >= 1024;
+        const int tm = (int)(big_rows ? (T + 127) / 128 : (T + 63) / 64), tn = (NC + 127) / 128;
+        const int zb = bgemm_zb((long)tm * tn, X);
+        const dim3 grid((unsigned)(tm * tn * (X / zb)));
+        if (big_rows && zb > 1)
+            hipLaunchKernelGGL((k_wino_bgemm_mz<2, 2, 2, 2>), grid, dim3(256), 0, st, V, U, M, (int)T, NC, Ca, zb, a_bytes, b_bytes, tm, tn);
+        else if (big_rows)
+            hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), grid, dim3(256), 0, st, V, U, M, (int)T, NC, Ca, a_bytes, b_bytes, tm, tn);
+        else if (zb > 1)
+            hipLaunchKernelGGL((k_wino_bgemm_mz<1, 2, 2, 2>), grid, dim3(256), 0, st, V, U, M, (int)T, NC, Ca, zb, a_bytes, b_bytes, tm, tn);
         else
-            hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), dim3((unsigned)((T + 127) / 128), (NC + 127) / 128, X), dim3(256), 0, st,
-                               V, U, M, (int)T, NC, Ca, a_bytes, b_bytes);
-    } else {
-        const int zb = bgemm_zb(((T + 63) / 64) * ((NC + 127) / 128), X);
-        if (zb > 1)
-            hipLaunchKernelGGL((k_wino_bgemm_mz<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (NC + 127) / 128, X / zb), dim3(256), 0,
-                               st, V, U, M, (int)T, NC, Ca, zb, a_bytes, b_bytes);
-        else
-            hipLaunchKernelGGL((k_wino_bgemm<1, 2, 2, 2>), dim3((unsigned)((T + 63) / 64), (NC + 127) / 128, X), dim3(256), 0, st, V,
-                               U, M, (int)T, NC, Ca, a_bytes, b_bytes);
+            hipLaunchKernelGGL((k_wino_bgemm<1, 2, 2, 2>), grid, dim3(256), 0, st, V, U, M, (int)T, NC, Ca, a_bytes, b_bytes, tm, tn);
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
@@ -1384,12 +1394,12 @@ int pg_wino2_wgrad(const float* small, int ld_small, const float* big, int ld_bi
     if (ev0) (void)hipEventRecord(ev0, st);
     if (pg_wino2_wgrad_tile64(Ca, Cb)) {
         const int tilesA = (Ca + 63) / 64, tilesB = (K + 63) / 64;
-        hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB, 16, slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                           K, cps, tilesB, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
+        hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB * 16 * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                           K, cps, tilesA, tilesB, 16, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
     } else {
         const int tilesA = (Ca + 127) / 128, tilesB = (K + 127) / 128;
-        hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB, 16, slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                           K, cps, tilesB, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
+        hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB * 16 * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                           K, cps, tilesA, tilesB, 16, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;

@@ -41,4 +41,12 @@ __device__ __forceinline__ bool pg_dropout_keep(uint64_t seed, uint64_t e, float
     return u >= p;
 }
 
+// XCD-aware work order (cdna_hip_programming.md T1): workgroups b and b+8 share an XCD (round-robin dispatch of the
+// flattened block id), so map block id -> work index such that each XCD walks a CONTIGUOUS run of work indices: neighbouring
+// work items (same operand slab) then hit that XCD's private 4 MiB L2 instead of the fabric.  Bijective for any count; speed only.
+__device__ __forceinline__ int pg_xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 static inline int pg_launch_status() { return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH; }

@@ -116,15 +116,12 @@ def _workspace(nbytes, device):
 class LaunchProfiler:
     """Optional per-launch timing of the conv kernels with HIP events on the launch stream (bench.py's roofline
     leg).  Enabled by assigning an instance to ``engine.PROFILER``; costs two event records per launch."""
-    TILE_NAMES = {0: '<2,2,2,2>', 1: '<2,1,2,2>', 2: '<1,1,4,1>', 3: '<1,2,2,2>', 4: '<1,1,2,2>'}
-    OP_NAMES = {0: 'k_big2small', 1: 'k_small2big', 2: 'k_wgrad'}
-
     def __init__(self, only=None):
         self.records = []   # (symbol, split, flops, start_event, end_event)
         self.only = only    # symbol: time only this kernel's launches
 
     def launch(self, op, opcode, fn):
-        if op.algo == L.ALGO_DIRECT:
+        if op.algo & L.ALGO_MASK == L.ALGO_DIRECT:
             return fn()
         sym, split = op.describe(opcode)
         if self.only is not None and sym != self.only:
@@ -184,61 +181,21 @@ class ConvOp:
 
     def kernel_flops(self, opcode):
         """FLOPs the main GEMM kernel of this call really executes on the MFMA pipe: the algorithmic count for the implicit
-        GEMM kernels, 2.25-2.56x fewer for the Winograd kernels (their tile counts include the ragged-edge padding)."""
-        sym = self.describe(opcode)[0]
-        cd = lambda a, b: -(-a // b)
-        if sym.startswith('k_wino_gemm'):            # stride 1, F(2x2, 4x4) / F(3x3, 4x4): 25 / 36 GEMMs of tiles x Cin x Cout
-            ho, wo = (self.Hs, self.Ws) if opcode == 0 else (self.Hb, self.Wb)
-            mo = 3 if sym.endswith(',3>') else 2
-            return 2.0 * (mo + 3) ** 2 * self.N * cd(ho, mo) * cd(wo, mo) * self.Ca * self.Cb
-        if sym.startswith('k_wino_wgrad_gemm'):
-            if self.stride == 1:
-                return 2.0 * 25 * self.N * cd(self.Hs, 2) * cd(self.Ws, 2) * self.Ca * self.Cb
-            return 2.0 * 16 * self.N * cd(self.Hs, 3) * cd(self.Ws, 3) * self.Ca * 4 * self.Cb
-        if sym.startswith('k_wino_bgemm'):
-            mo = 4 if os.environ.get('PATCHGAN_WINO2_TILE', '') == '4' else 3
-            if opcode == 0:
-                return 2.0 * (mo + 1) ** 2 * self.N * cd(self.Hs, mo) * cd(self.Ws, mo) * 4 * self.Cb * self.Ca
-            return 2.0 * 4 * (mo + 1) ** 2 * self.N * cd(cd(self.Hb, 2) + 1, mo) * cd(cd(self.Wb, 2) + 1, mo) * self.Ca * self.Cb
-        return self.flops
+        GEMM kernels, 2.25-4x fewer for the Winograd kernels (their tile counts include the ragged-edge padding)."""
+        return self._describe(opcode)[2]
 
     def describe(self, opcode):
+        """(kernel symbol, split-K factor) of the main GEMM kernel the C ABI launches for this op (pg_conv_kernel: the
+        dispatch code itself reports it)."""
+        return self._describe(opcode)[:2]
+
+    def _describe(self, opcode):
         if opcode not in self._desc:
-            t, s, w = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_long(0)
-            L.check(L.load().pg_conv_describe(ctypes.byref(self.g), opcode + 16 * self.algo, max(self.ws_bytes, 1 << 20), ctypes.byref(t),
-                                              ctypes.byref(s), ctypes.byref(w)), 'pg_conv_describe')
-            fast, rest = t.value // 100, t.value % 100
-            tid, mode = rest % 10, rest // 10
-            tn = LaunchProfiler.TILE_NAMES[tid]
-            if mode == 6:
-                self._desc[opcode] = ('k_wino_wgrad_gemm<1,1,2,2>' if tid in (2, 3) else 'k_wino_wgrad_gemm<2,2,2,2>', s.value)
-                return self._desc[opcode]
-            if mode == 8:
-                self._desc[opcode] = (f'k_b2s_tapk<{tid}>', 1)
-                return self._desc[opcode]
-            if mode == 7:
-                self._desc[opcode] = ({0: 'k_wino_bgemm<2,2,2,2>', 1: 'k_wino_bgemm<1,2,2,2>', 2: 'k_wino_bgemm_mz<2,2,2,2>',
-                                       3: 'k_wino_bgemm_mz<1,2,2,2>'}[tid], 1)
-                return self._desc[opcode]
-            if mode == 9:
-                name, s.value = 'k_wino_gemm<1,1,2,2,2,3>', 1
-            elif mode in (4, 5):
-                name, s.value = ('k_wino_gemm<2,1,2,2,2,2>' if mode == 4 else 'k_wino_gemm<1,1,2,2,4,2>'), 1
-            elif mode == 3:
-                name = 'k_b2s_fast' + tn[:-1] + ',true>+' + ('k_gather_big2small' if opcode == 0 else 'k_col2im_small2big')
-            elif mode:
-                name = 'k_wgrad_tapn' + tn[:-1] + f',{mode}>'
-            elif fast and opcode == 0:
-                name = 'k_b2s_fast' + tn[:-1] + ',false>'
-            elif fast and opcode == 1:
-                name = 'k_s2b_fast' + tn
-            elif fast:
-                name = 'k_wgrad_fast' + tn[:-1] + (',true>' if fast == 2 else ',false>')
-            else:
-                name = LaunchProfiler.OP_NAMES[opcode] + tn
-            if self.algo == L.ALGO_BF16 and fast and not mode:
-                name = name.replace('_fast', '_bf16')
-            self._desc[opcode] = (name, s.value)
+            name = ctypes.create_string_buffer(128)
+            s, fl = ctypes.c_int(0), ctypes.c_double(0)
+            L.check(L.load().pg_conv_kernel(ctypes.byref(self.g), opcode + 16 * self.algo, max(self.ws_bytes, 1 << 20), name, 128,
+                                            ctypes.byref(s), ctypes.byref(fl)), 'pg_conv_kernel')
+            self._desc[opcode] = (name.value.decode(), s.value, fl.value)
         return self._desc[opcode]
 
     def big2small(self, big, P, p_off, bias, b_off, small, act=L.ACT_NONE):
@@ -353,6 +310,16 @@ def tiles_blend(tiles, image_size, threshold, overlap):
     L.check(lib.pg_tiles_blend(tiles.ptr(), tiles.ld, tiles.C, size, eff, H, W, float(threshold), mask_p, arg_p, _stream()),
             'pg_tiles_blend')
     return out
+
+
+_GOLD = 0x9E3779B97F4A7C15
+
+
+def _shift_seed(seed, elem_offset):
+    """Seed whose dropout stream is `seed`'s shifted by elem_offset elements: pg_dropout_keep hashes
+    seed + GOLD * (e + 1), so the mask of local element e under the shifted seed is the mask of global element
+    e + elem_offset under `seed` (data parallelism: rank r's samples sit at r*N.. of the global batch)."""
+    return (seed + _GOLD * elem_offset) & _MASK64
 
 
 def _mix_seed(base, *vals):
@@ -494,15 +461,16 @@ class GeneratorEngine:
             self._ops[key] = (enc_ops, dec_ops)
         return self._ops[key]
 
-    def forward(self, flat, xin, gen_out, train, seed=0):
+    def forward(self, flat, xin, gen_out, train, seed=0, sample0=0):
         """xin: View [N,H,W,input_nc]; gen_out: View [N,H,W,output_nc] to receive final_act(dec6).
-        train selects dropout (InstanceNorm always uses instance statistics, unet.py:77)."""
+        train selects dropout (InstanceNorm always uses instance statistics, unet.py:77).  sample0 = index of this
+        batch's first sample in the global batch (data parallelism: the dropout masks are those of the global batch)."""
         N, H, W = xin.N, xin.H, xin.W
         dev = flat.device
         enc_ops, dec_ops = self.ops(N, H, W)
         F = [l.a for l in self.enc]
         c = GenContext()
-        c.N, c.H, c.W, c.xin, c.gen_out, c.seed, c.train = N, H, W, xin, gen_out, seed, train
+        c.N, c.H, c.W, c.xin, c.gen_out, c.seed, c.train, c.sample0 = N, H, W, xin, gen_out, seed, train, sample0
         # cat_i (i = 1..6): input of decoder i = [dec_{i-1} out | enc_{6-i} out]
         c.cat = [None] * 7
         for i in range(1, 7):
@@ -522,7 +490,7 @@ class GeneratorEngine:
                 out = c.hidden
             stats = torch.empty(N * l.a * 2, dtype=torch.float32, device=dev)
             drop = 0.2 if (train and l.dropout) else 0.0
-            instnorm_act_fwd(y, out, stats, act, drop, _mix_seed(seed, 1, i))
+            instnorm_act_fwd(y, out, stats, act, drop, _shift_seed(_mix_seed(seed, 1, i), sample0 * y.HW * y.C))
             c.y.append(y)
             c.stats.append(stats)
             c.enc_out.append(out)
@@ -545,7 +513,7 @@ class GeneratorEngine:
                 op.small2big(src, flat, l.p_off, None, 0, yd)
                 stats = torch.empty(N * l.b * 2, dtype=torch.float32, device=dev)
                 drop = 0.2 if (train and l.dropout) else 0.0
-                instnorm_act_fwd(yd, out, stats, act, drop, _mix_seed(seed, 2, i))
+                instnorm_act_fwd(yd, out, stats, act, drop, _shift_seed(_mix_seed(seed, 2, i), sample0 * yd.HW * yd.C))
                 c.yd[i], c.statsd[i] = yd, stats
             else:
                 op.small2big(src, flat, l.p_off, None, 0, out, act)
@@ -582,7 +550,8 @@ class GeneratorEngine:
             dy = View.alloc(N, op.Hb, op.Wb, l.b, dev)
             if l.norm:
                 drop = 0.2 if (c.train and l.dropout) else 0.0
-                instnorm_act_bwd(g, None, c.yd[i], c.statsd[i], dy, act, drop, _mix_seed(c.seed, 2, i))
+                instnorm_act_bwd(g, None, c.yd[i], c.statsd[i], dy, act, drop,
+                                 _shift_seed(_mix_seed(c.seed, 2, i), c.sample0 * dy.HW * dy.C))
             else:
                 act_bwd(g, None, c.cat[i + 1].channels(0, l.b), dy, act)
             src = c.hidden if i == 0 else c.cat[i]
@@ -599,7 +568,7 @@ class GeneratorEngine:
             dy = View.alloc(N, op.Hs, op.Ws, l.a, dev)
             drop = 0.2 if (c.train and l.dropout) else 0.0
             instnorm_act_bwd(g_main, dskip[j] if j < 6 else None, c.y[j], c.stats[j], dy, act, drop,
-                             _mix_seed(c.seed, 1, j))
+                             _shift_seed(_mix_seed(c.seed, 1, j), c.sample0 * dy.HW * dy.C))
             src = c.xin if j == 0 else c.enc_out[j - 1]
             op.wgrad(dy, src, gflat, l.p_off)
             done(l)
@@ -729,19 +698,36 @@ class LossBuffers:
         self.coef = torch.empty(N * C * 2, dtype=torch.float32, device=device)
 
 
-def loss_value_and_grad(p, y, tconst, mode, alpha, grad_out, loss_out, loss_slot, bglobal, beta=0.75, gamma=0.75,
-                        allreduce=None):
-    """Evaluate one loss term over prediction View p against target View y (or the constant tconst), write its
-    value into loss_out[loss_slot] and, if grad_out is not None, its gradient wrt p into View grad_out.
-    `allreduce(tensor)` sums the two global reduction terms across ranks under data parallelism."""
+class PendingLoss:
+    """A loss evaluation whose batch-global reduction terms are still being summed across ranks."""
+    __slots__ = ('buf', 'wait', 'args')
+
+
+def loss_begin(p, y, tconst, beta=0.75, allreduce=None):
+    """Phase 1 of a loss term over prediction View p against target View y (or the constant tconst): the per-sample
+    reductions and the two batch-global terms.  `allreduce(tensor)` starts their SUM across ranks under data parallelism
+    and returns a wait() callable; anything enqueued between loss_begin and loss_finish overlaps that exchange."""
     lib = L.load()
     buf = LossBuffers(p.N, p.C, p.t.device, p.HW)
     st = _stream()
     L.check(lib.pg_loss_reduce(p.ptr(), p.ld, y.ptr() if y is not None else None, y.ld if y is not None else 0,
                                float(tconst), p.N, p.HW, p.C, buf.S.data_ptr(), st), 'pg_loss_reduce')
     L.check(lib.pg_loss_prepare(buf.S.data_ptr(), p.N, p.C, beta, buf.sums.data_ptr(), st), 'pg_loss_prepare')
-    if allreduce is not None:
-        allreduce(buf.sums)
+    h = PendingLoss()
+    h.buf, h.args = buf, (p, y, tconst, beta)
+    h.wait = allreduce(buf.sums) if allreduce is not None else None
+    return h
+
+
+def loss_finish(h, mode, alpha, grad_out, loss_out, loss_slot, bglobal, gamma=0.75):
+    """Phase 2: the loss value into loss_out[loss_slot] and, if grad_out is not None, its gradient wrt p into View
+    grad_out (seeded with the GLOBAL batch terms)."""
+    lib = L.load()
+    p, y, tconst, beta = h.args
+    buf = h.buf
+    if h.wait is not None:
+        h.wait()
+    st = _stream()
     L.check(lib.pg_loss_finalize(buf.S.data_ptr(), buf.sums.data_ptr(), mode, p.N, p.C, p.HW, bglobal, alpha, beta, gamma,
                                  buf.coef.data_ptr(), L.ptr(loss_out, loss_slot), st), 'pg_loss_finalize')
     if grad_out is not None:
@@ -750,3 +736,12 @@ def loss_value_and_grad(p, y, tconst, mode, alpha, grad_out, loss_out, loss_slot
                                  float(tconst), buf.coef.data_ptr(), grad_out.ptr(), grad_out.ld, p.N, p.HW, p.C, gmode,
                                  st), 'pg_loss_grad')
     return buf
+
+
+def loss_value_and_grad(p, y, tconst, mode, alpha, grad_out, loss_out, loss_slot, bglobal, beta=0.75, gamma=0.75,
+                        allreduce=None):
+    """Evaluate one loss term over prediction View p against target View y (or the constant tconst), write its
+    value into loss_out[loss_slot] and, if grad_out is not None, its gradient wrt p into View grad_out.
+    `allreduce(tensor)` starts the SUM of the two global reduction terms across ranks and returns wait()."""
+    h = loss_begin(p, y, tconst, beta, allreduce)
+    return loss_finish(h, mode, alpha, grad_out, loss_out, loss_slot, bglobal, gamma)

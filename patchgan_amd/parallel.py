@@ -4,33 +4,90 @@ MI355X; "gloo" in the CPU tests).  The reference has no distributed code at all 
 What is exchanged per step:
   * SUM all-reduce of the flat generator gradient buffer (167 MB at nf=64) and of the flat discriminator gradient
     buffer (11 MB).  `GradReducer` cuts the flat buffer into buckets in the order backward produces them (the last
-    layer's block first) and launches each bucket's all-reduce asynchronously as soon as its last weight gradient has
-    been enqueued, so the collective runs on RCCL's stream under the remaining backward kernels and under the
-    discriminator step that follows; the optimizer waits on the handles.  xGMI is point to point (7 links x ~153 GB/s):
-    buckets are kept large (default 32 MiB) because a ring all-reduce is per-link bound, not latency bound.
+    layer's block first) and hands each bucket to the collective as soon as its last weight gradient has been
+    enqueued.  On a HIP device the collectives are issued from a SECOND HIP stream (`Dist.comm_stream`) that waits on
+    an event recorded behind the bucket's last kernel, so they run under the remaining backward kernels and under the
+    discriminator step that follows; the optimizer's stream waits on the comm stream.  xGMI is point to point
+    (7 links x ~153 GB/s): buckets are kept large (default 32 MiB) because a ring all-reduce is per-link bound, not
+    latency bound.
   * two fp64 scalars per generator loss (sum_b (1 - T_b) and sum(y)): focal-Tversky's batch mean under the power
     and weighted-BCE's global sum(y) are non-linear in the batch, so each rank needs the GLOBAL value before it
-    can seed its local gradient (engine.loss_value_and_grad).
+    can seed its local gradient (engine.loss_value_and_grad); issued on the comm stream too, under the
+    discriminator's forward pass over the fake batch.
   * the step's loss scalars for logging.
 InstanceNorm statistics are per sample: nothing else crosses ranks.
 """
+import os
+
 import torch
 
 
 class Dist:
-    """Thin view of torch.distributed; an uninitialised / single-rank group degrades to no-ops."""
+    """Thin view of torch.distributed; an uninitialised / single-rank group degrades to no-ops.
+    PATCHGAN_DP_FORCE=1 keeps the data-parallel code path on for a one-rank group (exercises the RCCL calls and the
+    comm-stream ordering on a single-GPU box)."""
 
     def __init__(self):
         import torch.distributed as dist
         self.dist = dist
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.world = dist.get_world_size() if self.on else 1
-        self.rank = dist.get_rank() if self.on else 0
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if ready else 1
+        self.rank = dist.get_rank() if ready else 0
+        self.on = ready and (self.world > 1 or os.environ.get('PATCHGAN_DP_FORCE') == '1')
+        self.backend = dist.get_backend() if ready else None
+        self._comm = None
+        self.timing = None          # list of (start_event, end_event, nbytes) when bench.py asks for it
 
     def all_reduce(self, t, async_op=False):
         if self.on:
             return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=async_op)
         return None
+
+    # ---- second-stream collectives (device tensors) ------------------------------------------------------------
+    def comm_stream(self, device):
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=device)
+        return self._comm
+
+    def all_reduce_side(self, t):
+        """SUM all-reduce of `t` ordered after everything enqueued so far on the current stream, without holding that
+        stream up.  Returns wait(): call it (on the stream that consumes `t`) before the result is read.  Device
+        tensors go through the comm stream; host tensors (gloo CPU tests) through an async work handle."""
+        if not self.on:
+            return lambda: None
+        if not t.is_cuda:
+            h = self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True)
+            return h.wait
+        comm = self.comm_stream(t.device)
+        ready = torch.cuda.Event()
+        ready.record()                                   # behind the producer kernels on the compute stream
+        with torch.cuda.stream(comm):
+            comm.wait_event(ready)
+            if self.timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            # a blocking-mode collective: ProcessGroupNCCL enqueues it on its own stream behind `comm` and makes `comm`
+            # wait for it, so `comm` is complete exactly when the reduced values are in place
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            if self.timing is not None:
+                e1.record()
+                self.timing.append((e0, e1, t.numel() * t.element_size()))
+        done = torch.cuda.Event()
+        done.record(comm)
+        return lambda: torch.cuda.current_stream().wait_event(done)
+
+
+_CURRENT = None
+
+
+def current():
+    """The process's Dist, rebuilt only when torch.distributed's state changed (Trainer.batch calls this every step)."""
+    global _CURRENT
+    import torch.distributed as dist
+    ready = dist.is_available() and dist.is_initialized()
+    if _CURRENT is None or (_CURRENT.backend is not None) != ready:
+        _CURRENT = Dist()
+    return _CURRENT
 
 
 class GradReducer:
@@ -42,7 +99,7 @@ class GradReducer:
         self.bucket_elems = max(1, bucket_bytes // flat.element_size())
         self.hi = flat.numel()      # everything in [hi, numel) has been handed to a collective
         self.lo = flat.numel()      # everything in [lo, hi) is ready but not yet launched
-        self.handles = []
+        self.waits = []
         self.launched = []          # (lo, hi) ranges, for tests
 
     def ready(self, lo, hi):
@@ -56,9 +113,7 @@ class GradReducer:
 
     def _launch(self):
         if self.lo < self.hi:
-            h = self.dist.all_reduce(self.flat[self.lo:self.hi], async_op=True)
-            if h is not None:
-                self.handles.append(h)
+            self.waits.append(self.dist.all_reduce_side(self.flat[self.lo:self.hi]))
             self.launched.append((self.lo, self.hi))
             self.hi = self.lo
 
@@ -66,9 +121,9 @@ class GradReducer:
         """Launch whatever is left (down to element 0) and make the current stream wait for every bucket."""
         self.lo = 0
         self._launch()
-        for h in self.handles:
-            h.wait()
-        self.handles = []
+        for w in self.waits:
+            w()
+        self.waits = []
 
 
 def shard_batch(x, y, rank, world):

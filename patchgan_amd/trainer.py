@@ -26,7 +26,7 @@ import tqdm
 
 from . import _lib as L
 from . import engine as E
-from .parallel import Dist as _Dist, GradReducer
+from .parallel import current as _dist, GradReducer
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
 
@@ -106,7 +106,7 @@ class Trainer:
                                f"discriminator input {de.input_nc}")
         if train and self._adam is None:
             self.setup_optimizers(self.gen_lr, self.dsc_lr)
-        dist = _Dist()
+        dist = _dist()
         Bglobal = N * dist.world
         Cd = Cin + Cout
         self._step += 1
@@ -125,16 +125,19 @@ class Trainer:
         xin, yv, gen = fake.channels(0, Cin), real.channels(Cin, Cout), fake.channels(Cin, Cout)
 
         losses = torch.zeros(8, dtype=torch.float32, device=dev)   # seg, gdisc, real*0.5, fake*0.5
-        allred = (lambda t: dist.all_reduce(t)) if dist.on else None
+        allred = dist.all_reduce_side if dist.on else None
 
         # ---- generator step
         seed = E._mix_seed(G._seed_base, self._step) if G.training else 0
-        gc = ge.forward(G.flat, xin, gen, G.training, seed)                                   # trainer.py:63
+        gc = ge.forward(G.flat, xin, gen, G.training, seed, sample0=dist.rank * N)            # trainer.py:63
         self.flush()          # D's deferred all-reduce + Adam from the previous step ran under this G forward
+        # seg loss, phase 1 (per-sample reductions); under data parallelism its two batch-global terms are summed across
+        # ranks on the comm stream while the discriminator's forward pass over the fake batch runs
+        seg_pending = E.loss_begin(gen, yv, 0.0, self.tversky_beta, allred)
         dc = de.forward(D.flat, fake)                                                         # trainer.py:66
         gseg = E.View.alloc(N, H, W, Cout, dev) if train else None
-        E.loss_value_and_grad(gen, yv, 0.0, _LOSS_MODES[self.loss_type], float(self.seg_alpha), gseg, losses, 0,
-                              Bglobal, self.tversky_beta, self.tversky_gamma, allred)        # trainer.py:71-82
+        E.loss_finish(seg_pending, _LOSS_MODES[self.loss_type], float(self.seg_alpha), gseg, losses, 0, Bglobal,
+                      self.tversky_gamma)                                                     # trainer.py:71-82
         o = dc.out
         gd = E.View.alloc(o.N, o.H, o.W, 1, dev) if train else None
         E.loss_value_and_grad(o, None, 1.0, L.LOSS_BCE, 1.0, gd, losses, 1, Bglobal)          # trainer.py:84
@@ -169,7 +172,7 @@ class Trainer:
                 self._adam_step('g')
                 # D's gradient (11 MB at ndf=64) is all-reduced asynchronously and applied by flush() at the first use of
                 # D's weights -- after the NEXT step's generator forward, which does not read them (trainer.py:63-66)
-                self._pending_d = dist.all_reduce(dflat, async_op=True)
+                self._pending_d = dist.all_reduce_side(dflat)
             else:
                 self._adam_step('d')                                                          # trainer.py:107
 
@@ -193,10 +196,10 @@ class Trainer:
     def flush(self):
         """Apply a discriminator update whose gradient all-reduce is still in flight (data parallelism only).  Called
         before anything reads the discriminator's weights: the next step's D forward, save(), load(), the end of train()."""
-        h = getattr(self, '_pending_d', None)
-        if h is not None:
+        wait = getattr(self, '_pending_d', None)
+        if wait is not None:
             self._pending_d = None
-            h.wait()
+            wait()
             self._adam_step('d')
 
     def _adam_step(self, which):
@@ -237,50 +240,25 @@ class Trainer:
             self.neptune_config['model/parameters/decay_freq'] = decay_freq
             self.neptune_config['model/parameters/lr_decay'] = lr_decay
 
-        rank0 = _Dist().rank == 0
-        D_loss_ep, G_loss_ep = [], []
+        history = {'gen': [], 'disc': []}
         for epoch in range(self.start, epochs + 1):
-            if rank0:
+            if _dist().rank == 0:
                 print(f"Epoch {epoch} -- lr: {self.gen_lr:5.3e}, {self.dsc_lr:5.3e}")
                 print("-------------------------------------------------------")
-            pbar = tqdm.tqdm(train_data, desc='Training: ', dynamic_ncols=True, disable=not rank0)
-            if hasattr(train_data, 'shuffle'):
-                train_data.shuffle()
-            self.generator.train()
-            self.discriminator.train()
-            losses = defaultdict(list)
-            loss_mean = {}
-            for i, (input_img, target_mask) in enumerate(pbar):
-                batch_loss = self.batch(input_img, target_mask, train=True)
-                for key, value in batch_loss.items():
-                    losses[key].append(value)
-                    loss_mean[key] = np.mean(losses[key], axis=0)
-                pbar.set_postfix_str(" ".join([f"{key}: {value:.2e}" for key, value in loss_mean.items()]))
-            D_loss_ep.append(loss_mean['disc'])
-            G_loss_ep.append(loss_mean['gen'])
+            train_mean = self._run_epoch(train_data, True, epoch, 'Training: ', dynamic_ncols=True)
+            for key in history:
+                history[key].append(train_mean[key])
+            # the reference keeps ONE running-mean dict across both loops: a validation pass without batches reports the
+            # training means (trainer.py:204-262)
+            val_mean = dict(train_mean, **self._run_epoch(val_data, False, epoch, 'Validation: '))
             if self.neptune_config is not None:
-                self.neptune_config['train/gen_loss'].append(loss_mean['gen'])
-                self.neptune_config['train/disc_loss'].append(loss_mean['disc'])
-
-            self.discriminator.eval()
-            self.generator.eval()
-            pbar = tqdm.tqdm(val_data, desc='Validation: ', disable=not rank0)
-            if hasattr(val_data, 'shuffle'):
-                val_data.shuffle()
-            losses = defaultdict(list)
-            for i, (input_img, target_mask) in enumerate(pbar):
-                batch_loss = self.batch(input_img, target_mask, train=False)
-                for key, value in batch_loss.items():
-                    losses[key].append(value)
-                    loss_mean[key] = np.mean(losses[key], axis=0)
-                pbar.set_postfix_str(" ".join([f"{key}: {value:.2e}" for key, value in loss_mean.items()]))
-            if self.neptune_config is not None:
-                self.neptune_config['eval/gen_loss'].append(loss_mean['gen'])
-                self.neptune_config['eval/disc_loss'].append(loss_mean['disc'])
+                for phase, mean in (('train', train_mean), ('eval', val_mean)):
+                    self.neptune_config[f'{phase}/gen_loss'].append(mean['gen'])
+                    self.neptune_config[f'{phase}/disc_loss'].append(mean['disc'])
 
             if plateau is not None:
-                self.gen_lr = plateau[0].step(loss_mean['gen'])
-                self.dsc_lr = plateau[1].step(loss_mean['disc'])
+                self.gen_lr = plateau[0].step(val_mean['gen'])
+                self.dsc_lr = plateau[1].step(val_mean['disc'])
             elif lr_decay is not None and epoch % decay_freq == 0:
                 self.gen_lr *= lr_decay        # ExponentialLR.step() (trainer.py:266-270)
                 self.dsc_lr *= lr_decay
@@ -288,13 +266,35 @@ class Trainer:
             if epoch % save_freq == 0:
                 self.save(epoch)
         self.flush()
-        return G_loss_ep, D_loss_ep
+        return history['gen'], history['disc']
+
+    def _run_epoch(self, data, train, epoch, desc, **bar_kwargs):
+        """One pass over `data` through batch(train=...): networks switched to train() / eval(), the data source
+        reshuffled (a `shuffle()` method as the reference calls it, trainer.py:206,236, or a DistributedSampler's
+        set_epoch under data parallelism), running means of the six loss scalars shown on the progress bar.
+        Returns {key: mean over the pass}."""
+        for net in (self.generator, self.discriminator):
+            net.train(train)
+        bar = tqdm.tqdm(data, desc=desc, disable=_dist().rank != 0, **bar_kwargs)
+        if hasattr(data, 'shuffle'):
+            data.shuffle()
+        sampler = getattr(data, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(epoch)           # otherwise every epoch repeats the first permutation / rank shards
+        sums, count, mean = defaultdict(float), 0, {}
+        for input_img, target_mask in bar:
+            count += 1
+            for key, value in self.batch(input_img, target_mask, train=train).items():
+                sums[key] += value
+            mean = {key: total / count for key, total in sums.items()}
+            bar.set_postfix_str(" ".join(f"{key}: {value:.2e}" for key, value in mean.items()))
+        return mean
 
     # -------------------------------------------------------------------------------------- checkpoints
     def save(self, epoch):
         """generator_ep_%03d.pth / discriminator_ep_%03d.pth holding torch-layout state_dicts (trainer.py:281-287)."""
         self.flush()
-        if _Dist().rank != 0:
+        if _dist().rank != 0:
             return
         gen_savefile = f'{self.savefolder}/generator_ep_{epoch:03d}.pth'
         disc_savefile = f'{self.savefolder}/discriminator_ep_{epoch:03d}.pth'

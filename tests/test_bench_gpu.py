@@ -1,0 +1,62 @@
+"""bench.py end to end on the GPU box: the plain N = 1 line, the self-spawned multi-rank launch (`--gpus 2` starts its own
+ranks; rehearsed on one GPU over gloo), and the RCCL code path itself (backend "nccl": a one-rank group with the
+data-parallel path forced on, and a real 2-rank run when two GPUs are visible).  Needs an MI355X."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra_args, extra_env, timeout=900):
+    env = dict(os.environ, **extra_env)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline'] + extra_args,
+                       env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    out = _bench([], {})
+    assert out['n_gpus'] == 1 and out['unit'] == 'images/sec' and out['value'] > 100
+    r = out['roofline']
+    assert r['bound'] == 'mfma' and 0.05 < r['frac'] < 1.0 and r['kernel'].startswith('k_')
+    assert 'comm' not in out
+
+
+def test_bench_rccl_path_one_rank():
+    """backend "nccl" (= RCCL) really executes: a one-rank process group with the data-parallel path forced on runs every
+    collective of the step (bucketed gradient all-reduces on the comm stream, loss terms, the deferred discriminator update)
+    through RCCL and must reproduce the single-process losses."""
+    plain = _bench([], {})
+    out = _bench([], {'PATCHGAN_DP_FORCE': '1', 'MASTER_PORT': '29631'})
+    assert out['comm']['backend'] == 'nccl' and out['comm']['ranks_in_group'] == 1
+    assert out['comm']['collectives_per_step'] >= 7            # 6 x 32 MiB G buckets + D gradient + loss terms
+    assert out['comm']['allreduce_MB_per_step'] > 170          # 167 MB + 11 MB of gradients
+    for k, v in plain['last_losses'].items():
+        assert abs(out['last_losses'][k] - v) <= 1e-5 * max(abs(v), 1e-3), (k, out['last_losses'], plain['last_losses'])
+
+
+def test_bench_spawns_its_own_ranks_gloo_rehearsal():
+    """`python bench.py --gpus 2` with no launcher: the parent (which never touches the GPU) starts two ranks and forwards rank
+    0's line.  On a one-GPU box both ranks share device 0 and the collectives go through gloo."""
+    out = _bench(['--gpus', '2'], {'PATCHGAN_SHARE_GPU': '1', 'PATCHGAN_DIST_BACKEND': 'gloo'})
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 32 and out['scaling'] == 'weak'
+    assert out['comm']['ranks_in_group'] == 2 and out['comm']['backend'] == 'gloo'
+    assert 'cpu_baseline' not in out
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: one rank per device over RCCL')
+def test_bench_two_ranks_over_rccl():
+    out = _bench(['--gpus', '2'], {})
+    assert out['n_gpus'] == 2 and out['comm']['backend'] == 'nccl' and out['comm']['ranks_in_group'] == 2
+    assert out['value'] > 100

@@ -1,7 +1,7 @@
 """Seeded random geometries through the three conv entry points: PG_ALGO_AUTO (implicit GEMM + every Winograd / small-channel
 path the planner picks) against PG_ALGO_DIRECT (one thread per output, no tiling) of the same library, on the GPU only.
-Covers ragged tiles, odd extents, N = 1, channel counts around the eligibility thresholds.  Run it also with
-PATCHGAN_WINO2=1 PATCHGAN_WINO2_WGRAD=1 (forces the polyphase paths wherever the geometry allows)."""
+Covers ragged tiles, odd extents, N = 1, channel counts around the eligibility thresholds; every seed runs with the default
+heuristics and with the polyphase / F(3x3,4x4) paths forced wherever the geometry allows (per-call PG_TUNE_* bits)."""
 import math
 import random
 
@@ -30,10 +30,12 @@ def _geoms(n, seed):
 import os
 
 
+@pytest.mark.parametrize('tuning', ['default', 'forced'])
 @pytest.mark.parametrize('seed', [0, 1, 2] + ([int(v) for v in os.environ['PATCHGAN_FUZZ_SEEDS'].split(',')] if os.environ.get('PATCHGAN_FUZZ_SEEDS') else []))
-def test_auto_matches_direct_on_random_geometries(seed):
-    from patchgan_amd import engine as E
+def test_auto_matches_direct_on_random_geometries(seed, tuning):
+    from patchgan_amd import engine as E, _lib as L
     from tests.gpu_util import to_view, empty_view, pack, unpack, rel_err, DEV
+    bits = 0 if tuning == 'default' else (L.TUNE_WINO2_ALL | L.TUNE_WINO2W_ALL | L.TUNE_WINO1_F3)
     picked = set()
     for geom in _geoms(40, seed):
         N, Hb, Wb, Ca, Cb, s = geom
@@ -46,7 +48,7 @@ def test_auto_matches_direct_on_random_geometries(seed):
         P = pack(Wt)
         res = {}
         for algo in (0, 1):
-            op = E.ConvOp(*geom, algo)
+            op = E.ConvOp(*geom, algo | (bits if algo == 0 else 0))
             if algo == 0:
                 picked.update(op.describe(i)[0].split('<')[0] for i in range(3))
             vs = empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=4)

@@ -112,15 +112,22 @@ def test_wgrad(geom, algo):
 WINO_GEOMS = [(9, 32, 32, 128, 64, 1), (3, 55, 58, 96, 64, 1), (10, 31, 31, 64, 160, 1)]
 
 
+@pytest.mark.parametrize('tile', ['auto', 'f2', 'f3'])
 @pytest.mark.parametrize('geom', WINO_GEOMS, ids=lambda g: 'x'.join(map(str, g)))
-def test_winograd_stride1(geom):
-    """AUTO (Winograd) against the fp32 CPU convolution and against the implicit-GEMM kernel of the same library."""
-    from patchgan_amd import engine as E
+def test_winograd_stride1(geom, tile):
+    """AUTO (Winograd) against the fp32 CPU convolution and against the implicit-GEMM kernel of the same library; the
+    F(2x2,4x4) and F(3x3,4x4) instances are also pinned explicitly through the PG_TUNE_WINO1_F2 / _F3 bits."""
+    from patchgan_amd import engine as E, _lib as L
     from tests.gpu_util import to_view, empty_view, pack, rel_err
     N, Hb, Wb, Ca, Cb, s = geom
     big, small, Wt, Hs, Ws = _mk(*geom)
-    auto, mfma = E.ConvOp(*geom, 0), E.ConvOp(*geom, 2)
+    bits = {'auto': 0, 'f2': L.TUNE_WINO1_F2, 'f3': L.TUNE_WINO1_F3}[tile]
+    auto, mfma = E.ConvOp(*geom, L.ALGO_AUTO | bits), E.ConvOp(*geom, 2)
     assert auto.describe(0)[0].startswith('k_wino_gemm') and auto.describe(1)[0].startswith('k_wino_gemm')
+    if tile != 'auto':       # F(3x3,4x4) needs Cin % 64 == 0 in each direction, else the F(2x2,4x4) instance runs
+        for oc, cin in ((0, Cb), (1, Ca)):
+            assert auto.describe(oc)[0].endswith(',3>') == (tile == 'f3' and cin % 64 == 0), (oc, auto.describe(oc))
+    assert not E.ConvOp(*geom, L.ALGO_AUTO | L.TUNE_WINO_OFF).describe(0)[0].startswith('k_wino')
     assert not mfma.describe(0)[0].startswith('k_wino_gemm')
     bias_a, bias_b = torch.randn(Ca), torch.randn(Cb)
     P = pack(Wt)
@@ -160,23 +167,22 @@ def test_winograd_stride1(geom):
 
 
 # stride-2 layers for the polyphase Winograd path: the last two pass the default size heuristic (channel-heavy layers), the
-# others run when the suite is started with PATCHGAN_WINO2=1 (forces the path wherever the geometry allows; also with
-# PATCHGAN_WINO2_TILE=4): odd tile counts, ragged extents, both GEMM tile variants
+# others are forced onto it with the per-call PG_TUNE_WINO2_ALL bit: odd tile counts, ragged extents, both GEMM tile variants
 WINO2_GEOMS = [(4, 32, 32, 128, 64, 2), (2, 64, 64, 64, 32, 2), (3, 36, 44, 96, 40, 2), (16, 16, 16, 256, 128, 2), (9, 64, 64, 160, 64, 2),
                (3, 35, 41, 64, 64, 2), (6, 62, 58, 256, 128, 2), (16, 32, 32, 288, 160, 2)]
 
 
 @pytest.mark.parametrize('geom', WINO2_GEOMS, ids=lambda g: 'x'.join(map(str, g)))
-def test_winograd_stride2_big2small(geom, monkeypatch):
+def test_winograd_stride2_big2small(geom):
     import os
-    from patchgan_amd import engine as E
+    from patchgan_amd import engine as E, _lib as L
     from tests.gpu_util import to_view, empty_view, pack, rel_err
     tol = 5e-5 if os.environ.get('PATCHGAN_WINO2_TILE') == '4' else 2e-5     # F(4x4,2x2) (opt-in) is 4x less accurate
     N, Hb, Wb, Ca, Cb, s = geom
     big, small, Wt, Hs, Ws = _mk(*geom)
-    auto, mfma = E.ConvOp(*geom, 0), E.ConvOp(*geom, 2)
-    if not (auto.describe(0)[0].startswith('k_wino_bgemm') and auto.describe(1)[0].startswith('k_wino_bgemm')):
-        pytest.skip('below the default size heuristic: covered when the suite runs with PATCHGAN_WINO2=1')
+    auto, mfma = E.ConvOp(*geom, L.ALGO_AUTO | L.TUNE_WINO2_ALL), E.ConvOp(*geom, 2)
+    assert auto.describe(0)[0].startswith('k_wino_bgemm') and auto.describe(1)[0].startswith('k_wino_bgemm'), auto.describe(0)
+    assert not E.ConvOp(*geom, L.ALGO_AUTO | L.TUNE_WINO2_OFF).describe(0)[0].startswith('k_wino')
     bias = torch.randn(Ca)
     P = pack(Wt)
     want = O.apply_act(F.conv2d(big, Wt, bias, stride=2, padding=1), 'leakyrelu')
@@ -204,14 +210,14 @@ def test_winograd_stride2_big2small(geom, monkeypatch):
                                   (9, 64, 64, 512, 128, 2)],
                          ids=lambda g: 'x'.join(map(str, g)))
 def test_winograd_stride2_wgrad(geom):
-    """Polyphase F(2x2, 3x3) weight gradient (PATCHGAN_WINO2_WGRAD=1 forces it wherever the geometry allows)."""
-    from patchgan_amd import engine as E
+    """Polyphase F(2x2, 3x3) weight gradient, forced wherever the geometry allows by the per-call PG_TUNE_WINO2W_ALL bit."""
+    from patchgan_amd import engine as E, _lib as L
     from tests.gpu_util import to_view, unpack, rel_err, DEV
     N, Hb, Wb, Ca, Cb, s = geom
     big, small, Wt, Hs, Ws = _mk(*geom)
-    auto, mfma = E.ConvOp(*geom, 0), E.ConvOp(*geom, 2)
-    if not auto.describe(2)[0].startswith('k_wino_wgrad_gemm'):
-        pytest.skip('below the default size heuristic: covered when the suite runs with PATCHGAN_WINO2_WGRAD=1')
+    auto, mfma = E.ConvOp(*geom, L.ALGO_AUTO | L.TUNE_WINO2W_ALL), E.ConvOp(*geom, 2)
+    assert auto.describe(2)[0].startswith('k_wino_wgrad_gemm'), auto.describe(2)
+    assert not E.ConvOp(*geom, L.ALGO_AUTO | L.TUNE_WINO2W_OFF).describe(2)[0].startswith('k_wino')
     Wr = Wt.clone().requires_grad_(True)
     br = torch.zeros(Ca, requires_grad=True)
     F.conv2d(big, Wr, br, stride=2, padding=1).backward(small)

@@ -135,3 +135,36 @@ def test_shard_batch():
     assert a.flatten().tolist() == [2, 3]
     with pytest.raises(ValueError):
         shard_batch(x, x, 0, 3)
+
+
+def test_train_reseeds_distributed_sampler_each_epoch(tmp_path):
+    """Under data parallelism the loaders carry a DistributedSampler: Trainer.train must call set_epoch(epoch) or every epoch
+    repeats the first permutation (and the same per-rank shards).  Host-only: batch() is stubbed out."""
+    import patchgan_amd as pg
+    from torch.utils.data import DataLoader, TensorDataset
+    from torch.utils.data.distributed import DistributedSampler
+    ds = TensorDataset(torch.arange(32).float().view(32, 1), torch.arange(32).float().view(32, 1))
+    loader = DataLoader(ds, batch_size=4, sampler=DistributedSampler(ds, num_replicas=2, rank=0, shuffle=True, seed=3))
+    val = DataLoader(ds, batch_size=8, sampler=DistributedSampler(ds, num_replicas=2, rank=0, shuffle=False))
+
+    class Recorder(pg.Trainer):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.seen = []
+
+        def setup_optimizers(self, *a, **k):
+            pass
+
+        def batch(self, x, y, train=False):
+            if train:
+                self.seen.append(x.flatten().tolist())
+            return dict(gen=1.0, gen_loss=1.0, gdisc=0.0, discr=0.5, discf=0.5, disc=0.5)
+
+    t = Recorder(pg.UNet(3, 1, 4), pg.Discriminator(4, 4), str(tmp_path))
+    G_ep, D_ep = t.train(loader, val, 2, save_freq=100)
+    assert G_ep == [1.0, 1.0] and D_ep == [0.5, 0.5]
+    per_epoch = len(loader)
+    first, second = t.seen[:per_epoch], t.seen[per_epoch:]
+    assert len(second) == per_epoch and first != second
+    assert sorted(sum(first, [])) != list(range(32))          # this rank sees only its half
+    assert len(set(sum(first, []))) == 16

@@ -461,37 +461,87 @@ def test_cfg2_loss_curve_10_steps_vs_oracle(tmp_path):
     assert (err64 <= np.maximum(LOSS_RTOL, 4 * env)).all(), (err64, env)
 
 
-def test_full_size_cfg2_matches_oracle(tmp_path):
+_FULL_SIZE_ORACLE = {}
+
+
+def _full_size_oracle():
+    """CPU oracle run shared by the tuning variants below: forward at the initial weights, two training steps (losses of
+    both, gradients of the first)."""
+    if not _FULL_SIZE_ORACLE:
+        import patchgan_amd as pg
+        torch.manual_seed(1234)
+        g = pg.UNet(3, 1, 64, use_dropout=False, activation='leakyrelu', final_act='sigmoid')
+        d = pg.Discriminator(4, 64, n_layers=3)
+        gw = {k: v.clone() for k, v in g.state_dict().items()}
+        dw = {k: v.clone() for k, v in d.state_dict().items()}
+        gen = torch.Generator().manual_seed(7)
+        x = torch.rand(4, 3, 256, 256, generator=gen)
+        y = (torch.rand(4, 1, 256, 256, generator=gen) > 0.7).float()
+        ot = O.OracleTrainer(gw, dw, activation='leakyrelu', final_act='sigmoid', n_layers=3, norm=False, loss_type='tversky')
+        with torch.no_grad():
+            ref = O.unet_forward(gw, x, 'leakyrelu', 'sigmoid')
+            dref = O.disc_forward(dw, torch.cat((x, ref), 1), 3, False)
+        losses, grads = [], None
+        for step in range(2):
+            losses.append(ot.batch(x, y, train=True))
+            if step == 0:
+                grads = ({k: v.clone() for k, v in ot.last['g_grads'].items()}, {k: v.clone() for k, v in ot.last['d_grads'].items()})
+        _FULL_SIZE_ORACLE.update(gw=gw, dw=dw, x=x, y=y, ref=ref, dref=dref, losses=losses, grads=grads)
+    return _FULL_SIZE_ORACLE
+
+
+@pytest.mark.parametrize('tuning', ['default', 'polyphase_everywhere', 'no_winograd', 'stride1_f3'])
+def test_full_size_cfg2_matches_oracle(tmp_path, tuning):
     """Parity at the BENCHMARK size (cfg2: nf = ndf = 64, B = 4 here to keep the CPU oracle to a few seconds per step,
     256x256): every fast kernel variant, every split-K plan and the taps-in-N paths of the real layer shapes, against the
-    CPU oracle for 2 training steps.  Tolerance 1e-4 relative on the six loss scalars, 2e-4 on the generator output."""
+    CPU oracle for 2 training steps.  Tolerance 1e-4 relative on the six loss scalars, 2e-4 on the generator output, 2e-4
+    (relative max-norm) on the step-1 weight gradients of the big layers.  Run under the default kernel selection and with
+    the selection overridden through the per-call PG_TUNE_* bits (module.set_tuning): polyphase Winograd forced onto every
+    stride-2 layer the geometry allows (forward, data and weight gradients), no Winograd at all (exact implicit GEMM), and
+    the stride-1 layer pinned to F(3x3,4x4)."""
     import patchgan_amd as pg
-    torch.manual_seed(1234)
+    from patchgan_amd import _lib as L
+    r = _full_size_oracle()
+    bits = {'default': 0, 'polyphase_everywhere': L.TUNE_WINO2_ALL | L.TUNE_WINO2W_ALL, 'no_winograd': L.TUNE_WINO_OFF,
+            'stride1_f3': L.TUNE_WINO1_F3}[tuning]
     g = pg.UNet(3, 1, 64, use_dropout=False, activation='leakyrelu', final_act='sigmoid')
     d = pg.Discriminator(4, 64, n_layers=3)
-    gw = {k: v.clone() for k, v in g.state_dict().items()}
-    dw = {k: v.clone() for k, v in d.state_dict().items()}
-    gen = torch.Generator().manual_seed(7)
-    x = torch.rand(4, 3, 256, 256, generator=gen)
-    y = (torch.rand(4, 1, 256, 256, generator=gen) > 0.7).float()
-    ot = O.OracleTrainer(gw, dw, activation='leakyrelu', final_act='sigmoid', n_layers=3, norm=False, loss_type='tversky')
+    g.load_state_dict(r['gw'])
+    d.load_state_dict(r['dw'])
+    g.set_tuning(bits)
+    d.set_tuning(bits)
+    x, y = r['x'], r['y']
     t = pg.Trainer(g.cuda(), d.cuda(), str(tmp_path / 'c'))
     t.setup_optimizers(1e-3, 1e-3)
     g.train()
     d.train()
+    # the override reaches the planner
+    enc_ops, dec_ops = g.engine.ops(4, 256, 256)
+    fams = [op.describe(0)[0].split('<')[0] for op in enc_ops] + [op.describe(1)[0].split('<')[0] for op in dec_ops] + \
+           [op.describe(2)[0].split('<')[0] for op in enc_ops + dec_ops] + [op.describe(0)[0].split('<')[0] for op in d.engine.ops(8, 256, 256)]
+    nw = sum(f.startswith('k_wino') for f in fams)
+    if tuning == 'no_winograd':
+        assert nw == 0, fams
+    elif tuning == 'polyphase_everywhere':
+        assert nw >= 9, fams
+    else:
+        assert nw >= 4, fams
+    if tuning == 'stride1_f3':
+        assert any(f.endswith(',3>') for f in [op.describe(0)[0] for op in d.engine.ops(8, 256, 256)])
     with torch.no_grad():          # forward at identical (initial) weights
         out = g(x.cuda()).cpu()
         dout = d(torch.cat((x.cuda(), out.cuda()), 1)).cpu()
-        ref = O.unet_forward(gw, x, 'leakyrelu', 'sigmoid')
-        dref = O.disc_forward(dw, torch.cat((x, ref), 1), 3, False)
-    assert _rel(out, ref) < 2e-4 and _rel(dout, dref) < 2e-4
+    assert _rel(out, r['ref']) < 2e-4 and _rel(dout, r['dref']) < 2e-4
     for step in range(2):
         got = t.batch(x, y, train=True)
-        want = ot.batch(x, y, train=True)
+        want = r['losses'][step]
         for k in LOSS_KEYS:
             assert abs(got[k] - want[k]) <= 1e-4 * max(abs(want[k]), 1e-3), (step, k, got[k], want[k])
-    # step-1 gradients of the big layers (checked through the first Adam moment: m = 0.1 * g after one step)
-    for key in ('encoder.3.model.DownConv3.weight', 'decoder.3.model.UpConv3.weight'):
-        lay = [l for l in g.engine.layers if l.key == key][0]
-        m_hip = E_views(t._adam[0], g)[key].cpu()
-        assert torch.isfinite(m_hip).all() and m_hip.abs().max() > 0
+        if step == 0:
+            # step-1 weight gradients of the big layers against the oracle's autograd gradients
+            # (tests/test_configs_gpu.py::test_cfg2_full_width_gradients_vs_oracle checks every parameter)
+            for net, ref, keys in ((g, r['grads'][0], ('encoder.3.model.DownConv3.weight', 'decoder.3.model.UpConv3.weight',
+                                                       'encoder.1.model.DownConv1.weight', 'decoder.5.model.UpConv5.weight')),
+                                   (d, r['grads'][1], ('model.6.weight', 'model.4.weight'))):
+                for key in keys:
+                    assert _rel(net.get_parameter(key).grad.cpu(), ref[key]) < 2e-4, (key, _rel(net.get_parameter(key).grad.cpu(), ref[key]))

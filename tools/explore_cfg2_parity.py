@@ -1,6 +1,6 @@
-"""Exploration (not collected by pytest): at the benchmark configuration (cfg2, bs 16) compare, per step and per loss scalar,
+"""Exploration script: at the benchmark configuration (cfg2, bs 16) compare, per step and per loss scalar,
    (a) the fp32 CPU oracle, (b) the HIP path, against (c) the oracle run in float64 on the GPU (torch ops in double).
-Usage on the GPU box: python tests/explore_cfg2_parity.py [steps] [batch]"""
+Usage on the GPU box: python tools/explore_cfg2_parity.py [steps] [batch]"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
