@@ -16,6 +16,7 @@ size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout, int mo_for
 // weight transform + input transform into ws
 int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N, int Hin, int Win, int Cin, int Hout,
                     int Wout, int Cout, int pad, void* ws, hipStream_t st, int mo_forced);
+int pg_wino_dma_mode();   // 0: register-staged k_wino_gemm only, 1: k_wino_gemm_dma<3,4,2> for F(3x3,4x4), 2: also <2,3,3> for 64-tile F(2x2,4x4)
 // the batched GEMM with fused output transform, bias and activation
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
                  void* ws, hipStream_t st, int mo_forced);

@@ -302,6 +302,139 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 }
 
 
+// The same batched GEMM + fused output transform for the 64-tile x 64-channel workgroup tile, with the operand tiles brought
+// in by LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS without staging registers) into a ring of NSTAGE stages of
+// 128 rows x 32 k, so the loads of chunk c + NSTAGE - 1 are in flight while chunk c is multiplied.  The register-staged
+// kernel above prefetches ONE chunk ahead; with its nine output accumulator sets the F(3x3,4x4) instance runs at 2 waves
+// per SIMD and stood at 0.53 MFMA-pipe utilisation: every load of the lock-stepped workgroups pays the fabric latency and one
+// chunk of MFMAs does not cover it.  One barrier per chunk (stage c + NSTAGE - 1 was last read in iteration c - 1).
+// LDS rows are 128 B linear with the 16-byte slot index XOR-swizzled by (row >> 1) & 7 on the SOURCE address (the DMA
+// destination is wave-uniform base + lane * 16), so the ds_read_b128 fragment reads stay conflict-free without padding.
+// Waves 0,1 stage the 64 V rows, waves 2,3 the 64 U rows; 4 DMA instructions per wave and chunk.
+template <int MO, int NSTAGE, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_gemm_dma(
+    const float* __restrict__ V, const float* __restrict__ U, const float* __restrict__ bias, float* __restrict__ out, int ld_out,
+    int T, int Ci, int Co, int TH, int TW, int Hout, int Wout, int act, int v_bytes, int u_bytes, int tiles_n) {
+    constexpr int NP = MO + 3, NXI = NP * NP, NY = MO * MO;
+    constexpr int KD = 32, STAGE = 128 * KD;                      // floats per stage: 64 A rows then 64 B rows
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+    __shared__ __attribute__((aligned(1024))) float smem[NSTAGE * STAGE];
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, v_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, u_bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably uniform: the DMA's LDS base goes to M0 directly
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int w = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (w / tiles_n) * 64, n0 = (w % tiles_n) * 64;
+    const int nch = Ci / KD, total = NXI * nch;
+    const bool isA = wave < 2;
+
+    int voff[4];                                                   // byte offset of this lane's 16 bytes in piece jj, xi = chunk = 0
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int row = (wave & 1) * 32 + jj * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((row >> 1) & 7);
+        const int g = (isA ? m0 : n0) + row, lim = isA ? T : Co;
+        voff[jj] = (int)(((unsigned)(min(g, lim - 1) * Ci + slot * 4) << 2) | (g < lim ? 0u : 0x80000000u));
+    }
+    const int xi_bytes = (isA ? T : Co) * Ci * 4;                  // bytes per xi slab of this wave's operand
+    float* const dst0 = smem + (isA ? 0 : 64 * KD) + (wave & 1) * 32 * KD;
+    int ld_ch = 0, ld_off = 0;                                     // chunk / byte offset of the NEXT chunk to load
+    auto dma = [&](int stage, bool on) {
+        const unsigned kill = on ? 0u : 0x80000000u;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            float* dst = dst0 + stage * STAGE + jj * 8 * KD;
+            const int off = (int)((unsigned)(voff[jj] + ld_off) | kill);
+            if (isA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, dst, 16, off, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rU, dst, 16, off, 0, 0, 0);
+        }
+        const bool wrap = ld_ch + 1 >= nch;
+        ld_off += wrap ? xi_bytes - (nch - 1) * KD * 4 : KD * 4;
+        ld_ch = wrap ? 0 : ld_ch + 1;
+    };
+
+    f32x16 accm, accy[NY];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        accm[r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < NY; ++p) accy[p][r] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) dma(s, s < total);
+    const int ra_ = wm * 32 + lrow, rb_ = wn * 32 + lrow;
+    const int sa = (ra_ >> 1) & 7, sb = (rb_ >> 1) & 7;
+    int xi = 0, ch = 0, stage = 0;
+    for (int it = 0; it < total; ++it) {
+        // this wave's pieces of chunk `it` have landed when at most the (NSTAGE - 2) younger chunks are outstanding
+        if (NSTAGE == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int nstage = (stage == 0) ? NSTAGE - 1 : stage - 1;   // == (it + NSTAGE - 1) % NSTAGE: read last in iteration it - 1
+        dma(nstage, it + NSTAGE - 1 < total);
+        const float* As = smem + stage * STAGE;
+        const float* Bs = As + 64 * KD;
+        f32x4 af[KD / 8], bf[KD / 8];                              // all eight fragment reads first: none waits behind an MFMA
+#pragma unroll
+        for (int kk = 0; kk < KD / 8; ++kk) {
+            af[kk] = *reinterpret_cast<const f32x4*>(&As[ra_ * KD + (((kk * 2 + lh) ^ sa) << 2)]);
+            bf[kk] = *reinterpret_cast<const f32x4*>(&Bs[rb_ * KD + (((kk * 2 + lh) ^ sb) << 2)]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // (hipcc otherwise sinks each read pair in front of its MFMAs)
+#pragma unroll
+        for (int kk = 0; kk < KD / 8; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accm = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][e], bf[kk][e], accm, 0, 0, 0);
+        if (ch == nch - 1) {
+            const int xa = xi / NP, xb = xi - xa * NP;
+            float ca[MO], cb[MO];
+#pragma unroll
+            for (int k = 0; k < MO; ++k) {
+                ca[k] = s1_at<MO>(k, xa);
+                cb[k] = s1_at<MO>(k, xb);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float mv = accm[r];
+#pragma unroll
+                for (int al = 0; al < MO; ++al)
+#pragma unroll
+                    for (int be = 0; be < MO; ++be) accy[al * MO + be][r] += (ca[al] * cb[be]) * mv;
+                accm[r] = 0.f;
+            }
+        }
+        const bool wrap = ch + 1 >= nch;
+        ch = wrap ? 0 : ch + 1;
+        xi = wrap ? xi + 1 : xi;
+        stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the killed tail DMAs (zeros into unused stages) drain before exit
+
+    const int col = n0 + wn * 32 + lrow;
+    const float bv = (bias != nullptr && col < Co) ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + wm * 32 + row;
+        if (m < T && col < Co) {
+            const int n = m / (TH * TW);
+            const int rem = m - n * (TH * TW);
+            const int ti = rem / TW, tj = rem - ti * TW;
+#pragma unroll
+            for (int p = 0; p < NY; ++p) {
+                const int y = MO * ti + p / MO, x = MO * tj + p % MO;
+                if (y < Hout && x < Wout) out[((long)(n * Hout + y) * Wout + x) * ld_out + col] = act_epi(accy[p][r] + bv, act);
+            }
+        }
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the same layer, F(4x4, 2x2):  dW[kh][kw][a][b] = sum_pix dy[pix][a] * x[pix + (kh-1, kw-1)][b]  is, per
 // 2x2 tile of dy and its 5x5 window of x, the 4x4 correlation of the window with the tile:
@@ -1102,6 +1235,16 @@ int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N,
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
 
+// PATCHGAN_WINO_DMA (A/B switch): 0 = register-staged stride-1 kernels only, 1 (default) = LDS-DMA ring kernel for the
+// F(3x3,4x4) instance, 2 = also for the 64-tile F(2x2,4x4) instance
+int pg_wino_dma_mode() {
+    static const int mode = [] {
+        const char* e = getenv("PATCHGAN_WINO_DMA");
+        return e ? atoi(e) : 1;
+    }();
+    return mode;
+}
+
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
                  void* ws, hipStream_t st, int forced) {
     const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
@@ -1111,10 +1254,19 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
     const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cin, Cout, forced);
     const int v_bytes = (int)(X * T * Cin * 4), u_bytes = (int)(X * Cout * Cin * 4);
     const int tn = (Cout + 63) / 64;
-    if (mo == 3) {
+    const int dma_mode = pg_wino_dma_mode();
+    if (mo == 3 && dma_mode) {
+        dim3 grid((unsigned)(((T + 63) / 64) * tn));
+        hipLaunchKernelGGL((k_wino_gemm_dma<3, 4, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH, TW,
+                           Hout, Wout, act, v_bytes, u_bytes, tn);
+    } else if (mo == 3) {
         dim3 grid((unsigned)(((T + 63) / 64) * tn));
         hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 2, 3>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
                            TW, Hout, Wout, act, v_bytes, u_bytes, tn);
+    } else if (small_tile && dma_mode == 2) {
+        dim3 grid((unsigned)(((T + 63) / 64) * tn));
+        hipLaunchKernelGGL((k_wino_gemm_dma<2, 3, 3>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH, TW,
+                           Hout, Wout, act, v_bytes, u_bytes, tn);
     } else if (small_tile) {
         dim3 grid((unsigned)(((T + 63) / 64) * tn));
         hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 4, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,

@@ -126,7 +126,8 @@ def test_winograd_stride1(geom, tile):
     assert auto.describe(0)[0].startswith('k_wino_gemm') and auto.describe(1)[0].startswith('k_wino_gemm')
     if tile != 'auto':       # F(3x3,4x4) needs Cin % 64 == 0 in each direction, else the F(2x2,4x4) instance runs
         for oc, cin in ((0, Cb), (1, Ca)):
-            assert auto.describe(oc)[0].endswith(',3>') == (tile == 'f3' and cin % 64 == 0), (oc, auto.describe(oc))
+            sym = auto.describe(oc)[0]          # F(3x3,4x4): k_wino_gemm<...,3> or its LDS-DMA form k_wino_gemm_dma<3,...>
+            assert (sym.endswith(',3>') or sym.startswith('k_wino_gemm_dma<3')) == (tile == 'f3' and cin % 64 == 0), (oc, sym)
     assert not E.ConvOp(*geom, L.ALGO_AUTO | L.TUNE_WINO_OFF).describe(0)[0].startswith('k_wino')
     assert not mfma.describe(0)[0].startswith('k_wino_gemm')
     bias_a, bias_b = torch.randn(Ca), torch.randn(Cb)
