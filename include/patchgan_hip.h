@@ -67,6 +67,7 @@ extern "C" {
 #define PG_TUNE_WINOW_OFF 0x200   /* stride-1 weight gradient on the implicit GEMM */
 #define PG_TUNE_WINO1_F2 0x400    /* stride-1 forward / data gradient: F(2x2,4x4) tiles */
 #define PG_TUNE_WINO1_F3 0x800    /* ... F(3x3,4x4) tiles (needs Cin % 64 == 0) */
+#define PG_TUNE_WINO_DMA 0x1000   /* stride-1 64-tile Winograd GEMMs staged by LDS-DMA (k_wino_gemm_dma) instead of registers */
 
 typedef struct pg_conv_geom {
     int N;        /* batch */

@@ -2533,6 +2533,7 @@ struct Tune {
     int wino2;      // polyphase stride-2 forward / data gradient: 0 off, 1 wherever the geometry allows, 2 size heuristic
     int wino2w;     // polyphase stride-2 weight gradient: same codes
     int mo1;        // stride-1 tile edge: 0 heuristic, 2 / 3 pinned
+    int dma;        // stride-1 GEMM staging: 0 registers, 1 LDS-DMA ring for F(3x3,4x4), 2 also for 64-tile F(2x2,4x4)
 };
 inline int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -2546,6 +2547,7 @@ inline Tune tune_of(int algo) {
         t.wino2 = env_int("PATCHGAN_WINO2", 2);
         t.wino2w = env_int("PATCHGAN_WINO2_WGRAD", 2);
         t.mo1 = env_int("PATCHGAN_WINO1_TILE", 0);
+        t.dma = pg_wino_dma_mode();
         return t;
     }();
     Tune t = env;
@@ -2557,11 +2559,12 @@ inline Tune tune_of(int algo) {
     if (algo & PG_TUNE_WINO2W_OFF) t.wino2w = 0;
     if (algo & PG_TUNE_WINO1_F2) t.mo1 = 2;
     if (algo & PG_TUNE_WINO1_F3) t.mo1 = 3;
+    if (algo & PG_TUNE_WINO_DMA) t.dma = 2;
     if (force_generic()) t.wino = false;
     return t;
 }
 // every path on, for sizing a workspace that serves any tuning
-inline Tune tune_widest(int mo1) { return Tune{true, true, 1, 1, mo1}; }
+inline Tune tune_widest(int mo1) { return Tune{true, true, 1, 1, mo1, 0}; }
 
 // stride-1 layers only: forward is a pad-1 correlation big -> small, the data gradient a pad-2 correlation small -> big
 inline bool wino_b2s_ok(const Geom& g, const Tune& t) {
@@ -2750,7 +2753,7 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
         sp = 1;
     } else if (mode == 9 || mode == 4 || mode == 5) {     // stride-1 Winograd forward / data gradient
         const int mo = mode == 9 ? 3 : 2;
-        const int dm = pg_wino_dma_mode();
+        const int dm = tune.dma;
         if (mode == 9 && dm) snprintf(buf, sizeof buf, "k_wino_gemm_dma<3,4,2>");
         else if (mode == 5 && dm == 2) snprintf(buf, sizeof buf, "k_wino_gemm_dma<2,3,3>");
         else snprintf(buf, sizeof buf, "k_wino_gemm<%s>", mode == 9 ? "1,1,2,2,2,3" : mode == 4 ? "2,1,2,2,2,2" : "1,1,2,2,4,2");
@@ -2768,7 +2771,6 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
         else if (fast) snprintf(buf, sizeof buf, "%s<%s,%s>", half ? "k_wgrad_bf16" : "k_wgrad_fast", TILE[tid], fast == 2 ? "true" : "false");
         else snprintf(buf, sizeof buf, "%s<%s>", oc == 0 ? "k_big2small" : oc == 1 ? "k_small2big" : "k_wgrad", TILE[tid]);
     }
-    (void)tune;
     if (name && name_len) snprintf(name, name_len, "%s", buf);
     if (split) *split = sp;
     if (mfma_flops) *mfma_flops = fl;
@@ -2798,7 +2800,7 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
         int rc = pg_wino_prepare(big, ld_big, P, 0, g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, 1, ws, st, tune.mo1);
         if (rc != PG_OK) return rc;
         TimedLaunch timed(st);
-        return pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st, tune.mo1);
+        return pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st, tune.mo1, tune.dma);
     }
     if (algo == PG_ALGO_AUTO && wino2_b2s_ok(g, tune) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
         aligned16(small) && aligned16(ws) && (!bias || aligned16(bias)) &&
@@ -2902,7 +2904,7 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
         int rc = pg_wino_prepare(small, ld_small, P, 1, g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, 2, ws, st, tune.mo1);
         if (rc != PG_OK) return rc;
         TimedLaunch timed(st);
-        return pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st, tune.mo1);
+        return pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st, tune.mo1, tune.dma);
     }
     if (algo == PG_ALGO_AUTO && wino2_s2b_ok(g, tune) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
         aligned16(small) && aligned16(ws) && (!bias || aligned16(bias)) &&

@@ -305,9 +305,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 // The same batched GEMM + fused output transform for the 64-tile x 64-channel workgroup tile, with the operand tiles brought
 // in by LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS without staging registers) into a ring of NSTAGE stages of
 // 128 rows x 32 k, so the loads of chunk c + NSTAGE - 1 are in flight while chunk c is multiplied.  The register-staged
-// kernel above prefetches ONE chunk ahead; with its nine output accumulator sets the F(3x3,4x4) instance runs at 2 waves
-// per SIMD and stood at 0.53 MFMA-pipe utilisation: every load of the lock-stepped workgroups pays the fabric latency and one
-// chunk of MFMAs does not cover it.  One barrier per chunk (stage c + NSTAGE - 1 was last read in iteration c - 1).
+// kernel above prefetches ONE chunk ahead.  Built to test whether the F(3x3,4x4) instance (nine output accumulator sets, 2 waves
+// per SIMD, 0.53 MFMA-pipe utilisation) is load-latency bound: it is not -- this kernel is as fast as the register-staged one
+// (opt-in, PATCHGAN_WINO_DMA=1).  One barrier per chunk (stage c + NSTAGE - 1 was last read in iteration c - 1).
 // LDS rows are 128 B linear with the 16-byte slot index XOR-swizzled by (row >> 1) & 7 on the SOURCE address (the DMA
 // destination is wave-uniform base + lane * 16), so the ds_read_b128 fragment reads stay conflict-free without padding.
 // Waves 0,1 stage the 64 V rows, waves 2,3 the 64 U rows; 4 DMA instructions per wave and chunk.
@@ -357,10 +357,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         ld_ch = wrap ? 0 : ld_ch + 1;
     };
 
-    f32x16 accm, accy[NY];
+    // two accumulators for M_xi (even / odd k steps): consecutive MFMAs of the wave are independent, their sum is folded
+    f32x16 accm, accm2, accy[NY];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         accm[r] = 0.f;
+        accm2[r] = 0.f;
 #pragma unroll
         for (int p = 0; p < NY; ++p) accy[p][r] = 0.f;
     }
@@ -389,7 +391,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
         for (int kk = 0; kk < KD / 8; ++kk)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) accm = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][e], bf[kk][e], accm, 0, 0, 0);
+            for (int e = 0; e < 4; e += 2) {
+                accm = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][e], bf[kk][e], accm, 0, 0, 0);
+                accm2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][e + 1], bf[kk][e + 1], accm2, 0, 0, 0);
+            }
         if (ch == nch - 1) {
             const int xa = xi / NP, xb = xi - xa * NP;
             float ca[MO], cb[MO];
@@ -400,7 +405,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float mv = accm[r];
+                const float mv = accm[r] + accm2[r];
+                accm2[r] = 0.f;
 #pragma unroll
                 for (int al = 0; al < MO; ++al)
 #pragma unroll
@@ -1235,18 +1241,20 @@ int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N,
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
 
-// PATCHGAN_WINO_DMA (A/B switch): 0 = register-staged stride-1 kernels only, 1 (default) = LDS-DMA ring kernel for the
-// F(3x3,4x4) instance, 2 = also for the 64-tile F(2x2,4x4) instance
+// PATCHGAN_WINO_DMA (A/B switch): 0 (default) = register-staged stride-1 kernels only, 1 = LDS-DMA ring kernel for the
+// F(3x3,4x4) instance, 2 = also for the 64-tile F(2x2,4x4) instance.  Measured equal within device noise (DESIGN.md section 3:
+// on this 64x64-tile loop every ds_read_b128 costs ~34 and every DMA piece / load + ds_write pair ~64 cycles of MFMA-pipe time
+// whichever way the tile is staged), so the register-staged kernel stays the default.
 int pg_wino_dma_mode() {
     static const int mode = [] {
         const char* e = getenv("PATCHGAN_WINO_DMA");
-        return e ? atoi(e) : 1;
+        return e ? atoi(e) : 0;
     }();
     return mode;
 }
 
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
-                 void* ws, hipStream_t st, int forced) {
+                 void* ws, hipStream_t st, int forced, int dma_mode) {
     const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
     const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
     const float* U = (const float*)ws;
@@ -1254,7 +1262,6 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
     const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cin, Cout, forced);
     const int v_bytes = (int)(X * T * Cin * 4), u_bytes = (int)(X * Cout * Cin * 4);
     const int tn = (Cout + 63) / 64;
-    const int dma_mode = pg_wino_dma_mode();
     if (mo == 3 && dma_mode) {
         dim3 grid((unsigned)(((T + 63) / 64) * tn));
         hipLaunchKernelGGL((k_wino_gemm_dma<3, 4, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH, TW,

@@ -88,7 +88,7 @@ def test_cfg4_shape_two_steps_vs_oracle(cfg4_reference, precision, tmp_path):
     enc_ops, dec_ops = g.engine.ops(2, 512, 512)
     names = [op.describe(0)[0] for op in enc_ops] + [op.describe(1)[0] for op in dec_ops]
     if precision == 'fp32':
-        assert sum(n.startswith('k_wino_bgemm') for n in names) >= 5, names
+        assert sum(n.startswith('k_wino_bgemm') for n in names) >= 3, names
         assert any(op.describe(0)[0].startswith('k_wino_gemm') for op in d.engine.ops(4, 512, 512)), 'stride-1 Winograd'
     else:
         assert sum('bf16' in n for n in names) >= 8, names

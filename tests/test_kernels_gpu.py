@@ -112,7 +112,7 @@ def test_wgrad(geom, algo):
 WINO_GEOMS = [(9, 32, 32, 128, 64, 1), (3, 55, 58, 96, 64, 1), (10, 31, 31, 64, 160, 1)]
 
 
-@pytest.mark.parametrize('tile', ['auto', 'f2', 'f3'])
+@pytest.mark.parametrize('tile', ['auto', 'f2', 'f3', 'f3_dma', 'f2_dma'])
 @pytest.mark.parametrize('geom', WINO_GEOMS, ids=lambda g: 'x'.join(map(str, g)))
 def test_winograd_stride1(geom, tile):
     """AUTO (Winograd) against the fp32 CPU convolution and against the implicit-GEMM kernel of the same library; the
@@ -121,13 +121,16 @@ def test_winograd_stride1(geom, tile):
     from tests.gpu_util import to_view, empty_view, pack, rel_err
     N, Hb, Wb, Ca, Cb, s = geom
     big, small, Wt, Hs, Ws = _mk(*geom)
-    bits = {'auto': 0, 'f2': L.TUNE_WINO1_F2, 'f3': L.TUNE_WINO1_F3}[tile]
+    bits = {'auto': 0, 'f2': L.TUNE_WINO1_F2, 'f3': L.TUNE_WINO1_F3, 'f3_dma': L.TUNE_WINO1_F3 | L.TUNE_WINO_DMA,
+            'f2_dma': L.TUNE_WINO1_F2 | L.TUNE_WINO_DMA}[tile]      # *_dma: the LDS-DMA ring kernels k_wino_gemm_dma
     auto, mfma = E.ConvOp(*geom, L.ALGO_AUTO | bits), E.ConvOp(*geom, 2)
     assert auto.describe(0)[0].startswith('k_wino_gemm') and auto.describe(1)[0].startswith('k_wino_gemm')
     if tile != 'auto':       # F(3x3,4x4) needs Cin % 64 == 0 in each direction, else the F(2x2,4x4) instance runs
         for oc, cin in ((0, Cb), (1, Ca)):
             sym = auto.describe(oc)[0]          # F(3x3,4x4): k_wino_gemm<...,3> or its LDS-DMA form k_wino_gemm_dma<3,...>
-            assert (sym.endswith(',3>') or sym.startswith('k_wino_gemm_dma<3')) == (tile == 'f3' and cin % 64 == 0), (oc, sym)
+            assert (sym.endswith(',3>') or sym.startswith('k_wino_gemm_dma<3')) == (tile.startswith('f3') and cin % 64 == 0), (oc, sym)
+            if tile == 'f3_dma' and cin % 64 == 0:
+                assert sym.startswith('k_wino_gemm_dma<3'), sym
     assert not E.ConvOp(*geom, L.ALGO_AUTO | L.TUNE_WINO_OFF).describe(0)[0].startswith('k_wino')
     assert not mfma.describe(0)[0].startswith('k_wino_gemm')
     bias_a, bias_b = torch.randn(Ca), torch.randn(Cb)
