@@ -486,7 +486,13 @@ def _full_size_oracle():
             losses.append(ot.batch(x, y, train=True))
             if step == 0:
                 grads = ({k: v.clone() for k, v in ot.last['g_grads'].items()}, {k: v.clone() for k, v in ot.last['d_grads'].items()})
-        _FULL_SIZE_ORACLE.update(gw=gw, dw=dw, x=x, y=y, ref=ref, dref=dref, losses=losses, grads=grads)
+        # the same first step in float64 (torch double ops on the GPU): the yardstick for how far ANY fp32 evaluation of these
+        # gradients sits from the exact value (the chain runs through InstanceNorm over 2x2 and 4x4 planes)
+        o64 = O.OracleTrainer({k: v.cuda() for k, v in gw.items()}, {k: v.cuda() for k, v in dw.items()}, dtype=torch.float64,
+                              activation='leakyrelu', final_act='sigmoid', n_layers=3, norm=False, loss_type='tversky')
+        o64.batch(x.cuda(), y.cuda(), train=True)
+        grads64 = ({k: v.cpu() for k, v in o64.last['g_grads'].items()}, {k: v.cpu() for k, v in o64.last['d_grads'].items()})
+        _FULL_SIZE_ORACLE.update(gw=gw, dw=dw, x=x, y=y, ref=ref, dref=dref, losses=losses, grads=grads, grads64=grads64)
     return _FULL_SIZE_ORACLE
 
 
@@ -494,8 +500,10 @@ def _full_size_oracle():
 def test_full_size_cfg2_matches_oracle(tmp_path, tuning):
     """Parity at the BENCHMARK size (cfg2: nf = ndf = 64, B = 4 here to keep the CPU oracle to a few seconds per step,
     256x256): every fast kernel variant, every split-K plan and the taps-in-N paths of the real layer shapes, against the
-    CPU oracle for 2 training steps.  Tolerance 1e-4 relative on the six loss scalars, 2e-4 on the generator output, 2e-4
-    (relative max-norm) on the step-1 weight gradients of the big layers.  Run under the default kernel selection and with
+    CPU oracle for 2 training steps.  Tolerance 1e-4 relative on the six loss scalars, 2e-4 on the generator output; the step-1
+    weight gradients of the big layers (relative max-norm) within max(2e-4, 4 x E) of the float64 gradient or of the fp32 CPU
+    gradient, E = the fp32 CPU oracle's own distance from float64 for that tensor (~1e-3 at this size: the exact implicit-GEMM
+    kernels sit as far from the CPU's fp32 result as the Winograd ones).  Run under the default kernel selection and with
     the selection overridden through the per-call PG_TUNE_* bits (module.set_tuning): polyphase Winograd forced onto every
     stride-2 layer the geometry allows (forward, data and weight gradients), no Winograd at all (exact implicit GEMM), and
     the stride-1 layer pinned to F(3x3,4x4)."""
@@ -540,8 +548,11 @@ def test_full_size_cfg2_matches_oracle(tmp_path, tuning):
         if step == 0:
             # step-1 weight gradients of the big layers against the oracle's autograd gradients
             # (tests/test_configs_gpu.py::test_cfg2_full_width_gradients_vs_oracle checks every parameter)
-            for net, ref, keys in ((g, r['grads'][0], ('encoder.3.model.DownConv3.weight', 'decoder.3.model.UpConv3.weight',
-                                                       'encoder.1.model.DownConv1.weight', 'decoder.5.model.UpConv5.weight')),
-                                   (d, r['grads'][1], ('model.6.weight', 'model.4.weight'))):
+            for net, i, keys in ((g, 0, ('encoder.3.model.DownConv3.weight', 'decoder.3.model.UpConv3.weight',
+                                         'encoder.1.model.DownConv1.weight', 'decoder.5.model.UpConv5.weight')),
+                                 (d, 1, ('model.6.weight', 'model.4.weight'))):
                 for key in keys:
-                    assert _rel(net.get_parameter(key).grad.cpu(), ref[key]) < 2e-4, (key, _rel(net.get_parameter(key).grad.cpu(), ref[key]))
+                    got_g = net.get_parameter(key).grad.cpu()
+                    e32, e64 = _rel(got_g, r['grads'][i][key]), _rel(got_g, r['grads64'][i][key])
+                    noise = _rel(r['grads'][i][key], r['grads64'][i][key])
+                    assert min(e32, e64) <= max(2e-4, 4 * noise), (key, e32, e64, noise)
