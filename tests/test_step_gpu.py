@@ -501,9 +501,8 @@ def test_full_size_cfg2_matches_oracle(tmp_path, tuning):
     """Parity at the BENCHMARK size (cfg2: nf = ndf = 64, B = 4 here to keep the CPU oracle to a few seconds per step,
     256x256): every fast kernel variant, every split-K plan and the taps-in-N paths of the real layer shapes, against the
     CPU oracle for 2 training steps.  Tolerance 1e-4 relative on the six loss scalars, 2e-4 on the generator output; the step-1
-    weight gradients of the big layers (relative max-norm) within max(2e-4, 4 x E) of the float64 gradient or of the fp32 CPU
-    gradient, E = the fp32 CPU oracle's own distance from float64 for that tensor (~1e-3 at this size: the exact implicit-GEMM
-    kernels sit as far from the CPU's fp32 result as the Winograd ones).  Run under the default kernel selection and with
+    weight gradients of the big layers against the float64 oracle (torch double ops on the GPU): discriminator 1e-4 relative
+    max-norm, generator 2e-2 relative L2 (ill-conditioned at this width, see the comment at the check).  Run under the default kernel selection and with
     the selection overridden through the per-call PG_TUNE_* bits (module.set_tuning): polyphase Winograd forced onto every
     stride-2 layer the geometry allows (forward, data and weight gradients), no Winograd at all (exact implicit GEMM), and
     the stride-1 layer pinned to F(3x3,4x4)."""
@@ -548,11 +547,13 @@ def test_full_size_cfg2_matches_oracle(tmp_path, tuning):
         if step == 0:
             # step-1 weight gradients of the big layers against the oracle's autograd gradients
             # (tests/test_configs_gpu.py::test_cfg2_full_width_gradients_vs_oracle checks every parameter)
-            for net, i, keys in ((g, 0, ('encoder.3.model.DownConv3.weight', 'decoder.3.model.UpConv3.weight',
-                                         'encoder.1.model.DownConv1.weight', 'decoder.5.model.UpConv5.weight')),
-                                 (d, 1, ('model.6.weight', 'model.4.weight'))):
-                for key in keys:
-                    got_g = net.get_parameter(key).grad.cpu()
-                    e32, e64 = _rel(got_g, r['grads'][i][key]), _rel(got_g, r['grads64'][i][key])
-                    noise = _rel(r['grads'][i][key], r['grads64'][i][key])
-                    assert min(e32, e64) <= max(2e-4, 4 * noise), (key, e32, e64, noise)
+            # D gradients are well conditioned: relative max-norm 1e-4 against float64 (measured <= 1.2e-5, Winograd layers
+            # included).  G gradients at this width are not: the backward chain amplifies fp32 rounding so much that EXACT fp32
+            # evaluations (one-thread-per-output kernels, implicit GEMM, the CPU oracle) sit 3e-4 .. 7e-3 (relative L2) and
+            # up to 1e-1 (max-norm) from float64 (tools/debug_grads_full.py), so they get a relative-L2 bound of 2e-2.
+            for key in ('model.6.weight', 'model.4.weight', 'model.2.weight'):
+                assert _rel(d.get_parameter(key).grad.cpu(), r['grads64'][1][key]) < 1e-4, key
+            for key in ('encoder.3.model.DownConv3.weight', 'decoder.3.model.UpConv3.weight', 'encoder.1.model.DownConv1.weight',
+                        'decoder.5.model.UpConv5.weight'):
+                got_g, want_g = g.get_parameter(key).grad.cpu().double(), r['grads64'][0][key].double()
+                assert ((got_g - want_g).norm() / want_g.norm()).item() < 2e-2, key
