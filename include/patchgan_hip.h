@@ -83,7 +83,7 @@ int pg_version(void);
 /* Bytes of workspace that lets op (0 = big2small, 1 = small2big, 2 = wgrad) use its preferred
  * split-K factor / Winograd path for geometry g under ANY algo / PG_TUNE_* combination.  A smaller (or NULL) workspace is
  * legal: the split shrinks, the Winograd paths fall back to the implicit GEMM. */
-size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);
+size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);   /* op 3 = pg_conv4x4_bwd_big */
 
 /* Reports which kernel the MFMA path of op would launch for g with a workspace of ws_bytes: tile_id
  * (0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 64x128, 4 = 64x64 output tile per workgroup; the kernel symbol is
@@ -135,6 +135,20 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
 int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_big,
                      float* dP, float* dbias, const pg_conv_geom* g, int algo,
                      void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of a layer whose BIG side carries the incoming gradient -- nn.ConvTranspose2d (unet.py:53) with small = the layer's
+ * input x and big = dL/dy -- in ONE call (aten::convolution_backward, trainer.py:89, is one op producing both):
+ *     dP     = pg_conv4x4_wgrad(small = x, big = dy)                  (no bias: UpSampleBlock has none)
+ *     dsmall = pg_conv4x4_big2small(big = dy, P)                      (dL/dx, no bias, no activation)
+ * Where both halves take the polyphase Winograd path, the transformed gradient V(dy) is computed ONCE and read by both
+ * GEMMs (the dy tile shared between the data- and the weight-gradient, north_star's "wgrad/dgrad fused"); otherwise the
+ * call is exactly the two calls above.  Bit-identical to them either way.  ws: pg_conv_workspace_bytes(g, 3). */
+int pg_conv4x4_bwd_big(const float* small, int ld_small, const float* big, int ld_big, const float* P, float* dP,
+                       float* dsmall, int ld_dsmall, const pg_conv_geom* g, int algo, void* ws, size_t ws_bytes, void* stream);
+
+/* As pg_conv_time_next, for pg_conv4x4_bwd_big: the first pair goes around its weight-gradient GEMM, the second around its
+ * data-gradient GEMM. */
+int pg_conv_time_next2(void* ev_start, void* ev_stop, void* ev_start2, void* ev_stop2);
 
 /* InstanceNorm2d(eps, biased var, no affine; unet.py:20,55, disc.py:32,42) + activation + Dropout(p)
  * (unet.py:28,65) over y[N, HW, C]:   out = dropout(act((y - mean_nc) * rstd_nc)).

@@ -2267,6 +2267,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // entry point on this thread records them immediately before and after its main GEMM kernel (not the split-K reduce,
 // not the bias column-sum), then disarms.  Thread-local; no effect unless armed.
 thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
+thread_local hipEvent_t t_ev2 = nullptr, t_ev3 = nullptr;   // second pair: the second GEMM of pg_conv4x4_bwd_big
 struct TimedLaunch {
     hipStream_t st;
     hipEvent_t e1;
@@ -2607,6 +2608,16 @@ extern "C" {
 
 size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
     if (!geom_ok(g)) return 0;
+    if (op == 3) {      // pg_conv4x4_bwd_big: its two halves back to back, or V shared + the larger of the two remainders
+        size_t bytes = std::max(pg_conv_workspace_bytes(g, 0), pg_conv_workspace_bytes(g, 2));
+        const Geom gq = to_geom(g);
+        const Tune tw = tune_widest(0);
+        if (wino2_b2s_ok(gq, tw) && wino2_wgrad_ok(gq, tw))
+            bytes = std::max(bytes, pg_wino2_v_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb) +
+                                        std::max(pg_wino2_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb),
+                                                 pg_wino2_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)));
+        return (bytes + 255) & ~(size_t)255;
+    }
     Plan p = (op == 0) ? plan_b2s(g) : (op == 1) ? plan_s2b(g) : plan_wgrad(g);
     size_t bytes = 0;
     int split = p.split;
@@ -2634,6 +2645,15 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
 int pg_conv_time_next(void* ev_start, void* ev_stop) {
     t_ev0 = (hipEvent_t)ev_start;
     t_ev1 = (hipEvent_t)ev_stop;
+    t_ev2 = t_ev3 = nullptr;
+    return PG_OK;
+}
+
+int pg_conv_time_next2(void* ev_start, void* ev_stop, void* ev_start2, void* ev_stop2) {
+    t_ev0 = (hipEvent_t)ev_start;
+    t_ev1 = (hipEvent_t)ev_stop;
+    t_ev2 = (hipEvent_t)ev_start2;
+    t_ev3 = (hipEvent_t)ev_stop2;
     return PG_OK;
 }
 
@@ -2808,7 +2828,7 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
         hipEvent_t e0 = t_ev0, e1 = t_ev1;
         t_ev0 = nullptr;
         t_ev1 = nullptr;
-        return pg_wino2_b2s(big, ld_big, P, bias, small, ld_small, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1);
+        return pg_wino2_b2s(big, ld_big, P, bias, small, ld_small, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, nullptr);
     }
     if (b2s_tapn_ok(g) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= b2s_tapn_ws(g) && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT) {
@@ -3035,7 +3055,7 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
         t_ev0 = nullptr;
         t_ev1 = nullptr;
         return pg_wino2_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, (char*)ws + reserved, st,
-                              e0, e1);
+                              e0, e1, nullptr);
     }
     Plan p = plan_wgrad(gg);
     clamp_split(p, ws_bytes, reserved);
@@ -3080,6 +3100,41 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     if (p.split == 1) return PG_OK;
     return launch_reduce(dst, p.out_elems, p.split, dP, g.Cb, 16L * g.Ca, g.Cb, nullptr, 0, st);
+}
+
+int pg_conv4x4_bwd_big(const float* small, int ld_small, const float* big, int ld_big, const float* P, float* dP,
+                       float* dsmall, int ld_dsmall, const pg_conv_geom* gg, int algo, void* ws, size_t ws_bytes, void* stream) {
+    if (!geom_ok(gg) || !small || !big || !P || !dP || !dsmall) return PG_EINVAL;
+    if (ld_small < gg->Ca || ld_big < gg->Cb || ld_dsmall < gg->Ca) return PG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const Geom g = to_geom(gg);
+    const Tune tune = tune_of(algo);
+    if (!ws) ws_bytes = 0;
+    const size_t vb = pg_wino2_v_bytes(g.N, g.Hs, g.Ws, g.Cb);
+    const bool share = (algo & PG_ALGO_MASK) == PG_ALGO_AUTO && pg_wino2_mo() == 3 && wino2_b2s_ok(g, tune) && wino2_wgrad_ok(g, tune) &&
+                       (ld_small % 4 == 0) && (ld_big % 4 == 0) && (ld_dsmall % 4 == 0) && aligned16(small) && aligned16(big) &&
+                       aligned16(P) && aligned16(dP) && aligned16(dsmall) && aligned16(ws) &&
+                       ws_bytes >= vb + std::max(pg_wino2_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb),
+                                                 pg_wino2_wgrad_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb));
+    hipEvent_t e0 = t_ev0, e1 = t_ev1, e2 = t_ev2, e3 = t_ev3;
+    if (!share) {       // the two halves as separate calls (each consumes one armed event pair)
+        t_ev2 = t_ev3 = nullptr;
+        int rc = pg_conv4x4_wgrad(small, ld_small, big, ld_big, dP, nullptr, gg, algo, ws, ws_bytes, stream);
+        if (rc != PG_OK) return rc;
+        t_ev0 = e2;
+        t_ev1 = e3;
+        return pg_conv4x4_big2small(big, ld_big, P, nullptr, dsmall, ld_dsmall, gg, PG_ACT_NONE, algo, ws, ws_bytes, stream);
+    }
+    t_ev0 = t_ev1 = t_ev2 = t_ev3 = nullptr;
+    // V(big) once; the weight-gradient GEMM and the data-gradient GEMM both read it (ws: V | DY S, then V | U M)
+    float* V = (float*)ws;
+    void* rest = (char*)ws + vb;
+    int rc = pg_wino2_v(big, ld_big, V, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Cb, st);
+    if (rc != PG_OK) return rc;
+    rc = pg_wino2_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, rest, st, e0, e1, V);
+    if (rc != PG_OK) return rc;
+    return pg_wino2_b2s(big, ld_big, P, nullptr, dsmall, ld_dsmall, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, PG_ACT_NONE, rest, st, e2,
+                        e3, V);
 }
 
 }  // extern "C"

@@ -39,8 +39,12 @@ int pg_wino2_b2s_zb(int N, int Hs, int Ws, int Ca);   // batches per workgroup (
 int pg_wino2_s2b_zb(int N, int Hb, int Wb, int Cb);
 bool pg_wino2_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
 size_t pg_wino2_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
+// Vpre (optional, F(3x3,2x2) only): the transformed input already computed by pg_wino2_v; ws then holds U | M only
 int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N, int Hb,
-                 int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+                 int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+                 const float* Vpre);
+size_t pg_wino2_v_bytes(int N, int Hs, int Ws, int Cb);
+int pg_wino2_v(const float* big, int ld_big, float* V, int N, int Hb, int Wb, int Hs, int Ws, int Cb, hipStream_t st);
 
 // small -> big, four parity classes as column blocks: U (X*4Cb*Ca) | V (X*tiles*Ca) | M (X*tiles*4Cb) in ws
 bool pg_wino2c_geom_ok(int N, int Hb, int Wb, int Ca, int Cb);
@@ -53,5 +57,6 @@ bool pg_wino2_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
 int pg_wino2_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb);
 bool pg_wino2_wgrad_tile64(int Ca, int Cb);     // k_wino_wgrad_gemm<1,1,2,2> (64x64 output tiles) instead of <2,2,2,2>
 size_t pg_wino2_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
+// Vpre (optional): as for pg_wino2_b2s; ws then holds DY | S only
 int pg_wino2_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
-                   int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+                   int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const float* Vpre);

@@ -1398,18 +1398,22 @@ size_t pg_wino2_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb) {
 template <int MO>
 static int wino2_b2s_run(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N,
                          int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0,
-                         hipEvent_t ev1) {
+                         hipEvent_t ev1, const float* Vpre) {
     constexpr int X = (MO + 1) * (MO + 1);
     const int TH = (Hs + MO - 1) / MO, TW = (Ws + MO - 1) / MO, K = 4 * Cb;
     const long T = (long)N * TH * TW;
+    // ws: U | V | M, or U | M when the caller supplies the transformed input (Vpre: shared with the weight gradient)
     float* U = (float*)ws;
-    float* V = (float*)((char*)U + align256((size_t)X * Ca * K * 4));
-    float* M = (float*)((char*)V + align256((size_t)X * T * K * 4));
+    float* Vown = (float*)((char*)U + align256((size_t)X * Ca * K * 4));
+    float* M = Vpre ? Vown : (float*)((char*)Vown + align256((size_t)X * T * K * 4));
+    const float* V = Vpre ? Vpre : Vown;
     hipLaunchKernelGGL(k_wino2_u<MO>, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, P, U, Ca, Cb);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
-    hipLaunchKernelGGL(k_wino2_v<MO>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb, TH,
-                       TW);
-    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    if (!Vpre) {
+        hipLaunchKernelGGL(k_wino2_v<MO>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, big, ld_big, Vown, N, Hb, Wb, Cb,
+                           TH, TW);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    }
     if (ev0) (void)hipEventRecord(ev0, st);
     const int a_bytes = (int)((long)X * T * K * 4), b_bytes = (int)((long)X * Ca * K * 4);
     {
@@ -1434,10 +1438,23 @@ static int wino2_b2s_run(const float* big, int ld_big, const float* P, const flo
 }
 
 int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N, int Hb,
-                 int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+                 int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+                 const float* Vpre) {
     if (pg_wino2_mo() == 4)
-        return wino2_b2s_run<4>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1);
-    return wino2_b2s_run<3>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1);
+        return wino2_b2s_run<4>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, nullptr);
+    return wino2_b2s_run<3>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, Vpre);
+}
+
+// the polyphase input transform V[xi][tile][ph*Cb + b] of `big` on its own (F(3x3,2x2) tiles over the small side): what
+// pg_wino2_b2s and pg_wino2_wgrad both start from -- computed once when a layer's data and weight gradients are taken together
+size_t pg_wino2_v_bytes(int N, int Hs, int Ws, int Cb) {
+    return align256((size_t)16 * N * ((Hs + 2) / 3) * ((Ws + 2) / 3) * 4 * Cb * 4);
+}
+int pg_wino2_v(const float* big, int ld_big, float* V, int N, int Hb, int Wb, int Hs, int Ws, int Cb, hipStream_t st) {
+    const int TH = (Hs + 2) / 3, TW = (Ws + 2) / 3;
+    const long T = (long)N * TH * TW;
+    hipLaunchKernelGGL(k_wino2_v<3>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb, TH, TW);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
 
 bool pg_wino2c_geom_ok(int N, int Hb, int Wb, int Ca, int Cb) {
@@ -1536,14 +1553,19 @@ size_t pg_wino2_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb) {
 }
 
 int pg_wino2_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
-                   int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+                   int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const float* Vpre) {
     const int TH = (Hs + 2) / 3, TW = (Ws + 2) / 3, K = 4 * Cb;
     const long T = (long)N * TH * TW;
-    float* V = (float*)ws;
-    float* DY = (float*)((char*)ws + align256((size_t)16 * T * K * 4));
+    // ws: V | DY | S, or DY | S when the caller supplies the transformed big-side tensor (Vpre)
+    float* Vown = (float*)ws;
+    float* DY = Vpre ? Vown : (float*)((char*)ws + align256((size_t)16 * T * K * 4));
     float* S = (float*)((char*)DY + align256((size_t)16 * T * Ca * 4));
-    hipLaunchKernelGGL(k_wino2_v<3>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb, TH, TW);
-    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    const float* V = Vpre ? Vpre : Vown;
+    if (!Vpre) {
+        hipLaunchKernelGGL(k_wino2_v<3>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, big, ld_big, Vown, N, Hb, Wb, Cb, TH,
+                           TW);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    }
     hipLaunchKernelGGL(k_wino2_dy, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, small, ld_small, DY, N, Hs, Ws,
                        Ca, TH, TW);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;

@@ -132,6 +132,20 @@ class LaunchProfiler:
         fn()
         self.records.append((sym, split, op.flops, op.kernel_flops(opcode), e0, e1))
 
+    def launch2(self, op, opcodes, fn):
+        """A fused call with two main GEMM kernels (pg_conv4x4_bwd_big): one event pair per kernel."""
+        if op.algo & L.ALGO_MASK == L.ALGO_DIRECT:
+            return fn()
+        syms = [op.describe(oc)[0] for oc in opcodes]
+        if self.only is not None and self.only not in syms:
+            return fn()
+        ev = [self._event() for _ in range(4)]
+        L.check(L.load().pg_conv_time_next2(*[e.cuda_event for e in ev]), 'pg_conv_time_next2')
+        fn()
+        for i, oc in enumerate(opcodes):
+            if self.only is None or syms[i] == self.only:
+                self.records.append((syms[i], op.describe(oc)[1], op.flops, op.kernel_flops(oc), ev[2 * i], ev[2 * i + 1]))
+
     @staticmethod
     def _event():
         e = torch.cuda.Event(enable_timing=True)
@@ -167,7 +181,7 @@ class ConvOp:
         self.N, self.Hb, self.Wb, self.Hs, self.Ws, self.Ca, self.Cb, self.stride = N, Hb, Wb, Hs, Ws, Ca, Cb, stride
         self.algo = algo
         lib = L.load()
-        self.ws_bytes = max(int(lib.pg_conv_workspace_bytes(ctypes.byref(self.g), op)) for op in (0, 1, 2))
+        self.ws_bytes = max(int(lib.pg_conv_workspace_bytes(ctypes.byref(self.g), op)) for op in (0, 1, 2, 3))
         self._desc = {}
 
     def _ws(self, device):
@@ -232,6 +246,21 @@ class ConvOp:
                                               L.ptr(dbias, b_off) if dbias is not None else None, ctypes.byref(self.g),
                                               self.algo, wp, wn, _stream()), 'pg_conv4x4_wgrad')
         PROFILER.launch(self, 2, go) if PROFILER is not None else go()
+
+
+    def bwd_big(self, small, big, P, dP, p_off, dsmall):
+        """Weight gradient (small = x, big = dy) and data gradient (big -> small) of a ConvTranspose2d layer in one call; where
+        both run the polyphase Winograd path the transformed dy is computed once and shared (pg_conv4x4_bwd_big)."""
+        assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
+        assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
+        assert (dsmall.N, dsmall.H, dsmall.W, dsmall.C) == (self.N, self.Hs, self.Ws, self.Ca), 'dsmall view mismatch'
+        wp, wn = self._ws(P.device)
+
+        def go():
+            L.check(L.load().pg_conv4x4_bwd_big(small.ptr(), small.ld, big.ptr(), big.ld, L.ptr(P, p_off), L.ptr(dP, p_off),
+                                                dsmall.ptr(), dsmall.ld, ctypes.byref(self.g), self.algo, wp, wn, _stream()),
+                    'pg_conv4x4_bwd_big')
+        PROFILER.launch2(self, (2, 0), go) if PROFILER is not None else go()
 
 
 def instnorm_act_fwd(y, out, stats, act, drop_p=0.0, seed=0):
@@ -538,10 +567,9 @@ class GeneratorEngine:
             softmax_bwd(g1, g2, c.gen_out, dy)
         else:
             act_bwd(g1, g2, c.gen_out, dy, L.ACT_CODES[self.final_act])
-        op.wgrad(c.cat[6], dy, gflat, l.p_off)
-        done(l)
         dcat = View.alloc(N, op.Hs, op.Ws, l.a, dev)
-        op.big2small(dy, flat, l.p_off, None, 0, dcat)
+        op.bwd_big(c.cat[6], dy, flat, gflat, l.p_off, dcat)      # weight gradient + data gradient of the ConvTranspose2d
+        done(l)
         dskip = [None] * 7   # dskip[j]: gradient wrt enc_j output arriving through the skip connection
         for i in range(5, -1, -1):
             l, op = self.dec[i], dec_ops[i]
@@ -555,10 +583,9 @@ class GeneratorEngine:
             else:
                 act_bwd(g, None, c.cat[i + 1].channels(0, l.b), dy, act)
             src = c.hidden if i == 0 else c.cat[i]
-            op.wgrad(src, dy, gflat, l.p_off)
-            done(l)
             dsrc = View.alloc(N, op.Hs, op.Ws, l.a, dev)
-            op.big2small(dy, flat, l.p_off, None, 0, dsrc)
+            op.bwd_big(src, dy, flat, gflat, l.p_off, dsrc)
+            done(l)
             dcat = dsrc
         # ---- encoder, last to first; dcat is now dL/d(hidden)
         g_main = dcat

@@ -70,7 +70,7 @@ def test_kernel_plan_of_the_benchmark_layers():
             if 'wino' in sym:
                 assert auto.kernel_flops(oc) < 0.6 * auto.flops
         g = _lib.ConvGeom(geom[0], geom[1], geom[2], auto.Hs, auto.Ws, geom[3], geom[4], geom[5])
-        assert auto.ws_bytes == max(_lib.load().pg_conv_workspace_bytes(ctypes.byref(g), oc) for oc in range(3))
+        assert auto.ws_bytes == max(_lib.load().pg_conv_workspace_bytes(ctypes.byref(g), oc) for oc in range(4))   # 3 = pg_conv4x4_bwd_big
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

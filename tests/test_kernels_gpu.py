@@ -412,3 +412,35 @@ def test_layout_roundtrip():
     v = to_view(x, ld=9, off=2)
     torch.cuda.synchronize()
     assert torch.equal(v.to_nchw().cpu(), x)
+
+
+@pytest.mark.parametrize('geom,bits', [((6, 62, 58, 256, 128, 2), 0), ((4, 70, 74, 96, 36, 2), 'all'), ((2, 16, 16, 64, 32, 2), 0),
+                                       ((16, 32, 32, 288, 160, 2), 0), ((2, 9, 9, 8, 8, 1), 0)],
+                         ids=lambda v: 'x'.join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_bwd_big_equals_its_two_halves(geom, bits):
+    """pg_conv4x4_bwd_big (ConvTranspose2d backward: weight gradient + data gradient in one call, the transformed dy shared
+    where both halves take the polyphase Winograd path) is bit-identical to pg_conv4x4_wgrad + pg_conv4x4_big2small, and within
+    the per-kernel tolerance of the CPU convolution's gradients."""
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view, empty_view, pack, unpack, rel_err, DEV
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    algo = L.ALGO_AUTO | ((L.TUNE_WINO2_ALL | L.TUNE_WINO2W_ALL) if bits == 'all' else 0)
+    op = E.ConvOp(*geom, algo)
+    P = pack(Wt)
+    vs, vb = to_view(small, ld=Ca + 4, off=4), to_view(big, ld=Cb + 8, off=4)
+    dP1 = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+    ds1 = empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=0)
+    op.bwd_big(vs, vb, P, dP1, 0, ds1)
+    dP2 = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+    ds2 = empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=0)
+    op.wgrad(vs, vb, dP2, 0)
+    op.big2small(vb, P, 0, None, 0, ds2)
+    torch.cuda.synchronize()
+    assert torch.equal(dP1, dP2) and torch.equal(ds1.to_nchw(), ds2.to_nchw())
+    # against autograd of the transposed convolution y = convT(x; W): dW = wgrad(x, dy), dx = conv(dy, W)
+    x = small.clone().requires_grad_(True)
+    Wr = Wt.clone().requires_grad_(True)
+    F.conv_transpose2d(x, Wr, None, stride=s, padding=1,
+                       output_padding=(Hb - ((Hs - 1) * s + 2), Wb - ((Ws - 1) * s + 2))).backward(big)
+    assert rel_err(unpack(dP1, Ca, Cb), Wr.grad) < 3e-5 and rel_err(ds1.to_nchw(), x.grad) < 2e-5
