@@ -164,6 +164,13 @@ class Trainer:
                               losses, 2, Bglobal)                                             # loss_real
         E.loss_value_and_grad(o2.samples(N, N), None, 0.0, L.LOSS_BCE, 0.5, god.samples(N, N) if train else None,
                               losses, 3, Bglobal)                                             # loss_fake
+        wait_losses = None
+        if dist.on:
+            # the step's loss scalars for logging: seg is already global for tversky, the BCE / MAE terms are per-rank partial
+            # means.  Summed on the comm stream under the discriminator's backward pass, ahead of its gradient all-reduce.
+            if self.loss_type == 'tversky':
+                losses[0] /= dist.world
+            wait_losses = dist.all_reduce_side(losses)
         if train:
             dflat = D.ensure_grad_flat()
             de.backward(D.flat, dflat, dc2, god, need_wgrad=True, need_dx=False)              # trainer.py:106
@@ -175,14 +182,8 @@ class Trainer:
                 self._pending_d = dist.all_reduce_side(dflat)
             else:
                 self._adam_step('d')                                                          # trainer.py:107
-
-        if dist.on:
-            # seg loss: tversky is already global; the BCE/MAE terms are per-rank partial means
-            part = losses.clone()
-            if self.loss_type == 'tversky':
-                part[0] = part[0] / dist.world
-            dist.all_reduce(part)
-            losses = part
+        if wait_losses is not None:
+            wait_losses()
         self._last_gen = gen
         v = losses.cpu().numpy()                                                              # the step's one sync
         seg, gdisc = np.float32(v[0]), np.float32(v[1])

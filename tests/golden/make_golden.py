@@ -209,11 +209,49 @@ def run_infer_tiles():
     print('infer_tiles', {k: v.tolist() for k, v in out.items() if k.endswith('ncrops')}, flush=True)
 
 
+def run_io_onehot():
+    """The reference dataset's per-item arithmetic (io.py:38-58): `/ 255.`, the uint8 `+ 1` on the label map (255 wraps to 0)
+    and the one-hot loop over np.sort(labels), driven on given decoded tensors.  patchgan.io imports torchvision (absent here) at
+    module scope for read_image / transforms only: an empty placeholder module is registered for the import, and read_image is
+    pointed at the tensors below, so everything that computes is the reference's own __getitem__."""
+    import types
+    for name in ('torchvision', 'torchvision.io', 'torchvision.transforms'):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.read_image = m.ImageReadMode = None
+            sys.modules[name] = m
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    sys.modules['torchvision'].io = sys.modules['torchvision.io']
+    sys.path.insert(0, REF)
+    import patchgan.io as rio
+    g = torch.Generator().manual_seed(11)
+    H, W = 40, 56
+    img = torch.randint(0, 256, (3, H, W), dtype=torch.uint8, generator=g)
+    lab = torch.randint(0, 9, (1, H, W), dtype=torch.uint8, generator=g)
+    lab[0, 0, :9] = 255                     # COCO-stuff "unlabeled": 255 + 1 wraps to 0 in uint8
+    lab[0, 1, :5] = 254
+    store = {'i.jpg': img, 'm.png': lab}
+
+    class Mode:
+        RGB, GRAY = 'RGB', 'GRAY'
+    rio.ImageReadMode = Mode
+    rio.read_image = lambda path, mode: store[path].clone()
+    labels = [6, 0, 3, 255]                 # unsorted on purpose: the reference sorts them
+    ds = object.__new__(rio.COCOStuffDataset)
+    ds.images, ds.masks, ds.labels, ds.size, ds.augmentation = np.asarray(['i.jpg']), np.asarray(['m.png']), np.sort(labels), H, None
+    x, y = ds[0]
+    out = {'img_u8': img.numpy(), 'lab_u8': lab.numpy(), 'labels': np.asarray(labels), 'x': x.numpy(), 'y': y.numpy()}
+    np.savez_compressed(os.path.join(HERE, 'io_onehot.npz'), **out)
+    print('io_onehot', x.shape, y.shape, y.sum((1, 2)).tolist(), flush=True)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
-    which = sys.argv[1:] or (list(CONFIGS) + ['train_driver', 'infer_tiles'])
+    which = sys.argv[1:] or (list(CONFIGS) + ['train_driver', 'infer_tiles', 'io_onehot'])
     for name in which:
-        if name == 'infer_tiles':
+        if name == 'io_onehot':
+            run_io_onehot()
+        elif name == 'infer_tiles':
             run_infer_tiles()
         elif name == 'train_driver':
             run_train_driver()

@@ -385,6 +385,26 @@ def test_device_input_pipeline_equals_float_path(tmp_path):
         t.batch(img, lab, train=False)
 
 
+def test_device_input_kernels_vs_reference_fixture():
+    """f3: pg_u8_to_f32 / pg_labels_to_onehot against tests/golden/io_onehot.npz -- the image and one-hot mask the reference's
+    own COCOStuffDataset.__getitem__ (io.py:38-58) produced for these decoded bytes, incl. the uint8 wrap of 255 + 1 -- bit
+    for bit, into strided channel slices."""
+    import os
+    from patchgan_amd import engine as E
+    from tests.golden_util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'io_onehot.npz'))
+    img = torch.from_numpy(z['img_u8']).permute(1, 2, 0).contiguous()[None].cuda()       # [1, H, W, 3] decoded bytes
+    lab = torch.from_numpy(z['lab_u8'])[0][None].contiguous().cuda()                     # [1, H, W]
+    labels = [int(v) for v in np.sort(z['labels'])]
+    H, W = lab.shape[1:]
+    buf = E.View.alloc(1, H, W, 12, 'cuda', zero=True)
+    buf.channels(1, 3).from_u8(img)
+    buf.channels(4, len(labels)).from_labels(lab, labels)
+    assert np.array_equal(buf.channels(1, 3).to_nchw().cpu().numpy()[0], z['x'])
+    assert np.array_equal(buf.channels(4, len(labels)).to_nchw().cpu().numpy()[0], z['y'])
+    assert float(buf.t.view(-1, 12)[:, [0, 8, 9, 10, 11]].abs().sum()) == 0           # neighbours untouched
+
+
 def test_bf16_precision_tracks_fp32(tmp_path):
     """f2: bf16-multiply / fp32-accumulate convolutions.  Stated tolerance: every loss scalar of the first 5 steps within
     2e-3 relative of the fp32 golden curve (bf16 has an 8-bit significand; products are rounded once, sums stay fp32;
