@@ -136,6 +136,21 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
                      float* dP, float* dbias, const pg_conv_geom* g, int algo,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* InstanceNorm statistics from the producing convolution (the conv epilogue emits sum / sum of squares, unet.py:19-20,53-55: the
+ * Conv2d / ConvTranspose2d feeding an InstanceNorm2d).  pg_conv_stats_chunks: how many partial-sum chunks per sample the kernel
+ * that pg_conv4x4_big2small (op 0) / _small2big (op 1) would launch for (g, algo, ws_bytes, 16-byte-aligned tensors) emits;
+ * 0 = that kernel has no such epilogue (call the plain entry point and pg_instnorm_act_fwd).  The *_stats entry points are the
+ * plain ones plus part[((n * chunks + chunk) * C + c) * 2 + {0, 1}] = (sum, sum of squares) of the output over the chunk, fp64,
+ * fixed summation order; they return PG_EINVAL when the call does not take the path pg_conv_stats_chunks assumed. */
+int pg_conv_stats_chunks(const pg_conv_geom* g, int op, int algo, size_t ws_bytes);
+int pg_conv4x4_big2small_stats(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small,
+                               const pg_conv_geom* g, int act, int algo, void* ws, size_t ws_bytes, void* stream, double* part);
+int pg_conv4x4_small2big_stats(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big,
+                               const pg_conv_geom* g, int act, int algo, void* ws, size_t ws_bytes, void* stream, double* part);
+/* pg_instnorm_act_fwd with the statistics pass replaced by the producer's partial sums: merge (fixed order) + normalise. */
+int pg_instnorm_act_fwd_parts(const float* y, int ld_y, float* out, int ld_out, float* stats, const double* part, int chunks,
+                              int N, int HW, int C, int act, float eps, float drop_p, uint64_t seed, void* stream);
+
 /* Backward of a layer whose BIG side carries the incoming gradient -- nn.ConvTranspose2d (unet.py:53) with small = the layer's
  * input x and big = dL/dy -- in ONE call (aten::convolution_backward, trainer.py:89, is one op producing both):
  *     dP     = pg_conv4x4_wgrad(small = x, big = dy)                  (no bias: UpSampleBlock has none)

@@ -54,6 +54,10 @@ SIGNATURES = {
     'pg_conv4x4_big2small': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p]),
     'pg_conv4x4_small2big': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p]),
     'pg_conv4x4_wgrad': (_i, [_p, _i, _p, _i, _p, _p, _G, _i, _p, _sz, _p]),
+    'pg_conv_stats_chunks': (_i, [_G, _i, _i, _sz]),
+    'pg_conv4x4_big2small_stats': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p, _p]),
+    'pg_conv4x4_small2big_stats': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p, _p]),
+    'pg_instnorm_act_fwd_parts': (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p]),
     'pg_instnorm_workspace_bytes': (_sz, [_i, _i, _i]),
     'pg_instnorm_act_fwd': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _f, _u64, _p, _sz, _p]),
     'pg_instnorm_act_bwd': (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p, _sz, _p]),

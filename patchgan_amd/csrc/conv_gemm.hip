@@ -2797,9 +2797,8 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     return PG_OK;
 }
 
-int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const float* bias, float* small,
-                         int ld_small, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
-                         void* stream) {
+static int b2s_impl(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small,
+                    const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes, void* stream, double* part) {
     if (!geom_ok(gg) || !big || !P || !small || ld_big < gg->Cb || ld_small < gg->Ca) return PG_EINVAL;
     if (act < PG_ACT_NONE || act > PG_ACT_SIGMOID) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -2828,8 +2827,11 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
         hipEvent_t e0 = t_ev0, e1 = t_ev1;
         t_ev0 = nullptr;
         t_ev1 = nullptr;
-        return pg_wino2_b2s(big, ld_big, P, bias, small, ld_small, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, nullptr);
+        if (part && pg_wino2_b2s_stats_chunks(g.N, g.Hs, g.Ws, g.Ca) == 0) return PG_EINVAL;
+        return pg_wino2_b2s(big, ld_big, P, bias, small, ld_small, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, nullptr,
+                            part);
     }
+    if (part) return PG_EINVAL;      // only the polyphase output transform emits the partial sums (pg_conv_stats_chunks said 0)
     if (b2s_tapn_ok(g) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= b2s_tapn_ws(g) && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT) {
         // D[big pixel][(tap, a)] = big . P^T (row GEMM over the pixels), then gather the 16 taps per output pixel
@@ -2901,9 +2903,21 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
     return launch_reduce(slabs, p.out_elems, p.split, small, ld_small, (long)g.N * g.Hs * g.Ws, g.Ca, bias, act, st);
 }
 
-int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const float* bias, float* big,
-                         int ld_big, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
+int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const float* bias, float* small,
+                         int ld_small, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
                          void* stream) {
+    return b2s_impl(big, ld_big, P, bias, small, ld_small, gg, act, algo, ws, ws_bytes, stream, nullptr);
+}
+
+int pg_conv4x4_big2small_stats(const float* big, int ld_big, const float* P, const float* bias, float* small,
+                               int ld_small, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
+                               void* stream, double* part) {
+    if (!part) return PG_EINVAL;
+    return b2s_impl(big, ld_big, P, bias, small, ld_small, gg, act, algo, ws, ws_bytes, stream, part);
+}
+
+static int s2b_impl(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big,
+                    const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes, void* stream, double* part) {
     if (!geom_ok(gg) || !big || !P || !small || ld_big < gg->Cb || ld_small < gg->Ca) return PG_EINVAL;
     if (act < PG_ACT_NONE || act > PG_ACT_SIGMOID) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -2932,8 +2946,10 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
         hipEvent_t e0 = t_ev0, e1 = t_ev1;
         t_ev0 = nullptr;
         t_ev1 = nullptr;
-        return pg_wino2_s2b(small, ld_small, P, bias, big, ld_big, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1);
+        if (part && pg_wino2_s2b_stats_chunks(g.N, g.Hb, g.Wb, g.Cb) == 0) return PG_EINVAL;
+        return pg_wino2_s2b(small, ld_small, P, bias, big, ld_big, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, part);
     }
+    if (part) return PG_EINVAL;
     if (s2b_tapn_ok(g) && (ld_small % 4 == 0) && aligned16(small) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= s2b_tapn_ws(g) && tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT) {
         // D[small pixel][(tap, b)] = small . W' (row GEMM), then col2im: each big pixel sums the taps that reach it
@@ -2998,6 +3014,37 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
     }
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     return launch_reduce(slabs, p.out_elems, p.split, big, ld_big, (long)g.N * g.Hb * g.Wb, g.Cb, bias, act, st);
+}
+
+int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const float* bias, float* big,
+                         int ld_big, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
+                         void* stream) {
+    return s2b_impl(small, ld_small, P, bias, big, ld_big, gg, act, algo, ws, ws_bytes, stream, nullptr);
+}
+
+int pg_conv4x4_small2big_stats(const float* small, int ld_small, const float* P, const float* bias, float* big,
+                               int ld_big, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
+                               void* stream, double* part) {
+    if (!part) return PG_EINVAL;
+    return s2b_impl(small, ld_small, P, bias, big, ld_big, gg, act, algo, ws, ws_bytes, stream, part);
+}
+
+int pg_conv_stats_chunks(const pg_conv_geom* gg, int op, int algo, size_t ws_bytes) {
+    if (!geom_ok(gg) || (op != 0 && op != 1)) return 0;
+    const Geom g = to_geom(gg);
+    const Tune tune = tune_of(algo);
+    if ((algo & PG_ALGO_MASK) != PG_ALGO_AUTO) return 0;
+    // mirrors the dispatch of b2s_impl / s2b_impl for 16-byte-aligned tensors: the stride-1 Winograd path comes first
+    if (op == 0) {
+        if (wino_b2s_ok(g, tune) && ws_bytes >= pg_wino_ws_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1)) return 0;
+        if (wino2_b2s_ok(g, tune) && ws_bytes >= pg_wino2_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb))
+            return pg_wino2_b2s_stats_chunks(g.N, g.Hs, g.Ws, g.Ca);
+        return 0;
+    }
+    if (wino_s2b_ok(g, tune) && ws_bytes >= pg_wino_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1)) return 0;
+    if (wino2_s2b_ok(g, tune) && ws_bytes >= pg_wino2c_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb))
+        return pg_wino2_s2b_stats_chunks(g.N, g.Hb, g.Wb, g.Cb);
+    return 0;
 }
 
 int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, float* dbias,
@@ -3134,7 +3181,7 @@ int pg_conv4x4_bwd_big(const float* small, int ld_small, const float* big, int l
     rc = pg_wino2_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, rest, st, e0, e1, V);
     if (rc != PG_OK) return rc;
     return pg_wino2_b2s(big, ld_big, P, nullptr, dsmall, ld_dsmall, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, PG_ACT_NONE, rest, st, e2,
-                        e3, V);
+                        e3, V, nullptr);
 }
 
 }  // extern "C"

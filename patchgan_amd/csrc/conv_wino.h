@@ -42,7 +42,11 @@ size_t pg_wino2_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
 // Vpre (optional, F(3x3,2x2) only): the transformed input already computed by pg_wino2_v; ws then holds U | M only
 int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                 const float* Vpre);
+                 const float* Vpre, double* part);
+// part (optional, both directions): the output transform also writes per-sample partial sums / sums of squares of the output,
+// part[((n * chunks + chunk) * C + c) * 2 + {0,1}] (fp64), chunks = pg_wino2_*_stats_chunks(...) (0: not available)
+int pg_wino2_b2s_stats_chunks(int N, int Hs, int Ws, int Ca);
+int pg_wino2_s2b_stats_chunks(int N, int Hb, int Wb, int Cb);
 size_t pg_wino2_v_bytes(int N, int Hs, int Ws, int Cb);
 int pg_wino2_v(const float* big, int ld_big, float* V, int N, int Hb, int Wb, int Hs, int Ws, int Cb, hipStream_t st);
 
@@ -50,7 +54,8 @@ int pg_wino2_v(const float* big, int ld_big, float* V, int N, int Hb, int Wb, in
 bool pg_wino2c_geom_ok(int N, int Hb, int Wb, int Ca, int Cb);
 size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb);
 int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N, int Hb,
-                 int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+                 int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+                 double* part);
 
 // weight gradient of the stride-2 layers, polyphase F(2x2, 3x3): V (16*tiles*4Cb) | DY (16*tiles*Ca) | S (slices*16*Ca*4Cb)
 bool pg_wino2_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);

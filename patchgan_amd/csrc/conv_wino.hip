@@ -956,11 +956,12 @@ __global__ __launch_bounds__(256) void k_wino_bgemm_mz(const float* __restrict__
     }
 }
 
-// shared output transform: M values at M[xi*zstride + mbase], outputs at (oy + st*k, ox + st*l) of an H x W image
-template <int MO>
+// shared output transform: M values at M[xi*zstride + mbase], outputs at (oy + st*k, ox + st*l) of an H x W image.
+// STATS: also returns the sum and the sum of squares (fp64) of the values it stored, per channel of the quad
+template <int MO, bool STATS = false>
 __device__ __forceinline__ void wino2_out_tile(const float* __restrict__ M, long zstride, long mbase, const float* __restrict__ bias,
                                                float* __restrict__ out, int ld_out, int n, int H, int W, int oy, int ox, int st,
-                                               int c0, int act) {
+                                               int c0, int act, double* s1 = nullptr, double* s2 = nullptr) {
     constexpr int NP = MO + 1;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     f32x4 t[MO][NP];
@@ -989,8 +990,49 @@ __device__ __forceinline__ void wino2_out_tile(const float* __restrict__ M, long
             for (int j = 0; j < NP; ++j) v += t[k][j] * w_at<MO>(l, j);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_epi(v[e], act);
+            if (STATS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double d = (double)v[e];
+                    s1[e] += d;
+                    s2[e] += d * d;
+                }
+            }
             *reinterpret_cast<f32x4*>(out + ((long)(n * H + y) * W + x) * ld_out + c0) = v;
         }
+}
+
+// InstanceNorm statistics from the producer (the conv epilogue emits the sums, the separate statistics pass over
+// y disappears).  The STATS forms of the two output-transform kernels run one grid row per sample (blockIdx.y = n) so that no
+// workgroup straddles two samples; a workgroup covers 256 / cq consecutive (tile[, class]) units x cq channel quads, sums its
+// units per channel in unit order through LDS (fixed order: deterministic) and writes part[(n * chunks + blockIdx.x) * C + c] =
+// (sum, sum of squares) in fp64 -- the layout k_in_merge (norm_act.hip) reads.  Requires 256 % cq == 0.
+template <int CQ_DUMMY = 0>
+__device__ __forceinline__ void stats_block_reduce(const double* s1, const double* s2, int cq, int c0, bool active, double* __restrict__ part,
+                                                   int n, int chunks, int C) {
+    __shared__ double red[8][256];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[e][tid] = active ? s1[e] : 0.0;
+        red[4 + e][tid] = active ? s2[e] : 0.0;
+    }
+    __syncthreads();
+    if (tid < cq) {
+        double a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = red[e][tid];
+        for (int u = tid + cq; u < 256; u += cq)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += red[e][u];
+        double* o = part + (((long)n * chunks + blockIdx.x) * C + tid * 4) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[2 * e] = a[e];
+            o[2 * e + 1] = a[4 + e];
+        }
+    }
+    (void)c0;
 }
 
 template <int MO>
@@ -1007,6 +1049,26 @@ __global__ __launch_bounds__(256) void k_wino2_out(const float* __restrict__ M, 
     const int rem = (int)(tile - (long)n * TH * TW);
     const int ti = rem / TW, tj = rem - ti * TW;
     wino2_out_tile<MO>(M, T * Ca, tile * Ca + c0, bias, out, ld_out, n, Hs, Ws, MO * ti, MO * tj, 1, c0, act);
+}
+
+// grid (chunks, N): the same transform + per-sample partial sums of the output (see stats_block_reduce)
+template <int MO>
+__global__ __launch_bounds__(256) void k_wino2_out_stats(const float* __restrict__ M, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int ld_out, int N, int Hs, int Ws, int Ca, int TH,
+                                                         int TW, int act, double* __restrict__ part) {
+    const int cq = Ca >> 2, TT = TH * TW, n = blockIdx.y;
+    const long T = (long)N * TT;
+    const int local = blockIdx.x * 256 + threadIdx.x;
+    const bool active = local < TT * cq;
+    const int c0 = (local % cq) << 2;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (active) {
+        const int rem = local / cq;
+        const long tile = (long)n * TT + rem;
+        const int ti = rem / TW, tj = rem - ti * TW;
+        wino2_out_tile<MO, true>(M, T * Ca, tile * Ca + c0, bias, out, ld_out, n, Hs, Ws, MO * ti, MO * tj, 1, c0, act, s1, s2);
+    }
+    stats_block_reduce(s1, s2, cq, c0, active, part, n, gridDim.x, Ca);
 }
 
 // P is [tap][a][b] (b fastest), U is [.][b][a] (a fastest): a block transposes a 32 (a) x 32 (b) tile of the 16 taps through
@@ -1086,6 +1148,28 @@ __global__ __launch_bounds__(256) void k_wino2c_out(const float* __restrict__ M,
     // class plane index i = MO*ti - r + al  ->  big row 2*i + r = 2*MO*ti - r + 2*al
     wino2_out_tile<MO>(M, 4L * T * Cb, tile * 4L * Cb + cls * Cb + c0, bias, out, ld_out, n, Hb, Wb, 2 * MO * ti - r,
                        2 * MO * tj - sc, 2, c0, act);
+}
+
+// grid (chunks, N): the same transform + per-sample partial sums of the output (see stats_block_reduce)
+template <int MO>
+__global__ __launch_bounds__(256) void k_wino2c_out_stats(const float* __restrict__ M, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int ld_out, int N, int Hb, int Wb, int Cb, int TH,
+                                                          int TW, int act, double* __restrict__ part) {
+    const int cq = Cb >> 2, TT = TH * TW, n = blockIdx.y;
+    const long T = (long)N * TT;
+    const int local = blockIdx.x * 256 + threadIdx.x;
+    const bool active = local < TT * 4 * cq;
+    const int c0 = (local % cq) << 2;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (active) {
+        const int rr = local / cq, cls = rr & 3, rem = rr >> 2;
+        const int r = cls >> 1, sc = cls & 1;
+        const long tile = (long)n * TT + rem;
+        const int ti = rem / TW, tj = rem - ti * TW;
+        wino2_out_tile<MO, true>(M, 4L * T * Cb, tile * 4L * Cb + cls * Cb + c0, bias, out, ld_out, n, Hb, Wb, 2 * MO * ti - r,
+                                 2 * MO * tj - sc, 2, c0, act, s1, s2);
+    }
+    stats_block_reduce(s1, s2, cq, c0, active, part, n, gridDim.x, Cb);
 }
 
 // Weight gradient of the stride-2 layers, polyphase F(2x2, 3x3): per phase (r, s) the taps (2u+r, 2v+s), u, v in {0,1}, are
@@ -1398,7 +1482,7 @@ size_t pg_wino2_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb) {
 template <int MO>
 static int wino2_b2s_run(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N,
                          int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0,
-                         hipEvent_t ev1, const float* Vpre) {
+                         hipEvent_t ev1, const float* Vpre, double* part) {
     constexpr int X = (MO + 1) * (MO + 1);
     const int TH = (Hs + MO - 1) / MO, TW = (Ws + MO - 1) / MO, K = 4 * Cb;
     const long T = (long)N * TH * TW;
@@ -1432,17 +1516,39 @@ static int wino2_b2s_run(const float* big, int ld_big, const float* P, const flo
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
-    hipLaunchKernelGGL(k_wino2_out<MO>, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, M, bias, small, ld_small, N,
-                       Hs, Ws, Ca, TH, TW, act);
+    if (part)
+        hipLaunchKernelGGL(k_wino2_out_stats<MO>, dim3((unsigned)pg_wino2_b2s_stats_chunks(N, Hs, Ws, Ca), N), dim3(256), 0, st, M, bias,
+                           small, ld_small, N, Hs, Ws, Ca, TH, TW, act, part);
+    else
+        hipLaunchKernelGGL(k_wino2_out<MO>, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, M, bias, small, ld_small,
+                           N, Hs, Ws, Ca, TH, TW, act);
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
 
 int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                 const float* Vpre) {
+                 const float* Vpre, double* part) {
     if (pg_wino2_mo() == 4)
-        return wino2_b2s_run<4>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, nullptr);
-    return wino2_b2s_run<3>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, Vpre);
+        return wino2_b2s_run<4>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, nullptr, part);
+    return wino2_b2s_run<3>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, Vpre, part);
+}
+
+// chunks of per-sample partial sums the output transforms emit (0: channel count not a power-of-two multiple of 4 up to 1024)
+static int stats_chunks(long units_per_sample, int C) {
+    const int cq = C >> 2;
+    if (C % 4 != 0 || cq < 1 || cq > 256 || (256 % cq) != 0) return 0;
+    return (int)((units_per_sample * cq + 255) / 256);
+}
+int pg_wino2_b2s_stats_chunks(int N, int Hs, int Ws, int Ca) {
+    (void)N;
+    const int mo = pg_wino2_mo();
+    return stats_chunks((long)((Hs + mo - 1) / mo) * ((Ws + mo - 1) / mo), Ca);
+}
+int pg_wino2_s2b_stats_chunks(int N, int Hb, int Wb, int Cb) {
+    (void)N;
+    const int mo = pg_wino2_mo();
+    const long TH = ((Hb + 1) / 2 + 1 + mo - 1) / mo, TW = ((Wb + 1) / 2 + 1 + mo - 1) / mo;
+    return stats_chunks(TH * TW * 4, Cb);
 }
 
 // the polyphase input transform V[xi][tile][ph*Cb + b] of `big` on its own (F(3x3,2x2) tiles over the small side): what
@@ -1473,7 +1579,7 @@ size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb) {
 template <int MO>
 static int wino2_s2b_run(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N,
                          int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0,
-                         hipEvent_t ev1) {
+                         hipEvent_t ev1, double* part) {
     constexpr int X = (MO + 1) * (MO + 1);
     const int TH = ((Hb + 1) / 2 + 1 + MO - 1) / MO, TW = ((Wb + 1) / 2 + 1 + MO - 1) / MO, NC = 4 * Cb;
     const long T = (long)N * TH * TW;
@@ -1503,16 +1609,21 @@ static int wino2_s2b_run(const float* small, int ld_small, const float* P, const
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
-    hipLaunchKernelGGL(k_wino2c_out<MO>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, M, bias, big, ld_big, N, Hb, Wb,
-                       Cb, TH, TW, act);
+    if (part)
+        hipLaunchKernelGGL(k_wino2c_out_stats<MO>, dim3((unsigned)pg_wino2_s2b_stats_chunks(N, Hb, Wb, Cb), N), dim3(256), 0, st, M, bias,
+                           big, ld_big, N, Hb, Wb, Cb, TH, TW, act, part);
+    else
+        hipLaunchKernelGGL(k_wino2c_out<MO>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, M, bias, big, ld_big, N, Hb,
+                           Wb, Cb, TH, TW, act);
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
 
 int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N, int Hb,
-                 int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+                 int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+                 double* part) {
     if (pg_wino2_mo() == 4)
-        return wino2_s2b_run<4>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1);
-    return wino2_s2b_run<3>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1);
+        return wino2_s2b_run<4>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part);
+    return wino2_s2b_run<3>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part);
 }
 
 // ---- weight gradient of the stride-2 layers (polyphase F(2x2, 3x3)) ----

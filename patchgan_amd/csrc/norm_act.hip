@@ -568,6 +568,25 @@ int pg_instnorm_act_fwd(const float* y, int ld_y, float* out, int ld_out, float*
     return pg_launch_status();
 }
 
+int pg_instnorm_act_fwd_parts(const float* y, int ld_y, float* out, int ld_out, float* stats, const double* part, int chunks,
+                              int N, int HW, int C, int act, float eps, float drop_p, uint64_t seed, void* stream) {
+    if (!y || !out || !stats || !part || chunks <= 0 || N <= 0 || HW <= 0 || C <= 0 || ld_y < C || ld_out < C) return PG_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID) return PG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (C % 4 == 0) && (ld_y % 4 == 0) && (ld_out % 4 == 0) && al16(y) && al16(out);
+    hipLaunchKernelGGL((k_in_merge<false>), dim3((N * C + 255) / 256), dim3(256), 0, st, part, chunks, N * C, C, HW, eps, stats,
+                       (float*)nullptr);
+    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    if (vec)
+        hipLaunchKernelGGL((k_in_apply<4, false>), dim3(ew_blocks((long)N * HW * (C / 4))), dim3(256), 0, st, y, ld_y,
+                           (const float*)nullptr, 0, (const float*)nullptr, 0, stats, (const float*)nullptr, out, ld_out, N, HW, C,
+                           act, drop_p, seed);
+    else
+        hipLaunchKernelGGL((k_in_apply<1, false>), dim3(ew_blocks((long)N * HW * C)), dim3(256), 0, st, y, ld_y, (const float*)nullptr,
+                           0, (const float*)nullptr, 0, stats, (const float*)nullptr, out, ld_out, N, HW, C, act, drop_p, seed);
+    return pg_launch_status();
+}
+
 int pg_instnorm_act_bwd(const float* g1, int ld_g1, const float* g2, int ld_g2, const float* y, int ld_y,
                         const float* stats, float* dy, int ld_dy, int N, int HW, int C, int act, float drop_p,
                         uint64_t seed, void* ws, size_t ws_bytes, void* stream) {

@@ -212,28 +212,44 @@ class ConvOp:
             self._desc[opcode] = (name.value.decode(), s.value, fl.value)
         return self._desc[opcode]
 
-    def big2small(self, big, P, p_off, bias, b_off, small, act=L.ACT_NONE):
+    def stats_chunks(self, opcode, view_in, view_out):
+        """Partial-sum chunks per sample the kernel of big2small (0) / small2big (1) can emit next to its output (K5: InstanceNorm
+        statistics from the conv epilogue); 0 = not on this path (or the views are not 16-byte aligned)."""
+        for v in (view_in, view_out):
+            if v.ld % 4 or v.ptr() % 16:
+                return 0
+        key = ('chunks', opcode)
+        if key not in self._desc:
+            self._desc[key] = int(L.load().pg_conv_stats_chunks(ctypes.byref(self.g), opcode, self.algo, max(self.ws_bytes, 1 << 20)))
+        return self._desc[key]
+
+    def big2small(self, big, P, p_off, bias, b_off, small, act=L.ACT_NONE, part=None):
+        """part: float64 tensor [N * stats_chunks(0) * Ca * 2] to receive the output's partial sums (pg_conv4x4_big2small_stats)."""
         assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         wp, wn = self._ws(P.device)
+        args = (big.ptr(), big.ld, L.ptr(P, p_off), L.ptr(bias, b_off) if bias is not None else None, small.ptr(), small.ld,
+                ctypes.byref(self.g), act, self.algo, wp, wn, _stream())
 
         def go():
-            L.check(L.load().pg_conv4x4_big2small(big.ptr(), big.ld, L.ptr(P, p_off),
-                                                  L.ptr(bias, b_off) if bias is not None else None, small.ptr(), small.ld,
-                                                  ctypes.byref(self.g), act, self.algo, wp, wn, _stream()),
-                    'pg_conv4x4_big2small')
+            if part is None:
+                L.check(L.load().pg_conv4x4_big2small(*args), 'pg_conv4x4_big2small')
+            else:
+                L.check(L.load().pg_conv4x4_big2small_stats(*args, part.data_ptr()), 'pg_conv4x4_big2small_stats')
         PROFILER.launch(self, 0, go) if PROFILER is not None else go()
 
-    def small2big(self, small, P, p_off, bias, b_off, big, act=L.ACT_NONE):
+    def small2big(self, small, P, p_off, bias, b_off, big, act=L.ACT_NONE, part=None):
         assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         wp, wn = self._ws(P.device)
+        args = (small.ptr(), small.ld, L.ptr(P, p_off), L.ptr(bias, b_off) if bias is not None else None, big.ptr(), big.ld,
+                ctypes.byref(self.g), act, self.algo, wp, wn, _stream())
 
         def go():
-            L.check(L.load().pg_conv4x4_small2big(small.ptr(), small.ld, L.ptr(P, p_off),
-                                                  L.ptr(bias, b_off) if bias is not None else None, big.ptr(), big.ld,
-                                                  ctypes.byref(self.g), act, self.algo, wp, wn, _stream()),
-                    'pg_conv4x4_small2big')
+            if part is None:
+                L.check(L.load().pg_conv4x4_small2big(*args), 'pg_conv4x4_small2big')
+            else:
+                L.check(L.load().pg_conv4x4_small2big_stats(*args, part.data_ptr()), 'pg_conv4x4_small2big_stats')
         PROFILER.launch(self, 1, go) if PROFILER is not None else go()
 
     def wgrad(self, small, big, dP, p_off, dbias=None, b_off=0):
@@ -271,6 +287,29 @@ def instnorm_act_fwd(y, out, stats, act, drop_p=0.0, seed=0):
     L.check(L.load().pg_instnorm_act_fwd(y.ptr(), y.ld, out.ptr(), out.ld, stats.data_ptr(), y.N, y.HW, y.C, act, 1e-5,
                                          drop_p, seed & _MASK64, ws.data_ptr(), ws.numel(), _stream()),
             'pg_instnorm_act_fwd')
+
+
+def conv_instnorm_act(op, opcode, src, flat, p_off, y, out, stats, act, drop_p=0.0, seed=0):
+    """Conv2d / ConvTranspose2d (no bias) -> InstanceNorm2d -> activation -> dropout (unet.py:19-30,53-67).  Where the conv's
+    kernel can emit the per-sample sums of its output (polyphase Winograd output transform) the InstanceNorm statistics come
+    from those partials and the separate statistics pass over y is skipped; otherwise conv, then pg_instnorm_act_fwd."""
+    conv = op.big2small if opcode == 0 else op.small2big
+    if y.HW <= 1:
+        raise ValueError(f"Expected more than 1 spatial element when training, got input size "
+                         f"torch.Size([{y.N}, {y.C}, {y.H}, {y.W}])")
+    chunks = op.stats_chunks(opcode, src, y) if FUSE_IN_STATS else 0
+    if chunks:
+        part = torch.empty(y.N * chunks * y.C * 2, dtype=torch.float64, device=y.t.device)
+        conv(src, flat, p_off, None, 0, y, part=part)
+        L.check(L.load().pg_instnorm_act_fwd_parts(y.ptr(), y.ld, out.ptr(), out.ld, stats.data_ptr(), part.data_ptr(), chunks, y.N,
+                                                   y.HW, y.C, act, 1e-5, drop_p, seed & _MASK64, _stream()),
+                'pg_instnorm_act_fwd_parts')
+    else:
+        conv(src, flat, p_off, None, 0, y)
+        instnorm_act_fwd(y, out, stats, act, drop_p, seed)
+
+
+FUSE_IN_STATS = os.environ.get('PATCHGAN_FUSE_IN_STATS', '1') != '0'      # A/B switch
 
 
 def instnorm_act_bwd(g1, g2, y, stats, dy, act, drop_p=0.0, seed=0):
@@ -511,7 +550,6 @@ class GeneratorEngine:
         src = xin
         for i, (l, op) in enumerate(zip(self.enc, enc_ops)):
             y = View.alloc(N, op.Hs, op.Ws, l.a, dev)
-            op.big2small(src, flat, l.p_off, None, 0, y)
             if i < 6:
                 cat = c.cat[6 - i]
                 out = cat.channels(cat.C - l.a, l.a)
@@ -519,7 +557,7 @@ class GeneratorEngine:
                 out = c.hidden
             stats = torch.empty(N * l.a * 2, dtype=torch.float32, device=dev)
             drop = 0.2 if (train and l.dropout) else 0.0
-            instnorm_act_fwd(y, out, stats, act, drop, _shift_seed(_mix_seed(seed, 1, i), sample0 * y.HW * y.C))
+            conv_instnorm_act(op, 0, src, flat, l.p_off, y, out, stats, act, drop, _shift_seed(_mix_seed(seed, 1, i), sample0 * y.HW * y.C))
             c.y.append(y)
             c.stats.append(stats)
             c.enc_out.append(out)
@@ -539,10 +577,10 @@ class GeneratorEngine:
             out = cat.channels(0, l.b)
             if l.norm:
                 yd = View.alloc(N, op.Hb, op.Wb, l.b, dev)
-                op.small2big(src, flat, l.p_off, None, 0, yd)
                 stats = torch.empty(N * l.b * 2, dtype=torch.float32, device=dev)
                 drop = 0.2 if (train and l.dropout) else 0.0
-                instnorm_act_fwd(yd, out, stats, act, drop, _shift_seed(_mix_seed(seed, 2, i), sample0 * yd.HW * yd.C))
+                conv_instnorm_act(op, 1, src, flat, l.p_off, yd, out, stats, act, drop,
+                                  _shift_seed(_mix_seed(seed, 2, i), sample0 * yd.HW * yd.C))
                 c.yd[i], c.statsd[i] = yd, stats
             else:
                 op.small2big(src, flat, l.p_off, None, 0, out, act)

@@ -444,3 +444,53 @@ def test_bwd_big_equals_its_two_halves(geom, bits):
     F.conv_transpose2d(x, Wr, None, stride=s, padding=1,
                        output_padding=(Hb - ((Hs - 1) * s + 2), Wb - ((Ws - 1) * s + 2))).backward(big)
     assert rel_err(unpack(dP1, Ca, Cb), Wr.grad) < 3e-5 and rel_err(ds1.to_nchw(), x.grad) < 2e-5
+
+
+@pytest.mark.parametrize('geom', [(4, 32, 32, 128, 64, 2), (3, 36, 44, 64, 32, 2), (16, 16, 16, 256, 128, 2), (2, 64, 64, 64, 32, 2)],
+                         ids=lambda g: 'x'.join(map(str, g)))
+def test_conv_emits_instancenorm_partials(geom):
+    """K5: the polyphase output transforms also write per-sample partial sums / sums of squares of the conv output (fp64, fixed
+    order); pg_instnorm_act_fwd_parts normalises from them.  The conv output is bit-identical to the plain call, the merged
+    sums equal the sums of the output, and the normalised result equals pg_instnorm_act_fwd's to fp32 rounding."""
+    import ctypes
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view, empty_view, pack, rel_err, DEV
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    op = E.ConvOp(*geom, L.ALGO_AUTO | L.TUNE_WINO2_ALL)
+    P = pack(Wt)
+    for opcode, src, (Ho, Wo, Co) in ((0, big, (Hs, Ws, Ca)), (1, small, (Hb, Wb, Cb))):
+        vin = to_view(src, ld=src.shape[1] + 4, off=0)
+        y1, y2 = empty_view(N, Ho, Wo, Co, ld=Co + 4, off=4), empty_view(N, Ho, Wo, Co, ld=Co + 4, off=4)
+        chunks = op.stats_chunks(opcode, vin, y1)
+        assert chunks > 0, (opcode, op.describe(opcode))
+        part = torch.full((N * chunks * Co * 2,), float('nan'), dtype=torch.float64, device=DEV)
+        conv = op.big2small if opcode == 0 else op.small2big
+        conv(vin, P, 0, None, 0, y1, part=part)
+        conv(vin, P, 0, None, 0, y2)
+        torch.cuda.synchronize()
+        o1 = y1.to_nchw()
+        assert torch.equal(o1, y2.to_nchw())
+        sums = part.view(N, chunks, Co, 2).sum(1).cpu()
+        od = o1.double().cpu()
+        assert torch.allclose(sums[..., 0], od.sum((2, 3)), rtol=1e-12, atol=1e-9)
+        assert torch.allclose(sums[..., 1], (od * od).sum((2, 3)), rtol=1e-12, atol=1e-9)
+        outs, stats = [], []
+        for fused in (True, False):
+            out = empty_view(N, Ho, Wo, Co, ld=Co + 8, off=4)
+            st = torch.empty(N * Co * 2, device=DEV)
+            if fused:
+                L.check(L.load().pg_instnorm_act_fwd_parts(y1.ptr(), y1.ld, out.ptr(), out.ld, st.data_ptr(), part.data_ptr(), chunks, N,
+                                                           Ho * Wo, Co, ACTS['leakyrelu'], 1e-5, 0.0, 0, None), 'parts')
+            else:
+                E.instnorm_act_fwd(y1, out, st, ACTS['leakyrelu'])
+            outs.append(out.to_nchw())
+            stats.append(st.clone())
+        torch.cuda.synchronize()
+        assert rel_err(outs[0], outs[1]) < 1e-6 and rel_err(stats[0], stats[1]) < 1e-6
+    # a layer off the polyphase path reports 0 chunks and the *_stats entry point refuses
+    plain = E.ConvOp(*geom, L.ALGO_MFMA)
+    vin, y = to_view(big, ld=Cb + 4), empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=4)
+    assert plain.stats_chunks(0, vin, y) == 0
+    with pytest.raises(RuntimeError):
+        plain.big2small(vin, P, 0, None, 0, y, part=torch.empty(16, dtype=torch.float64, device=DEV))
