@@ -52,8 +52,8 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--files', type=int, default=512)
     ap.add_argument('--batch', type=int, default=16)
-    ap.add_argument('--workers', default='0,4,8,16')
-    ap.add_argument('--seconds', type=float, default=6.0)
+    ap.add_argument('--workers', default='0,4,8,12')
+    ap.add_argument('--seconds', type=float, default=4.0)
     ap.add_argument('--labels', default='1,2,3,4')
     ap.add_argument('--step-images-per-sec', type=float, default=1478.0)
     args = ap.parse_args()
@@ -61,6 +61,7 @@ def main():
     from torch.utils.data import DataLoader
     from patchgan_amd.io import COCOStuffDataset
     labels = [int(v) for v in args.labels.split(',')]
+    torch.set_num_threads(min(usable_cpus(), 16))      # the GPU box shows 256 logical CPUs under a 16-CPU quota: do not oversubscribe
     dev = torch.device('cuda') if torch.cuda.is_available() else None
     out = {'size': args.size, 'batch': args.batch, 'labels': len(labels), 'host_cpus': usable_cpus(), 'h2d': dev is not None,
            'step_images_per_sec': args.step_images_per_sec, 'results': []}
