@@ -50,10 +50,10 @@ def usable_cpus():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--files', type=int, default=512)
+    ap.add_argument('--files', type=int, default=256)
     ap.add_argument('--batch', type=int, default=16)
-    ap.add_argument('--workers', default='0,4,8,12')
-    ap.add_argument('--seconds', type=float, default=4.0)
+    ap.add_argument('--workers', default='0,4,8')
+    ap.add_argument('--seconds', type=float, default=3.0)
     ap.add_argument('--labels', default='1,2,3,4')
     ap.add_argument('--step-images-per-sec', type=float, default=1478.0)
     args = ap.parse_args()
@@ -71,6 +71,8 @@ def main():
             for nw in [int(v) for v in args.workers.split(',')]:
                 ds = COCOStuffDataset(os.path.join(folder, 'img'), os.path.join(folder, 'mask'), labels=labels, size=args.size,
                                       augmentation='resize', device_pipeline=(fmt == 'u8'))
+                # a COCO-sized epoch (the synthetic files repeated): the timed window never crosses an epoch restart
+                ds = torch.utils.data.ConcatDataset([ds] * max(1, 65536 // len(ds)))
                 kw = dict(num_workers=nw, persistent_workers=True, prefetch_factor=4) if nw else {}
                 dl = DataLoader(ds, batch_size=args.batch, shuffle=True, pin_memory=dev is not None, drop_last=True, **kw)
                 n_img, n_bytes, t0 = 0, 0, None
