@@ -136,17 +136,35 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
                      float* dP, float* dbias, const pg_conv_geom* g, int algo,
                      void* ws, size_t ws_bytes, void* stream);
 
-/* InstanceNorm statistics from the producing convolution (the conv epilogue emits sum / sum of squares, unet.py:19-20,53-55: the
- * Conv2d / ConvTranspose2d feeding an InstanceNorm2d).  pg_conv_stats_chunks: how many partial-sum chunks per sample the kernel
- * that pg_conv4x4_big2small (op 0) / _small2big (op 1) would launch for (g, algo, ws_bytes, 16-byte-aligned tensors) emits;
- * 0 = that kernel has no such epilogue (call the plain entry point and pg_instnorm_act_fwd).  The *_stats entry points are the
- * plain ones plus part[((n * chunks + chunk) * C + c) * 2 + {0, 1}] = (sum, sum of squares) of the output over the chunk, fp64,
- * fixed summation order; they return PG_EINVAL when the call does not take the path pg_conv_stats_chunks assumed. */
-int pg_conv_stats_chunks(const pg_conv_geom* g, int op, int algo, size_t ws_bytes);
-int pg_conv4x4_big2small_stats(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small,
-                               const pg_conv_geom* g, int act, int algo, void* ws, size_t ws_bytes, void* stream, double* part);
-int pg_conv4x4_small2big_stats(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big,
-                               const pg_conv_geom* g, int act, int algo, void* ws, size_t ws_bytes, void* stream, double* part);
+/* Optional hand-overs between calls on the SAME layer, for the Winograd paths of PG_ALGO_AUTO (all fields may be NULL / 0):
+ *   part     out: InstanceNorm partial sums of the output (the conv epilogue emits sum / sum of squares -- unet.py:19-20,53-55,
+ *            a Conv2d / ConvTranspose2d feeding an InstanceNorm2d): part[((n * chunks + chunk) * C + c) * 2 + {0, 1}], fp64,
+ *            fixed summation order, chunks = pg_conv_stats_chunks(...)
+ *   v_keep   big2small: write the polyphase-transformed input here (pg_conv_v_bytes) instead of into the workspace ...
+ *   v_pre    wgrad: ... so that the weight gradient of the same layer (same `big` tensor) reads it instead of redoing the transform
+ *   u_cache  big2small / small2big: the transformed weights of this (layer, direction) live here (pg_conv_u_bytes) ...
+ *   u_valid  ... and, when non-zero, already hold the transform of the CURRENT weights: the weight transform is skipped
+ *            (the discriminator's weights serve two forward and two data-gradient passes per step, trainer.py:66,98-99).
+ * The size queries mirror the dispatch for 16-byte-aligned tensors and return 0 when the call would not take a path that has
+ * such an operand; passing a hand-over to a call that does not take that path returns PG_EINVAL (nothing is launched). */
+typedef struct pg_conv_extras {
+    double* part;
+    float* v_keep;
+    const float* v_pre;
+    float* u_cache;
+    int u_valid;
+} pg_conv_extras;
+int pg_conv_stats_chunks(const pg_conv_geom* g, int op, int algo, size_t ws_bytes);   /* op 0 big2small, 1 small2big */
+size_t pg_conv_u_bytes(const pg_conv_geom* g, int op, int algo, size_t ws_bytes);      /* op 0 big2small, 1 small2big */
+size_t pg_conv_v_bytes(const pg_conv_geom* g, int algo, size_t ws_bytes);              /* big2small forward -> wgrad */
+int pg_conv4x4_big2small_x(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small,
+                           const pg_conv_geom* g, int act, int algo, void* ws, size_t ws_bytes, void* stream,
+                           const pg_conv_extras* x);
+int pg_conv4x4_small2big_x(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big,
+                           const pg_conv_geom* g, int act, int algo, void* ws, size_t ws_bytes, void* stream,
+                           const pg_conv_extras* x);
+int pg_conv4x4_wgrad_x(const float* small, int ld_small, const float* big, int ld_big, float* dP, float* dbias,
+                       const pg_conv_geom* g, int algo, void* ws, size_t ws_bytes, void* stream, const pg_conv_extras* x);
 /* pg_instnorm_act_fwd with the statistics pass replaced by the producer's partial sums: merge (fixed order) + normalise. */
 int pg_instnorm_act_fwd_parts(const float* y, int ld_y, float* out, int ld_out, float* stats, const double* part, int chunks,
                               int N, int HW, int C, int act, float eps, float drop_p, uint64_t seed, void* stream);

@@ -42,6 +42,15 @@ _sz = ctypes.c_size_t
 _u64 = ctypes.c_uint64
 _G = ctypes.POINTER(ConvGeom)
 
+
+class ConvExtras(ctypes.Structure):
+    """struct pg_conv_extras: optional hand-overs between calls on the same layer"""
+    _fields_ = [('part', ctypes.c_void_p), ('v_keep', ctypes.c_void_p), ('v_pre', ctypes.c_void_p), ('u_cache', ctypes.c_void_p),
+                ('u_valid', ctypes.c_int)]
+
+
+_X = ctypes.POINTER(ConvExtras)
+
 # name -> (restype, argtypes); mirrors include/patchgan_hip.h one to one
 SIGNATURES = {
     'pg_version': (_i, []),
@@ -55,8 +64,11 @@ SIGNATURES = {
     'pg_conv4x4_small2big': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p]),
     'pg_conv4x4_wgrad': (_i, [_p, _i, _p, _i, _p, _p, _G, _i, _p, _sz, _p]),
     'pg_conv_stats_chunks': (_i, [_G, _i, _i, _sz]),
-    'pg_conv4x4_big2small_stats': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p, _p]),
-    'pg_conv4x4_small2big_stats': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p, _p]),
+    'pg_conv_u_bytes': (_sz, [_G, _i, _i, _sz]),
+    'pg_conv_v_bytes': (_sz, [_G, _i, _sz]),
+    'pg_conv4x4_big2small_x': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p, _X]),
+    'pg_conv4x4_small2big_x': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p, _X]),
+    'pg_conv4x4_wgrad_x': (_i, [_p, _i, _p, _i, _p, _p, _G, _i, _p, _sz, _p, _X]),
     'pg_instnorm_act_fwd_parts': (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p]),
     'pg_instnorm_workspace_bytes': (_sz, [_i, _i, _i]),
     'pg_instnorm_act_fwd': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _f, _u64, _p, _sz, _p]),

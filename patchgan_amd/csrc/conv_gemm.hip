@@ -2797,8 +2797,13 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     return PG_OK;
 }
 
+static const pg_conv_extras NO_EXTRAS = {nullptr, nullptr, nullptr, nullptr, 0};
+
 static int b2s_impl(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small,
-                    const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes, void* stream, double* part) {
+                    const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes, void* stream, const pg_conv_extras* xp) {
+    const pg_conv_extras& x = xp ? *xp : NO_EXTRAS;
+    double* part = x.part;
+    if ((x.u_cache && !aligned16(x.u_cache)) || (x.v_keep && !aligned16(x.v_keep)) || x.v_pre) return PG_EINVAL;
     if (!geom_ok(gg) || !big || !P || !small || ld_big < gg->Cb || ld_small < gg->Ca) return PG_EINVAL;
     if (act < PG_ACT_NONE || act > PG_ACT_SIGMOID) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -2816,10 +2821,11 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
     if (algo == PG_ALGO_AUTO && wino_b2s_ok(g, tune) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= pg_wino_ws_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1) &&
         pg_wino_eligible(g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, ld_big, big, tune.mo1)) {
-        int rc = pg_wino_prepare(big, ld_big, P, 0, g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, 1, ws, st, tune.mo1);
+        if (part || x.v_keep) return PG_EINVAL;
+        int rc = pg_wino_prepare(big, ld_big, P, 0, g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, 1, ws, st, tune.mo1, x.u_cache, x.u_valid);
         if (rc != PG_OK) return rc;
         TimedLaunch timed(st);
-        return pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st, tune.mo1, tune.dma);
+        return pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st, tune.mo1, tune.dma, x.u_cache);
     }
     if (algo == PG_ALGO_AUTO && wino2_b2s_ok(g, tune) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
         aligned16(small) && aligned16(ws) && (!bias || aligned16(bias)) &&
@@ -2828,10 +2834,12 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
         t_ev0 = nullptr;
         t_ev1 = nullptr;
         if (part && pg_wino2_b2s_stats_chunks(g.N, g.Hs, g.Ws, g.Ca) == 0) return PG_EINVAL;
+        if (x.v_keep && pg_wino2_mo() != 3) return PG_EINVAL;
         return pg_wino2_b2s(big, ld_big, P, bias, small, ld_small, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, nullptr,
-                            part);
+                            part, x.v_keep, x.u_cache, x.u_valid);
     }
-    if (part) return PG_EINVAL;      // only the polyphase output transform emits the partial sums (pg_conv_stats_chunks said 0)
+    // only the Winograd paths have partial sums / transformed operands to hand over (the pg_conv_*_bytes / _chunks queries said 0)
+    if (part || x.v_keep || x.u_cache) return PG_EINVAL;
     if (b2s_tapn_ok(g) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= b2s_tapn_ws(g) && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT) {
         // D[big pixel][(tap, a)] = big . P^T (row GEMM over the pixels), then gather the 16 taps per output pixel
@@ -2909,15 +2917,17 @@ int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const flo
     return b2s_impl(big, ld_big, P, bias, small, ld_small, gg, act, algo, ws, ws_bytes, stream, nullptr);
 }
 
-int pg_conv4x4_big2small_stats(const float* big, int ld_big, const float* P, const float* bias, float* small,
-                               int ld_small, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
-                               void* stream, double* part) {
-    if (!part) return PG_EINVAL;
-    return b2s_impl(big, ld_big, P, bias, small, ld_small, gg, act, algo, ws, ws_bytes, stream, part);
+int pg_conv4x4_big2small_x(const float* big, int ld_big, const float* P, const float* bias, float* small,
+                           int ld_small, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
+                           void* stream, const pg_conv_extras* x) {
+    return b2s_impl(big, ld_big, P, bias, small, ld_small, gg, act, algo, ws, ws_bytes, stream, x);
 }
 
 static int s2b_impl(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big,
-                    const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes, void* stream, double* part) {
+                    const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes, void* stream, const pg_conv_extras* xp) {
+    const pg_conv_extras& x = xp ? *xp : NO_EXTRAS;
+    double* part = x.part;
+    if ((x.u_cache && !aligned16(x.u_cache)) || x.v_keep || x.v_pre) return PG_EINVAL;
     if (!geom_ok(gg) || !big || !P || !small || ld_big < gg->Cb || ld_small < gg->Ca) return PG_EINVAL;
     if (act < PG_ACT_NONE || act > PG_ACT_SIGMOID) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -2935,10 +2945,11 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
     if (algo == PG_ALGO_AUTO && wino_s2b_ok(g, tune) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= pg_wino_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1) &&
         pg_wino_eligible(g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, ld_small, small, tune.mo1)) {
-        int rc = pg_wino_prepare(small, ld_small, P, 1, g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, 2, ws, st, tune.mo1);
+        if (part) return PG_EINVAL;
+        int rc = pg_wino_prepare(small, ld_small, P, 1, g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, 2, ws, st, tune.mo1, x.u_cache, x.u_valid);
         if (rc != PG_OK) return rc;
         TimedLaunch timed(st);
-        return pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st, tune.mo1, tune.dma);
+        return pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st, tune.mo1, tune.dma, x.u_cache);
     }
     if (algo == PG_ALGO_AUTO && wino2_s2b_ok(g, tune) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
         aligned16(small) && aligned16(ws) && (!bias || aligned16(bias)) &&
@@ -2947,9 +2958,10 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         t_ev0 = nullptr;
         t_ev1 = nullptr;
         if (part && pg_wino2_s2b_stats_chunks(g.N, g.Hb, g.Wb, g.Cb) == 0) return PG_EINVAL;
-        return pg_wino2_s2b(small, ld_small, P, bias, big, ld_big, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, part);
+        return pg_wino2_s2b(small, ld_small, P, bias, big, ld_big, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, part,
+                            x.u_cache, x.u_valid);
     }
-    if (part) return PG_EINVAL;
+    if (part || x.u_cache) return PG_EINVAL;
     if (s2b_tapn_ok(g) && (ld_small % 4 == 0) && aligned16(small) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= s2b_tapn_ws(g) && tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT) {
         // D[small pixel][(tap, b)] = small . W' (row GEMM), then col2im: each big pixel sums the taps that reach it
@@ -3022,11 +3034,37 @@ int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const
     return s2b_impl(small, ld_small, P, bias, big, ld_big, gg, act, algo, ws, ws_bytes, stream, nullptr);
 }
 
-int pg_conv4x4_small2big_stats(const float* small, int ld_small, const float* P, const float* bias, float* big,
-                               int ld_big, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
-                               void* stream, double* part) {
-    if (!part) return PG_EINVAL;
-    return s2b_impl(small, ld_small, P, bias, big, ld_big, gg, act, algo, ws, ws_bytes, stream, part);
+int pg_conv4x4_small2big_x(const float* small, int ld_small, const float* P, const float* bias, float* big,
+                           int ld_big, const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes,
+                           void* stream, const pg_conv_extras* x) {
+    return s2b_impl(small, ld_small, P, bias, big, ld_big, gg, act, algo, ws, ws_bytes, stream, x);
+}
+
+size_t pg_conv_u_bytes(const pg_conv_geom* gg, int op, int algo, size_t ws_bytes) {
+    if (!geom_ok(gg) || (op != 0 && op != 1) || (algo & PG_ALGO_MASK) != PG_ALGO_AUTO) return 0;
+    const Geom g = to_geom(gg);
+    const Tune tune = tune_of(algo);
+    if (op == 0) {
+        if (wino_b2s_ok(g, tune) && ws_bytes >= pg_wino_ws_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1))
+            return pg_wino_u_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1);
+        if (wino2_b2s_ok(g, tune) && ws_bytes >= pg_wino2_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) return pg_wino2_u_bytes(g.Ca, g.Cb);
+        return 0;
+    }
+    if (wino_s2b_ok(g, tune) && ws_bytes >= pg_wino_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1))
+        return pg_wino_u_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1);
+    if (wino2_s2b_ok(g, tune) && ws_bytes >= pg_wino2c_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb)) return pg_wino2_u_bytes(g.Ca, g.Cb);
+    return 0;
+}
+
+size_t pg_conv_v_bytes(const pg_conv_geom* gg, int algo, size_t ws_bytes) {
+    if (!geom_ok(gg) || (algo & PG_ALGO_MASK) != PG_ALGO_AUTO || pg_wino2_mo() != 3) return 0;
+    const Geom g = to_geom(gg);
+    const Tune tune = tune_of(algo);
+    const size_t colsum = ((size_t)COLSUM_CHUNKS * g.Ca * sizeof(float) + 255) & ~(size_t)255;
+    if (wino2_b2s_ok(g, tune) && ws_bytes >= pg_wino2_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb) && wino2_wgrad_ok(g, tune) &&
+        ws_bytes >= colsum + pg_wino2_wgrad_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb))
+        return pg_wino2_v_bytes(g.N, g.Hs, g.Ws, g.Cb);
+    return 0;
 }
 
 int pg_conv_stats_chunks(const pg_conv_geom* gg, int op, int algo, size_t ws_bytes) {
@@ -3047,9 +3085,10 @@ int pg_conv_stats_chunks(const pg_conv_geom* gg, int op, int algo, size_t ws_byt
     return 0;
 }
 
-int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, float* dbias,
-                     const pg_conv_geom* gg, int algo, void* ws, size_t ws_bytes, void* stream) {
+static int wgrad_impl(const float* small, int ld_small, const float* big, int ld_big, float* dP, float* dbias,
+                      const pg_conv_geom* gg, int algo, void* ws, size_t ws_bytes, void* stream, const float* v_pre) {
     if (!geom_ok(gg) || !big || !dP || !small || ld_big < gg->Cb || ld_small < gg->Ca) return PG_EINVAL;
+    if (v_pre && !aligned16(v_pre)) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     Geom g = to_geom(gg);
     const Tune tune = tune_of(algo);
@@ -3093,6 +3132,7 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
         hipEvent_t e0 = t_ev0, e1 = t_ev1;
         t_ev0 = nullptr;
         t_ev1 = nullptr;
+        if (v_pre) return PG_EINVAL;
         return pg_wino_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, (char*)ws + reserved, st,
                              e0, e1);
     }
@@ -3102,8 +3142,9 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
         t_ev0 = nullptr;
         t_ev1 = nullptr;
         return pg_wino2_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, (char*)ws + reserved, st,
-                              e0, e1, nullptr);
+                              e0, e1, v_pre);
     }
+    if (v_pre) return PG_EINVAL;     // pg_conv_v_bytes said 0 for this call: there is no transformed operand to reuse
     Plan p = plan_wgrad(gg);
     clamp_split(p, ws_bytes, reserved);
     const int vecm = (g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned16(small);
@@ -3149,6 +3190,17 @@ int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_
     return launch_reduce(dst, p.out_elems, p.split, dP, g.Cb, 16L * g.Ca, g.Cb, nullptr, 0, st);
 }
 
+int pg_conv4x4_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, float* dbias,
+                     const pg_conv_geom* gg, int algo, void* ws, size_t ws_bytes, void* stream) {
+    return wgrad_impl(small, ld_small, big, ld_big, dP, dbias, gg, algo, ws, ws_bytes, stream, nullptr);
+}
+
+int pg_conv4x4_wgrad_x(const float* small, int ld_small, const float* big, int ld_big, float* dP, float* dbias,
+                       const pg_conv_geom* gg, int algo, void* ws, size_t ws_bytes, void* stream, const pg_conv_extras* x) {
+    if (x && (x->part || x->v_keep || x->u_cache)) return PG_EINVAL;
+    return wgrad_impl(small, ld_small, big, ld_big, dP, dbias, gg, algo, ws, ws_bytes, stream, x ? x->v_pre : nullptr);
+}
+
 int pg_conv4x4_bwd_big(const float* small, int ld_small, const float* big, int ld_big, const float* P, float* dP,
                        float* dsmall, int ld_dsmall, const pg_conv_geom* gg, int algo, void* ws, size_t ws_bytes, void* stream) {
     if (!geom_ok(gg) || !small || !big || !P || !dP || !dsmall) return PG_EINVAL;
@@ -3181,7 +3233,7 @@ int pg_conv4x4_bwd_big(const float* small, int ld_small, const float* big, int l
     rc = pg_wino2_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, rest, st, e0, e1, V);
     if (rc != PG_OK) return rc;
     return pg_wino2_b2s(big, ld_big, P, nullptr, dsmall, ld_dsmall, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, PG_ACT_NONE, rest, st, e2,
-                        e3, V, nullptr);
+                        e3, V, nullptr, nullptr, nullptr, 0);
 }
 
 }  // extern "C"

@@ -15,11 +15,15 @@ bool pg_wino_small_tile(int N, int Hout, int Wout, int Cin, int Cout, int mo_for
 size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced);
 // weight transform + input transform into ws
 int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N, int Hin, int Win, int Cin, int Hout,
-                    int Wout, int Cout, int pad, void* ws, hipStream_t st, int mo_forced);
+                    int Wout, int Cout, int pad, void* ws, hipStream_t st, int mo_forced, float* Uext, int u_valid);
+// Uext (optional, all paths with a weight transform): caller-owned cache of the transformed weights; u_valid != 0: it already
+// holds the transform of the current weights and the transform kernel is skipped
+size_t pg_wino_u_bytes(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced);
+size_t pg_wino2_u_bytes(int Ca, int Cb);     // both polyphase directions
 int pg_wino_dma_mode();   // process default (PATCHGAN_WINO_DMA): 0 register-staged k_wino_gemm only, 1: k_wino_gemm_dma<3,4,2> for F(3x3,4x4), 2: also <2,3,3> for 64-tile F(2x2,4x4)
 // the batched GEMM with fused output transform, bias and activation
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
-                 void* ws, hipStream_t st, int mo_forced, int dma_mode);
+                 void* ws, hipStream_t st, int mo_forced, int dma_mode, const float* Uext);
 
 // weight gradient of the same layers, F(4x4, 2x2): V (25*tiles*Cb) | DY (25*tiles*Ca) | S (slices*25*Ca*Cb) in ws
 bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
@@ -42,7 +46,7 @@ size_t pg_wino2_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
 // Vpre (optional, F(3x3,2x2) only): the transformed input already computed by pg_wino2_v; ws then holds U | M only
 int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                 const float* Vpre, double* part);
+                 const float* Vpre, double* part, float* Vkeep, float* Uext, int u_valid);
 // part (optional, both directions): the output transform also writes per-sample partial sums / sums of squares of the output,
 // part[((n * chunks + chunk) * C + c) * 2 + {0,1}] (fp64), chunks = pg_wino2_*_stats_chunks(...) (0: not available)
 int pg_wino2_b2s_stats_chunks(int N, int Hs, int Ws, int Ca);
@@ -55,7 +59,7 @@ bool pg_wino2c_geom_ok(int N, int Hb, int Wb, int Ca, int Cb);
 size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb);
 int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                 double* part);
+                 double* part, float* Uext, int u_valid);
 
 // weight gradient of the stride-2 layers, polyphase F(2x2, 3x3): V (16*tiles*4Cb) | DY (16*tiles*Ca) | S (slices*16*Ca*4Cb)
 bool pg_wino2_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);

@@ -1301,23 +1301,28 @@ bool pg_wino_small_tile(int N, int Hout, int Wout, int Cin, int Cout, int mo_for
     return forced ? forced == 1 : wg128 < 400;
 }
 
+size_t pg_wino_u_bytes(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
+    return align256((size_t)wino1_nxi(N, Hout, Wout, Cin, Cout, forced) * Cout * Cin * 4);
+}
 size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
     const long T = wino1_tiles(N, Hout, Wout, Cin, Cout, forced), X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
     return align256((size_t)X * Cout * Cin * 4) + align256((size_t)X * T * Cin * 4);
 }
 
 int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N, int Hin, int Win, int Cin, int Hout,
-                    int Wout, int Cout, int pad, void* ws, hipStream_t st, int forced) {
+                    int Wout, int Cout, int pad, void* ws, hipStream_t st, int forced, float* Uext, int u_valid) {
     const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
     const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
-    float* U = (float*)ws;
+    float* U = Uext ? Uext : (float*)ws;       // Uext: caller-owned cache of the transformed weights (u_valid: already filled)
     float* V = (float*)((char*)ws + align256((size_t)X * Cout * Cin * 4));
     const dim3 gu((unsigned)(((long)Cout * Cin + 255) / 256)), gv((unsigned)((T * (Cin / 4) + 255) / 256));
-    if (mo == 3)
-        hipLaunchKernelGGL(k_wino_u<3>, gu, dim3(256), 0, st, P, U, Cout, Cin, flip);
-    else
-        hipLaunchKernelGGL(k_wino_u<2>, gu, dim3(256), 0, st, P, U, Cout, Cin, flip);
-    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    if (!(Uext && u_valid)) {
+        if (mo == 3)
+            hipLaunchKernelGGL(k_wino_u<3>, gu, dim3(256), 0, st, P, U, Cout, Cin, flip);
+        else
+            hipLaunchKernelGGL(k_wino_u<2>, gu, dim3(256), 0, st, P, U, Cout, Cin, flip);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    }
     if (mo == 3)
         hipLaunchKernelGGL(k_wino_v<3>, gv, dim3(256), 0, st, in, ld_in, V, N, Hin, Win, Cin, TH, TW, pad);
     else
@@ -1338,10 +1343,10 @@ int pg_wino_dma_mode() {
 }
 
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
-                 void* ws, hipStream_t st, int forced, int dma_mode) {
+                 void* ws, hipStream_t st, int forced, int dma_mode, const float* Uext) {
     const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
     const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
-    const float* U = (const float*)ws;
+    const float* U = Uext ? Uext : (const float*)ws;
     const float* V = (const float*)((const char*)ws + align256((size_t)X * Cout * Cin * 4));
     const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cin, Cout, forced);
     const int v_bytes = (int)(X * T * Cin * 4), u_bytes = (int)(X * Cout * Cin * 4);
@@ -1482,17 +1487,22 @@ size_t pg_wino2_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb) {
 template <int MO>
 static int wino2_b2s_run(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N,
                          int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0,
-                         hipEvent_t ev1, const float* Vpre, double* part) {
+                         hipEvent_t ev1, const float* Vpre, double* part, float* Vkeep, float* Uext, int u_valid) {
     constexpr int X = (MO + 1) * (MO + 1);
     const int TH = (Hs + MO - 1) / MO, TW = (Ws + MO - 1) / MO, K = 4 * Cb;
     const long T = (long)N * TH * TW;
-    // ws: U | V | M, or U | M when the caller supplies the transformed input (Vpre: shared with the weight gradient)
-    float* U = (float*)ws;
-    float* Vown = (float*)((char*)U + align256((size_t)X * Ca * K * 4));
-    float* M = Vpre ? Vown : (float*)((char*)Vown + align256((size_t)X * T * K * 4));
+    // ws: U | V | M, or U | M when the caller supplies the transformed input (Vpre: shared with the weight gradient).
+    // Vkeep: write V there (caller-owned, kept for the layer's weight gradient); Uext: caller-owned cache of U
+    float* Uws = (float*)ws;
+    float* U = Uext ? Uext : Uws;
+    float* Vws = (float*)((char*)Uws + align256((size_t)X * Ca * K * 4));
+    float* M = Vpre ? Vws : (float*)((char*)Vws + align256((size_t)X * T * K * 4));
+    float* Vown = Vkeep ? Vkeep : Vws;
     const float* V = Vpre ? Vpre : Vown;
-    hipLaunchKernelGGL(k_wino2_u<MO>, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, P, U, Ca, Cb);
-    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    if (!(Uext && u_valid)) {
+        hipLaunchKernelGGL(k_wino2_u<MO>, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, P, U, Ca, Cb);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    }
     if (!Vpre) {
         hipLaunchKernelGGL(k_wino2_v<MO>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, big, ld_big, Vown, N, Hb, Wb, Cb,
                            TH, TW);
@@ -1527,11 +1537,14 @@ static int wino2_b2s_run(const float* big, int ld_big, const float* P, const flo
 
 int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                 const float* Vpre, double* part) {
+                 const float* Vpre, double* part, float* Vkeep, float* Uext, int u_valid) {
     if (pg_wino2_mo() == 4)
-        return wino2_b2s_run<4>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, nullptr, part);
-    return wino2_b2s_run<3>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, Vpre, part);
+        return wino2_b2s_run<4>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, nullptr, part,
+                                nullptr, Uext, u_valid);
+    return wino2_b2s_run<3>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, Vpre, part, Vkeep,
+                            Uext, u_valid);
 }
+size_t pg_wino2_u_bytes(int Ca, int Cb) { return align256((size_t)wino2_nxi() * Ca * 4 * Cb * 4); }
 
 // chunks of per-sample partial sums the output transforms emit (0: channel count not a power-of-two multiple of 4 up to 1024)
 static int stats_chunks(long units_per_sample, int C) {
@@ -1579,15 +1592,18 @@ size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb) {
 template <int MO>
 static int wino2_s2b_run(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N,
                          int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0,
-                         hipEvent_t ev1, double* part) {
+                         hipEvent_t ev1, double* part, float* Uext, int u_valid) {
     constexpr int X = (MO + 1) * (MO + 1);
     const int TH = ((Hb + 1) / 2 + 1 + MO - 1) / MO, TW = ((Wb + 1) / 2 + 1 + MO - 1) / MO, NC = 4 * Cb;
     const long T = (long)N * TH * TW;
-    float* U = (float*)ws;
-    float* V = (float*)((char*)U + align256((size_t)X * Ca * NC * 4));
+    float* Uws = (float*)ws;
+    float* U = Uext ? Uext : Uws;
+    float* V = (float*)((char*)Uws + align256((size_t)X * Ca * NC * 4));
     float* M = (float*)((char*)V + align256((size_t)X * T * Ca * 4));
-    hipLaunchKernelGGL(k_wino2c_u<MO>, dim3((Cb + 31) / 32, (Ca + 31) / 32), dim3(1024), 0, st, P, U, Ca, Cb);
-    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    if (!(Uext && u_valid)) {
+        hipLaunchKernelGGL(k_wino2c_u<MO>, dim3((Cb + 31) / 32, (Ca + 31) / 32), dim3(1024), 0, st, P, U, Ca, Cb);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    }
     hipLaunchKernelGGL(k_wino2c_v<MO>, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, small, ld_small, V, N, Hs, Ws,
                        Ca, TH, TW);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
@@ -1620,10 +1636,10 @@ static int wino2_s2b_run(const float* small, int ld_small, const float* P, const
 
 int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                 double* part) {
+                 double* part, float* Uext, int u_valid) {
     if (pg_wino2_mo() == 4)
-        return wino2_s2b_run<4>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part);
-    return wino2_s2b_run<3>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part);
+        return wino2_s2b_run<4>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part, Uext, u_valid);
+    return wino2_s2b_run<3>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part, Uext, u_valid);
 }
 
 // ---- weight gradient of the stride-2 layers (polyphase F(2x2, 3x3)) ----

@@ -212,57 +212,87 @@ class ConvOp:
             self._desc[opcode] = (name.value.decode(), s.value, fl.value)
         return self._desc[opcode]
 
+    @staticmethod
+    def _aligned(*views):
+        return all(v.ld % 4 == 0 and v.ptr() % 16 == 0 for v in views)
+
+    def _query(self, key, fn):
+        if key not in self._desc:
+            self._desc[key] = int(fn())
+        return self._desc[key]
+
     def stats_chunks(self, opcode, view_in, view_out):
         """Partial-sum chunks per sample the kernel of big2small (0) / small2big (1) can emit next to its output (K5: InstanceNorm
         statistics from the conv epilogue); 0 = not on this path (or the views are not 16-byte aligned)."""
-        for v in (view_in, view_out):
-            if v.ld % 4 or v.ptr() % 16:
-                return 0
-        key = ('chunks', opcode)
-        if key not in self._desc:
-            self._desc[key] = int(L.load().pg_conv_stats_chunks(ctypes.byref(self.g), opcode, self.algo, max(self.ws_bytes, 1 << 20)))
-        return self._desc[key]
+        if not self._aligned(view_in, view_out):
+            return 0
+        return self._query(('chunks', opcode), lambda: L.load().pg_conv_stats_chunks(ctypes.byref(self.g), opcode, self.algo,
+                                                                                    max(self.ws_bytes, 1 << 20)))
 
-    def big2small(self, big, P, p_off, bias, b_off, small, act=L.ACT_NONE, part=None):
-        """part: float64 tensor [N * stats_chunks(0) * Ca * 2] to receive the output's partial sums (pg_conv4x4_big2small_stats)."""
+    def u_bytes(self, opcode):
+        """Bytes of the transformed weights the kernel of big2small (0) / small2big (1) works from (0: no weight transform on
+        this path): what a caller-owned cache for pg_conv_extras.u_cache must hold."""
+        return self._query(('u', opcode), lambda: L.load().pg_conv_u_bytes(ctypes.byref(self.g), opcode, self.algo,
+                                                                           max(self.ws_bytes, 1 << 20)))
+
+    def v_bytes(self):
+        """Bytes of the polyphase-transformed `big` tensor that big2small can keep (v_keep) for the weight gradient of the
+        same layer (v_pre); 0 when the two calls do not both take the polyphase Winograd path."""
+        return self._query(('v',), lambda: L.load().pg_conv_v_bytes(ctypes.byref(self.g), self.algo, max(self.ws_bytes, 1 << 20)))
+
+    @staticmethod
+    def _extras(part=None, v_keep=None, v_pre=None, u_cache=None, u_valid=False):
+        if part is None and v_keep is None and v_pre is None and u_cache is None:
+            return None
+        p = lambda t: t.data_ptr() if t is not None else None
+        return L.ConvExtras(p(part), p(v_keep), p(v_pre), p(u_cache), 1 if u_valid else 0)
+
+    def big2small(self, big, P, p_off, bias, b_off, small, act=L.ACT_NONE, part=None, v_keep=None, u_cache=None, u_valid=False):
+        """part / v_keep / u_cache: the optional hand-overs of pg_conv_extras (sizes: stats_chunks(0), v_bytes(), u_bytes(0))."""
         assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         wp, wn = self._ws(P.device)
         args = (big.ptr(), big.ld, L.ptr(P, p_off), L.ptr(bias, b_off) if bias is not None else None, small.ptr(), small.ld,
                 ctypes.byref(self.g), act, self.algo, wp, wn, _stream())
+        x = self._extras(part=part, v_keep=v_keep, u_cache=u_cache, u_valid=u_valid)
 
         def go():
-            if part is None:
+            if x is None:
                 L.check(L.load().pg_conv4x4_big2small(*args), 'pg_conv4x4_big2small')
             else:
-                L.check(L.load().pg_conv4x4_big2small_stats(*args, part.data_ptr()), 'pg_conv4x4_big2small_stats')
+                L.check(L.load().pg_conv4x4_big2small_x(*args, ctypes.byref(x)), 'pg_conv4x4_big2small_x')
         PROFILER.launch(self, 0, go) if PROFILER is not None else go()
 
-    def small2big(self, small, P, p_off, bias, b_off, big, act=L.ACT_NONE, part=None):
+    def small2big(self, small, P, p_off, bias, b_off, big, act=L.ACT_NONE, part=None, u_cache=None, u_valid=False):
         assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         wp, wn = self._ws(P.device)
         args = (small.ptr(), small.ld, L.ptr(P, p_off), L.ptr(bias, b_off) if bias is not None else None, big.ptr(), big.ld,
                 ctypes.byref(self.g), act, self.algo, wp, wn, _stream())
+        x = self._extras(part=part, u_cache=u_cache, u_valid=u_valid)
 
         def go():
-            if part is None:
+            if x is None:
                 L.check(L.load().pg_conv4x4_small2big(*args), 'pg_conv4x4_small2big')
             else:
-                L.check(L.load().pg_conv4x4_small2big_stats(*args, part.data_ptr()), 'pg_conv4x4_small2big_stats')
+                L.check(L.load().pg_conv4x4_small2big_x(*args, ctypes.byref(x)), 'pg_conv4x4_small2big_x')
         PROFILER.launch(self, 1, go) if PROFILER is not None else go()
 
-    def wgrad(self, small, big, dP, p_off, dbias=None, b_off=0):
+    def wgrad(self, small, big, dP, p_off, dbias=None, b_off=0, v_pre=None):
+        """v_pre: the transformed `big` tensor kept by this layer's big2small(..., v_keep=) (same tensor, v_bytes() > 0)."""
         assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         wp, wn = self._ws(dP.device)
+        args = (small.ptr(), small.ld, big.ptr(), big.ld, L.ptr(dP, p_off), L.ptr(dbias, b_off) if dbias is not None else None,
+                ctypes.byref(self.g), self.algo, wp, wn, _stream())
+        x = self._extras(v_pre=v_pre)
 
         def go():
-            L.check(L.load().pg_conv4x4_wgrad(small.ptr(), small.ld, big.ptr(), big.ld, L.ptr(dP, p_off),
-                                              L.ptr(dbias, b_off) if dbias is not None else None, ctypes.byref(self.g),
-                                              self.algo, wp, wn, _stream()), 'pg_conv4x4_wgrad')
+            if x is None:
+                L.check(L.load().pg_conv4x4_wgrad(*args), 'pg_conv4x4_wgrad')
+            else:
+                L.check(L.load().pg_conv4x4_wgrad_x(*args, ctypes.byref(x)), 'pg_conv4x4_wgrad_x')
         PROFILER.launch(self, 2, go) if PROFILER is not None else go()
-
 
     def bwd_big(self, small, big, P, dP, p_off, dsmall):
         """Weight gradient (small = x, big = dy) and data gradient (big -> small) of a ConvTranspose2d layer in one call; where
@@ -289,27 +319,30 @@ def instnorm_act_fwd(y, out, stats, act, drop_p=0.0, seed=0):
             'pg_instnorm_act_fwd')
 
 
-def conv_instnorm_act(op, opcode, src, flat, p_off, y, out, stats, act, drop_p=0.0, seed=0):
+def conv_instnorm_act(op, opcode, src, flat, p_off, y, out, stats, act, drop_p=0.0, seed=0, v_keep=None):
     """Conv2d / ConvTranspose2d (no bias) -> InstanceNorm2d -> activation -> dropout (unet.py:19-30,53-67).  Where the conv's
     kernel can emit the per-sample sums of its output (polyphase Winograd output transform) the InstanceNorm statistics come
     from those partials and the separate statistics pass over y is skipped; otherwise conv, then pg_instnorm_act_fwd."""
     conv = op.big2small if opcode == 0 else op.small2big
+    kw = {'v_keep': v_keep} if v_keep is not None else {}
     if y.HW <= 1:
         raise ValueError(f"Expected more than 1 spatial element when training, got input size "
                          f"torch.Size([{y.N}, {y.C}, {y.H}, {y.W}])")
     chunks = op.stats_chunks(opcode, src, y) if FUSE_IN_STATS else 0
     if chunks:
         part = torch.empty(y.N * chunks * y.C * 2, dtype=torch.float64, device=y.t.device)
-        conv(src, flat, p_off, None, 0, y, part=part)
+        conv(src, flat, p_off, None, 0, y, part=part, **kw)
         L.check(L.load().pg_instnorm_act_fwd_parts(y.ptr(), y.ld, out.ptr(), out.ld, stats.data_ptr(), part.data_ptr(), chunks, y.N,
                                                    y.HW, y.C, act, 1e-5, drop_p, seed & _MASK64, _stream()),
                 'pg_instnorm_act_fwd_parts')
     else:
-        conv(src, flat, p_off, None, 0, y)
+        conv(src, flat, p_off, None, 0, y, **kw)
         instnorm_act_fwd(y, out, stats, act, drop_p, seed)
 
 
-FUSE_IN_STATS = os.environ.get('PATCHGAN_FUSE_IN_STATS', '1') != '0'      # A/B switch
+FUSE_IN_STATS = os.environ.get('PATCHGAN_FUSE_IN_STATS', '1') != '0'      # A/B switches (same-device timing)
+KEEP_V = os.environ.get('PATCHGAN_KEEP_V', '1') != '0'
+CACHE_U = os.environ.get('PATCHGAN_CACHE_U', '1') != '0'
 
 
 def instnorm_act_bwd(g1, g2, y, stats, dy, act, drop_p=0.0, seed=0):
@@ -529,10 +562,12 @@ class GeneratorEngine:
             self._ops[key] = (enc_ops, dec_ops)
         return self._ops[key]
 
-    def forward(self, flat, xin, gen_out, train, seed=0, sample0=0):
+    def forward(self, flat, xin, gen_out, train, seed=0, sample0=0, keep_v=False):
         """xin: View [N,H,W,input_nc]; gen_out: View [N,H,W,output_nc] to receive final_act(dec6).
         train selects dropout (InstanceNorm always uses instance statistics, unet.py:77).  sample0 = index of this
-        batch's first sample in the global batch (data parallelism: the dropout masks are those of the global batch)."""
+        batch's first sample in the global batch (data parallelism: the dropout masks are those of the global batch).
+        keep_v: a backward pass follows -- encoder layers on the polyphase Winograd path keep their transformed input for the
+        weight gradient (pg_conv_extras.v_keep / v_pre) instead of transforming it again."""
         N, H, W = xin.N, xin.H, xin.W
         dev = flat.device
         enc_ops, dec_ops = self.ops(N, H, W)
@@ -545,7 +580,7 @@ class GeneratorEngine:
             op = dec_ops[i]
             c.cat[i] = View.alloc(N, op.Hs, op.Ws, self.dec[i].a, dev)
         c.hidden = View.alloc(N, enc_ops[6].Hs, enc_ops[6].Ws, F[6], dev)
-        c.y, c.stats, c.enc_out = [], [], []
+        c.y, c.stats, c.enc_out, c.v = [], [], [], []
         act = L.ACT_CODES[self.activation]
         src = xin
         for i, (l, op) in enumerate(zip(self.enc, enc_ops)):
@@ -557,7 +592,11 @@ class GeneratorEngine:
                 out = c.hidden
             stats = torch.empty(N * l.a * 2, dtype=torch.float32, device=dev)
             drop = 0.2 if (train and l.dropout) else 0.0
-            conv_instnorm_act(op, 0, src, flat, l.p_off, y, out, stats, act, drop, _shift_seed(_mix_seed(seed, 1, i), sample0 * y.HW * y.C))
+            vb = op.v_bytes() if (keep_v and KEEP_V and ConvOp._aligned(src, y)) else 0
+            vk = torch.empty(vb, dtype=torch.uint8, device=dev) if vb else None
+            conv_instnorm_act(op, 0, src, flat, l.p_off, y, out, stats, act, drop, _shift_seed(_mix_seed(seed, 1, i), sample0 * y.HW * y.C),
+                              v_keep=vk)
+            c.v.append(vk)
             c.y.append(y)
             c.stats.append(stats)
             c.enc_out.append(out)
@@ -635,7 +674,7 @@ class GeneratorEngine:
             instnorm_act_bwd(g_main, dskip[j] if j < 6 else None, c.y[j], c.stats[j], dy, act, drop,
                              _shift_seed(_mix_seed(c.seed, 1, j), c.sample0 * dy.HW * dy.C))
             src = c.xin if j == 0 else c.enc_out[j - 1]
-            op.wgrad(dy, src, gflat, l.p_off)
+            op.wgrad(dy, src, gflat, l.p_off, v_pre=c.v[j] if ConvOp._aligned(dy, src) else None)
             done(l)
             if j > 0 or need_dx:
                 dsrc = View.alloc(N, op.Hb, op.Wb, l.b, dev)
@@ -697,18 +736,39 @@ class DiscriminatorEngine:
         op = self.ops(N, H, W)[-1]
         return (N, 1, op.Hs, op.Ws)
 
-    def forward(self, flat, din):
-        """din: View [N,H,W,input_nc].  Returns a context; ctx.out is the sigmoid patch map View [N,h,w,1]."""
+    @staticmethod
+    def _ucache(ucache, li, opcode, op, dev, *views):
+        """(buffer, valid) of the transformed weights of layer li / direction opcode in the caller's per-step cache."""
+        if ucache is None or not CACHE_U or not ConvOp._aligned(*views):
+            return None, False
+        nb = op.u_bytes(opcode)
+        if not nb:
+            return None, False
+        key = (li, opcode, nb)         # nb separates the F(2x2,4x4) / F(3x3,4x4) transforms of the stride-1 layer
+        if key in ucache:
+            return ucache[key], True
+        ucache[key] = torch.empty(nb, dtype=torch.uint8, device=dev)
+        return ucache[key], False
+
+    def forward(self, flat, din, ucache=None, keep_v=False):
+        """din: View [N,H,W,input_nc].  Returns a context; ctx.out is the sigmoid patch map View [N,h,w,1].
+        ucache: a dict owned by the caller that lives exactly as long as the weights in `flat` stay unchanged (Trainer.batch: one
+        step) -- the Winograd-transformed weights are computed once per (layer, direction) and reused by every pass that
+        shares the dict.  keep_v: a backward pass with weight gradients follows (see GeneratorEngine.forward)."""
         ops = self.ops(din.N, din.H, din.W)
         dev = flat.device
         c = DiscContext()
         c.din, c.N, c.H, c.W = din, din.N, din.H, din.W
-        c.t, c.stats, c.a = [], [], []
+        c.t, c.stats, c.a, c.v = [], [], [], []
         src = din
-        for l, op in zip(self.layers, ops):
+        for li, (l, op) in enumerate(zip(self.layers, ops)):
             t = View.alloc(din.N, op.Hs, op.Ws, l.a, dev)
             bias = flat if l.bias_key is not None else None
-            op.big2small(src, flat, l.p_off, bias, l.b_off, t, L.ACT_CODES[l.act])   # conv + bias + act fused
+            u, uv = self._ucache(ucache, li, 0, op, dev, src, t)
+            vb = op.v_bytes() if (keep_v and KEEP_V and ConvOp._aligned(src, t)) else 0
+            vk = torch.empty(vb, dtype=torch.uint8, device=dev) if vb else None
+            c.v.append(vk)
+            op.big2small(src, flat, l.p_off, bias, l.b_off, t, L.ACT_CODES[l.act], v_keep=vk, u_cache=u, u_valid=uv)   # conv + bias + act fused
             if l.norm:                                                              # disc.py:31-32: Conv -> Tanh -> IN
                 a = View.alloc(din.N, op.Hs, op.Ws, l.a, dev)
                 stats = torch.empty(din.N * l.a * 2, dtype=torch.float32, device=dev)
@@ -722,9 +782,9 @@ class DiscriminatorEngine:
         c.out = src
         return c
 
-    def backward(self, flat, gflat, c, gout, need_wgrad=True, need_dx=False):
+    def backward(self, flat, gflat, c, gout, need_wgrad=True, need_dx=False, ucache=None):
         """gout: View of dL/d(out).  need_wgrad=False skips the weight gradients (the generator step's pass
-        through D, whose D-gradients the reference zeroes at trainer.py:93-94)."""
+        through D, whose D-gradients the reference zeroes at trainer.py:93-94).  ucache: as in forward."""
         ops = self.ops(c.N, c.H, c.W)
         dev = flat.device
         g = gout
@@ -739,10 +799,12 @@ class DiscriminatorEngine:
             act_bwd(g, None, c.t[li], dy, L.ACT_CODES[l.act])
             src = c.din if li == 0 else c.a[li - 1]
             if need_wgrad:
-                op.wgrad(dy, src, gflat, l.p_off, gflat if l.bias_key is not None else None, l.b_off)
+                op.wgrad(dy, src, gflat, l.p_off, gflat if l.bias_key is not None else None, l.b_off,
+                         v_pre=c.v[li] if ConvOp._aligned(dy, src) else None)
             if li > 0 or need_dx:
                 dsrc = View.alloc(c.N, op.Hb, op.Wb, l.b, dev)
-                op.small2big(dy, flat, l.p_off, None, 0, dsrc)
+                u, uv = self._ucache(ucache, li, 1, op, dev, dy, dsrc)
+                op.small2big(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
                 g = dsrc
                 if li == 0:
                     dx = dsrc

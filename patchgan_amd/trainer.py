@@ -129,12 +129,15 @@ class Trainer:
 
         # ---- generator step
         seed = E._mix_seed(G._seed_base, self._step) if G.training else 0
-        gc = ge.forward(G.flat, xin, gen, G.training, seed, sample0=dist.rank * N)            # trainer.py:63
+        gc = ge.forward(G.flat, xin, gen, G.training, seed, sample0=dist.rank * N, keep_v=train)   # trainer.py:63
         self.flush()          # D's deferred all-reduce + Adam from the previous step ran under this G forward
         # seg loss, phase 1 (per-sample reductions); under data parallelism its two batch-global terms are summed across
         # ranks on the comm stream while the discriminator's forward pass over the fake batch runs
         seg_pending = E.loss_begin(gen, yv, 0.0, self.tversky_beta, allred)
-        dc = de.forward(D.flat, fake)                                                         # trainer.py:66
+        # D's weights do not change until the Adam step at the end of this call: its Winograd-transformed weights are computed
+        # once per (layer, direction) and shared by the passes below through this per-step cache
+        ucache = {}
+        dc = de.forward(D.flat, fake, ucache=ucache)                                          # trainer.py:66
         gseg = E.View.alloc(N, H, W, Cout, dev) if train else None
         E.loss_finish(seg_pending, _LOSS_MODES[self.loss_type], float(self.seg_alpha), gseg, losses, 0, Bglobal,
                       self.tversky_gamma)                                                     # trainer.py:71-82
@@ -144,7 +147,7 @@ class Trainer:
         g_reducer = None
         if train:
             gflat = G.ensure_grad_flat()
-            ddin = de.backward(D.flat, None, dc, gd, need_wgrad=False, need_dx=True)          # dL/d(x|gen)
+            ddin = de.backward(D.flat, None, dc, gd, need_wgrad=False, need_dx=True, ucache=ucache)   # dL/d(x|gen)
             if dist.on:
                 # buckets of the flat G gradient are all-reduced on RCCL's stream as backward finishes them; the
                 # collective keeps running under the discriminator step below (which does not read G's new weights:
@@ -157,7 +160,7 @@ class Trainer:
         del dc
 
         # ---- discriminator step: real and (pre-update, detached) fake in one 2N batch        trainer.py:96-99
-        dc2 = de.forward(D.flat, din)
+        dc2 = de.forward(D.flat, din, ucache=ucache, keep_v=train)
         o2 = dc2.out
         god = E.View.alloc(o2.N, o2.H, o2.W, 1, dev) if train else None
         E.loss_value_and_grad(o2.samples(0, N), None, 1.0, L.LOSS_BCE, 0.5, god.samples(0, N) if train else None,
@@ -173,7 +176,7 @@ class Trainer:
             wait_losses = dist.all_reduce_side(losses)
         if train:
             dflat = D.ensure_grad_flat()
-            de.backward(D.flat, dflat, dc2, god, need_wgrad=True, need_dx=False)              # trainer.py:106
+            de.backward(D.flat, dflat, dc2, god, need_wgrad=True, need_dx=False, ucache=ucache)   # trainer.py:106
             if g_reducer is not None:
                 g_reducer.finish()                 # G's buckets have been in flight since the generator backward
                 self._adam_step('g')

@@ -494,3 +494,63 @@ def test_conv_emits_instancenorm_partials(geom):
     assert plain.stats_chunks(0, vin, y) == 0
     with pytest.raises(RuntimeError):
         plain.big2small(vin, P, 0, None, 0, y, part=torch.empty(16, dtype=torch.float64, device=DEV))
+
+
+@pytest.mark.parametrize('geom,bits', [((6, 62, 58, 256, 128, 2), 0), ((16, 32, 32, 288, 160, 2), 0), ((9, 32, 32, 128, 64, 1), 0),
+                                       ((4, 70, 74, 96, 36, 2), 'all')],
+                         ids=lambda v: 'x'.join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_conv_hand_overs_between_calls(geom, bits):
+    """pg_conv_extras: (1) the forward call keeps its polyphase-transformed input (v_keep) and the layer's weight gradient reads
+    it (v_pre) instead of transforming again; (2) the transformed weights live in a caller-owned cache (u_cache) and a second
+    call marked u_valid skips the weight transform.  Both are bit-identical to the plain calls; a cache marked valid is really
+    what the kernel reads (a changed weight tensor has no effect until the cache is refreshed); hand-overs offered to a call
+    that does not take such a path are refused."""
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view, empty_view, pack, unpack, DEV
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    algo = L.ALGO_AUTO | ((L.TUNE_WINO2_ALL | L.TUNE_WINO2W_ALL) if bits == 'all' else 0)
+    op = E.ConvOp(*geom, algo)
+    P = pack(Wt)
+    vb, vs = to_view(big, ld=Cb + 4, off=0), to_view(small, ld=Ca + 4, off=4)
+
+    def fwd(**kw):
+        out = empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=4)
+        op.big2small(vb, P, 0, None, 0, out, ACTS['leakyrelu'], **kw)
+        return out.to_nchw()
+
+    def dgrad(Pq, **kw):
+        out = empty_view(N, Hb, Wb, Cb, ld=Cb + 8, off=4)
+        op.small2big(vs, Pq, 0, None, 0, out, **kw)
+        return out.to_nchw()
+
+    ref = fwd()
+    if s == 2:                                       # (1) v_keep -> v_pre
+        assert op.v_bytes() > 0
+        vk = torch.empty(op.v_bytes(), dtype=torch.uint8, device=DEV)
+        assert torch.equal(fwd(v_keep=vk), ref)
+        dP1 = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+        dP2 = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+        op.wgrad(vs, vb, dP1, 0, v_pre=vk)
+        op.wgrad(vs, vb, dP2, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(dP1, dP2)
+    else:
+        assert op.v_bytes() == 0
+    for opcode, call, refv in ((0, lambda **kw: fwd(**kw), ref), (1, lambda **kw: dgrad(P, **kw), dgrad(P))):   # (2) u_cache
+        assert op.u_bytes(opcode) > 0
+        u = torch.empty(op.u_bytes(opcode), dtype=torch.uint8, device=DEV)
+        assert torch.equal(call(u_cache=u, u_valid=False), refv)
+        assert torch.equal(call(u_cache=u, u_valid=True), refv)
+    u = torch.empty(op.u_bytes(1), dtype=torch.uint8, device=DEV)
+    d0 = dgrad(P, u_cache=u, u_valid=False)
+    P2 = P * 2
+    assert torch.equal(dgrad(P2, u_cache=u, u_valid=True), d0)            # the cache is what is read ...
+    assert torch.equal(dgrad(P2, u_cache=u, u_valid=False), dgrad(P2))    # ... until it is refreshed
+    # a path without such operands refuses them
+    plain = E.ConvOp(*geom, L.ALGO_MFMA)
+    assert plain.u_bytes(0) == 0 and plain.v_bytes() == 0
+    with pytest.raises(RuntimeError):
+        plain.big2small(vb, P, 0, None, 0, empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=4), u_cache=torch.empty(1 << 20, dtype=torch.uint8, device=DEV))
+    with pytest.raises(RuntimeError):
+        plain.wgrad(vs, vb, torch.empty(16 * Ca * Cb, device=DEV), 0, v_pre=torch.empty(1 << 20, dtype=torch.uint8, device=DEV))
