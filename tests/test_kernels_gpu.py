@@ -497,7 +497,7 @@ def test_conv_emits_instancenorm_partials(geom):
 
 
 @pytest.mark.parametrize('geom,bits', [((6, 62, 58, 256, 128, 2), 0), ((16, 32, 32, 288, 160, 2), 0), ((9, 32, 32, 128, 64, 1), 0),
-                                       ((4, 70, 74, 96, 36, 2), 'all')],
+                                       ((4, 70, 74, 96, 40, 2), 'all')],
                          ids=lambda v: 'x'.join(map(str, v)) if isinstance(v, tuple) else str(v))
 def test_conv_hand_overs_between_calls(geom, bits):
     """pg_conv_extras: (1) the forward call keeps its polyphase-transformed input (v_keep) and the layer's weight gradient reads
