@@ -69,6 +69,15 @@ extern "C" {
 #define PG_TUNE_WINO1_F3 0x800    /* ... F(3x3,4x4) tiles (needs Cin % 64 == 0) */
 #define PG_TUNE_WINO_DMA 0x1000   /* stride-1 64-tile Winograd GEMMs staged by LDS-DMA (k_wino_gemm_dma) instead of registers */
 
+/* bf16 activation storage on the PG_ALGO_BF16 kernels: OR-ed into `algo` like the PG_TUNE_* bits.  The tensor named carries bf16
+ * elements (NHWC, `ld` in bf16 elements, 8-byte-aligned base); weights, biases, weight gradients and split-K slabs stay fp32.
+ * pg_conv4x4_big2small: BIG = input, SMALL = output; pg_conv4x4_small2big: SMALL = input, BIG = output; pg_conv4x4_wgrad: both
+ * or neither (no dbias).  Honoured on the fast bf16 kernels only (channels % 4 == 0 and >= 32 on the input side); any other
+ * path returns PG_EINVAL. */
+#define PG_IO_BIG_BF16 0x10000
+#define PG_IO_SMALL_BF16 0x20000
+#define PG_IO_MASK 0x30000
+
 typedef struct pg_conv_geom {
     int N;        /* batch */
     int Hb, Wb;   /* big spatial extent  (conv input  / convT output) */
@@ -168,6 +177,26 @@ int pg_conv4x4_wgrad_x(const float* small, int ld_small, const float* big, int l
 /* pg_instnorm_act_fwd with the statistics pass replaced by the producer's partial sums: merge (fixed order) + normalise. */
 int pg_instnorm_act_fwd_parts(const float* y, int ld_y, float* out, int ld_out, float* stats, const double* part, int chunks,
                               int N, int HW, int C, int act, float eps, float drop_p, uint64_t seed, void* stream);
+
+/* bf16 activation storage.  The *_t forms of the InstanceNorm / activation entry points take tensors that are
+ * fp32 OR bf16 (NHWC, `ld` in elements of the tensor's own type; 4-element accesses need 16- resp. 8-byte alignment, else the
+ * scalar kernels run): bit i of `dt` set = the i-th tensor argument, in signature order, is bf16 --
+ *     pg_instnorm_act_fwd_t / _fwd_parts_t: y, out;   pg_instnorm_act_bwd_t: g1, g2, y, dy;   pg_act_fwd_t: y, out;
+ *     pg_act_bwd_t: g1, g2, a, dy.
+ * Statistics (fp32), partial sums (fp64) and every arithmetic step are those of the fp32 entry points: a bf16 tensor is widened
+ * on load and rounded to nearest-even on store.  dt = 0 is exactly the fp32 entry point.  pg_act_fwd_t with PG_ACT_NONE converts
+ * between the two storage types. */
+int pg_instnorm_act_fwd_t(const void* y, int ld_y, void* out, int ld_out, float* stats, int N, int HW, int C, int act, float eps,
+                          float drop_p, uint64_t seed, void* ws, size_t ws_bytes, void* stream, int dt);
+int pg_instnorm_act_fwd_parts_t(const void* y, int ld_y, void* out, int ld_out, float* stats, const double* part, int chunks,
+                                int N, int HW, int C, int act, float eps, float drop_p, uint64_t seed, void* stream, int dt);
+int pg_instnorm_act_bwd_t(const void* g1, int ld_g1, const void* g2, int ld_g2, const void* y, int ld_y, const float* stats,
+                          void* dy, int ld_dy, int N, int HW, int C, int act, float drop_p, uint64_t seed, void* ws,
+                          size_t ws_bytes, void* stream, int dt);
+int pg_act_fwd_t(const void* y, int ld_y, void* out, int ld_out, long npix, int C, int act, float drop_p, uint64_t seed,
+                 void* stream, int dt);
+int pg_act_bwd_t(const void* g1, int ld_g1, const void* g2, int ld_g2, const void* a, int ld_a, void* dy, int ld_dy, long npix,
+                 int C, int act, float drop_p, uint64_t seed, void* stream, int dt);
 
 /* Backward of a layer whose BIG side carries the incoming gradient -- nn.ConvTranspose2d (unet.py:53) with small = the layer's
  * input x and big = dL/dy -- in ONE call (aten::convolution_backward, trainer.py:89, is one op producing both):

@@ -15,6 +15,7 @@ ACT_CODES = {None: ACT_NONE, 'none': ACT_NONE, 'leakyrelu': ACT_LEAKY, 'relu': A
              'sigmoid': ACT_SIGMOID}
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_BF16 = 0, 1, 2, 3
 ALGO_MASK = 0xF
+IO_BIG_BF16, IO_SMALL_BF16, IO_MASK = 0x10000, 0x20000, 0x30000      # bf16 activation storage (PG_IO_*)
 # per-call tuning bits OR-ed into `algo` (include/patchgan_hip.h PG_TUNE_*)
 TUNE_WINO2_ALL, TUNE_WINO2_OFF, TUNE_WINO2W_ALL, TUNE_WINO2W_OFF = 0x010, 0x020, 0x040, 0x080
 TUNE_WINO_OFF, TUNE_WINOW_OFF, TUNE_WINO1_F2, TUNE_WINO1_F3, TUNE_WINO_DMA = 0x100, 0x200, 0x400, 0x800, 0x1000
@@ -75,6 +76,11 @@ SIGNATURES = {
     'pg_instnorm_act_bwd': (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p, _sz, _p]),
     'pg_act_bwd': (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _i, _f, _u64, _p]),
     'pg_act_fwd': (_i, [_p, _i, _p, _i, _l, _i, _i, _f, _u64, _p]),
+    'pg_instnorm_act_fwd_t': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _f, _u64, _p, _sz, _p, _i]),
+    'pg_instnorm_act_fwd_parts_t': (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _i]),
+    'pg_instnorm_act_bwd_t': (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _u64, _p, _sz, _p, _i]),
+    'pg_act_fwd_t': (_i, [_p, _i, _p, _i, _l, _i, _i, _f, _u64, _p, _i]),
+    'pg_act_bwd_t': (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _i, _f, _u64, _p, _i]),
     'pg_softmax_fwd': (_i, [_p, _i, _p, _i, _l, _i, _p]),
     'pg_softmax_bwd': (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _p]),
     'pg_dropout_mask': (_i, [_p, _l, _f, _u64, _p]),

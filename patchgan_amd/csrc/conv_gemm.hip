@@ -1475,11 +1475,27 @@ __device__ __forceinline__ bf16x4 to_bf16(f32x4 v) {
     return r;
 }
 
-template <int MR, int NR, int WM, int WN, bool ONE>
+// bf16 activation storage: 8-byte loads of 4 bf16 (byte offset = element offset * 2), stored to LDS as they are
+__device__ __forceinline__ bf16x4 bload2h(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ int voffh(int elem_off, bool ok) {
+    return (int)(((unsigned)elem_off << 1) | (ok ? 0u : 0x80000000u));
+}
+// epilogue store of one value into an fp32 or a bf16 tensor (element index idx)
+__device__ __forceinline__ void store_io(float* base, long idx, float v, int out_bf) {
+    if (out_bf)
+        reinterpret_cast<__bf16*>(base)[idx] = (__bf16)v;
+    else
+        base[idx] = v;
+}
+
+// HIN: the activation operand(s) are stored as bf16 in HBM (bf16 storage mode) instead of fp32 rounded in the kernel
+template <int MR, int NR, int WM, int WN, bool ONE, bool HIN = false>
 __global__ __launch_bounds__(256) void k_b2s_bf16(const float* __restrict__ big, int ld_big,
                                                   const float* __restrict__ P, float* __restrict__ out, int ld_out,
                                                   long slab_stride, Geom g, int chunks_per_slice,
-                                                  const float* __restrict__ bias, int act, int big_bytes, int p_bytes) {
+                                                  const float* __restrict__ bias, int act, int big_bytes, int p_bytes, int out_bf) {
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
     constexpr int AI = BM / 32, BI = BN / 32;
     __shared__ __attribute__((aligned(16))) __bf16 smem[(BM + BN) * LDKH];
@@ -1531,6 +1547,7 @@ __global__ __launch_bounds__(256) void k_b2s_bf16(const float* __restrict__ big,
     int cur_b = (c_begin * KC + kq * 4) - cur_tap * g.Cb;
 
     f32x4 ra[AI], rb[BI];
+    bf16x4 rah[AI];
     int tapoff = 0, pboff = 0, ctap = 0;
     auto next_tap = [&]() {   // (tap, b) of the next chunk for this thread's float4; Cb >= KC: at most one wrap
         const int tap = cur_tap, b = cur_b;
@@ -1544,12 +1561,15 @@ __global__ __launch_bounds__(256) void k_b2s_bf16(const float* __restrict__ big,
     };
     auto load_a = [&](int i, bool on) {
         const bool ok = on && ((a_mask[i] >> ctap) & 1);
-        ra[i] = bload4(rbig, voff(a_off[i] + tapoff, ok));
+        if constexpr (HIN)
+            rah[i] = bload2h(rbig, voffh(a_off[i] + tapoff, ok));
+        else
+            ra[i] = bload4(rbig, voff(a_off[i] + tapoff, ok));
     };
     auto load_b = [&](int i, bool on) { rb[i] = bload4(rP, voff(b_off[i] + pboff, on)); };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < AI; ++i) *reinterpret_cast<bf16x4*>(&As[(r0 + 32 * i) * LDKH + kq * 4]) = to_bf16(ra[i]);
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<bf16x4*>(&As[(r0 + 32 * i) * LDKH + kq * 4]) = HIN ? rah[i] : to_bf16(ra[i]);
 #pragma unroll
         for (int i = 0; i < BI; ++i) *reinterpret_cast<bf16x4*>(&Bs[(r0 + 32 * i) * LDKH + kq * 4]) = to_bf16(rb[i]);
     };
@@ -1616,18 +1636,18 @@ __global__ __launch_bounds__(256) void k_b2s_bf16(const float* __restrict__ big,
                 if (m < M && col < g.Ca) {
                     float v = acc[i][j][r];
                     if (fin) v = pg_act_epi(v + bv, act);
-                    o[(long)m * ld_out + col] = v;
+                    store_io(o, (long)m * ld_out + col, v, out_bf);
                 }
             }
         }
 }
 
-template <int MR, int NR, int WM, int WN>
+template <int MR, int NR, int WM, int WN, bool HIN = false>
 __global__ __launch_bounds__(256) void k_s2b_bf16(const float* __restrict__ small, int ld_small,
                                                   const float* __restrict__ P, float* __restrict__ out, int ld_out,
                                                   long slab_stride, Geom g, int chunks_per_slice,
                                                   const float* __restrict__ bias, int act, int small_bytes,
-                                                  int p_bytes) {
+                                                  int p_bytes, int out_bf) {
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
     constexpr int AI = BM / 32;
     constexpr int BG = 256 / BN;        // thread groups along k
@@ -1702,6 +1722,7 @@ __global__ __launch_bounds__(256) void k_s2b_bf16(const float* __restrict__ smal
     };
 
     f32x4 ra[AI], rb[NQ];
+    bf16x4 rah[AI];
     int a_tl = 0, a_koff = OOB;
     auto next_a = [&](int c) {
         const int k = c * KC + kq * 4;
@@ -1713,7 +1734,10 @@ __global__ __launch_bounds__(256) void k_s2b_bf16(const float* __restrict__ smal
     };
     auto load_a = [&](int i, bool on) {
         const bool ok = on && ((a_mask[i] >> a_tl) & 1) && (a_koff < 0x10000000);
-        ra[i] = bload4(rsm, voff(a_off[i] + a_koff, ok));
+        if constexpr (HIN)
+            rah[i] = bload2h(rsm, voffh(a_off[i] + a_koff, ok));
+        else
+            ra[i] = bload4(rsm, voff(a_off[i] + a_koff, ok));
     };
     auto load_b = [&](int i, int c, bool on) {
         const int kb = c * KC + 4 * (bg + BG * i);
@@ -1734,7 +1758,7 @@ __global__ __launch_bounds__(256) void k_s2b_bf16(const float* __restrict__ smal
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < AI; ++i) *reinterpret_cast<bf16x4*>(&As[(r0 + 32 * i) * LDKH + kq * 4]) = to_bf16(ra[i]);
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<bf16x4*>(&As[(r0 + 32 * i) * LDKH + kq * 4]) = HIN ? rah[i] : to_bf16(ra[i]);
 #pragma unroll
         for (int i = 0; i < NQ; ++i) *reinterpret_cast<bf16x4*>(&Bs[bn * LDKH + 4 * (bg + BG * i)]) = to_bf16(rb[i]);
     };
@@ -1832,14 +1856,14 @@ __global__ __launch_bounds__(256) void k_s2b_bf16(const float* __restrict__ smal
                     jj = rem - ii * Wc;
                 }
                 const int h = (g.s == 2) ? 2 * ii + ah : ii, w = (g.s == 2) ? 2 * jj + aw : jj;
-                float* orow = o + (long)((n * g.Hb + h) * g.Wb + w) * ldo;
+                const long orow = (long)((n * g.Hb + h) * g.Wb + w) * ldo;
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
                     const int col = n0 + (wn * NR + j) * 32 + lrow;
                     if (col < g.Cb) {
                         float v = acc[i][j][r];
                         if (fin) v = pg_act_epi(v + bv[j], act);
-                        orow[col] = v;
+                        store_io(o, orow + col, v, out_bf);
                     }
                 }
             }
@@ -1847,7 +1871,7 @@ __global__ __launch_bounds__(256) void k_s2b_bf16(const float* __restrict__ smal
     }
 }
 
-template <int MR, int NR, int WM, int WN, bool POW2>
+template <int MR, int NR, int WM, int WN, bool POW2, bool HIN = false>
 __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ small, int ld_small,
                                                     const float* __restrict__ big, int ld_big,
                                                     float* __restrict__ out, long slab_stride, Geom g,
@@ -1891,10 +1915,14 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ sm
     }
 
     f32x4 ra[AI], rb[BI];
+    bf16x4 rah[AI], rbh[BI];
     auto load_a = [&](int i, int c, bool on) {
         const int pix = c * KC + arow0 + AROWS * i;
         const bool ok = on && pix < Kp;
-        ra[i] = bload4(rsm, voff(pix * ld_small + a_col, ok));
+        if constexpr (HIN)
+            rah[i] = bload2h(rsm, voffh(pix * ld_small + a_col, ok));
+        else
+            ra[i] = bload4(rsm, voff(pix * ld_small + a_col, ok));
     };
     auto load_b = [&](int i, int c, bool on) {
         const int pix = c * KC + brow0 + BROWS * i;
@@ -1923,13 +1951,16 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ sm
         }
         const int h = g.s * p - 1 + kh, w = g.s * q - 1 + kw;
         const bool ok = on && pix < Kp && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
-        rb[i] = bload4(rbig, voff(((n * g.Hb + h) * g.Wb + w) * ld_big + b_col, ok));
+        if constexpr (HIN)
+            rbh[i] = bload2h(rbig, voffh(((n * g.Hb + h) * g.Wb + w) * ld_big + b_col, ok));
+        else
+            rb[i] = bload4(rbig, voff(((n * g.Hb + h) * g.Wb + w) * ld_big + b_col, ok));
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < AI; ++i) *reinterpret_cast<bf16x4*>(&As[(arow0 + AROWS * i) * LDA + aq * 4]) = to_bf16(ra[i]);
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<bf16x4*>(&As[(arow0 + AROWS * i) * LDA + aq * 4]) = HIN ? rah[i] : to_bf16(ra[i]);
 #pragma unroll
-        for (int i = 0; i < BI; ++i) *reinterpret_cast<bf16x4*>(&Bs[(brow0 + BROWS * i) * LDB + bq * 4]) = to_bf16(rb[i]);
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<bf16x4*>(&Bs[(brow0 + BROWS * i) * LDB + bq * 4]) = HIN ? rbh[i] : to_bf16(rb[i]);
     };
 
     f32x16 acc[MR][NR];
@@ -2074,7 +2105,7 @@ __global__ void k_pack_taps_b(const float* __restrict__ P, float* __restrict__ W
 // split-K reduce (+ bias + activation):  out[r*ld_out + c] = act(sum_z slab[z][r*cols + c] + bias[c])
 // ------------------------------------------------------------------------------------------------
 __global__ void k_slab_reduce(const float* __restrict__ slabs, long slab_stride, int S, float* __restrict__ out,
-                              int ld_out, long rows, int cols, const float* __restrict__ bias, int act) {
+                              int ld_out, long rows, int cols, const float* __restrict__ bias, int act, int out_bf) {
     const long total = rows * cols;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / cols;
@@ -2082,12 +2113,12 @@ __global__ void k_slab_reduce(const float* __restrict__ slabs, long slab_stride,
         float v = slabs[i];
         for (int z = 1; z < S; ++z) v += slabs[(long)z * slab_stride + i];
         if (bias) v += bias[c];
-        out[r * ld_out + c] = pg_act(v, act);
+        store_io(out, r * ld_out + c, pg_act(v, act), out_bf);
     }
 }
 
 __global__ void k_slab_reduce4(const float* __restrict__ slabs, long slab_stride, int S, float* __restrict__ out,
-                               int ld_out, long rows, int cols, const float* __restrict__ bias, int act) {
+                               int ld_out, long rows, int cols, const float* __restrict__ bias, int act, int out_bf) {
     const int cq = cols >> 2;
     const long total = rows * cq;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -2099,7 +2130,10 @@ __global__ void k_slab_reduce4(const float* __restrict__ slabs, long slab_stride
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = pg_act_epi(v[e], act);
-        *reinterpret_cast<f32x4*>(out + r * ld_out + c) = v;
+        if (out_bf)
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + r * ld_out + c) = to_bf16(v);
+        else
+            *reinterpret_cast<f32x4*>(out + r * ld_out + c) = v;
     }
 }
 
@@ -2282,7 +2316,8 @@ struct TimedLaunch {
 };
 
 // bytes spanned by a [pixels][C] view with pixel stride ld (what the buffer descriptor of the fast kernels covers)
-inline long tensor_bytes(long pixels, int ld, int C) { return ((pixels - 1) * (long)ld + C) * 4; }
+inline long tensor_bytes(long pixels, int ld, int C, bool bf = false) { return ((pixels - 1) * (long)ld + C) * (bf ? 2 : 4); }
+inline bool aligned_io(const void* p, bool bf) { return (reinterpret_cast<uintptr_t>(p) & (bf ? 7 : 15)) == 0; }
 constexpr long FAST_LIMIT = 0x60000000L;   // 1.5 GiB: keeps every 32-bit byte offset, incl. the +0x40000000 sentinel, < 2^32
 constexpr long FAST_P_LIMIT = 0x40000000L; // packed weights: the invalid-row sentinel (+1 GiB) must land beyond the block
 inline bool force_generic() {
@@ -2433,20 +2468,20 @@ void clamp_split(Plan& p, size_t ws_bytes, size_t reserved) {
 }
 
 int launch_reduce(const float* slabs, long slab_stride, int S, float* out, int ld_out, long rows, int cols,
-                  const float* bias, int act, hipStream_t st) {
-    if (S >= 64 && !bias && act == PG_ACT_NONE && rows * cols <= (1L << 22)) {
+                  const float* bias, int act, hipStream_t st, int out_bf = 0) {
+    if (S >= 64 && !bias && act == PG_ACT_NONE && rows * cols <= (1L << 22) && !out_bf) {
         const long total = rows * cols;
         hipLaunchKernelGGL(k_slab_reduce_z, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, slabs, slab_stride, S, out,
                            ld_out, rows, cols);
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
-    if ((cols % 4 == 0) && (ld_out % 4 == 0) && (slab_stride % 4 == 0) && aligned16(slabs) && aligned16(out) &&
-        (!bias || aligned16(bias))) {
+    if ((cols % 4 == 0) && (ld_out % 4 == 0) && (slab_stride % 4 == 0) && aligned16(slabs) &&
+        ((reinterpret_cast<uintptr_t>(out) & (out_bf ? 7 : 15)) == 0) && (!bias || aligned16(bias))) {
         const long total4 = rows * (cols / 4);
         int blocks = (int)std::min<long>((total4 + 255) / 256, 16384);
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(k_slab_reduce4, dim3(blocks), dim3(256), 0, st, slabs, slab_stride, S, out, ld_out, rows, cols,
-                           bias, act);
+                           bias, act, out_bf);
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     const long total = rows * cols;
@@ -2454,7 +2489,7 @@ int launch_reduce(const float* slabs, long slab_stride, int S, float* out, int l
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, st, slabs, slab_stride, S, out, ld_out, rows, cols,
-                       bias, act);
+                       bias, act, out_bf);
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
 
@@ -2493,21 +2528,29 @@ inline size_t b2s_tapn_ws(const Geom& g) { return (size_t)g.N * g.Hb * g.Wb * 16
         default: hipLaunchKernelGGL((k_b2s_fast<1, 1, 2, 2, ONE>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
     }
 
-#define PG_DISPATCH_B2SH(tile_id, grid, st, ...)                                                                    \
-    switch (tile_id) {                                                                                             \
-        case 0: hipLaunchKernelGGL((k_b2s_bf16<2, 2, 2, 2, false>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 1: hipLaunchKernelGGL((k_b2s_bf16<2, 1, 2, 2, false>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 2: hipLaunchKernelGGL((k_b2s_bf16<1, 1, 4, 1, false>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 3: hipLaunchKernelGGL((k_b2s_bf16<1, 2, 2, 2, false>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
-        default: hipLaunchKernelGGL((k_b2s_bf16<1, 1, 2, 2, false>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+#define PG_DISPATCH_B2SH(HIN, tile_id, grid, st, ...)                                                                    \
+    switch (tile_id) {                                                                                                  \
+        case 0: hipLaunchKernelGGL((k_b2s_bf16<2, 2, 2, 2, false, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 1: hipLaunchKernelGGL((k_b2s_bf16<2, 1, 2, 2, false, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 2: hipLaunchKernelGGL((k_b2s_bf16<1, 1, 4, 1, false, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 3: hipLaunchKernelGGL((k_b2s_bf16<1, 2, 2, 2, false, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        default: hipLaunchKernelGGL((k_b2s_bf16<1, 1, 2, 2, false, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
     }
-#define PG_DISPATCH_WGH(POW2, tile_id, grid, st, ...)                                                              \
+#define PG_DISPATCH_S2BH(HIN, tile_id, grid, st, ...)                                                              \
     switch (tile_id) {                                                                                            \
-        case 0: hipLaunchKernelGGL((k_wgrad_bf16<2, 2, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
-        case 1: hipLaunchKernelGGL((k_wgrad_bf16<2, 1, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
-        case 2: hipLaunchKernelGGL((k_wgrad_bf16<1, 1, 4, 1, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
-        case 3: hipLaunchKernelGGL((k_wgrad_bf16<1, 2, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
-        default: hipLaunchKernelGGL((k_wgrad_bf16<1, 1, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
+        case 0: hipLaunchKernelGGL((k_s2b_bf16<2, 2, 2, 2, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+        case 1: hipLaunchKernelGGL((k_s2b_bf16<2, 1, 2, 2, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+        case 2: hipLaunchKernelGGL((k_s2b_bf16<1, 1, 4, 1, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+        case 3: hipLaunchKernelGGL((k_s2b_bf16<1, 2, 2, 2, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+        default: hipLaunchKernelGGL((k_s2b_bf16<1, 1, 2, 2, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+    }
+#define PG_DISPATCH_WGH(POW2, HIN, tile_id, grid, st, ...)                                                              \
+    switch (tile_id) {                                                                                                 \
+        case 0: hipLaunchKernelGGL((k_wgrad_bf16<2, 2, 2, 2, POW2, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        case 1: hipLaunchKernelGGL((k_wgrad_bf16<2, 1, 2, 2, POW2, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        case 2: hipLaunchKernelGGL((k_wgrad_bf16<1, 1, 4, 1, POW2, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        case 3: hipLaunchKernelGGL((k_wgrad_bf16<1, 2, 2, 2, POW2, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL((k_wgrad_bf16<1, 1, 2, 2, POW2, HIN>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
     }
 
 #define PG_DISPATCH_WGF(POW2, tile_id, grid, st, ...)                                                              \
@@ -2809,7 +2852,9 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
     hipStream_t st = (hipStream_t)stream;
     Geom g = to_geom(gg);
     const Tune tune = tune_of(algo);
+    const int io = algo & PG_IO_MASK;                 // bf16 activation storage: PG_IO_BIG_BF16 = input, PG_IO_SMALL_BF16 = output
     algo &= PG_ALGO_MASK;
+    if (io && algo != PG_ALGO_BF16) return PG_EINVAL;
     if (algo == PG_ALGO_DIRECT) {
         const long total = (long)g.N * g.Hs * g.Ws * g.Ca;
         int blocks = (int)std::min<long>((total + 255) / 256, 65536);
@@ -2840,7 +2885,7 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
     }
     // only the Winograd paths have partial sums / transformed operands to hand over (the pg_conv_*_bytes / _chunks queries said 0)
     if (part || x.v_keep || x.u_cache) return PG_EINVAL;
-    if (b2s_tapn_ok(g) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P) && aligned16(ws) &&
+    if (!io && b2s_tapn_ok(g) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= b2s_tapn_ws(g) && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT) {
         // D[big pixel][(tap, a)] = big . P^T (row GEMM over the pixels), then gather the 16 taps per output pixel
         float* D = (float*)ws;
@@ -2875,15 +2920,20 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
     }
     Plan p = plan_b2s(gg);
     clamp_split(p, ws_bytes, 0);
-    const int veck = (g.Cb % 4 == 0) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P);
+    const bool in_bf = io & PG_IO_BIG_BF16, out_bf = io & PG_IO_SMALL_BF16;
+    const int veck = (g.Cb % 4 == 0) && (ld_big % 4 == 0) && aligned_io(big, in_bf) && aligned16(P);
     dim3 grid(p.tiles_m, p.tiles_n, p.split);
-    const long big_bytes = tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb), p_bytes = 16L * g.Ca * g.Cb * 4;
+    const long big_bytes = tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb, in_bf), p_bytes = 16L * g.Ca * g.Cb * 4;
     const bool fast = veck && g.Cb >= KC && big_bytes < FAST_LIMIT && p_bytes < FAST_P_LIMIT && !force_generic();
+    if (io && !fast) return PG_EINVAL;               // bf16 tensors only on the fast bf16 kernels
     if (p.split == 1) {
         TimedLaunch timed(st);
-        if (fast && algo == PG_ALGO_BF16) {
-            PG_DISPATCH_B2SH(p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, bias, act, (int)big_bytes,
-                             (int)p_bytes);
+        if (fast && algo == PG_ALGO_BF16 && in_bf) {
+            PG_DISPATCH_B2SH(true, p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, bias, act, (int)big_bytes,
+                             (int)p_bytes, (int)out_bf);
+        } else if (fast && algo == PG_ALGO_BF16) {
+            PG_DISPATCH_B2SH(false, p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, bias, act, (int)big_bytes,
+                             (int)p_bytes, (int)out_bf);
         } else if (fast) {
             PG_DISPATCH_B2SF(false, p.t.id, grid, st, big, ld_big, P, small, ld_small, 0L, g, p.cps, bias, act,
                              (int)big_bytes, (int)p_bytes);
@@ -2896,9 +2946,12 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
     float* slabs = (float*)ws;
     {
         TimedLaunch timed(st);
-        if (fast && algo == PG_ALGO_BF16) {
-            PG_DISPATCH_B2SH(p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps, (const float*)nullptr, 0,
-                             (int)big_bytes, (int)p_bytes);
+        if (fast && algo == PG_ALGO_BF16 && in_bf) {
+            PG_DISPATCH_B2SH(true, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps, (const float*)nullptr, 0,
+                             (int)big_bytes, (int)p_bytes, 0);
+        } else if (fast && algo == PG_ALGO_BF16) {
+            PG_DISPATCH_B2SH(false, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps, (const float*)nullptr, 0,
+                             (int)big_bytes, (int)p_bytes, 0);
         } else if (fast) {
             PG_DISPATCH_B2SF(false, p.t.id, grid, st, big, ld_big, P, slabs, g.Ca, p.out_elems, g, p.cps,
                              (const float*)nullptr, 0, (int)big_bytes, (int)p_bytes);
@@ -2908,7 +2961,7 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
         }
     }
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
-    return launch_reduce(slabs, p.out_elems, p.split, small, ld_small, (long)g.N * g.Hs * g.Ws, g.Ca, bias, act, st);
+    return launch_reduce(slabs, p.out_elems, p.split, small, ld_small, (long)g.N * g.Hs * g.Ws, g.Ca, bias, act, st, out_bf);
 }
 
 int pg_conv4x4_big2small(const float* big, int ld_big, const float* P, const float* bias, float* small,
@@ -2933,7 +2986,9 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
     hipStream_t st = (hipStream_t)stream;
     Geom g = to_geom(gg);
     const Tune tune = tune_of(algo);
+    const int io = algo & PG_IO_MASK;                 // PG_IO_SMALL_BF16 = input, PG_IO_BIG_BF16 = output
     algo &= PG_ALGO_MASK;
+    if (io && algo != PG_ALGO_BF16) return PG_EINVAL;
     if (algo == PG_ALGO_DIRECT) {
         const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
         int blocks = (int)std::min<long>((total + 255) / 256, 65536);
@@ -2962,7 +3017,7 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
                             x.u_cache, x.u_valid);
     }
     if (part || x.u_cache) return PG_EINVAL;
-    if (s2b_tapn_ok(g) && (ld_small % 4 == 0) && aligned16(small) && aligned16(P) && aligned16(ws) &&
+    if (!io && s2b_tapn_ok(g) && (ld_small % 4 == 0) && aligned16(small) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= s2b_tapn_ws(g) && tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT) {
         // D[small pixel][(tap, b)] = small . W' (row GEMM), then col2im: each big pixel sums the taps that reach it
         const int Nc = 16 * g.Cb;
@@ -2991,16 +3046,21 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
     }
     Plan p = plan_s2b(gg);
     clamp_split(p, ws_bytes, 0);
-    const int veck = (g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned16(small);
+    const bool in_bf = io & PG_IO_SMALL_BF16, out_bf = io & PG_IO_BIG_BF16;
+    const int veck = (g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned_io(small, in_bf);
     const int vecn = (g.Cb % 4 == 0) && aligned16(P);
     dim3 grid(p.tiles_m, p.tiles_n, p.ncls * p.split);
-    const long small_bytes = tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca), p_bytes = 16L * g.Ca * g.Cb * 4;
+    const long small_bytes = tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca, in_bf), p_bytes = 16L * g.Ca * g.Cb * 4;
     const bool fast = veck && g.Ca >= KC && small_bytes < FAST_LIMIT && p_bytes < FAST_P_LIMIT && !force_generic();
+    if (io && !fast) return PG_EINVAL;
     if (p.split == 1) {
         TimedLaunch timed(st);
-        if (fast && algo == PG_ALGO_BF16) {
-            PG_DISPATCH_TILE(k_s2b_bf16, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, bias, act,
-                             (int)small_bytes, (int)p_bytes);
+        if (fast && algo == PG_ALGO_BF16 && in_bf) {
+            PG_DISPATCH_S2BH(true, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, bias, act,
+                             (int)small_bytes, (int)p_bytes, (int)out_bf);
+        } else if (fast && algo == PG_ALGO_BF16) {
+            PG_DISPATCH_S2BH(false, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, bias, act,
+                             (int)small_bytes, (int)p_bytes, (int)out_bf);
         } else if (fast) {
             PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, big, ld_big, 0L, g, p.cps, bias, act,
                              (int)small_bytes, (int)p_bytes);
@@ -3013,9 +3073,12 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
     float* slabs = (float*)ws;
     {
         TimedLaunch timed(st);
-        if (fast && algo == PG_ALGO_BF16) {
-            PG_DISPATCH_TILE(k_s2b_bf16, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
-                             (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes);
+        if (fast && algo == PG_ALGO_BF16 && in_bf) {
+            PG_DISPATCH_S2BH(true, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
+                             (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes, 0);
+        } else if (fast && algo == PG_ALGO_BF16) {
+            PG_DISPATCH_S2BH(false, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
+                             (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes, 0);
         } else if (fast) {
             PG_DISPATCH_TILE(k_s2b_fast, p.t.id, grid, st, small, ld_small, P, slabs, g.Cb, p.out_elems, g, p.cps,
                              (const float*)nullptr, 0, (int)small_bytes, (int)p_bytes);
@@ -3025,7 +3088,7 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         }
     }
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
-    return launch_reduce(slabs, p.out_elems, p.split, big, ld_big, (long)g.N * g.Hb * g.Wb, g.Cb, bias, act, st);
+    return launch_reduce(slabs, p.out_elems, p.split, big, ld_big, (long)g.N * g.Hb * g.Wb, g.Cb, bias, act, st, out_bf);
 }
 
 int pg_conv4x4_small2big(const float* small, int ld_small, const float* P, const float* bias, float* big,
@@ -3092,7 +3155,9 @@ static int wgrad_impl(const float* small, int ld_small, const float* big, int ld
     hipStream_t st = (hipStream_t)stream;
     Geom g = to_geom(gg);
     const Tune tune = tune_of(algo);
+    const int io = algo & PG_IO_MASK;                 // both activation operands bf16, or neither
     algo &= PG_ALGO_MASK;
+    if (io && (algo != PG_ALGO_BF16 || io != PG_IO_MASK || dbias)) return PG_EINVAL;
     if (!ws) ws_bytes = 0;
     const long Kp = (long)g.N * g.Hs * g.Ws;
     size_t reserved = 0;
@@ -3147,23 +3212,35 @@ static int wgrad_impl(const float* small, int ld_small, const float* big, int ld
     if (v_pre) return PG_EINVAL;     // pg_conv_v_bytes said 0 for this call: there is no transformed operand to reuse
     Plan p = plan_wgrad(gg);
     clamp_split(p, ws_bytes, reserved);
-    const int vecm = (g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned16(small);
-    const int vecn = (g.Cb % 4 == 0) && (ld_big % 4 == 0) && aligned16(big);
+    const bool in_bf = io != 0;
+    const int vecm = (g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned_io(small, in_bf);
+    const int vecn = (g.Cb % 4 == 0) && (ld_big % 4 == 0) && aligned_io(big, in_bf);
     const int mode = wgrad_mode(gg);
+    if (io && mode != 0) return PG_EINVAL;
     float* dst = p.split == 1 ? dP : (float*)((char*)ws + reserved);
     TimedLaunch* timed = new (alloca(sizeof(TimedLaunch))) TimedLaunch(st);
     if (mode == 0) {
         dim3 grid(p.tiles_m * p.tiles_n, 16, p.split);
-        const long small_bytes = tensor_bytes(Kp, ld_small, g.Ca);
-        const long big_bytes = tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb);
+        const long small_bytes = tensor_bytes(Kp, ld_small, g.Ca, in_bf);
+        const long big_bytes = tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb, in_bf);
         const bool pow2 = ((g.Hs & (g.Hs - 1)) == 0) && ((g.Ws & (g.Ws - 1)) == 0);
         const bool fast = vecm && vecn && small_bytes < FAST_LIMIT && big_bytes < FAST_LIMIT && !force_generic() &&
                           (pow2 || (g.Ws >= 16 && g.Hs >= 2));
-        if (fast && algo == PG_ALGO_BF16 && pow2) {
-            PG_DISPATCH_WGH(true, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
+        if (io && !fast) {
+            timed->~TimedLaunch();
+            return PG_EINVAL;
+        }
+        if (fast && algo == PG_ALGO_BF16 && pow2 && in_bf) {
+            PG_DISPATCH_WGH(true, true, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
+                            (int)small_bytes, (int)big_bytes);
+        } else if (fast && algo == PG_ALGO_BF16 && in_bf) {
+            PG_DISPATCH_WGH(false, true, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
+                            (int)small_bytes, (int)big_bytes);
+        } else if (fast && algo == PG_ALGO_BF16 && pow2) {
+            PG_DISPATCH_WGH(true, false, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
                             (int)small_bytes, (int)big_bytes);
         } else if (fast && algo == PG_ALGO_BF16) {
-            PG_DISPATCH_WGH(false, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
+            PG_DISPATCH_WGH(false, false, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,
                             (int)small_bytes, (int)big_bytes);
         } else if (fast && pow2) {
             PG_DISPATCH_WGF(true, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps, p.tiles_n,

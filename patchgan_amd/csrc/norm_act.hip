@@ -20,23 +20,58 @@ struct Vec {
     float v[VEC];
 };
 
+// Pointer to an fp32 or a bf16 activation tensor (bf16 storage mode); arithmetic in ELEMENTS.  Statistics, partial
+// sums and all arithmetic stay fp32 / fp64 either way: a bf16 tensor is widened on load and rounded (RNE) on store.
+struct TPtr {
+    const char* p;
+    int bf;
+    __host__ __device__ TPtr operator+(long n) const { return TPtr{p + n * (bf ? 2 : 4), bf}; }
+    __host__ __device__ explicit operator bool() const { return p != nullptr; }
+};
+inline TPtr tp(const void* p, bool bf) { return TPtr{(const char*)p, bf ? 1 : 0}; }
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
 template <int VEC>
-__device__ __forceinline__ Vec<VEC> vload(const float* p) {
+__device__ __forceinline__ Vec<VEC> vload(TPtr t) {
     Vec<VEC> r;
-    if constexpr (VEC == 4) {
-        float4 t = *reinterpret_cast<const float4*>(p);
-        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    if (t.bf) {
+        if constexpr (VEC == 4) {
+            const uint2 u = *reinterpret_cast<const uint2*>(t.p);
+            r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+            r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+        } else {
+            r.v[0] = bf2f(*reinterpret_cast<const unsigned short*>(t.p));
+        }
     } else {
-        r.v[0] = *p;
+        if constexpr (VEC == 4) {
+            float4 f = *reinterpret_cast<const float4*>(t.p);
+            r.v[0] = f.x; r.v[1] = f.y; r.v[2] = f.z; r.v[3] = f.w;
+        } else {
+            r.v[0] = *reinterpret_cast<const float*>(t.p);
+        }
     }
     return r;
 }
 template <int VEC>
-__device__ __forceinline__ void vstore(float* p, const Vec<VEC>& r) {
-    if constexpr (VEC == 4) {
-        *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+__device__ __forceinline__ void vstore(TPtr t, const Vec<VEC>& r) {
+    char* q = const_cast<char*>(t.p);
+    if (t.bf) {
+        if constexpr (VEC == 4) {
+            uint2 u;
+            u.x = (unsigned)f2bf(r.v[0]) | ((unsigned)f2bf(r.v[1]) << 16);
+            u.y = (unsigned)f2bf(r.v[2]) | ((unsigned)f2bf(r.v[3]) << 16);
+            *reinterpret_cast<uint2*>(q) = u;
+        } else {
+            *reinterpret_cast<unsigned short*>(q) = f2bf(r.v[0]);
+        }
     } else {
-        *p = r.v[0];
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<float4*>(q) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+        } else {
+            *reinterpret_cast<float*>(q) = r.v[0];
+        }
     }
 }
 
@@ -66,7 +101,7 @@ __device__ __forceinline__ void lane_tree(double (*red)[256], int tid, int G) {
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256) void k_instnorm_fwd(const float* __restrict__ y, int ld_y, float* __restrict__ out,
+__global__ __launch_bounds__(256) void k_instnorm_fwd(TPtr y, int ld_y, TPtr out,
                                                       int ld_out, float* __restrict__ stats, int HW, int C, int G,
                                                       int act, float eps, float drop_p, uint64_t seed) {
     __shared__ double red[VEC][256];
@@ -74,15 +109,15 @@ __global__ __launch_bounds__(256) void k_instnorm_fwd(const float* __restrict__ 
     const int c0 = (blockIdx.x * G + cu) * VEC;
     const int n = blockIdx.y;
     const bool on = c0 < C;
-    const float* yb = y + (long)n * HW * ld_y + c0;
-    float* ob = out + (long)n * HW * ld_out + c0;
+    const TPtr yb = y + ((long)n * HW * ld_y + c0);
+    const TPtr ob = out + ((long)n * HW * ld_out + c0);
 
     double s[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) s[k] = 0.0;
     if (on)
         for (int pix = pl; pix < HW; pix += PL) {
-            Vec<VEC> v = vload<VEC>(yb + (long)pix * ld_y);
+            Vec<VEC> v = vload<VEC>(yb + (long)((long)pix * ld_y));
 #pragma unroll
             for (int k = 0; k < VEC; ++k) s[k] += (double)v.v[k];
         }
@@ -98,7 +133,7 @@ __global__ __launch_bounds__(256) void k_instnorm_fwd(const float* __restrict__ 
     for (int k = 0; k < VEC; ++k) s[k] = 0.0;
     if (on)
         for (int pix = pl; pix < HW; pix += PL) {
-            Vec<VEC> v = vload<VEC>(yb + (long)pix * ld_y);
+            Vec<VEC> v = vload<VEC>(yb + (long)((long)pix * ld_y));
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 double d = (double)v.v[k] - mean[k];
@@ -124,7 +159,7 @@ __global__ __launch_bounds__(256) void k_instnorm_fwd(const float* __restrict__ 
     if (!on) return;
     const float keep_scale = 1.f / (1.f - drop_p);
     for (int pix = pl; pix < HW; pix += PL) {
-        Vec<VEC> v = vload<VEC>(yb + (long)pix * ld_y);
+        Vec<VEC> v = vload<VEC>(yb + (long)((long)pix * ld_y));
         Vec<VEC> o;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
@@ -137,15 +172,15 @@ __global__ __launch_bounds__(256) void k_instnorm_fwd(const float* __restrict__ 
             }
             o.v[k] = a;
         }
-        vstore<VEC>(ob + (long)pix * ld_out, o);
+        vstore<VEC>(ob + (long)((long)pix * ld_out), o);
     }
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256) void k_instnorm_bwd(const float* __restrict__ g1, int ld_g1,
-                                                      const float* __restrict__ g2, int ld_g2,
-                                                      const float* __restrict__ y, int ld_y,
-                                                      const float* __restrict__ stats, float* __restrict__ dy,
+__global__ __launch_bounds__(256) void k_instnorm_bwd(TPtr g1, int ld_g1,
+                                                      TPtr g2, int ld_g2,
+                                                      TPtr y, int ld_y,
+                                                      const float* __restrict__ stats, TPtr dy,
                                                       int ld_dy, int HW, int C, int G, int act, float drop_p,
                                                       uint64_t seed) {
     __shared__ double red[2 * VEC][256];
@@ -163,10 +198,10 @@ __global__ __launch_bounds__(256) void k_instnorm_bwd(const float* __restrict__ 
     const float keep_scale = 1.f / (1.f - drop_p);
 
     auto dz_of = [&](int pix, Vec<VEC>& xm, Vec<VEC>& dz) {
-        Vec<VEC> v = vload<VEC>(y + (nb + pix) * ld_y + c0);
-        Vec<VEC> g = vload<VEC>(g1 + (nb + pix) * ld_g1 + c0);
+        Vec<VEC> v = vload<VEC>(y + (long)((nb + pix) * ld_y + c0));
+        Vec<VEC> g = vload<VEC>(g1 + (long)((nb + pix) * ld_g1 + c0));
         if (g2) {
-            Vec<VEC> h = vload<VEC>(g2 + (nb + pix) * ld_g2 + c0);
+            Vec<VEC> h = vload<VEC>(g2 + (long)((nb + pix) * ld_g2 + c0));
 #pragma unroll
             for (int k = 0; k < VEC; ++k) g.v[k] += h.v[k];
         }
@@ -222,7 +257,7 @@ __global__ __launch_bounds__(256) void k_instnorm_bwd(const float* __restrict__ 
         dz_of(pix, xm, dz);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) o.v[k] = (dz.v[k] - gmean[k] - xm.v[k] * kk[k]) * rstd[k];
-        vstore<VEC>(dy + (nb + pix) * ld_dy + c0, o);
+        vstore<VEC>(dy + (long)((nb + pix) * ld_dy + c0), o);
     }
 }
 
@@ -235,9 +270,9 @@ __global__ __launch_bounds__(256) void k_instnorm_bwd(const float* __restrict__ 
 // two-pass variance: relative error ~1e-16 * mean^2/var.
 // ------------------------------------------------------------------------------------------------
 template <int VEC, bool BWD>
-__global__ __launch_bounds__(256) void k_in_partial(const float* __restrict__ y, int ld_y,
-                                                    const float* __restrict__ g1, int ld_g1,
-                                                    const float* __restrict__ g2, int ld_g2,
+__global__ __launch_bounds__(256) void k_in_partial(TPtr y, int ld_y,
+                                                    TPtr g1, int ld_g1,
+                                                    TPtr g2, int ld_g2,
                                                     const float* __restrict__ stats, double* __restrict__ part, int HW,
                                                     int C, int G, int pix_per_chunk, int act, float drop_p,
                                                     uint64_t seed) {
@@ -262,7 +297,7 @@ __global__ __launch_bounds__(256) void k_in_partial(const float* __restrict__ y,
     for (int k = 0; k < VEC; ++k) s1[k] = s2[k] = 0.0;
     if (on)
         for (int pix = p_begin + pl; pix < p_end; pix += PL) {
-            Vec<VEC> v = vload<VEC>(y + (nb + pix) * ld_y + c0);
+            Vec<VEC> v = vload<VEC>(y + (long)((nb + pix) * ld_y + c0));
             if (!BWD) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
@@ -271,9 +306,9 @@ __global__ __launch_bounds__(256) void k_in_partial(const float* __restrict__ y,
                     s2[k] += d * d;
                 }
             } else {
-                Vec<VEC> g = vload<VEC>(g1 + (nb + pix) * ld_g1 + c0);
+                Vec<VEC> g = vload<VEC>(g1 + (long)((nb + pix) * ld_g1 + c0));
                 if (g2) {
-                    Vec<VEC> h = vload<VEC>(g2 + (nb + pix) * ld_g2 + c0);
+                    Vec<VEC> h = vload<VEC>(g2 + (long)((nb + pix) * ld_g2 + c0));
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) g.v[k] += h.v[k];
                 }
@@ -336,9 +371,9 @@ __global__ void k_in_merge(const double* __restrict__ part, int nchunk, int NC, 
 }
 
 template <int VEC, bool BWD>
-__global__ void k_in_apply(const float* __restrict__ y, int ld_y, const float* __restrict__ g1, int ld_g1,
-                           const float* __restrict__ g2, int ld_g2, const float* __restrict__ stats,
-                           const float* __restrict__ coef, float* __restrict__ out, int ld_out, int N, int HW, int C,
+__global__ void k_in_apply(TPtr y, int ld_y, TPtr g1, int ld_g1,
+                           TPtr g2, int ld_g2, const float* __restrict__ stats,
+                           const float* __restrict__ coef, TPtr out, int ld_out, int N, int HW, int C,
                            int act, float drop_p, uint64_t seed) {
     const int cq = C / VEC;
     const long total = (long)N * HW * cq;
@@ -348,7 +383,7 @@ __global__ void k_in_apply(const float* __restrict__ y, int ld_y, const float* _
         const int c0 = (int)(i - pix * cq) * VEC;
         const int n = (int)(pix / HW);
         const float* st = stats + ((long)n * C + c0) * 2;
-        Vec<VEC> v = vload<VEC>(y + pix * ld_y + c0), o;
+        Vec<VEC> v = vload<VEC>(y + (long)(pix * ld_y + c0)), o;
         if (!BWD) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
@@ -359,9 +394,9 @@ __global__ void k_in_apply(const float* __restrict__ y, int ld_y, const float* _
             }
         } else {
             const float* cf = coef + ((long)n * C + c0) * 2;
-            Vec<VEC> g = vload<VEC>(g1 + pix * ld_g1 + c0);
+            Vec<VEC> g = vload<VEC>(g1 + (long)(pix * ld_g1 + c0));
             if (g2) {
-                Vec<VEC> h = vload<VEC>(g2 + pix * ld_g2 + c0);
+                Vec<VEC> h = vload<VEC>(g2 + (long)(pix * ld_g2 + c0));
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) g.v[k] += h.v[k];
             }
@@ -375,12 +410,12 @@ __global__ void k_in_apply(const float* __restrict__ y, int ld_y, const float* _
                 o.v[k] = (dz - cf[2 * k] - (v.v[k] - mf) * cf[2 * k + 1]) * rs;
             }
         }
-        vstore<VEC>(out + pix * ld_out + c0, o);
+        vstore<VEC>(out + (long)(pix * ld_out + c0), o);
     }
 }
 
 template <int VEC>
-__global__ void k_act_fwd(const float* __restrict__ y, int ld_y, float* __restrict__ out, int ld_out, long npix, int C,
+__global__ void k_act_fwd(TPtr y, int ld_y, TPtr out, int ld_out, long npix, int C,
                           int act, float drop_p, uint64_t seed) {
     const int cq = C / VEC;
     const long total = npix * cq;
@@ -388,20 +423,20 @@ __global__ void k_act_fwd(const float* __restrict__ y, int ld_y, float* __restri
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long pix = i / cq;
         const int c0 = (int)(i - pix * cq) * VEC;
-        Vec<VEC> v = vload<VEC>(y + pix * ld_y + c0), o;
+        Vec<VEC> v = vload<VEC>(y + (long)(pix * ld_y + c0)), o;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             float a = pg_act(v.v[k], act);
             if (drop_p > 0.f) a = pg_dropout_keep(seed, (uint64_t)pix * C + c0 + k, drop_p) ? a * keep_scale : 0.f;
             o.v[k] = a;
         }
-        vstore<VEC>(out + pix * ld_out + c0, o);
+        vstore<VEC>(out + (long)(pix * ld_out + c0), o);
     }
 }
 
 template <int VEC>
-__global__ void k_act_bwd(const float* __restrict__ g1, int ld_g1, const float* __restrict__ g2, int ld_g2,
-                          const float* __restrict__ a, int ld_a, float* __restrict__ dy, int ld_dy, long npix, int C,
+__global__ void k_act_bwd(TPtr g1, int ld_g1, TPtr g2, int ld_g2,
+                          TPtr a, int ld_a, TPtr dy, int ld_dy, long npix, int C,
                           int act, float drop_p, uint64_t seed) {
     const int cq = C / VEC;
     const long total = npix * cq;
@@ -409,14 +444,14 @@ __global__ void k_act_bwd(const float* __restrict__ g1, int ld_g1, const float* 
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long pix = i / cq;
         const int c0 = (int)(i - pix * cq) * VEC;
-        Vec<VEC> g = vload<VEC>(g1 + pix * ld_g1 + c0), o;
+        Vec<VEC> g = vload<VEC>(g1 + (long)(pix * ld_g1 + c0)), o;
         if (g2) {
-            Vec<VEC> h = vload<VEC>(g2 + pix * ld_g2 + c0);
+            Vec<VEC> h = vload<VEC>(g2 + (long)(pix * ld_g2 + c0));
 #pragma unroll
             for (int k = 0; k < VEC; ++k) g.v[k] += h.v[k];
         }
         Vec<VEC> av;
-        if (a) av = vload<VEC>(a + pix * ld_a + c0);
+        if (a) av = vload<VEC>(a + (long)(pix * ld_a + c0));
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             float gg = g.v[k];
@@ -429,7 +464,7 @@ __global__ void k_act_bwd(const float* __restrict__ g1, int ld_g1, const float* 
             }
             o.v[k] = gg * pg_act_grad_from_out(ao, act);
         }
-        vstore<VEC>(dy + pix * ld_dy + c0, o);
+        vstore<VEC>(dy + (long)(pix * ld_dy + c0), o);
     }
 }
 
@@ -525,142 +560,174 @@ size_t pg_instnorm_workspace_bytes(int N, int HW, int C) {
     return x > y ? x : y;
 }
 
-int pg_instnorm_act_fwd(const float* y, int ld_y, float* out, int ld_out, float* stats, int N, int HW, int C,
-                        int act, float eps, float drop_p, uint64_t seed, void* ws, size_t ws_bytes, void* stream) {
+// ---- dtype masks of the *_t entry points: bit i set = tensor i (in the order of the signature's tensor arguments) is bf16.
+// An 8-byte-per-4-elements access needs 8-byte alignment for bf16, 16 for fp32.
+static inline bool al_ok(const void* p, bool bf) { return (reinterpret_cast<uintptr_t>(p) & (bf ? 7 : 15)) == 0; }
+
+int pg_instnorm_act_fwd_t(const void* y, int ld_y, void* out, int ld_out, float* stats, int N, int HW, int C, int act, float eps,
+                          float drop_p, uint64_t seed, void* ws, size_t ws_bytes, void* stream, int dt) {
     if (!y || !out || !stats || N <= 0 || HW <= 0 || C <= 0 || ld_y < C || ld_out < C) return PG_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID) return PG_EINVAL;
-    if (N > 65535) return PG_EINVAL;
+    if (N > 65535 || (dt & ~3)) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = (C % 4 == 0) && (ld_y % 4 == 0) && (ld_out % 4 == 0) && al16(y) && al16(out);
+    const TPtr ty = tp(y, dt & 1), to = tp(out, dt & 2), none = tp(nullptr, false);
+    const bool vec = (C % 4 == 0) && (ld_y % 4 == 0) && (ld_out % 4 == 0) && al_ok(y, dt & 1) && al_ok(out, dt & 2);
     ChunkPlan cp = chunk_plan(N, HW, C, vec ? 4 : 1);
     if (cp.nchunk > 1 && ws && ws_bytes >= cp.part_bytes) {
         double* part = (double*)ws;
         dim3 grid(cp.groups, cp.nchunk, N);
         if (vec)
-            hipLaunchKernelGGL((k_in_partial<4, false>), grid, dim3(256), 0, st, y, ld_y, (const float*)nullptr, 0,
-                               (const float*)nullptr, 0, (const float*)nullptr, part, HW, C, cp.G, cp.ppc, act, drop_p, seed);
+            hipLaunchKernelGGL((k_in_partial<4, false>), grid, dim3(256), 0, st, ty, ld_y, none, 0, none, 0, (const float*)nullptr, part,
+                               HW, C, cp.G, cp.ppc, act, drop_p, seed);
         else
-            hipLaunchKernelGGL((k_in_partial<1, false>), grid, dim3(256), 0, st, y, ld_y, (const float*)nullptr, 0,
-                               (const float*)nullptr, 0, (const float*)nullptr, part, HW, C, cp.G, cp.ppc, act, drop_p, seed);
+            hipLaunchKernelGGL((k_in_partial<1, false>), grid, dim3(256), 0, st, ty, ld_y, none, 0, none, 0, (const float*)nullptr, part,
+                               HW, C, cp.G, cp.ppc, act, drop_p, seed);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         hipLaunchKernelGGL((k_in_merge<false>), dim3((N * C + 255) / 256), dim3(256), 0, st, part, cp.nchunk, N * C, C, HW, eps,
                            stats, (float*)nullptr);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         if (vec)
-            hipLaunchKernelGGL((k_in_apply<4, false>), dim3(ew_blocks((long)N * HW * (C / 4))), dim3(256), 0, st, y, ld_y,
-                               (const float*)nullptr, 0, (const float*)nullptr, 0, stats, (const float*)nullptr, out,
-                               ld_out, N, HW, C, act, drop_p, seed);
+            hipLaunchKernelGGL((k_in_apply<4, false>), dim3(ew_blocks((long)N * HW * (C / 4))), dim3(256), 0, st, ty, ld_y, none, 0,
+                               none, 0, stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
         else
-            hipLaunchKernelGGL((k_in_apply<1, false>), dim3(ew_blocks((long)N * HW * C)), dim3(256), 0, st, y, ld_y,
-                               (const float*)nullptr, 0, (const float*)nullptr, 0, stats, (const float*)nullptr, out,
-                               ld_out, N, HW, C, act, drop_p, seed);
+            hipLaunchKernelGGL((k_in_apply<1, false>), dim3(ew_blocks((long)N * HW * C)), dim3(256), 0, st, ty, ld_y, none, 0, none, 0,
+                               stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
         return pg_launch_status();
     }
     if (vec) {
         const int units = C / 4, G = pick_group(N, units);
-        hipLaunchKernelGGL(k_instnorm_fwd<4>, dim3((units + G - 1) / G, N), dim3(256), 0, st, y, ld_y, out, ld_out, stats,
+        hipLaunchKernelGGL(k_instnorm_fwd<4>, dim3((units + G - 1) / G, N), dim3(256), 0, st, ty, ld_y, to, ld_out, stats,
                            HW, C, G, act, eps, drop_p, seed);
     } else {
         const int G = pick_group(N, C);
-        hipLaunchKernelGGL(k_instnorm_fwd<1>, dim3((C + G - 1) / G, N), dim3(256), 0, st, y, ld_y, out, ld_out, stats, HW,
+        hipLaunchKernelGGL(k_instnorm_fwd<1>, dim3((C + G - 1) / G, N), dim3(256), 0, st, ty, ld_y, to, ld_out, stats, HW,
                            C, G, act, eps, drop_p, seed);
     }
     return pg_launch_status();
 }
 
-int pg_instnorm_act_fwd_parts(const float* y, int ld_y, float* out, int ld_out, float* stats, const double* part, int chunks,
-                              int N, int HW, int C, int act, float eps, float drop_p, uint64_t seed, void* stream) {
+int pg_instnorm_act_fwd(const float* y, int ld_y, float* out, int ld_out, float* stats, int N, int HW, int C,
+                        int act, float eps, float drop_p, uint64_t seed, void* ws, size_t ws_bytes, void* stream) {
+    return pg_instnorm_act_fwd_t(y, ld_y, out, ld_out, stats, N, HW, C, act, eps, drop_p, seed, ws, ws_bytes, stream, 0);
+}
+
+int pg_instnorm_act_fwd_parts_t(const void* y, int ld_y, void* out, int ld_out, float* stats, const double* part, int chunks,
+                                int N, int HW, int C, int act, float eps, float drop_p, uint64_t seed, void* stream, int dt) {
     if (!y || !out || !stats || !part || chunks <= 0 || N <= 0 || HW <= 0 || C <= 0 || ld_y < C || ld_out < C) return PG_EINVAL;
-    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID) return PG_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID || (dt & ~3)) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = (C % 4 == 0) && (ld_y % 4 == 0) && (ld_out % 4 == 0) && al16(y) && al16(out);
+    const TPtr ty = tp(y, dt & 1), to = tp(out, dt & 2), none = tp(nullptr, false);
+    const bool vec = (C % 4 == 0) && (ld_y % 4 == 0) && (ld_out % 4 == 0) && al_ok(y, dt & 1) && al_ok(out, dt & 2);
     hipLaunchKernelGGL((k_in_merge<false>), dim3((N * C + 255) / 256), dim3(256), 0, st, part, chunks, N * C, C, HW, eps, stats,
                        (float*)nullptr);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     if (vec)
-        hipLaunchKernelGGL((k_in_apply<4, false>), dim3(ew_blocks((long)N * HW * (C / 4))), dim3(256), 0, st, y, ld_y,
-                           (const float*)nullptr, 0, (const float*)nullptr, 0, stats, (const float*)nullptr, out, ld_out, N, HW, C,
-                           act, drop_p, seed);
+        hipLaunchKernelGGL((k_in_apply<4, false>), dim3(ew_blocks((long)N * HW * (C / 4))), dim3(256), 0, st, ty, ld_y, none, 0, none,
+                           0, stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
     else
-        hipLaunchKernelGGL((k_in_apply<1, false>), dim3(ew_blocks((long)N * HW * C)), dim3(256), 0, st, y, ld_y, (const float*)nullptr,
-                           0, (const float*)nullptr, 0, stats, (const float*)nullptr, out, ld_out, N, HW, C, act, drop_p, seed);
+        hipLaunchKernelGGL((k_in_apply<1, false>), dim3(ew_blocks((long)N * HW * C)), dim3(256), 0, st, ty, ld_y, none, 0, none, 0,
+                           stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
     return pg_launch_status();
 }
 
-int pg_instnorm_act_bwd(const float* g1, int ld_g1, const float* g2, int ld_g2, const float* y, int ld_y,
-                        const float* stats, float* dy, int ld_dy, int N, int HW, int C, int act, float drop_p,
-                        uint64_t seed, void* ws, size_t ws_bytes, void* stream) {
+int pg_instnorm_act_fwd_parts(const float* y, int ld_y, float* out, int ld_out, float* stats, const double* part, int chunks,
+                              int N, int HW, int C, int act, float eps, float drop_p, uint64_t seed, void* stream) {
+    return pg_instnorm_act_fwd_parts_t(y, ld_y, out, ld_out, stats, part, chunks, N, HW, C, act, eps, drop_p, seed, stream, 0);
+}
+
+int pg_instnorm_act_bwd_t(const void* g1, int ld_g1, const void* g2, int ld_g2, const void* y, int ld_y, const float* stats,
+                          void* dy, int ld_dy, int N, int HW, int C, int act, float drop_p, uint64_t seed, void* ws,
+                          size_t ws_bytes, void* stream, int dt) {
     if (!g1 || !y || !stats || !dy || N <= 0 || HW <= 0 || C <= 0) return PG_EINVAL;
     if (ld_g1 < C || ld_y < C || ld_dy < C || (g2 && ld_g2 < C)) return PG_EINVAL;
-    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID || N > 65535) return PG_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID || N > 65535 || (dt & ~15)) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = (C % 4 == 0) && (ld_g1 % 4 == 0) && (ld_y % 4 == 0) && (ld_dy % 4 == 0) && al16(g1) && al16(y) &&
-                     al16(dy) && (!g2 || ((ld_g2 % 4 == 0) && al16(g2)));
+    const TPtr tg1 = tp(g1, dt & 1), tg2 = tp(g2, dt & 2), ty = tp(y, dt & 4), tdy = tp(dy, dt & 8);
+    const bool vec = (C % 4 == 0) && (ld_g1 % 4 == 0) && (ld_y % 4 == 0) && (ld_dy % 4 == 0) && al_ok(g1, dt & 1) &&
+                     al_ok(y, dt & 4) && al_ok(dy, dt & 8) && (!g2 || ((ld_g2 % 4 == 0) && al_ok(g2, dt & 2)));
     ChunkPlan cp = chunk_plan(N, HW, C, vec ? 4 : 1);
     if (cp.nchunk > 1 && ws && ws_bytes >= cp.part_bytes + cp.coef_bytes) {
         double* part = (double*)ws;
         float* coef = (float*)((char*)ws + cp.part_bytes);
         dim3 grid(cp.groups, cp.nchunk, N);
         if (vec)
-            hipLaunchKernelGGL((k_in_partial<4, true>), grid, dim3(256), 0, st, y, ld_y, g1, ld_g1, g2, ld_g2, stats, part, HW,
+            hipLaunchKernelGGL((k_in_partial<4, true>), grid, dim3(256), 0, st, ty, ld_y, tg1, ld_g1, tg2, ld_g2, stats, part, HW,
                                C, cp.G, cp.ppc, act, drop_p, seed);
         else
-            hipLaunchKernelGGL((k_in_partial<1, true>), grid, dim3(256), 0, st, y, ld_y, g1, ld_g1, g2, ld_g2, stats, part, HW,
+            hipLaunchKernelGGL((k_in_partial<1, true>), grid, dim3(256), 0, st, ty, ld_y, tg1, ld_g1, tg2, ld_g2, stats, part, HW,
                                C, cp.G, cp.ppc, act, drop_p, seed);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         hipLaunchKernelGGL((k_in_merge<true>), dim3((N * C + 255) / 256), dim3(256), 0, st, part, cp.nchunk, N * C, C, HW, 0.f,
                            const_cast<float*>(stats), coef);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         if (vec)
-            hipLaunchKernelGGL((k_in_apply<4, true>), dim3(ew_blocks((long)N * HW * (C / 4))), dim3(256), 0, st, y, ld_y, g1,
-                               ld_g1, g2, ld_g2, stats, coef, dy, ld_dy, N, HW, C, act, drop_p, seed);
+            hipLaunchKernelGGL((k_in_apply<4, true>), dim3(ew_blocks((long)N * HW * (C / 4))), dim3(256), 0, st, ty, ld_y, tg1,
+                               ld_g1, tg2, ld_g2, stats, coef, tdy, ld_dy, N, HW, C, act, drop_p, seed);
         else
-            hipLaunchKernelGGL((k_in_apply<1, true>), dim3(ew_blocks((long)N * HW * C)), dim3(256), 0, st, y, ld_y, g1, ld_g1,
-                               g2, ld_g2, stats, coef, dy, ld_dy, N, HW, C, act, drop_p, seed);
+            hipLaunchKernelGGL((k_in_apply<1, true>), dim3(ew_blocks((long)N * HW * C)), dim3(256), 0, st, ty, ld_y, tg1, ld_g1,
+                               tg2, ld_g2, stats, coef, tdy, ld_dy, N, HW, C, act, drop_p, seed);
         return pg_launch_status();
     }
     if (vec) {
         const int units = C / 4, G = pick_group(N, units);
-        hipLaunchKernelGGL(k_instnorm_bwd<4>, dim3((units + G - 1) / G, N), dim3(256), 0, st, g1, ld_g1, g2, ld_g2, y,
-                           ld_y, stats, dy, ld_dy, HW, C, G, act, drop_p, seed);
+        hipLaunchKernelGGL(k_instnorm_bwd<4>, dim3((units + G - 1) / G, N), dim3(256), 0, st, tg1, ld_g1, tg2, ld_g2, ty,
+                           ld_y, stats, tdy, ld_dy, HW, C, G, act, drop_p, seed);
     } else {
         const int G = pick_group(N, C);
-        hipLaunchKernelGGL(k_instnorm_bwd<1>, dim3((C + G - 1) / G, N), dim3(256), 0, st, g1, ld_g1, g2, ld_g2, y, ld_y,
-                           stats, dy, ld_dy, HW, C, G, act, drop_p, seed);
+        hipLaunchKernelGGL(k_instnorm_bwd<1>, dim3((C + G - 1) / G, N), dim3(256), 0, st, tg1, ld_g1, tg2, ld_g2, ty, ld_y,
+                           stats, tdy, ld_dy, HW, C, G, act, drop_p, seed);
     }
+    return pg_launch_status();
+}
+
+int pg_instnorm_act_bwd(const float* g1, int ld_g1, const float* g2, int ld_g2, const float* y, int ld_y,
+                        const float* stats, float* dy, int ld_dy, int N, int HW, int C, int act, float drop_p,
+                        uint64_t seed, void* ws, size_t ws_bytes, void* stream) {
+    return pg_instnorm_act_bwd_t(g1, ld_g1, g2, ld_g2, y, ld_y, stats, dy, ld_dy, N, HW, C, act, drop_p, seed, ws, ws_bytes, stream, 0);
+}
+
+int pg_act_fwd_t(const void* y, int ld_y, void* out, int ld_out, long npix, int C, int act, float drop_p, uint64_t seed,
+                 void* stream, int dt) {
+    if (!y || !out || npix <= 0 || C <= 0 || ld_y < C || ld_out < C) return PG_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID || (dt & ~3)) return PG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const TPtr ty = tp(y, dt & 1), to = tp(out, dt & 2);
+    const bool vec = (C % 4 == 0) && (ld_y % 4 == 0) && (ld_out % 4 == 0) && al_ok(y, dt & 1) && al_ok(out, dt & 2);
+    if (vec)
+        hipLaunchKernelGGL(k_act_fwd<4>, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, st, ty, ld_y, to, ld_out, npix, C,
+                           act, drop_p, seed);
+    else
+        hipLaunchKernelGGL(k_act_fwd<1>, dim3(ew_blocks(npix * C)), dim3(256), 0, st, ty, ld_y, to, ld_out, npix, C, act,
+                           drop_p, seed);
     return pg_launch_status();
 }
 
 int pg_act_fwd(const float* y, int ld_y, float* out, int ld_out, long npix, int C, int act, float drop_p,
                uint64_t seed, void* stream) {
-    if (!y || !out || npix <= 0 || C <= 0 || ld_y < C || ld_out < C) return PG_EINVAL;
-    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID) return PG_EINVAL;
+    return pg_act_fwd_t(y, ld_y, out, ld_out, npix, C, act, drop_p, seed, stream, 0);
+}
+
+int pg_act_bwd_t(const void* g1, int ld_g1, const void* g2, int ld_g2, const void* a, int ld_a, void* dy, int ld_dy, long npix,
+                 int C, int act, float drop_p, uint64_t seed, void* stream, int dt) {
+    if (!g1 || !dy || npix <= 0 || C <= 0 || ld_g1 < C || ld_dy < C) return PG_EINVAL;
+    if ((g2 && ld_g2 < C) || (a && ld_a < C) || (!a && act != PG_ACT_NONE)) return PG_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID || (dt & ~15)) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = (C % 4 == 0) && (ld_y % 4 == 0) && (ld_out % 4 == 0) && al16(y) && al16(out);
+    const TPtr tg1 = tp(g1, dt & 1), tg2 = tp(g2, dt & 2), ta = tp(a, dt & 4), tdy = tp(dy, dt & 8);
+    const bool vec = (C % 4 == 0) && (ld_g1 % 4 == 0) && (ld_dy % 4 == 0) && al_ok(g1, dt & 1) && al_ok(dy, dt & 8) &&
+                     (!g2 || ((ld_g2 % 4 == 0) && al_ok(g2, dt & 2))) && (!a || ((ld_a % 4 == 0) && al_ok(a, dt & 4)));
     if (vec)
-        hipLaunchKernelGGL(k_act_fwd<4>, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, st, y, ld_y, out, ld_out, npix, C,
-                           act, drop_p, seed);
+        hipLaunchKernelGGL(k_act_bwd<4>, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, st, tg1, ld_g1, tg2, ld_g2, ta, ld_a,
+                           tdy, ld_dy, npix, C, act, drop_p, seed);
     else
-        hipLaunchKernelGGL(k_act_fwd<1>, dim3(ew_blocks(npix * C)), dim3(256), 0, st, y, ld_y, out, ld_out, npix, C, act,
-                           drop_p, seed);
+        hipLaunchKernelGGL(k_act_bwd<1>, dim3(ew_blocks(npix * C)), dim3(256), 0, st, tg1, ld_g1, tg2, ld_g2, ta, ld_a, tdy,
+                           ld_dy, npix, C, act, drop_p, seed);
     return pg_launch_status();
 }
 
 int pg_act_bwd(const float* g1, int ld_g1, const float* g2, int ld_g2, const float* a, int ld_a, float* dy,
                int ld_dy, long npix, int C, int act, float drop_p, uint64_t seed, void* stream) {
-    if (!g1 || !dy || npix <= 0 || C <= 0 || ld_g1 < C || ld_dy < C) return PG_EINVAL;
-    if ((g2 && ld_g2 < C) || (a && ld_a < C) || (!a && act != PG_ACT_NONE)) return PG_EINVAL;
-    if (drop_p < 0.f || drop_p >= 1.f || act < 0 || act > PG_ACT_SIGMOID) return PG_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    const bool vec = (C % 4 == 0) && (ld_g1 % 4 == 0) && (ld_dy % 4 == 0) && al16(g1) && al16(dy) &&
-                     (!g2 || ((ld_g2 % 4 == 0) && al16(g2))) && (!a || ((ld_a % 4 == 0) && al16(a)));
-    if (vec)
-        hipLaunchKernelGGL(k_act_bwd<4>, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, st, g1, ld_g1, g2, ld_g2, a, ld_a,
-                           dy, ld_dy, npix, C, act, drop_p, seed);
-    else
-        hipLaunchKernelGGL(k_act_bwd<1>, dim3(ew_blocks(npix * C)), dim3(256), 0, st, g1, ld_g1, g2, ld_g2, a, ld_a, dy,
-                           ld_dy, npix, C, act, drop_p, seed);
-    return pg_launch_status();
+    return pg_act_bwd_t(g1, ld_g1, g2, ld_g2, a, ld_a, dy, ld_dy, npix, C, act, drop_p, seed, stream, 0);
 }
 
 int pg_softmax_fwd(const float* y, int ld_y, float* out, int ld_out, long npix, int C, void* stream) {

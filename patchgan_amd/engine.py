@@ -34,27 +34,37 @@ def _stream():
 
 
 class View:
-    """NHWC channel-slice of a device buffer."""
-    __slots__ = ('t', 'off', 'ld', 'N', 'H', 'W', 'C')
+    """NHWC channel-slice of a device buffer; `bf` = the buffer holds bf16 elements (bf16 activation storage), else fp32.
+    `off` and `ld` count elements of the buffer's own type."""
+    __slots__ = ('t', 'off', 'ld', 'N', 'H', 'W', 'C', 'bf')
 
-    def __init__(self, t, off, ld, N, H, W, C):
-        self.t, self.off, self.ld, self.N, self.H, self.W, self.C = t, off, ld, N, H, W, C
+    def __init__(self, t, off, ld, N, H, W, C, bf=False):
+        self.t, self.off, self.ld, self.N, self.H, self.W, self.C, self.bf = t, off, ld, N, H, W, C, bf
 
     @staticmethod
-    def alloc(N, H, W, C, device, zero=False):
-        t = (torch.zeros if zero else torch.empty)(N * H * W * C, dtype=torch.float32, device=device)
-        return View(t, 0, C, N, H, W, C)
+    def alloc(N, H, W, C, device, zero=False, bf=False):
+        t = (torch.zeros if zero else torch.empty)(N * H * W * C, dtype=torch.bfloat16 if bf else torch.float32, device=device)
+        return View(t, 0, C, N, H, W, C, bf)
 
     def ptr(self):
-        return self.t.data_ptr() + self.off * 4
+        return self.t.data_ptr() + self.off * (2 if self.bf else 4)
 
     def channels(self, c0, c):
         assert 0 <= c0 and c0 + c <= self.C
-        return View(self.t, self.off + c0, self.ld, self.N, self.H, self.W, c)
+        return View(self.t, self.off + c0, self.ld, self.N, self.H, self.W, c, self.bf)
 
     def samples(self, n0, n):
         assert 0 <= n0 and n0 + n <= self.N
-        return View(self.t, self.off + n0 * self.H * self.W * self.ld, self.ld, n, self.H, self.W, self.C)
+        return View(self.t, self.off + n0 * self.H * self.W * self.ld, self.ld, n, self.H, self.W, self.C, self.bf)
+
+    def converted(self, bf):
+        """A dense copy of this view in the other storage type (pg_act_fwd_t with PG_ACT_NONE), or self if it already has it."""
+        if self.bf == bf:
+            return self
+        out = View.alloc(self.N, self.H, self.W, self.C, self.t.device, bf=bf)
+        L.check(L.load().pg_act_fwd_t(self.ptr(), self.ld, out.ptr(), out.ld, self.npix, self.C, L.ACT_NONE, 0.0, 0, _stream(),
+                                      (1 if self.bf else 0) | (2 if bf else 0)), 'pg_act_fwd_t')
+        return out
 
     @property
     def HW(self):
@@ -65,7 +75,9 @@ class View:
         return self.N * self.H * self.W
 
     def to_nchw(self):
-        """Materialise as a contiguous NCHW torch tensor (API edge)."""
+        """Materialise as a contiguous NCHW fp32 torch tensor (API edge)."""
+        if self.bf:
+            return self.converted(False).to_nchw()
         out = torch.empty(self.N, self.C, self.H, self.W, dtype=torch.float32, device=self.t.device)
         L.check(L.load().pg_nhwc_to_nchw(self.ptr(), self.ld, out.data_ptr(), self.N, self.C, self.H, self.W,
                                          _stream()), 'pg_nhwc_to_nchw')
@@ -74,6 +86,7 @@ class View:
     def from_nchw(self, src):
         """Fill from a contiguous NCHW torch tensor of shape [N, C, H, W]."""
         assert tuple(src.shape) == (self.N, self.C, self.H, self.W), (tuple(src.shape), (self.N, self.C, self.H, self.W))
+        assert not self.bf, 'API-edge layout kernels write fp32 views'
         src = src.contiguous()
         L.check(L.load().pg_nchw_to_nhwc(src.data_ptr(), self.ptr(), self.ld, self.N, self.C, self.H, self.W,
                                          _stream()), 'pg_nchw_to_nhwc')
@@ -214,7 +227,11 @@ class ConvOp:
 
     @staticmethod
     def _aligned(*views):
-        return all(v.ld % 4 == 0 and v.ptr() % 16 == 0 for v in views)
+        return all(v.ld % 4 == 0 and v.ptr() % 16 == 0 and not v.bf for v in views)     # (the Winograd hand-overs are fp32 paths)
+
+    @staticmethod
+    def _io(big, small):
+        return (L.IO_BIG_BF16 if big.bf else 0) | (L.IO_SMALL_BF16 if small.bf else 0)
 
     def _query(self, key, fn):
         if key not in self._desc:
@@ -253,7 +270,7 @@ class ConvOp:
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         wp, wn = self._ws(P.device)
         args = (big.ptr(), big.ld, L.ptr(P, p_off), L.ptr(bias, b_off) if bias is not None else None, small.ptr(), small.ld,
-                ctypes.byref(self.g), act, self.algo, wp, wn, _stream())
+                ctypes.byref(self.g), act, self.algo | self._io(big, small), wp, wn, _stream())
         x = self._extras(part=part, v_keep=v_keep, u_cache=u_cache, u_valid=u_valid)
 
         def go():
@@ -268,7 +285,7 @@ class ConvOp:
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         wp, wn = self._ws(P.device)
         args = (small.ptr(), small.ld, L.ptr(P, p_off), L.ptr(bias, b_off) if bias is not None else None, big.ptr(), big.ld,
-                ctypes.byref(self.g), act, self.algo, wp, wn, _stream())
+                ctypes.byref(self.g), act, self.algo | self._io(big, small), wp, wn, _stream())
         x = self._extras(part=part, u_cache=u_cache, u_valid=u_valid)
 
         def go():
@@ -284,7 +301,7 @@ class ConvOp:
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         wp, wn = self._ws(dP.device)
         args = (small.ptr(), small.ld, big.ptr(), big.ld, L.ptr(dP, p_off), L.ptr(dbias, b_off) if dbias is not None else None,
-                ctypes.byref(self.g), self.algo, wp, wn, _stream())
+                ctypes.byref(self.g), self.algo | self._io(big, small), wp, wn, _stream())
         x = self._extras(v_pre=v_pre)
 
         def go():
@@ -303,10 +320,20 @@ class ConvOp:
         wp, wn = self._ws(P.device)
 
         def go():
+            assert small.bf == big.bf == dsmall.bf, 'bwd_big: one storage type for the three activation tensors'
             L.check(L.load().pg_conv4x4_bwd_big(small.ptr(), small.ld, big.ptr(), big.ld, L.ptr(P, p_off), L.ptr(dP, p_off),
-                                                dsmall.ptr(), dsmall.ld, ctypes.byref(self.g), self.algo, wp, wn, _stream()),
-                    'pg_conv4x4_bwd_big')
+                                                dsmall.ptr(), dsmall.ld, ctypes.byref(self.g), self.algo | self._io(big, small), wp, wn,
+                                                _stream()), 'pg_conv4x4_bwd_big')
         PROFILER.launch2(self, (2, 0), go) if PROFILER is not None else go()
+
+
+def _dt(*views):
+    """dtype mask of the *_t entry points: bit i = the i-th tensor argument is bf16."""
+    m = 0
+    for i, v in enumerate(views):
+        if v is not None and v.bf:
+            m |= 1 << i
+    return m
 
 
 def instnorm_act_fwd(y, out, stats, act, drop_p=0.0, seed=0):
@@ -314,8 +341,8 @@ def instnorm_act_fwd(y, out, stats, act, drop_p=0.0, seed=0):
         raise ValueError(f"Expected more than 1 spatial element when training, got input size "
                          f"torch.Size([{y.N}, {y.C}, {y.H}, {y.W}])")
     ws = _workspace(int(L.load().pg_instnorm_workspace_bytes(y.N, y.HW, y.C)), y.t.device)
-    L.check(L.load().pg_instnorm_act_fwd(y.ptr(), y.ld, out.ptr(), out.ld, stats.data_ptr(), y.N, y.HW, y.C, act, 1e-5,
-                                         drop_p, seed & _MASK64, ws.data_ptr(), ws.numel(), _stream()),
+    L.check(L.load().pg_instnorm_act_fwd_t(y.ptr(), y.ld, out.ptr(), out.ld, stats.data_ptr(), y.N, y.HW, y.C, act, 1e-5,
+                                           drop_p, seed & _MASK64, ws.data_ptr(), ws.numel(), _stream(), _dt(y, out)),
             'pg_instnorm_act_fwd')
 
 
@@ -332,8 +359,8 @@ def conv_instnorm_act(op, opcode, src, flat, p_off, y, out, stats, act, drop_p=0
     if chunks:
         part = torch.empty(y.N * chunks * y.C * 2, dtype=torch.float64, device=y.t.device)
         conv(src, flat, p_off, None, 0, y, part=part, **kw)
-        L.check(L.load().pg_instnorm_act_fwd_parts(y.ptr(), y.ld, out.ptr(), out.ld, stats.data_ptr(), part.data_ptr(), chunks, y.N,
-                                                   y.HW, y.C, act, 1e-5, drop_p, seed & _MASK64, _stream()),
+        L.check(L.load().pg_instnorm_act_fwd_parts_t(y.ptr(), y.ld, out.ptr(), out.ld, stats.data_ptr(), part.data_ptr(), chunks, y.N,
+                                                     y.HW, y.C, act, 1e-5, drop_p, seed & _MASK64, _stream(), _dt(y, out)),
                 'pg_instnorm_act_fwd_parts')
     else:
         conv(src, flat, p_off, None, 0, y, **kw)
@@ -347,16 +374,16 @@ CACHE_U = os.environ.get('PATCHGAN_CACHE_U', '1') != '0'
 
 def instnorm_act_bwd(g1, g2, y, stats, dy, act, drop_p=0.0, seed=0):
     ws = _workspace(int(L.load().pg_instnorm_workspace_bytes(y.N, y.HW, y.C)), y.t.device)
-    L.check(L.load().pg_instnorm_act_bwd(g1.ptr(), g1.ld, g2.ptr() if g2 is not None else None,
-                                         g2.ld if g2 is not None else 0, y.ptr(), y.ld, stats.data_ptr(), dy.ptr(), dy.ld,
-                                         y.N, y.HW, y.C, act, drop_p, seed & _MASK64, ws.data_ptr(), ws.numel(), _stream()),
-            'pg_instnorm_act_bwd')
+    L.check(L.load().pg_instnorm_act_bwd_t(g1.ptr(), g1.ld, g2.ptr() if g2 is not None else None,
+                                           g2.ld if g2 is not None else 0, y.ptr(), y.ld, stats.data_ptr(), dy.ptr(), dy.ld,
+                                           y.N, y.HW, y.C, act, drop_p, seed & _MASK64, ws.data_ptr(), ws.numel(), _stream(),
+                                           _dt(g1, g2, y, dy)), 'pg_instnorm_act_bwd')
 
 
 def act_bwd(g1, g2, a, dy, act):
-    L.check(L.load().pg_act_bwd(g1.ptr(), g1.ld, g2.ptr() if g2 is not None else None, g2.ld if g2 is not None else 0,
-                                a.ptr() if a is not None else None, a.ld if a is not None else 0, dy.ptr(), dy.ld,
-                                dy.npix, dy.C, act, 0.0, 0, _stream()), 'pg_act_bwd')
+    L.check(L.load().pg_act_bwd_t(g1.ptr(), g1.ld, g2.ptr() if g2 is not None else None, g2.ld if g2 is not None else 0,
+                                  a.ptr() if a is not None else None, a.ld if a is not None else 0, dy.ptr(), dy.ld,
+                                  dy.npix, dy.C, act, 0.0, 0, _stream(), _dt(g1, g2, a, dy)), 'pg_act_bwd')
 
 
 def softmax_fwd(y, out):

@@ -34,3 +34,21 @@ def unpack(P, a, b):
 def rel_err(got, want):
     got, want = got.double().cpu(), want.double().cpu()
     return ((got - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
+
+
+def to_view_bf(x, ld=None, off=0):
+    """NCHW CPU tensor -> bf16 NHWC View on the GPU (bf16 activation storage), optionally a channel slice of a wider buffer."""
+    from patchgan_amd import _lib as L
+    N, C, H, W = x.shape
+    ld = ld or C
+    src = to_view(x)
+    buf = torch.full((N * H * W * ld + 64,), float('nan'), dtype=torch.bfloat16, device=DEV)
+    v = E.View(buf, off, ld, N, H, W, C, True)
+    L.check(L.load().pg_act_fwd_t(src.ptr(), src.ld, v.ptr(), v.ld, v.npix, C, L.ACT_NONE, 0.0, 0, None, 2), 'pg_act_fwd_t')
+    return v
+
+
+def empty_view_bf(N, H, W, C, ld=None, off=0):
+    ld = ld or C
+    buf = torch.full((N * H * W * ld + 64,), float('nan'), dtype=torch.bfloat16, device=DEV)
+    return E.View(buf, off, ld, N, H, W, C, True)

@@ -1,0 +1,123 @@
+"""bf16 activation storage: the conv kernels of PG_ALGO_BF16 reading / writing bf16 NHWC tensors (PG_IO_* bits)
+and the InstanceNorm / activation kernels with per-tensor storage types (*_t entry points), against the fp32-storage results of
+the same kernels fed the bf16-rounded inputs (the arithmetic is identical: only loads widen and stores round) and against the
+CPU oracle.  Needs an MI355X."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import patchgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GEOMS = [(2, 64, 64, 128, 64, 2), (3, 34, 38, 40, 36, 2), (2, 32, 32, 64, 32, 1), (2, 4, 4, 512, 64, 2), (1, 8, 8, 160, 96, 2)]
+
+
+def _mk(N, Hb, Wb, Ca, Cb, s, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    Hs, Ws = (Hb - 2) // s + 1, (Wb - 2) // s + 1
+    big = torch.randn(N, Cb, Hb, Wb, generator=g).bfloat16().float()        # bf16-representable inputs
+    small = torch.randn(N, Ca, Hs, Ws, generator=g).bfloat16().float()
+    Wt = torch.randn(Ca, Cb, 4, 4, generator=g) / math.sqrt(Cb * 16)
+    return big, small, Wt, Hs, Ws
+
+
+@pytest.mark.parametrize('geom', GEOMS, ids=lambda g: 'x'.join(map(str, g)))
+def test_conv_kernels_on_bf16_tensors(geom):
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view, to_view_bf, empty_view, empty_view_bf, pack, unpack, rel_err, DEV
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    op = E.ConvOp(*geom, L.ALGO_BF16)
+    P = pack(Wt)
+    bias = torch.randn(Ca)
+    # big2small: bf16 in -> {bf16, fp32} out equals the fp32-storage kernel on the same (bf16-representable) input, up to the
+    # rounding of the stored output
+    ref = empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=4)
+    op.big2small(to_view(big, ld=Cb + 4), P, 0, bias.cuda(), 0, ref, 1)
+    for out_bf in (True, False):
+        out = (empty_view_bf if out_bf else empty_view)(N, Hs, Ws, Ca, ld=Ca + 4, off=4)
+        op.big2small(to_view_bf(big, ld=Cb + 8, off=4), P, 0, bias.cuda(), 0, out, 1)
+        torch.cuda.synchronize()
+        want = ref.to_nchw().bfloat16().float() if out_bf else ref.to_nchw()
+        assert torch.equal(out.to_nchw(), want), (out_bf, rel_err(out.to_nchw(), want))
+    assert rel_err(ref.to_nchw(), O.apply_act(F.conv2d(big, Wt, bias, stride=s, padding=1), 'leakyrelu')) < 2e-2
+    # small2big
+    bias_b = torch.randn(Cb)
+    ref = empty_view(N, Hb, Wb, Cb, ld=Cb + 4, off=0)
+    op.small2big(to_view(small, ld=Ca + 4, off=4), P, 0, bias_b.cuda(), 0, ref, 3)
+    for out_bf in (True, False):
+        out = (empty_view_bf if out_bf else empty_view)(N, Hb, Wb, Cb, ld=Cb + 8, off=4)
+        op.small2big(to_view_bf(small, ld=Ca + 4, off=4), P, 0, bias_b.cuda(), 0, out, 3)
+        torch.cuda.synchronize()
+        want = ref.to_nchw().bfloat16().float() if out_bf else ref.to_nchw()
+        assert torch.equal(out.to_nchw(), want), (out_bf, rel_err(out.to_nchw(), want))
+    # weight gradient: both operands bf16
+    dP1 = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+    dP2 = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+    op.wgrad(to_view_bf(small, ld=Ca + 4, off=4), to_view_bf(big, ld=Cb + 8, off=4), dP1, 0)
+    op.wgrad(to_view(small, ld=Ca + 4, off=4), to_view(big, ld=Cb + 8, off=4), dP2, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(dP1, dP2)
+    Wr = Wt.clone().requires_grad_(True)
+    F.conv2d(big, Wr, None, stride=s, padding=1).backward(small)
+    assert rel_err(unpack(dP1, Ca, Cb), Wr.grad) < 2e-2
+    # ConvTranspose2d backward in one call on bf16 tensors = its two halves
+    dP3 = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+    ds1, ds2 = empty_view_bf(N, Hs, Ws, Ca), empty_view_bf(N, Hs, Ws, Ca)
+    vb, vs = to_view_bf(big), to_view_bf(small)
+    op.bwd_big(vs, vb, P, dP3, 0, ds1)
+    op.big2small(vb, P, 0, None, 0, ds2)
+    torch.cuda.synchronize()
+    assert torch.equal(dP3, dP1) and torch.equal(ds1.to_nchw(), ds2.to_nchw())
+    # tensors the fast bf16 kernels cannot take are refused, not silently misread
+    thin = E.ConvOp(2, 16, 16, 16, 3, 2, L.ALGO_BF16)
+    with pytest.raises(RuntimeError):
+        thin.big2small(empty_view_bf(2, 16, 16, 3, ld=4), torch.zeros(16 * 16 * 3, device=DEV), 0, None, 0, empty_view(2, 8, 8, 16))
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 16, 16), (3, 6, 5, 7), (2, 512, 2, 2), (2, 64, 64, 64), (1, 136, 48, 48)])
+@pytest.mark.parametrize('mix', ['all_bf16', 'y32_out16', 'g16_y32_dy32'])
+def test_instnorm_act_mixed_storage(shape, mix):
+    """InstanceNorm + activation forward / backward with per-tensor storage types: equal to the fp32-storage kernels on the same
+    (bf16-representable) inputs, outputs rounded where they are stored as bf16."""
+    from patchgan_amd import engine as E
+    from tests.gpu_util import to_view, to_view_bf, empty_view, empty_view_bf, rel_err, DEV
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(1)
+    y = (torch.randn(shape, generator=g) * 2 + 0.5).bfloat16().float()
+    g1 = torch.randn(shape, generator=g).bfloat16().float()
+    g2 = torch.randn(shape, generator=g).bfloat16().float()
+    y_bf = mix == 'all_bf16'
+    out_bf = mix in ('all_bf16', 'y32_out16')
+    g_bf = mix in ('all_bf16', 'g16_y32_dy32')
+    dy_bf = mix == 'all_bf16'
+    mk = lambda t, bf, **kw: (to_view_bf if bf else to_view)(t, **kw)
+    em = lambda bf, **kw: (empty_view_bf if bf else empty_view)(N, H, W, C, **kw)
+    act = 1
+    # reference: fp32 storage everywhere
+    st0 = torch.empty(N * C * 2, device=DEV)
+    o0 = empty_view(N, H, W, C)
+    E.instnorm_act_fwd(to_view(y), o0, st0, act)
+    d0 = empty_view(N, H, W, C)
+    E.instnorm_act_bwd(to_view(g1), to_view(g2), to_view(y), st0, d0, act)
+    # mixed storage
+    st1 = torch.empty(N * C * 2, device=DEV)
+    o1 = em(out_bf, ld=C + 8, off=4)
+    vy = mk(y, y_bf, ld=C + 4)
+    E.instnorm_act_fwd(vy, o1, st1, act)
+    d1 = em(dy_bf, ld=C + 4, off=0)
+    E.instnorm_act_bwd(mk(g1, g_bf, ld=C + 4), mk(g2, g_bf), vy, st1, d1, act)
+    torch.cuda.synchronize()
+    assert torch.equal(st0, st1)
+    want_o = o0.to_nchw().bfloat16().float() if out_bf else o0.to_nchw()
+    want_d = d0.to_nchw().bfloat16().float() if dy_bf else d0.to_nchw()
+    assert torch.equal(o1.to_nchw(), want_o) and torch.equal(d1.to_nchw(), want_d)
+    # act_bwd with mixed storage
+    a0, a1 = empty_view(N, H, W, C), em(dy_bf)
+    E.act_bwd(to_view(g1), to_view(g2), o0, a0, 3)
+    E.act_bwd(mk(g1, g_bf), mk(g2, g_bf), o0, a1, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(a1.to_nchw(), a0.to_nchw().bfloat16().float() if dy_bf else a0.to_nchw())
