@@ -142,6 +142,8 @@ def main():
     ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg2', help='workload (default: the BASELINE metric config)')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
                     help="f32 = the parity path the metric is quoted on; bf16 = bf16-multiply / fp32-accumulate conv kernels ('next' row f2)")
+    ap.add_argument('--fp32-activations', action='store_true',
+                    help='with --dtype bf16: keep the activations fp32 in HBM (round-1 behaviour) instead of bf16 activation storage')
     ap.add_argument('--events', choices=['dominant', 'all', 'none'], default='dominant',
                     help='which conv launches get HIP events in the timed region (roofline leg)')
     args = ap.parse_args()
@@ -188,8 +190,8 @@ def main():
                 final_act=CFG['final_act']).to(dev)
     D = pg.Discriminator(3 + CFG['out_nc'], CFG['ndf'], n_layers=CFG['n_layers'], norm=False).to(dev)
     if args.dtype == 'bf16':
-        G.set_precision('bf16')
-        D.set_precision('bf16')
+        G.set_precision('bf16', bf16_storage=not args.fp32_activations)
+        D.set_precision('bf16', bf16_storage=not args.fp32_activations)
     t = pg.Trainer(G, D, tempfile.mkdtemp(prefix='pgbench_'))
     t.loss_type, t.seg_alpha = CFG['loss_type'], 200
     t.setup_optimizers(1e-3, 1e-3)
@@ -277,6 +279,7 @@ def main():
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'activation_storage': ('bf16' if (args.dtype == 'bf16' and G.engine.act_bf) else 'f32'),
             'config': {'workload': CFG['desc'] + ', dropout ' + ('on' if args.dropout else 'off'),
                        'global_batch': BATCH_PER_GPU * world, 'parallelism': f'dp{world}'},
             'last_losses': {k: round(v, 5) for k, v in last.items()},

@@ -46,13 +46,17 @@ class FlatParamModule(nn.Module):
             p.grad = None
         return self
 
-    def set_precision(self, precision):
-        """'fp32' (default: exact fp32 MFMA, the parity path) or 'bf16' (operand tiles rounded to bf16 in LDS, bf16
-        MFMA, fp32 accumulation; weights, activations, InstanceNorm statistics and Adam stay fp32).  Returns self."""
+    def set_precision(self, precision, bf16_storage=True):
+        """'fp32' (default: exact fp32 MFMA, the parity path) or 'bf16': bf16 MFMA with fp32 accumulation, and -- unless
+        bf16_storage=False or a channel count rules it out -- the interior activations and their gradients stored as bf16 in
+        HBM.  Master weights, weight gradients, InstanceNorm statistics, losses and Adam stay fp32 either way.  Returns self."""
         from . import _lib as L
         algo = {'fp32': L.ALGO_AUTO, 'bf16': L.ALGO_BF16}[precision]
         self.engine.algo = algo | (self.engine.algo & ~L.ALGO_MASK)
         self.engine._ops = {}
+        # bf16 activation storage wherever every interior tensor can take it (channel counts % 4 == 0 and >= 32); otherwise the
+        # bf16 kernels keep reading fp32 tensors and rounding them in flight
+        self.engine.act_bf = bool(precision == 'bf16' and bf16_storage and self.engine.bf16_storage_ok())
         self.precision = precision
         return self
 

@@ -558,7 +558,12 @@ class GeneratorEngine:
         self.layers = self.enc + self.dec
         self.nparams = assign_offsets(self.layers)
         self.algo = DEFAULT_ALGO if algo is None else algo
+        self.act_bf = False          # bf16 activation storage (set_precision('bf16'); needs nf % 4 == 0 and nf >= 32)
         self._ops = {}
+
+    def bf16_storage_ok(self):
+        """Every interior tensor feeds / comes from a fast bf16 conv kernel: channel counts multiples of 4 and >= 32."""
+        return self.nf % 4 == 0 and self.nf >= 32
 
     def ops(self, N, H, W):
         """ConvOps for input extent (N, H, W); cached."""
@@ -602,16 +607,20 @@ class GeneratorEngine:
         c = GenContext()
         c.N, c.H, c.W, c.xin, c.gen_out, c.seed, c.train, c.sample0 = N, H, W, xin, gen_out, seed, train, sample0
         # cat_i (i = 1..6): input of decoder i = [dec_{i-1} out | enc_{6-i} out]
+        # bf16 activation storage: every interior activation (conv outputs, normalised outputs, their gradients) is a bf16 tensor;
+        # the image-facing tensors (x, enc0's conv output, the generator output and its gradient) stay fp32 and the InstanceNorm /
+        # activation kernels next to them read one type and write the other
+        bf = c.bf = bool(self.act_bf)
         c.cat = [None] * 7
         for i in range(1, 7):
             op = dec_ops[i]
-            c.cat[i] = View.alloc(N, op.Hs, op.Ws, self.dec[i].a, dev)
-        c.hidden = View.alloc(N, enc_ops[6].Hs, enc_ops[6].Ws, F[6], dev)
+            c.cat[i] = View.alloc(N, op.Hs, op.Ws, self.dec[i].a, dev, bf=bf)
+        c.hidden = View.alloc(N, enc_ops[6].Hs, enc_ops[6].Ws, F[6], dev, bf=bf)
         c.y, c.stats, c.enc_out, c.v = [], [], [], []
         act = L.ACT_CODES[self.activation]
         src = xin
         for i, (l, op) in enumerate(zip(self.enc, enc_ops)):
-            y = View.alloc(N, op.Hs, op.Ws, l.a, dev)
+            y = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=bf and i > 0)
             if i < 6:
                 cat = c.cat[6 - i]
                 out = cat.channels(cat.C - l.a, l.a)
@@ -632,6 +641,7 @@ class GeneratorEngine:
         src = c.hidden
         for i, (l, op) in enumerate(zip(self.dec, dec_ops)):
             if i == 6:
+                src = c.cat6_f32 = src.converted(False)      # the 1..4-channel head runs the fp32 row-GEMM path
                 if self.final_act == 'softmax':
                     c.gen_raw = View.alloc(N, op.Hb, op.Wb, l.b, dev)
                     op.small2big(src, flat, l.p_off, None, 0, c.gen_raw)
@@ -642,7 +652,7 @@ class GeneratorEngine:
             cat = c.cat[i + 1]
             out = cat.channels(0, l.b)
             if l.norm:
-                yd = View.alloc(N, op.Hb, op.Wb, l.b, dev)
+                yd = View.alloc(N, op.Hb, op.Wb, l.b, dev, bf=bf)
                 stats = torch.empty(N * l.b * 2, dtype=torch.float32, device=dev)
                 drop = 0.2 if (train and l.dropout) else 0.0
                 conv_instnorm_act(op, 1, src, flat, l.p_off, yd, out, stats, act, drop,
@@ -671,15 +681,16 @@ class GeneratorEngine:
             softmax_bwd(g1, g2, c.gen_out, dy)
         else:
             act_bwd(g1, g2, c.gen_out, dy, L.ACT_CODES[self.final_act])
-        dcat = View.alloc(N, op.Hs, op.Ws, l.a, dev)
-        op.bwd_big(c.cat[6], dy, flat, gflat, l.p_off, dcat)      # weight gradient + data gradient of the ConvTranspose2d
+        bf = c.bf
+        dcat = View.alloc(N, op.Hs, op.Ws, l.a, dev)            # fp32 (the head's kernels); the blocks below read it as is
+        op.bwd_big(c.cat6_f32, dy, flat, gflat, l.p_off, dcat)    # weight gradient + data gradient of the ConvTranspose2d
         done(l)
         dskip = [None] * 7   # dskip[j]: gradient wrt enc_j output arriving through the skip connection
         for i in range(5, -1, -1):
             l, op = self.dec[i], dec_ops[i]
             g = dcat.channels(0, l.b)
             dskip[5 - i] = dcat.channels(l.b, dcat.C - l.b)
-            dy = View.alloc(N, op.Hb, op.Wb, l.b, dev)
+            dy = View.alloc(N, op.Hb, op.Wb, l.b, dev, bf=bf)
             if l.norm:
                 drop = 0.2 if (c.train and l.dropout) else 0.0
                 instnorm_act_bwd(g, None, c.yd[i], c.statsd[i], dy, act, drop,
@@ -687,7 +698,7 @@ class GeneratorEngine:
             else:
                 act_bwd(g, None, c.cat[i + 1].channels(0, l.b), dy, act)
             src = c.hidden if i == 0 else c.cat[i]
-            dsrc = View.alloc(N, op.Hs, op.Ws, l.a, dev)
+            dsrc = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=bf)
             op.bwd_big(src, dy, flat, gflat, l.p_off, dsrc)
             done(l)
             dcat = dsrc
@@ -696,7 +707,7 @@ class GeneratorEngine:
         dx = None
         for j in range(6, -1, -1):
             l, op = self.enc[j], enc_ops[j]
-            dy = View.alloc(N, op.Hs, op.Ws, l.a, dev)
+            dy = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=bf and j > 0)
             drop = 0.2 if (c.train and l.dropout) else 0.0
             instnorm_act_bwd(g_main, dskip[j] if j < 6 else None, c.y[j], c.stats[j], dy, act, drop,
                              _shift_seed(_mix_seed(c.seed, 1, j), c.sample0 * dy.HW * dy.C))
@@ -704,7 +715,7 @@ class GeneratorEngine:
             op.wgrad(dy, src, gflat, l.p_off, v_pre=c.v[j] if ConvOp._aligned(dy, src) else None)
             done(l)
             if j > 0 or need_dx:
-                dsrc = View.alloc(N, op.Hb, op.Wb, l.b, dev)
+                dsrc = View.alloc(N, op.Hb, op.Wb, l.b, dev, bf=bf and j > 0)
                 op.small2big(dy, flat, l.p_off, None, 0, dsrc)
                 if j == 0:
                     dx = dsrc
@@ -745,7 +756,11 @@ class DiscriminatorEngine:
         self.layers = disc_layers(input_nc, ndf, n_layers, norm)
         self.nparams = assign_offsets(self.layers)
         self.algo = DEFAULT_ALGO if algo is None else algo
+        self.act_bf = False          # bf16 activation storage (set_precision('bf16'); needs ndf % 4 == 0 and ndf >= 32)
         self._ops = {}
+
+    def bf16_storage_ok(self):
+        return self.ndf % 4 == 0 and self.ndf >= 32
 
     def ops(self, N, H, W):
         key = (N, H, W)
@@ -786,10 +801,17 @@ class DiscriminatorEngine:
         dev = flat.device
         c = DiscContext()
         c.din, c.N, c.H, c.W = din, din.N, din.H, din.W
-        c.t, c.stats, c.a, c.v = [], [], [], []
+        c.t, c.stats, c.a, c.v, c.src = [], [], [], [], []
+        # bf16 activation storage: the tensors between the first and the last layer are bf16; the input (x | mask), the first
+        # layer's conv output (4-channel input: generic kernel) and the 1-channel head stay fp32
+        bf = c.bf = bool(self.act_bf)
+        last = len(self.layers) - 1
         src = din
         for li, (l, op) in enumerate(zip(self.layers, ops)):
-            t = View.alloc(din.N, op.Hs, op.Ws, l.a, dev)
+            if li == last:
+                src = src.converted(False)
+            c.src.append(src)
+            t = View.alloc(din.N, op.Hs, op.Ws, l.a, dev, bf=bf and 0 < li < last)
             bias = flat if l.bias_key is not None else None
             u, uv = self._ucache(ucache, li, 0, op, dev, src, t)
             vb = op.v_bytes() if (keep_v and KEEP_V and ConvOp._aligned(src, t)) else 0
@@ -797,10 +819,12 @@ class DiscriminatorEngine:
             c.v.append(vk)
             op.big2small(src, flat, l.p_off, bias, l.b_off, t, L.ACT_CODES[l.act], v_keep=vk, u_cache=u, u_valid=uv)   # conv + bias + act fused
             if l.norm:                                                              # disc.py:31-32: Conv -> Tanh -> IN
-                a = View.alloc(din.N, op.Hs, op.Ws, l.a, dev)
+                a = View.alloc(din.N, op.Hs, op.Ws, l.a, dev, bf=bf and li < last)
                 stats = torch.empty(din.N * l.a * 2, dtype=torch.float32, device=dev)
                 instnorm_act_fwd(t, a, stats, L.ACT_NONE)
             else:
+                if bf and li == 0:
+                    t = t.converted(True)          # the next layer's kernel reads bf16
                 a, stats = t, None
             c.t.append(t)
             c.stats.append(stats)
@@ -816,20 +840,22 @@ class DiscriminatorEngine:
         dev = flat.device
         g = gout
         dx = None
-        for li in range(len(self.layers) - 1, -1, -1):
+        bf, last = c.bf, len(self.layers) - 1
+        for li in range(last, -1, -1):
             l, op = self.layers[li], ops[li]
+            inner = bf and 0 < li < last
             if l.norm:
-                dt = View.alloc(c.N, op.Hs, op.Ws, l.a, dev)
+                dt = View.alloc(c.N, op.Hs, op.Ws, l.a, dev, bf=inner)
                 instnorm_act_bwd(g, None, c.t[li], c.stats[li], dt, L.ACT_NONE)
                 g = dt
-            dy = View.alloc(c.N, op.Hs, op.Ws, l.a, dev)
+            dy = View.alloc(c.N, op.Hs, op.Ws, l.a, dev, bf=inner)
             act_bwd(g, None, c.t[li], dy, L.ACT_CODES[l.act])
-            src = c.din if li == 0 else c.a[li - 1]
+            src = c.src[li]
             if need_wgrad:
                 op.wgrad(dy, src, gflat, l.p_off, gflat if l.bias_key is not None else None, l.b_off,
                          v_pre=c.v[li] if ConvOp._aligned(dy, src) else None)
             if li > 0 or need_dx:
-                dsrc = View.alloc(c.N, op.Hb, op.Wb, l.b, dev)
+                dsrc = View.alloc(c.N, op.Hb, op.Wb, l.b, dev, bf=bf and 0 < li < last)
                 u, uv = self._ucache(ucache, li, 1, op, dev, dy, dsrc)
                 op.small2big(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
                 g = dsrc

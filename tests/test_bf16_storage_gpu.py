@@ -121,3 +121,55 @@ def test_instnorm_act_mixed_storage(shape, mix):
     E.act_bwd(mk(g1, g_bf), mk(g2, g_bf), o0, a1, 3)
     torch.cuda.synchronize()
     assert torch.equal(a1.to_nchw(), a0.to_nchw().bfloat16().float() if dy_bf else a0.to_nchw())
+
+
+def test_networks_bf16_storage_vs_fp32_storage(tmp_path):
+    """Whole networks at the benchmark width (nf = ndf = 64, 256x256, B = 2): bf16 mode with bf16 activation storage against the
+    same bf16 kernels on fp32-stored activations (round-1 behaviour) and against the fp32 CPU oracle.  Stated tolerance: forward
+    outputs within 2e-2 (max-norm) of the oracle, two training steps' losses within 5e-2 of the fp32 oracle's and within 2e-2 of the
+    fp32-storage run."""
+    import numpy as np
+    import patchgan_amd as pg
+    from tests.golden_util import LOSS_KEYS
+    torch.manual_seed(1234)
+    g0 = pg.UNet(3, 1, 64, use_dropout=False, activation='leakyrelu', final_act='sigmoid')
+    d0 = pg.Discriminator(4, 64, n_layers=3)
+    gw = {k: v.clone() for k, v in g0.state_dict().items()}
+    dw = {k: v.clone() for k, v in d0.state_dict().items()}
+    gen = torch.Generator().manual_seed(7)
+    x = torch.rand(2, 3, 256, 256, generator=gen)
+    y = (torch.rand(2, 1, 256, 256, generator=gen) > 0.7).float()
+    ot = O.OracleTrainer(gw, dw, activation='leakyrelu', final_act='sigmoid', n_layers=3, norm=False, loss_type='tversky')
+    with torch.no_grad():
+        ref = O.unet_forward(gw, x, 'leakyrelu', 'sigmoid')
+        dref = O.disc_forward(dw, torch.cat((x, ref), 1), 3, False)
+    want = [ot.batch(x, y, train=True) for _ in range(2)]
+    curves = {}
+    for storage in (True, False):
+        g = pg.UNet(3, 1, 64, use_dropout=False, activation='leakyrelu', final_act='sigmoid')
+        d = pg.Discriminator(4, 64, n_layers=3)
+        g.load_state_dict(gw)
+        d.load_state_dict(dw)
+        g.cuda().set_precision('bf16', bf16_storage=storage)
+        d.cuda().set_precision('bf16', bf16_storage=storage)
+        assert g.engine.act_bf == storage and d.engine.act_bf == storage
+        g.train()
+        d.train()
+        with torch.no_grad():
+            out, hid = g(x.cuda(), return_hidden=True)
+            dout = d(torch.cat((x.cuda(), out), 1))
+        e_out = ((out.cpu() - ref).abs().max() / ref.abs().max()).item()
+        e_d = ((dout.cpu() - dref).abs().max() / dref.abs().max()).item()
+        assert e_out < 2e-2 and e_d < 2e-2 and torch.isfinite(hid).all(), (storage, e_out, e_d)
+        t = pg.Trainer(g, d, str(tmp_path / f's{int(storage)}'))
+        t.setup_optimizers(1e-3, 1e-3)
+        got = [t.batch(x, y, train=True) for _ in range(2)]
+        curves[storage] = np.array([[r[k] for k in LOSS_KEYS] for r in got])
+        err = np.abs(curves[storage] - np.array([[r[k] for k in LOSS_KEYS] for r in want])) / np.maximum(np.abs(np.array([[r[k] for k in LOSS_KEYS] for r in want])), 1e-3)
+        print(f'bf16 mode, bf16 activation storage {storage}: output {e_out:.1e}, D out {e_d:.1e}, losses vs fp32 oracle per step {err.max(axis=1)}')
+        assert err.max() < 5e-2, err
+    rel = np.abs(curves[True] - curves[False]) / np.maximum(np.abs(curves[False]), 1e-3)
+    assert rel.max() < 2e-2, rel
+    # a narrow network keeps fp32 activations (the fast bf16 kernels need >= 32 channels on every interior tensor)
+    small = pg.UNet(3, 1, 4).cuda().set_precision('bf16')
+    assert small.engine.act_bf is False
