@@ -132,12 +132,22 @@ class LaunchProfiler:
     def __init__(self, only=None):
         self.records = []   # (symbol, split, flops, start_event, end_event)
         self.only = only    # symbol: time only this kernel's launches
+        self.limit = None   # stop arming events after this many records (bench.py: a bounded sample of the timed region)
+        self._pool = []
+
+    def reserve(self, n):
+        """Create n events ahead of the timed region: creating (and first-recording, which is what makes torch allocate the
+        hipEvent_t) an event per launch inside it costs host time and a stream operation each."""
+        for _ in range(n):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._pool.append(e)
 
     def launch(self, op, opcode, fn):
         if op.algo & L.ALGO_MASK == L.ALGO_DIRECT:
             return fn()
         sym, split = op.describe(opcode)
-        if self.only is not None and sym != self.only:
+        if (self.only is not None and sym != self.only) or (self.limit is not None and len(self.records) >= self.limit):
             return fn()
         e0, e1 = self._event(), self._event()
         # the C ABI records the pair tightly around the main GEMM kernel of this call (not its split-K reduce)
@@ -150,7 +160,7 @@ class LaunchProfiler:
         if op.algo & L.ALGO_MASK == L.ALGO_DIRECT:
             return fn()
         syms = [op.describe(oc)[0] for oc in opcodes]
-        if self.only is not None and self.only not in syms:
+        if (self.only is not None and self.only not in syms) or (self.limit is not None and len(self.records) >= self.limit):
             return fn()
         ev = [self._event() for _ in range(4)]
         L.check(L.load().pg_conv_time_next2(*[e.cuda_event for e in ev]), 'pg_conv_time_next2')
@@ -159,8 +169,9 @@ class LaunchProfiler:
             if self.only is None or syms[i] == self.only:
                 self.records.append((syms[i], op.describe(oc)[1], op.flops, op.kernel_flops(oc), ev[2 * i], ev[2 * i + 1]))
 
-    @staticmethod
-    def _event():
+    def _event(self):
+        if self._pool:
+            return self._pool.pop()
         e = torch.cuda.Event(enable_timing=True)
         e.record()          # torch creates the hipEvent_t lazily: force it, the C side re-records it
         return e

@@ -18,6 +18,7 @@ by the GLOBAL batch so the summed gradient equals the single-process large-batch
 """
 import glob
 import os
+import time
 from collections import defaultdict
 
 import numpy as np
@@ -77,6 +78,7 @@ class Trainer:
 
     # -------------------------------------------------------------------------------------- one G+D step
     def batch(self, x, y, train=False):
+        t_host0 = time.perf_counter()
         G, D = self.generator, self.discriminator
         dev = G.flat.device
         if dev.type != 'cuda':
@@ -188,6 +190,7 @@ class Trainer:
         if wait_losses is not None:
             wait_losses()
         self._last_gen = gen
+        self.host_ms = (time.perf_counter() - t_host0) * 1e3       # host time to enqueue the whole step (bench.py reports it)
         v = losses.cpu().numpy()                                                              # the step's one sync
         seg, gdisc = np.float32(v[0]), np.float32(v[1])
         loss_real, loss_fake = np.float32(v[2]) * np.float32(2), np.float32(v[3]) * np.float32(2)
