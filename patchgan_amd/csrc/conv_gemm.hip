@@ -2829,9 +2829,15 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
         snprintf(buf, sizeof buf, "k_wgrad_tapn<%s,%d>", TILE[tid], mode);
     } else {
         const bool half = (algo == PG_ALGO_BF16) && fast;
-        if (fast && oc == 0) snprintf(buf, sizeof buf, "%s<%s,false>", half ? "k_b2s_bf16" : "k_b2s_fast", TILE[tid]);
-        else if (fast && oc == 1) snprintf(buf, sizeof buf, "%s<%s>", half ? "k_s2b_bf16" : "k_s2b_fast", TILE[tid]);
-        else if (fast) snprintf(buf, sizeof buf, "%s<%s,%s>", half ? "k_wgrad_bf16" : "k_wgrad_fast", TILE[tid], fast == 2 ? "true" : "false");
+        // bf16 kernels: the trailing template argument says whether the activation operand(s) are stored as bf16 (PG_IO_* bits)
+        const int io = algo_full & PG_IO_MASK;
+        const char* hin = (oc == 0 ? (io & PG_IO_BIG_BF16) : oc == 1 ? (io & PG_IO_SMALL_BF16) : io == PG_IO_MASK) ? "true" : "false";
+        if (half && oc == 0) snprintf(buf, sizeof buf, "k_b2s_bf16<%s,false,%s>", TILE[tid], hin);
+        else if (half && oc == 1) snprintf(buf, sizeof buf, "k_s2b_bf16<%s,%s>", TILE[tid], hin);
+        else if (half) snprintf(buf, sizeof buf, "k_wgrad_bf16<%s,%s,%s>", TILE[tid], fast == 2 ? "true" : "false", hin);
+        else if (fast && oc == 0) snprintf(buf, sizeof buf, "k_b2s_fast<%s,false>", TILE[tid]);
+        else if (fast && oc == 1) snprintf(buf, sizeof buf, "k_s2b_fast<%s>", TILE[tid]);
+        else if (fast) snprintf(buf, sizeof buf, "k_wgrad_fast<%s,%s>", TILE[tid], fast == 2 ? "true" : "false");
         else snprintf(buf, sizeof buf, "%s<%s>", oc == 0 ? "k_big2small" : oc == 1 ? "k_small2big" : "k_wgrad", TILE[tid]);
     }
     if (name && name_len) snprintf(name, name_len, "%s", buf);

@@ -143,23 +143,23 @@ class LaunchProfiler:
             e.record()
             self._pool.append(e)
 
-    def launch(self, op, opcode, fn):
+    def launch(self, op, opcode, fn, io=0):
         if op.algo & L.ALGO_MASK == L.ALGO_DIRECT:
             return fn()
-        sym, split = op.describe(opcode)
+        sym, split = op.describe(opcode, io)
         if (self.only is not None and sym != self.only) or (self.limit is not None and len(self.records) >= self.limit):
             return fn()
         e0, e1 = self._event(), self._event()
         # the C ABI records the pair tightly around the main GEMM kernel of this call (not its split-K reduce)
         L.check(L.load().pg_conv_time_next(e0.cuda_event, e1.cuda_event), 'pg_conv_time_next')
         fn()
-        self.records.append((sym, split, op.flops, op.kernel_flops(opcode), e0, e1))
+        self.records.append((sym, split, op.flops, op.kernel_flops(opcode, io), e0, e1))
 
-    def launch2(self, op, opcodes, fn):
+    def launch2(self, op, opcodes, fn, io=0):
         """A fused call with two main GEMM kernels (pg_conv4x4_bwd_big): one event pair per kernel."""
         if op.algo & L.ALGO_MASK == L.ALGO_DIRECT:
             return fn()
-        syms = [op.describe(oc)[0] for oc in opcodes]
+        syms = [op.describe(oc, io)[0] for oc in opcodes]
         if (self.only is not None and self.only not in syms) or (self.limit is not None and len(self.records) >= self.limit):
             return fn()
         ev = [self._event() for _ in range(4)]
@@ -167,7 +167,7 @@ class LaunchProfiler:
         fn()
         for i, oc in enumerate(opcodes):
             if self.only is None or syms[i] == self.only:
-                self.records.append((syms[i], op.describe(oc)[1], op.flops, op.kernel_flops(oc), ev[2 * i], ev[2 * i + 1]))
+                self.records.append((syms[i], op.describe(oc, io)[1], op.flops, op.kernel_flops(oc, io), ev[2 * i], ev[2 * i + 1]))
 
     def _event(self):
         if self._pool:
@@ -217,24 +217,25 @@ class ConvOp:
         """Algorithmic FLOPs of any of the three kernels on this geometry: 2 * N*Hs*Ws * 16 * Ca * Cb."""
         return 2.0 * self.N * self.Hs * self.Ws * 16 * self.Ca * self.Cb
 
-    def kernel_flops(self, opcode):
+    def kernel_flops(self, opcode, io=0):
         """FLOPs the main GEMM kernel of this call really executes on the MFMA pipe: the algorithmic count for the implicit
         GEMM kernels, 2.25-4x fewer for the Winograd kernels (their tile counts include the ragged-edge padding)."""
-        return self._describe(opcode)[2]
+        return self._describe(opcode, io)[2]
 
-    def describe(self, opcode):
+    def describe(self, opcode, io=0):
         """(kernel symbol, split-K factor) of the main GEMM kernel the C ABI launches for this op (pg_conv_kernel: the
-        dispatch code itself reports it)."""
-        return self._describe(opcode)[:2]
+        dispatch code itself reports it).  io: the PG_IO_* bits of the call (bf16 activation storage)."""
+        return self._describe(opcode, io)[:2]
 
-    def _describe(self, opcode):
-        if opcode not in self._desc:
+    def _describe(self, opcode, io=0):
+        key = (opcode, io)
+        if key not in self._desc:
             name = ctypes.create_string_buffer(128)
             s, fl = ctypes.c_int(0), ctypes.c_double(0)
-            L.check(L.load().pg_conv_kernel(ctypes.byref(self.g), opcode + 16 * self.algo, max(self.ws_bytes, 1 << 20), name, 128,
+            L.check(L.load().pg_conv_kernel(ctypes.byref(self.g), opcode + 16 * (self.algo | io), max(self.ws_bytes, 1 << 20), name, 128,
                                             ctypes.byref(s), ctypes.byref(fl)), 'pg_conv_kernel')
-            self._desc[opcode] = (name.value.decode(), s.value, fl.value)
-        return self._desc[opcode]
+            self._desc[key] = (name.value.decode(), s.value, fl.value)
+        return self._desc[key]
 
     @staticmethod
     def _aligned(*views):
@@ -289,7 +290,7 @@ class ConvOp:
                 L.check(L.load().pg_conv4x4_big2small(*args), 'pg_conv4x4_big2small')
             else:
                 L.check(L.load().pg_conv4x4_big2small_x(*args, ctypes.byref(x)), 'pg_conv4x4_big2small_x')
-        PROFILER.launch(self, 0, go) if PROFILER is not None else go()
+        PROFILER.launch(self, 0, go, self._io(big, small)) if PROFILER is not None else go()
 
     def small2big(self, small, P, p_off, bias, b_off, big, act=L.ACT_NONE, part=None, u_cache=None, u_valid=False):
         assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
@@ -304,7 +305,7 @@ class ConvOp:
                 L.check(L.load().pg_conv4x4_small2big(*args), 'pg_conv4x4_small2big')
             else:
                 L.check(L.load().pg_conv4x4_small2big_x(*args, ctypes.byref(x)), 'pg_conv4x4_small2big_x')
-        PROFILER.launch(self, 1, go) if PROFILER is not None else go()
+        PROFILER.launch(self, 1, go, self._io(big, small)) if PROFILER is not None else go()
 
     def wgrad(self, small, big, dP, p_off, dbias=None, b_off=0, v_pre=None):
         """v_pre: the transformed `big` tensor kept by this layer's big2small(..., v_keep=) (same tensor, v_bytes() > 0)."""
@@ -320,7 +321,7 @@ class ConvOp:
                 L.check(L.load().pg_conv4x4_wgrad(*args), 'pg_conv4x4_wgrad')
             else:
                 L.check(L.load().pg_conv4x4_wgrad_x(*args, ctypes.byref(x)), 'pg_conv4x4_wgrad_x')
-        PROFILER.launch(self, 2, go) if PROFILER is not None else go()
+        PROFILER.launch(self, 2, go, self._io(big, small)) if PROFILER is not None else go()
 
     def bwd_big(self, small, big, P, dP, p_off, dsmall):
         """Weight gradient (small = x, big = dy) and data gradient (big -> small) of a ConvTranspose2d layer in one call; where
@@ -335,7 +336,7 @@ class ConvOp:
             L.check(L.load().pg_conv4x4_bwd_big(small.ptr(), small.ld, big.ptr(), big.ld, L.ptr(P, p_off), L.ptr(dP, p_off),
                                                 dsmall.ptr(), dsmall.ld, ctypes.byref(self.g), self.algo | self._io(big, small), wp, wn,
                                                 _stream()), 'pg_conv4x4_bwd_big')
-        PROFILER.launch2(self, (2, 0), go) if PROFILER is not None else go()
+        PROFILER.launch2(self, (2, 0), go, self._io(big, small)) if PROFILER is not None else go()
 
 
 def _dt(*views):
