@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q, name, nsteps):
+def _worker(rank, world, port, q, name, nsteps, dropout=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
@@ -23,12 +23,13 @@ def _worker(rank, world, port, q, name, nsteps):
     from tests.golden_util import Golden, LOSS_KEYS
     gold = Golden(name)
     c = gold.cfg
-    g = pg.UNet(c['in_nc'], c['out_nc'], c['nf'], activation=c['activation'], final_act=c['final_act'])
+    g = pg.UNet(c['in_nc'], c['out_nc'], c['nf'], activation=c['activation'], final_act=c['final_act'], use_dropout=dropout)
     d = pg.Discriminator(c['in_nc'] + c['out_nc'], c['ndf'], n_layers=c['n_layers'], norm=c['norm'])
     g.load_state_dict(gold.weights('g0'))
     d.load_state_dict(gold.weights('d0'))
     g.cuda()
     d.cuda()
+    g._seed_base = 4242          # the same dropout stream on every rank (the CLI gets this from torch's default seed)
     t = pg.Trainer(g, d, tempfile.mkdtemp())
     t.loss_type = c['loss_type']
     t.bucket_bytes = 64 << 10          # several buckets even for the nf=4 generator
@@ -72,4 +73,48 @@ def test_two_rank_step_matches_single_process_golden(name):
     want = gold.z['losses'][:nsteps]
     err = np.abs(c0 - want) / np.maximum(np.abs(want), 1e-6)
     print(name, 'dp2 vs single-process golden: max rel err per step', err.max(axis=1))
+    assert err.max() < 1e-4, err
+
+
+def test_two_rank_dropout_masks_are_those_of_the_global_batch(tmp_path):
+    """use_dropout=True (the CLI default, train.py:92) under data parallelism: rank r offsets the element index of the counter-based
+    dropout hash by r * N * HW * C, so the two half-batches draw exactly the masks the single-process run draws for the whole
+    batch -- the 2-rank loss curve equals the single-process one (same seed base) to fp32 reduction-order noise."""
+    import patchgan_amd as pg
+    from tests.golden_util import Golden, LOSS_KEYS
+    name, nsteps = 'a_lrelu_tversky', 4
+    gold = Golden(name)
+    c = gold.cfg
+    g = pg.UNet(c['in_nc'], c['out_nc'], c['nf'], activation=c['activation'], final_act=c['final_act'], use_dropout=True)
+    d = pg.Discriminator(c['in_nc'] + c['out_nc'], c['ndf'], n_layers=c['n_layers'], norm=c['norm'])
+    g.load_state_dict(gold.weights('g0'))
+    d.load_state_dict(gold.weights('d0'))
+    g.cuda()
+    d.cuda()
+    g._seed_base = 4242
+    t = pg.Trainer(g, d, str(tmp_path / 'single'))
+    t.loss_type = c['loss_type']
+    t.setup_optimizers(1e-3, 1e-3)
+    g.train()
+    d.train()
+    x, y = gold.inputs()
+    single = np.array([[t.batch(x, y, train=True)[k] for k in LOSS_KEYS] for _ in range(nsteps)])
+    nodrop = gold.z['losses'][:nsteps]
+    assert np.abs(single - nodrop).max() > 1e-3          # dropout really changes the trajectory
+    torch.cuda.synchronize()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, name, nsteps, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    err = np.abs(res[0][1] - single) / np.maximum(np.abs(single), 1e-6)
+    print('dp2 with dropout vs single process: max rel err per step', err.max(axis=1))
     assert err.max() < 1e-4, err
