@@ -98,7 +98,8 @@ def test_two_rank_dropout_masks_are_those_of_the_global_batch(tmp_path):
     g.train()
     d.train()
     x, y = gold.inputs()
-    single = np.array([[t.batch(x, y, train=True)[k] for k in LOSS_KEYS] for _ in range(nsteps)])
+    rows = [t.batch(x, y, train=True) for _ in range(nsteps)]
+    single = np.array([[r[k] for k in LOSS_KEYS] for r in rows])
     nodrop = gold.z['losses'][:nsteps]
     assert np.abs(single - nodrop).max() > 1e-3          # dropout really changes the trajectory
     torch.cuda.synchronize()
