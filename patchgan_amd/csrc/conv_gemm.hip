@@ -1871,6 +1871,20 @@ __global__ __launch_bounds__(256) void k_s2b_bf16(const float* __restrict__ smal
     }
 }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// 8 consecutive k (rows p .. p + 7*pitch) of this lane's column as an MFMA bf16 fragment: two ds_read_b64_tr_b16
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* p, int pitch) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * pitch));
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = __builtin_bit_cast(__bf16, lo[e]);
+        r[4 + e] = __builtin_bit_cast(__bf16, hi[e]);
+    }
+    return r;
+}
+
 template <int MR, int NR, int WM, int WN, bool POW2, bool HIN = false>
 __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ small, int ld_small,
                                                     const float* __restrict__ big, int ld_big,
@@ -1897,6 +1911,8 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ sm
     const int c_begin = blockIdx.z * chunks_per_slice;
     const int c_end = min(nchunks, c_begin + chunks_per_slice);
 
+    // transposed fragment reads: 16-lane group gr = lane >> 4 covers columns (gr & 1) * 16 .. +15 and k rows (gr >> 1) * 8 .. +7
+    const int tr_row = ((lane >> 4) >> 1) * 8 + ((lane & 15) >> 2), tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
     const int aq = tid % AQ, arow0 = tid / AQ;
     const int bq = tid % BQ, brow0 = tid / BQ;
     const int a_col = (m0 + aq * 4 < g.Ca) ? m0 + aq * 4 : 0x10000000;      // small rows beyond Kp are out of range by
@@ -1988,17 +2004,15 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ sm
         PIN_VMEM();
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
-            // tiles are [k][m]: a lane's 8 consecutive k of its column are 8 ds_read_u16 (K is the pixel axis here and
-            // both operands are contiguous along channels in memory, so there is no K-contiguous image to stage)
+            // tiles are [k][m] (K is the pixel axis here and both operands are contiguous along channels in memory, so there is
+            // no K-contiguous image to stage): the fragments -- 8 consecutive k of the lane's column -- come from two transposed
+            // LDS reads (ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block, lane 4q+p addresses row q / columns
+            // 4p.., lane i receives column i of the four rows; verified with tools/tr_probe.hip) instead of 8 ds_read_u16
             bf16x8 af[MR], bf[NR];
 #pragma unroll
-            for (int i = 0; i < MR; ++i)
+            for (int i = 0; i < MR; ++i) af[i] = tr_frag(&As[(ks * 16 + tr_row) * LDA + (wm * MR + i) * 32 + tr_col], LDA);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) af[i][e] = As[(ks * 16 + lh * 8 + e) * LDA + (wm * MR + i) * 32 + lrow];
-#pragma unroll
-            for (int j = 0; j < NR; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bf[j][e] = Bs[(ks * 16 + lh * 8 + e) * LDB + (wn * NR + j) * 32 + lrow];
+            for (int j = 0; j < NR; ++j) bf[j] = tr_frag(&Bs[(ks * 16 + tr_row) * LDB + (wn * NR + j) * 32 + tr_col], LDB);
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
