@@ -1876,13 +1876,11 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* p, int pitch) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * pitch));
-    bf16x8 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        r[e] = __builtin_bit_cast(__bf16, lo[e]);
-        r[4 + e] = __builtin_bit_cast(__bf16, hi[e]);
-    }
-    return r;
+    // (whole-vector casts: an element-by-element short -> __bf16 bit_cast of the two results is miscompiled by this hipcc
+    // into v_perm / v_mov of the first dword only)
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
 }
 
 template <int MR, int NR, int WM, int WN, bool POW2, bool HIN = false>

@@ -15,7 +15,40 @@ __global__ void k(short* out) {
     s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)addr);
     for (int e = 0; e < 4; ++e) out[lane * 4 + e] = v[e];
 }
+// the fragment formula of k_wgrad_bf16: LDS tile [k][m] of pitch LDA; lane l must receive (k = 8 * (l / 32) + j, m = l % 32)
+constexpr int LDA = 136;
+__global__ void k2(short* out) {
+    __shared__ short As[32 * LDA];
+    for (int i = threadIdx.x; i < 32 * LDA; i += 64) As[i] = (short)((i / LDA) * 256 + (i % LDA));
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const int tr_row = ((lane >> 4) >> 1) * 8 + ((lane & 15) >> 2), tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    const short* p = &As[(0 * 16 + tr_row) * LDA + 0 * 32 + tr_col];
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * LDA));
+    for (int e = 0; e < 4; ++e) {
+        out[lane * 8 + e] = lo[e];
+        out[lane * 8 + 4 + e] = hi[e];
+    }
+}
 int main() {
+    {
+        short* d2;
+        hipMalloc(&d2, 64 * 8 * 2);
+        hipLaunchKernelGGL(k2, dim3(1), dim3(64), 0, 0, d2);
+        short h2[512];
+        hipMemcpy(h2, d2, sizeof h2, hipMemcpyDeviceToHost);
+        int bad = 0;
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * (l / 32) + j, m = l % 32;
+                if (h2[l * 8 + j] != (short)(k * 256 + m)) {
+                    if (bad < 12) printf("lane %d j %d: got (k%d,m%d) want (k%d,m%d)\n", l, j, h2[l * 8 + j] / 256, h2[l * 8 + j] % 256, k, m);
+                    ++bad;
+                }
+            }
+        printf("fragment formula mismatches: %d\n", bad);
+    }
     short* d;
     hipMalloc(&d, 64 * 4 * 2);
     hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d);
