@@ -1,0 +1,33 @@
+// conv_bf16.h -- internal interface of the bf16-tensor convolution kernels (conv_bf16.hip): implicit GEMMs on
+// v_mfma_f32_32x32x16_bf16 whose operand tiles are brought in by LDS-DMA straight from bf16 tensors in HBM.  Used by the
+// C-ABI entry points in conv_gemm.hip for PG_ALGO_BF16 calls whose activations are stored as bf16 (PG_IO_*_BF16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+// direction: 0 = big -> small (Conv2d forward / ConvTranspose2d data gradient), 1 = small -> big
+struct pg_bf16x_plan {
+    int tile;              // 0: 256x128 rows x channels per workgroup, 1: 128x128, 2: 256x64
+    int bm, bn;
+    int tiles_m, tiles_n, ncls;
+    int nchunks;           // 64-wide K chunks: taps * Cin / 64
+    int split, cps;        // split-K slices and chunks per slice (after pg_bf16x_clamp)
+    long out_elems;        // elements of one fp32 slab
+};
+
+// geometry gate (channel multiples, 32-bit byte offsets); alignment of the actual pointers is checked by the caller
+bool pg_bf16x_geom_ok(int dir, int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride);
+pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride);
+void pg_bf16x_clamp(pg_bf16x_plan* p, size_t slab_bytes_available);
+const char* pg_bf16x_kernel_name(int dir, int tile);
+
+// bf16 copy of the packed weights P[tap][a][b] (fp32): dir 0 keeps the layout, dir 1 transposes each tap to [tap][b][a]
+// (the GEMM's K index must be the contiguous one of both operands)
+size_t pg_bf16x_w_bytes(int Ca, int Cb);
+int pg_bf16x_pack(const float* P, void* W, int Ca, int Cb, int dir, hipStream_t st);
+
+// out: the destination tensor (bf16 if out_bf, else fp32; bias and activation applied) when slab_stride == 0, else fp32 slabs
+// [split][pixels][Cout] for the caller's reduce pass
+int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void* W, void* out, int ld_out, long slab_stride,
+                  int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, const pg_bf16x_plan* p, const float* bias,
+                  int act, int out_bf, hipStream_t st);

@@ -22,6 +22,7 @@
 #include "patchgan_hip.h"
 #include "pg_common.h"
 #include "conv_wino.h"
+#include "conv_bf16.h"
 
 namespace {
 
@@ -2590,6 +2591,7 @@ struct Tune {
     int wino2w;     // polyphase stride-2 weight gradient: same codes
     int mo1;        // stride-1 tile edge: 0 heuristic, 2 / 3 pinned
     int dma;        // stride-1 GEMM staging: 0 registers, 1 LDS-DMA ring for F(3x3,4x4), 2 also for 64-tile F(2x2,4x4)
+    bool bf16x;     // PG_ALGO_BF16 on bf16 tensors: the LDS-DMA kernels of conv_bf16.hip (off: the register-staged k_*_bf16)
 };
 inline int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -2604,6 +2606,7 @@ inline Tune tune_of(int algo) {
         t.wino2w = env_int("PATCHGAN_WINO2_WGRAD", 2);
         t.mo1 = env_int("PATCHGAN_WINO1_TILE", 0);
         t.dma = pg_wino_dma_mode();
+        t.bf16x = env_int("PATCHGAN_NO_BF16X", 0) != 1;
         return t;
     }();
     Tune t = env;
@@ -2616,11 +2619,12 @@ inline Tune tune_of(int algo) {
     if (algo & PG_TUNE_WINO1_F2) t.mo1 = 2;
     if (algo & PG_TUNE_WINO1_F3) t.mo1 = 3;
     if (algo & PG_TUNE_WINO_DMA) t.dma = 2;
+    if (algo & PG_TUNE_BF16X_OFF) t.bf16x = false;
     if (force_generic()) t.wino = false;
     return t;
 }
 // every path on, for sizing a workspace that serves any tuning
-inline Tune tune_widest(int mo1) { return Tune{true, true, 1, 1, mo1, 0}; }
+inline Tune tune_widest(int mo1) { return Tune{true, true, 1, 1, mo1, 0, true}; }
 
 // stride-1 layers only: forward is a pad-1 correlation big -> small, the data gradient a pad-2 correlation small -> big
 inline bool wino_b2s_ok(const Geom& g, const Tune& t) {
@@ -2657,6 +2661,62 @@ inline bool wino_wgrad_ok(const Geom& g, const Tune& t) {
     return g.s == 1 && t.winow && t.wino && pg_wino_wgrad_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb);
 }
 
+// PG_ALGO_BF16 with the input activation stored as bf16: the LDS-DMA kernels of conv_bf16.hip (dir 0: big -> small, 1: small -> big)
+inline bool bf16x_ok(const Geom& g, int dir, int algo_full, const Tune& t) {
+    if ((algo_full & PG_ALGO_MASK) != PG_ALGO_BF16 || !t.bf16x || force_generic()) return false;
+    if (!(algo_full & (dir == 0 ? PG_IO_BIG_BF16 : PG_IO_SMALL_BF16))) return false;
+    return pg_bf16x_geom_ok(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s);
+}
+// packed bf16 weights (unless the caller owns them) followed by the split-K slabs
+inline size_t bf16x_ws(const Geom& g, int dir) {
+    const pg_bf16x_plan p = pg_bf16x_plan_of(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s);
+    return pg_bf16x_w_bytes(g.Ca, g.Cb) + (p.split > 1 ? (size_t)p.split * p.out_elems * sizeof(float) : 0);
+}
+inline bool aligned_bf_view(const void* p, int ld, bool bf) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % (bf ? 8 : 4)) == 0;
+}
+
+// the whole bf16x call: pack (or reuse) the weights, main kernel, split-K reduce.  Returns PG_EINVAL + 1000 when the call is not
+// eligible after all (alignment, workspace): the caller then falls through to the register-staged kernels.
+constexpr int BF16X_SKIP = -1000;
+int bf16x_run(int dir, const void* in, int ld_in, const float* P, const float* bias, void* out, int ld_out, const Geom& g, int act,
+              bool out_bf, void* ws, size_t ws_bytes, hipStream_t st, const pg_conv_extras& x) {
+    const int Cin = dir == 0 ? g.Cb : g.Ca, Cout = dir == 0 ? g.Ca : g.Cb;
+    const long in_pix = (long)g.N * (dir == 0 ? g.Hb * g.Wb : g.Hs * g.Ws), out_pix = (long)g.N * (dir == 0 ? g.Hs * g.Ws : g.Hb * g.Wb);
+    const long in_bytes = tensor_bytes(in_pix, ld_in, Cin, true);
+    if (!aligned_bf_view(in, ld_in, true) || !aligned_bf_view(out, ld_out, out_bf) || !aligned16(P) || (bias && !aligned16(bias)) ||
+        in_bytes >= FAST_LIMIT)
+        return BF16X_SKIP;
+    const size_t wb = pg_bf16x_w_bytes(g.Ca, g.Cb);
+    void* W = x.u_cache;
+    char* rest = (char*)ws;
+    size_t avail = ws_bytes;
+    if (!W) {
+        if (!ws || !aligned16(ws) || ws_bytes < wb) return BF16X_SKIP;
+        W = ws;
+        rest += wb;
+        avail -= wb;
+    }
+    if (!(x.u_cache && x.u_valid)) {
+        int rc = pg_bf16x_pack(P, W, g.Ca, g.Cb, dir, st);
+        if (rc != PG_OK) return rc;
+    }
+    pg_bf16x_plan p = pg_bf16x_plan_of(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s);
+    pg_bf16x_clamp(&p, avail);
+    int rc;
+    {
+        TimedLaunch timed(st);
+        if (p.split == 1)
+            rc = pg_bf16x_conv(dir, in, ld_in, in_bytes, W, out, ld_out, 0L, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, &p, bias, act,
+                               out_bf ? 1 : 0, st);
+        else
+            rc = pg_bf16x_conv(dir, in, ld_in, in_bytes, W, rest, Cout, p.out_elems, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, &p,
+                               nullptr, 0, 0, st);
+    }
+    if (rc != PG_OK || p.split == 1) return rc;
+    return launch_reduce((const float*)rest, p.out_elems, p.split, (float*)out, ld_out, out_pix, Cout, bias, act, st, out_bf ? 1 : 0);
+}
+
 }  // namespace
 
 extern "C" {
@@ -2688,6 +2748,7 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
         if (op == 0 && wino_b2s_ok(gq, t)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca, mo1));
         if (op == 1 && wino_s2b_ok(gq, t)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb, mo1));
     }
+    if ((op == 0 || op == 1) && pg_bf16x_geom_ok(op, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s)) bytes = std::max(bytes, bf16x_ws(gq, op));
     const Tune tw = tune_widest(0);
     const size_t colsum = ((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255;
     if (op == 0 && wino2_b2s_ok(gq, tw)) bytes = std::max(bytes, pg_wino2_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb));
@@ -2733,6 +2794,15 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
     clamp_split(p, ws_bytes, reserved);
     if (tile_id) *tile_id = p.t.id + ((op == 2) ? 10 * wgrad_mode(g) : 0) + fastcode;
     const Geom gq = to_geom(g);
+    // 1000 + 10 * dir + tile: the LDS-DMA bf16 kernels (k_conv_bf16x) on bf16 tensors
+    if ((op == 0 || op == 1) && bf16x_ok(gq, op, algo_full, tune) && ws_bytes >= pg_bf16x_w_bytes(g->Ca, g->Cb)) {
+        pg_bf16x_plan bp = pg_bf16x_plan_of(op, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s);
+        pg_bf16x_clamp(&bp, ws_bytes - pg_bf16x_w_bytes(g->Ca, g->Cb));
+        if (tile_id) *tile_id = 1000 + 10 * op + bp.tile;
+        if (split) *split = bp.split;
+        if (workgroups) *workgroups = (long)bp.tiles_m * bp.tiles_n * bp.ncls * bp.split;
+        return PG_OK;
+    }
     if ((op == 0 && b2s_tapn_ok(gq) && ws_bytes >= b2s_tapn_ws(gq)) || (op == 1 && s2b_tapn_ok(gq) && ws_bytes >= s2b_tapn_ws(gq))) {
         const long M1 = (op == 0) ? (long)g->N * g->Hb * g->Wb : (long)g->N * g->Hs * g->Ws;
         const int Nc = 16 * ((op == 0) ? g->Ca : g->Cb);
@@ -2811,7 +2881,9 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     const double direct = 2.0 * g->N * g->Hs * g->Ws * 16.0 * g->Ca * g->Cb;
     double fl = direct;
     char buf[128];
-    if (algo == PG_ALGO_DIRECT) {
+    if (code >= 1000) {
+        snprintf(buf, sizeof buf, "%s", pg_bf16x_kernel_name((code / 10) % 10, code % 10));
+    } else if (algo == PG_ALGO_DIRECT) {
         snprintf(buf, sizeof buf, "%s", oc == 0 ? "k_big2small_direct" : oc == 1 ? "k_small2big_direct" : "k_wgrad_direct");
     } else if (mode == 6) {          // Winograd weight gradients: 60 / 63 stride 1 (F(4x4,2x2)), 61 / 62 polyphase stride 2
         snprintf(buf, sizeof buf, "k_wino_wgrad_gemm<%s>", (tid == 2 || tid == 3) ? "1,1,2,2" : "2,2,2,2");
@@ -2900,6 +2972,10 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
         if (x.v_keep && pg_wino2_mo() != 3) return PG_EINVAL;
         return pg_wino2_b2s(big, ld_big, P, bias, small, ld_small, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, nullptr,
                             part, x.v_keep, x.u_cache, x.u_valid);
+    }
+    if (bf16x_ok(g, 0, algo | io, tune) && !part && !x.v_keep) {
+        const int rc = bf16x_run(0, big, ld_big, P, bias, small, ld_small, g, act, io & PG_IO_SMALL_BF16, ws, ws_bytes, st, x);
+        if (rc != BF16X_SKIP) return rc;
     }
     // only the Winograd paths have partial sums / transformed operands to hand over (the pg_conv_*_bytes / _chunks queries said 0)
     if (part || x.v_keep || x.u_cache) return PG_EINVAL;
@@ -3034,6 +3110,10 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         return pg_wino2_s2b(small, ld_small, P, bias, big, ld_big, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, part,
                             x.u_cache, x.u_valid);
     }
+    if (bf16x_ok(g, 1, algo | io, tune) && !part) {
+        const int rc = bf16x_run(1, small, ld_small, P, bias, big, ld_big, g, act, io & PG_IO_BIG_BF16, ws, ws_bytes, st, x);
+        if (rc != BF16X_SKIP) return rc;
+    }
     if (part || x.u_cache) return PG_EINVAL;
     if (!io && s2b_tapn_ok(g) && (ld_small % 4 == 0) && aligned16(small) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= s2b_tapn_ws(g) && tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT) {
@@ -3122,9 +3202,11 @@ int pg_conv4x4_small2big_x(const float* small, int ld_small, const float* P, con
 }
 
 size_t pg_conv_u_bytes(const pg_conv_geom* gg, int op, int algo, size_t ws_bytes) {
-    if (!geom_ok(gg) || (op != 0 && op != 1) || (algo & PG_ALGO_MASK) != PG_ALGO_AUTO) return 0;
+    if (!geom_ok(gg) || (op != 0 && op != 1)) return 0;
     const Geom g = to_geom(gg);
     const Tune tune = tune_of(algo);
+    if (bf16x_ok(g, op, algo, tune)) return pg_bf16x_w_bytes(g.Ca, g.Cb);
+    if ((algo & PG_ALGO_MASK) != PG_ALGO_AUTO) return 0;
     if (op == 0) {
         if (wino_b2s_ok(g, tune) && ws_bytes >= pg_wino_ws_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1))
             return pg_wino_u_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1);

@@ -258,11 +258,12 @@ class ConvOp:
         return self._query(('chunks', opcode), lambda: L.load().pg_conv_stats_chunks(ctypes.byref(self.g), opcode, self.algo,
                                                                                     max(self.ws_bytes, 1 << 20)))
 
-    def u_bytes(self, opcode):
+    def u_bytes(self, opcode, io=0):
         """Bytes of the transformed weights the kernel of big2small (0) / small2big (1) works from (0: no weight transform on
-        this path): what a caller-owned cache for pg_conv_extras.u_cache must hold."""
-        return self._query(('u', opcode), lambda: L.load().pg_conv_u_bytes(ctypes.byref(self.g), opcode, self.algo,
-                                                                           max(self.ws_bytes, 1 << 20)))
+        this path): what a caller-owned cache for pg_conv_extras.u_cache must hold.  io: the PG_IO_* bits of the call (the bf16
+        kernels on bf16 tensors work from a packed bf16 copy of the weights)."""
+        return self._query(('u', opcode, io), lambda: L.load().pg_conv_u_bytes(ctypes.byref(self.g), opcode, self.algo | io,
+                                                                               max(self.ws_bytes, 1 << 20)))
 
     def v_bytes(self):
         """Bytes of the polyphase-transformed `big` tensor that big2small can keep (v_keep) for the weight gradient of the
@@ -791,11 +792,18 @@ class DiscriminatorEngine:
         return (N, 1, op.Hs, op.Ws)
 
     @staticmethod
-    def _ucache(ucache, li, opcode, op, dev, *views):
-        """(buffer, valid) of the transformed weights of layer li / direction opcode in the caller's per-step cache."""
-        if ucache is None or not CACHE_U or not ConvOp._aligned(*views):
+    def _ucache(ucache, li, opcode, op, dev, src, dst):
+        """(buffer, valid) of the transformed / packed weights of layer li / direction opcode in the caller's per-step cache."""
+        if ucache is None or not CACHE_U:
             return None, False
-        nb = op.u_bytes(opcode)
+        big, small = (src, dst) if opcode == 0 else (dst, src)
+        io = ConvOp._io(big, small)
+        if io:      # bf16 tensors: the LDS-DMA kernels' packed bf16 weights (16-byte-aligned views)
+            if not all(v.ptr() % 16 == 0 and v.ld % (8 if v.bf else 4) == 0 for v in (src, dst)):
+                return None, False
+        elif not ConvOp._aligned(src, dst):
+            return None, False
+        nb = op.u_bytes(opcode, io)
         if not nb:
             return None, False
         key = (li, opcode, nb)         # nb separates the F(2x2,4x4) / F(3x3,4x4) transforms of the stride-1 layer

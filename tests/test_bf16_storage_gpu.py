@@ -30,7 +30,7 @@ def test_conv_kernels_on_bf16_tensors(geom):
     from tests.gpu_util import to_view, to_view_bf, empty_view, empty_view_bf, pack, unpack, rel_err, DEV
     N, Hb, Wb, Ca, Cb, s = geom
     big, small, Wt, Hs, Ws = _mk(*geom)
-    op = E.ConvOp(*geom, L.ALGO_BF16)
+    op = E.ConvOp(*geom, L.ALGO_BF16 | L.TUNE_BF16X_OFF)      # (the LDS-DMA kernels: test_lds_dma_bf16_kernels)
     P = pack(Wt)
     bias = torch.randn(Ca)
     # big2small: bf16 in -> {bf16, fp32} out equals the fp32-storage kernel on the same (bf16-representable) input, up to the
@@ -76,6 +76,71 @@ def test_conv_kernels_on_bf16_tensors(geom):
     thin = E.ConvOp(2, 16, 16, 16, 3, 2, L.ALGO_BF16)
     with pytest.raises(RuntimeError):
         thin.big2small(empty_view_bf(2, 16, 16, 3, ld=4), torch.zeros(16 * 16 * 3, device=DEV), 0, None, 0, empty_view(2, 8, 8, 16))
+
+
+XGEOMS = [(2, 64, 64, 128, 64, 2), (2, 32, 32, 64, 64, 2), (1, 24, 20, 96, 128, 2), (2, 31, 29, 64, 64, 1), (2, 8, 8, 512, 512, 2),
+          (3, 35, 37, 72, 64, 2), (5, 128, 128, 128, 64, 2), (1, 16, 16, 256, 1024, 2), (2, 2, 2, 128, 128, 2), (2, 31, 31, 128, 256, 1)]
+
+
+@pytest.mark.parametrize('geom', XGEOMS, ids=lambda g: 'x'.join(map(str, g)))
+def test_lds_dma_bf16_kernels(geom):
+    """k_conv_bf16x (conv_bf16.hip: LDS-DMA operand tiles, 256 x 128 / 128 x 128 / 256 x 64 workgroup tiles, transposed product
+    with 16-byte stores) on 16-byte-aligned bf16 tensors, both directions, against torch in float64 on the same bf16-representable
+    inputs AND weights -- every product is then exact in fp32, so only the summation order differs: fp32 outputs within 2e-5
+    (max-norm), bf16 outputs within one bf16 ulp of the rounded reference.  Also: the register-staged kernels (PG_TUNE_BF16X_OFF)
+    agree to the same bound, split-K slabs / ragged tiles / odd parity classes / stride 1 are in the list, and a caller-owned
+    packed-weight cache marked valid is what the kernel reads."""
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view_bf, empty_view, empty_view_bf, pack, rel_err, DEV
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    Wt = Wt.bfloat16().float()
+    P = pack(Wt)
+    op = E.ConvOp(*geom, L.ALGO_BF16)
+    old = E.ConvOp(*geom, L.ALGO_BF16 | L.TUNE_BF16X_OFF)
+
+    def check(got_view, want, out_bf):
+        got = got_view.to_nchw().double().cpu()
+        if out_bf:
+            ref = want.float().bfloat16().double()
+            assert ((got - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-5 * want.abs().max()).all(), rel_err(got, ref)
+        else:
+            assert rel_err(got, want) < 2e-5, rel_err(got, want)
+
+    def run(opcode, o, src, out, bias, act, **kw):
+        (o.big2small if opcode == 0 else o.small2big)(src, P, 0, bias, 0, out, act, **kw)
+        torch.cuda.synchronize()
+
+    for opcode in (0, 1):
+        cin, cout = (Cb, Ca) if opcode == 0 else (Ca, Cb)
+        if cin % 64:
+            continue
+        io_in = L.IO_BIG_BF16 if opcode == 0 else L.IO_SMALL_BF16
+        assert op.describe(opcode, io_in)[0].startswith('k_conv_bf16x'), op.describe(opcode, io_in)
+        assert not old.describe(opcode, io_in)[0].startswith('k_conv_bf16x')
+        bias = torch.randn(cout)
+        if opcode == 0:
+            lin = F.conv2d(big.double(), Wt.double(), bias.double(), stride=s, padding=1)
+            src, oshape = to_view_bf(big, ld=Cb + 8, off=8), (N, Hs, Ws, Ca)
+        else:
+            lin = torch.nn.grad.conv2d_input((N, Cb, Hb, Wb), Wt.double(), small.double(), stride=s, padding=1) + bias.double().view(1, -1, 1, 1)
+            src, oshape = to_view_bf(small, ld=Ca + 16, off=8), (N, Hb, Wb, Cb)
+        want = O.apply_act(lin, 'leakyrelu')
+        for out_bf in (True, False):
+            for o in (op, old):
+                out = (empty_view_bf if out_bf else empty_view)(*oshape, ld=cout + 8, off=8)
+                run(opcode, o, src, out, bias.cuda(), 1)
+                check(out, want, out_bf)
+        # caller-owned packed weights: filled by the first call, read (not rebuilt) by a call that marks them valid
+        nb = op.u_bytes(opcode, io_in)
+        assert nb >= 16 * Ca * Cb * 2
+        u = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+        out1, out2 = empty_view_bf(*oshape), empty_view_bf(*oshape)
+        run(opcode, op, src, out1, None, 0, u_cache=u)
+        (op.big2small if opcode == 0 else op.small2big)(src, torch.zeros_like(P), 0, None, 0, out2, 0, u_cache=u, u_valid=True)
+        torch.cuda.synchronize()
+        check(out1, lin - bias.double().view(1, -1, 1, 1), True)
+        assert torch.equal(out1.to_nchw(), out2.to_nchw())
 
 
 @pytest.mark.parametrize('shape', [(2, 64, 16, 16), (3, 6, 5, 7), (2, 512, 2, 2), (2, 64, 64, 64), (1, 136, 48, 48)])
