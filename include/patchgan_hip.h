@@ -70,6 +70,8 @@ extern "C" {
 #define PG_TUNE_WINO_DMA 0x1000   /* stride-1 64-tile Winograd GEMMs staged by LDS-DMA (k_wino_gemm_dma) instead of registers */
 #define PG_TUNE_BF16X_OFF 0x2000  /* PG_ALGO_BF16 on bf16 tensors: the register-staged k_*_bf16 kernels instead of the LDS-DMA
                                      kernels of conv_bf16.hip (k_conv_bf16x; input channels % 64 == 0) */
+#define PG_TUNE_BF16X_RING 0x4000 /* k_conv_bf16x staging pinned: three-stage LDS ring of 32-wide K chunks (DMA two chunks ahead) */
+#define PG_TUNE_BF16X_FLAT 0x8000 /* ... one LDS buffer of 64-wide K chunks */
 
 /* bf16 activation storage on the PG_ALGO_BF16 kernels: OR-ed into `algo` like the PG_TUNE_* bits.  The tensor named carries bf16
  * elements (NHWC, `ld` in bf16 elements, 8-byte-aligned base); weights, biases, weight gradients and split-K slabs stay fp32.

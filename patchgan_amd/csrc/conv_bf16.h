@@ -12,14 +12,16 @@ struct pg_bf16x_plan {
     int tiles_m, tiles_n, ncls;
     int nchunks;           // 64-wide K chunks: taps * Cin / 64
     int split, cps;        // split-K slices and chunks per slice (after pg_bf16x_clamp)
+    int ring;              // 1: the three-stage ring kernel (32-wide chunks), 0: one buffer of 64-wide chunks
     long out_elems;        // elements of one fp32 slab
 };
 
 // geometry gate (channel multiples, 32-bit byte offsets); alignment of the actual pointers is checked by the caller
 bool pg_bf16x_geom_ok(int dir, int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride);
-pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride);
+// ring: 1 / 0 pins the staging variant, -1 = per-layer default
+pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, int ring);
 void pg_bf16x_clamp(pg_bf16x_plan* p, size_t slab_bytes_available);
-const char* pg_bf16x_kernel_name(int dir, int tile);
+const char* pg_bf16x_kernel_name(int dir, int tile, int ring);
 
 // bf16 copy of the packed weights P[tap][a][b] (fp32): dir 0 keeps the layout, dir 1 transposes each tap to [tap][b][a]
 // (the GEMM's K index must be the contiguous one of both operands)
@@ -31,3 +33,12 @@ int pg_bf16x_pack(const float* P, void* W, int Ca, int Cb, int dir, hipStream_t 
 int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void* W, void* out, int ld_out, long slab_stride,
                   int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, const pg_bf16x_plan* p, const float* bias,
                   int act, int out_bf, hipStream_t st);
+
+// weight gradient on bf16 tensors (both operands), k_wgrad_bf16x: out = dP (slab_stride == 0, split 1) or fp32 slabs
+// [split][16 * Ca * Cb].  The plan's tile / tiles_m / tiles_n are over (Ca, Cb), nchunks in 64-pixel chunks.
+bool pg_bf16x_wgrad_geom_ok(int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride);
+pg_bf16x_plan pg_bf16x_wgrad_plan(int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride);
+const char* pg_bf16x_wgrad_kernel_name(int tile);
+int pg_bf16x_wgrad(const void* small, int ld_small, long small_bytes, const void* big, int ld_big, long big_bytes, float* out,
+                   long slab_stride, int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, const pg_bf16x_plan* p,
+                   hipStream_t st);

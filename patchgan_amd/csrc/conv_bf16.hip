@@ -34,8 +34,7 @@ struct XGeom {
     int N, Hb, Wb, Hs, Ws, Ca, Cb, s;
 };
 
-constexpr int BK = 64;                  // K chunk (bf16 elements): 128-byte LDS rows
-constexpr int ROWB = BK * 2;            // bytes per LDS row
+constexpr int BK = 64;                  // K granularity of the plan (bf16 elements): Cin % 64 == 0, split-K slices in 64-chunks
 
 __device__ __forceinline__ float act_epi(float v, int act) {
     if (act == PG_ACT_NONE) return v;
@@ -57,18 +56,27 @@ __device__ __forceinline__ unsigned pack2(float x, float y) {
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds, int byte_off) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (void __attribute__((address_space(3)))*)lds, 16, byte_off, 0, 0, 0);
 }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
-template <int MR, int NR, int WM, int WN, int DRC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv_bf16x(const __bf16* __restrict__ in, int ld_in, const __bf16* __restrict__ W,
-                                                    void* __restrict__ out, int ld_out, long slab_stride, XGeom g, int cps,
-                                                    const float* __restrict__ bias, int act, int in_bytes, int w_bytes, int out_bf,
-                                                    int tiles_n) {
+// KB = 64: one LDS buffer of 128-byte rows, all of a chunk's DMA, wait, barrier, 4 MFMA k-steps, barrier; two workgroups per CU
+//          cover each other's DMA phase.
+// KB = 32: a ring of three stages of 64-byte rows: chunk c + 2 is in flight while chunk c is multiplied, one barrier per chunk,
+//          counted vmcnt (never 0 in the loop).
+template <int MR, int NR, int WM, int WN, int DRC, int KB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv_bf16x(
+    const __bf16* __restrict__ in, int ld_in, const __bf16* __restrict__ W, void* __restrict__ out, int ld_out, long slab_stride, XGeom g,
+    int cps, const float* __restrict__ bias, int act, int in_bytes, int w_bytes, int out_bf, int tiles_n) {
     static_assert(WM * WN == 4, "four waves");
+    static_assert(KB == 32 || KB == 64, "chunk width");
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
-    constexpr int AP = BM / 32, BP = BN / 32;                      // DMA pieces (8 rows x 128 B) per wave and chunk
-    __shared__ __attribute__((aligned(1024))) char smem[(BM + BN) * ROWB];
-    char* const As = smem;
-    char* const Bs = smem + BM * ROWB;
+    constexpr int ROWB = KB * 2;                                   // bytes per LDS row
+    constexpr int RPP = 1024 / ROWB, SPR = ROWB / 16;              // rows per DMA piece, 16-byte slots per row
+    constexpr int AP = BM / (4 * RPP), BP = BN / (4 * RPP);        // pieces per wave and chunk
+    constexpr int NST = (KB == 32) ? 3 : 1, STAGE = (BM + BN) * ROWB;
+    __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, w_bytes, 0x00020000);
 
@@ -93,16 +101,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tm = wk / tiles_n, tn = wk - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     if (m0 >= Mc) return;                                          // a smaller parity class (odd Hb / Wb): whole workgroup
-    const int nchunks = T * T * Cin / BK;
-    const int c_begin = slice * cps, c_end = min(nchunks, c_begin + cps);
+    constexpr int CPB = BK / KB;                                   // kernel chunks per plan chunk
+    const int nchunks = T * T * Cin / KB;
+    const int c_begin = slice * cps * CPB, c_end = min(nchunks, c_begin + cps * CPB);
 
-    // ---- per-lane DMA sources: piece i of this wave covers tile rows (wave * AP + i) * 8 .. + 7, lane -> (row, 16-byte slot)
+    // ---- per-lane DMA sources: piece i of this wave covers tile rows (wave * AP + i) * RPP .. + RPP - 1, lane -> (row, slot);
+    //      slot s of row r holds the logical 8-element K group s ^ swz(r)
+    auto swz = [](int r) { return KB == 64 ? (r >> 1) & 7 : (r >> 2) & 3; };
     int a_off[AP];
     unsigned a_mask[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        const int r = (wave * AP + i) * 8 + (lane >> 3);
-        const int cc = (lane & 7) ^ ((r >> 1) & 7);               // logical 8-element K group stored in this slot
+        const int r = (wave * AP + i) * RPP + lane / SPR;
+        const int cc = (lane % SPR) ^ swz(r);
         const int m = m0 + r, mm = min(m, Mc - 1);
         const int n = mm / (Hc * Wc);
         const int rem = mm - n * (Hc * Wc);
@@ -128,21 +139,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int b_off[BP];
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
-        const int r = (wave * BP + j) * 8 + (lane >> 3);
-        const int cc = (lane & 7) ^ ((r >> 1) & 7);
+        const int r = (wave * BP + j) * RPP + lane / SPR;
+        const int cc = (lane % SPR) ^ swz(r);
         const int n = n0 + r;
         b_off[j] = (n < Cout) ? (n * Cin + cc * 8) * 2 : (int)0x80000000u;
     }
-    char* const a_dst = As + wave * AP * 8 * ROWB;
-    char* const b_dst = Bs + wave * BP * 8 * ROWB;
+    char* const a_dst = smem + wave * AP * 1024;
+    char* const b_dst = smem + BM * ROWB + wave * BP * 1024;
 
     // ---- fragment read addresses: row = 32 * tile + lrow, so the swizzle term depends on lrow only
-    const int sw = (lrow >> 1) & 7;
-    int slot[BK / 16];
+    int slot[KB / 16];
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) slot[ks] = lrow * ROWB + (((ks * 2 + lh) ^ sw) << 4);
-    const char* const a_rd = As + wm * MR * 32 * ROWB;
-    const char* const b_rd = Bs + wn * NR * 32 * ROWB;
+    for (int ks = 0; ks < KB / 16; ++ks) slot[ks] = lrow * ROWB + (((ks * 2 + lh) ^ swz(lrow)) << 4);
+    const char* const a_rd = smem + wm * MR * 32 * ROWB;
+    const char* const b_rd = smem + BM * ROWB + wn * NR * 32 * ROWB;
 
     f32x16 acc[MR][NR];
 #pragma unroll
@@ -152,10 +162,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int tl = (c_begin * BK) / Cin;                                 // local tap and first input channel of the chunk (uniform)
-    int cin0 = c_begin * BK - tl * Cin;
+    int tl = (c_begin * KB) / Cin;                                 // local tap and first input channel of the next chunk to load
+    int cin0 = c_begin * KB - tl * Cin;
     const int CC = Cout * Cin;
-    for (int c = c_begin; c < c_end; ++c) {
+    auto issue = [&](int stage, bool on) {                         // DMA of that chunk into `stage`; off: zeros (keeps vmcnt counts)
         int a_uni, w_uni;
         if (DRC == 0) {
             a_uni = (((tl >> 2) * Win + (tl & 3)) * ld_in + cin0) * 2;
@@ -165,36 +175,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             a_uni = (cin0 - (th * Win + tw) * ld_in) * 2;
             w_uni = (((kh0 + g.s * th) * 4 + (kw0 + g.s * tw)) * CC + cin0) * 2;
         }
+        const unsigned kill = on ? 0u : 0x80000000u;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const bool ok = (a_mask[i] >> tl) & 1u;
-            const int off = ok ? a_off[i] + a_uni : (int)0x80000000u;
-            dma16(rin, a_dst + i * 8 * ROWB, off);
+            const int off = ok ? (int)((unsigned)(a_off[i] + a_uni) | kill) : (int)0x80000000u;
+            dma16(rin, a_dst + stage * STAGE + i * 1024, off);
         }
 #pragma unroll
-        for (int j = 0; j < BP; ++j)
-            dma16(rw, b_dst + j * 8 * ROWB, b_off[j] + w_uni);
-        cin0 += BK;
+        for (int j = 0; j < BP; ++j) dma16(rw, b_dst + stage * STAGE + j * 1024, (int)((unsigned)(b_off[j] + w_uni) | kill));
+        cin0 += KB;
         if (cin0 >= Cin) {
             cin0 = 0;
             ++tl;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    };
+    auto multiply = [&](int stage) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < KB / 16; ++ks) {
             bf16x8 af[MR], bf[NR];
 #pragma unroll
-            for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_rd + i * 32 * ROWB + slot[ks]);
+            for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_rd + stage * STAGE + i * 32 * ROWB + slot[ks]);
 #pragma unroll
-            for (int j = 0; j < NR; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(b_rd + j * 32 * ROWB + slot[ks]);
+            for (int j = 0; j < NR; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(b_rd + stage * STAGE + j * 32 * ROWB + slot[ks]);
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int j = 0; j < NR; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // D[channel][pixel]
         }
-        __syncthreads();                                           // every wave's reads are done before the next chunk's DMA lands
+    };
+
+    if constexpr (KB == 64) {
+        for (int c = c_begin; c < c_end; ++c) {
+            issue(0, true);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            multiply(0);
+            __syncthreads();                                       // every wave's reads are done before the next chunk's DMA lands
+        }
+    } else {
+        const int nloc = c_end - c_begin;
+        issue(0, 0 < nloc);
+        issue(1, 1 < nloc);
+        int stage = 0;
+        for (int it = 0; it < nloc; ++it) {
+            wait_vmcnt<AP + BP>();                                 // this wave's pieces of chunk `it` have landed (chunk it + 1 may be in flight)
+            __builtin_amdgcn_s_barrier();                          // ... and everyone's; stage (it + 2) % 3 was last read in iteration it - 1
+            const int s2 = (stage >= 1) ? stage - 1 : 2;           // == (it + 2) % 3
+            issue(s2, it + 2 < nloc);
+            multiply(stage);
+            stage = (stage == 2) ? 0 : stage + 1;
+        }
+        wait_vmcnt<0>();                                           // the killed tail DMAs drain before the kernel ends
     }
 
     // ---- epilogue: lane = pixel lrow of tile i; register r = channel (r & 3) + 8 * (r >> 2) + 4 * lh of tile j
@@ -254,6 +287,168 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient on bf16 tensors:  dP[tap][a][b] = sum_m small[m][a] * big[pix(m, tap)][b]  -- per tap a GEMM whose K index is
+// the pixel m, the STRIDED index of both operands (channels are the contiguous one).  The tiles therefore sit in LDS as
+// [pixel][channel] rows exactly as they lie in HBM (LDS-DMA, 16 B per lane, zero padding by the descriptor's range check) and the
+// MFMA fragments -- 8 consecutive pixels of one channel -- come out of ds_read_b64_tr_b16, the transposing read (two per fragment).
+// Bank conflicts of the transposed reads: a 32-lane half reads 4 pixel rows x one 64-byte segment (32 channels); rows are 128 /
+// 256 / 512 bytes, so the segment index is XOR-swizzled with the row (on the DMA source address and on the read address) to spread
+// the four rows over the four quarters of the 256-byte bank window.
+// Output transposed (D[b][a]): a lane owns 4 consecutive b of one a per accumulator quad = one 16-byte fp32 store.
+// Grid: flat, XCD-remapped so that the 16 taps of one (tile, K slice) run back to back on one XCD: they share the `small` tile and
+// read shifted windows of the same `big` pixels from that XCD's L2.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_frag2(const char* p, int second) {   // rows p and p + second (4 pixel rows further)
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + second));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+template <int MR, int NR, int WM, int WN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wgrad_bf16x(
+    const __bf16* __restrict__ small, int ld_small, const __bf16* __restrict__ big, int ld_big, float* __restrict__ out, long slab_stride,
+    XGeom g, int cps, int small_bytes, int big_bytes, int tiles_b, int ntiles, float inv_hw, float inv_w) {
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int BA = WM * MR * 32, BB = WN * NR * 32;            // a (small-side) and b (big-side) channels per workgroup
+    constexpr int KP = 64;                                         // pixels per chunk
+    constexpr int RBA = BA * 2, RBB = BB * 2;                      // LDS row bytes
+    constexpr int RPA = 1024 / RBA, RPB = 1024 / RBB;              // pixel rows per DMA piece
+    constexpr int AP = KP / RPA / 4, BP = KP / RPB / 4;            // pieces per wave and chunk
+    __shared__ __attribute__((aligned(1024))) char smem[KP * (RBA + RBB)];
+    char* const As = smem;
+    char* const Bs = smem + KP * RBA;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)small, 0, small_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)big, 0, big_bytes, 0x00020000);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lh = lane >> 5;
+
+    const int wk = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int tap = wk & 15, tile = (wk >> 4) % ntiles, slice = (wk >> 4) / ntiles;
+    const int ta = tile / tiles_b, tb = tile - ta * tiles_b;
+    const int a0 = ta * BA, b0 = tb * BB;
+    const int kh = tap >> 2, kw = tap & 3;
+    const int HW = g.Hs * g.Ws, M = g.N * HW;
+    const int nchunks = (M + KP - 1) / KP;
+    const int c_begin = slice * cps, c_end = min(nchunks, c_begin + cps);
+
+    // swizzle of the 64-byte segment index by the pixel row (see above)
+    auto swz = [](int r, int rowbytes) { return rowbytes >= 256 ? (r & 3) << 2 : ((r >> 1) & 1) << 2; };
+    // ---- DMA sources.  A: pixel rows are consecutive in `small`; B: the tap's window of `big`, decoded per chunk
+    int a_off[AP], a_row[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        constexpr int LPR = RBA / 16;
+        const int r = (wave * AP + i) * RPA + lane / LPR;
+        const int ch = (lane % LPR) ^ swz(r, RBA);
+        const int a = a0 + ch * 8;
+        a_row[i] = (a < g.Ca) ? r : 0x40000000;                    // beyond the channel count: never valid
+        a_off[i] = (r * ld_small + a) * 2;
+    }
+    int b_col[BP], b_row[BP];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+        constexpr int LPR = RBB / 16;
+        const int r = (wave * BP + j) * RPB + lane / LPR;
+        const int ch = (lane % LPR) ^ swz(r, RBB);
+        const int b = b0 + ch * 8;
+        b_row[j] = (b < g.Cb) ? r : 0x40000000;
+        b_col[j] = b * 2;
+    }
+    char* const a_dst = As + wave * AP * 1024;
+    char* const b_dst = Bs + wave * BP * 1024;
+
+    // ---- transposed-read addresses: lane -> (pixel row q of its 4-row block, 4 channels), see T10 of the CDNA4 guide
+    const int q = (lane & 15) >> 2, g4 = lane >> 4;
+    const int chl = (g4 & 1) * 2 + ((lane & 3) >> 1), half8 = (lane & 1) * 8;    // 16-byte chunk within the 32-channel segment
+    int a_rd[MR], b_rd[NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int seg = (wm * MR + i);                             // 32-channel segment of the tile
+        a_rd[i] = (lh * 8 + q) * RBA + (((seg * 4 + chl) ^ swz(q, RBA)) << 4) + half8;
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int seg = (wn * NR + j);
+        b_rd[j] = (lh * 8 + q) * RBB + (((seg * 4 + chl) ^ swz(q, RBB)) << 4) + half8;
+    }
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int c = c_begin; c < c_end; ++c) {
+        const int pix0 = c * KP;
+        const int a_uni = pix0 * ld_small * 2;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const bool ok = pix0 + a_row[i] < M;
+            dma16(rs, a_dst + i * 1024, ok ? a_off[i] + a_uni : (int)0x80000000u);
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int m = pix0 + b_row[j];
+            // m -> (n, p, qq) by float reciprocals, exact after one correction step for m < 2^24
+            int n = (int)((float)m * inv_hw);
+            int rem = m - n * HW;
+            n += (rem >= HW) - (rem < 0);
+            rem = m - n * HW;
+            int pp = (int)((float)rem * inv_w);
+            int qq = rem - pp * g.Ws;
+            pp += (qq >= g.Ws) - (qq < 0);
+            qq = rem - pp * g.Ws;
+            const int h = g.s * pp - 1 + kh, w = g.s * qq - 1 + kw;
+            const bool ok = m < M && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
+            const int off = ((n * g.Hb + h) * g.Wb + w) * ld_big * 2 + b_col[j];
+            dma16(rb, b_dst + j * 1024, ok ? off : (int)0x80000000u);
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int ks = 0; ks < KP / 16; ++ks) {
+            bf16x8 af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) af[i] = tr_frag2(As + ks * 16 * RBA + a_rd[i], 4 * RBA);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) bf[j] = tr_frag2(Bs + ks * 16 * RBB + b_rd[j], 4 * RBB);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // D[b][a]
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = channel a (lane & 31) of tile i; register r = channel b (r & 3) + 8 * (r >> 2) + 4 * lh of tile j
+    float* const o = out + (long)slice * slab_stride + (long)tap * g.Ca * g.Cb;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int a = a0 + (wm * MR + i) * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int bb = b0 + (wn * NR + j) * 32 + 4 * lh;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int b = bb + 8 * qd;
+                if (a < g.Ca && b < g.Cb) {
+                    const f32x4 v = {acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
+                    *reinterpret_cast<f32x4*>(o + (long)a * g.Cb + b) = v;
+                }
+            }
+        }
+    }
+}
+
 // P[tap][a][b] fp32 -> bf16, optionally transposing each tap to [b][a] (32 x 32 tiles through LDS)
 __global__ __launch_bounds__(256) void k_pack_w_bf16(const float* __restrict__ P, __bf16* __restrict__ W, int Ca, int Cb, int transpose) {
     if (!transpose) {
@@ -299,7 +494,7 @@ bool pg_bf16x_geom_ok(int dir, int N, int Hb, int Wb, int Hs, int Ws, int Ca, in
     return true;
 }
 
-pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride) {
+pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, int ring) {
     pg_bf16x_plan p;
     const int Cin = dir == 0 ? Cb : Ca, Cout = dir == 0 ? Ca : Cb;
     p.ncls = (dir == 1 && stride == 2) ? 4 : 1;
@@ -326,6 +521,7 @@ pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, i
     p.split = (int)s;
     p.cps = (p.nchunks + p.split - 1) / p.split;
     p.split = (p.nchunks + p.cps - 1) / p.cps;
+    p.ring = (ring >= 0) ? (ring ? 1 : 0) : 0;
     return p;
 }
 
@@ -336,10 +532,13 @@ void pg_bf16x_clamp(pg_bf16x_plan* p, size_t avail) {
     p->split = (p->nchunks + p->cps - 1) / p->cps;
 }
 
-const char* pg_bf16x_kernel_name(int dir, int tile) {
-    static const char* const names[2][3] = {{"k_conv_bf16x<4,2,2,2,0>", "k_conv_bf16x<2,2,2,2,0>", "k_conv_bf16x<2,2,4,1,0>"},
-                                            {"k_conv_bf16x<4,2,2,2,1>", "k_conv_bf16x<2,2,2,2,1>", "k_conv_bf16x<2,2,4,1,1>"}};
-    return names[dir ? 1 : 0][tile < 0 || tile > 2 ? 0 : tile];
+const char* pg_bf16x_kernel_name(int dir, int tile, int ring) {
+    static const char* const names[2][2][3] = {
+        {{"k_conv_bf16x<4,2,2,2,0,64>", "k_conv_bf16x<2,2,2,2,0,64>", "k_conv_bf16x<2,2,4,1,0,64>"},
+         {"k_conv_bf16x<4,2,2,2,1,64>", "k_conv_bf16x<2,2,2,2,1,64>", "k_conv_bf16x<2,2,4,1,1,64>"}},
+        {{"k_conv_bf16x<4,2,2,2,0,32>", "k_conv_bf16x<2,2,2,2,0,32>", "k_conv_bf16x<2,2,4,1,0,32>"},
+         {"k_conv_bf16x<4,2,2,2,1,32>", "k_conv_bf16x<2,2,2,2,1,32>", "k_conv_bf16x<2,2,4,1,1,32>"}}};
+    return names[ring ? 1 : 0][dir ? 1 : 0][tile < 0 || tile > 2 ? 0 : tile];
 }
 
 size_t pg_bf16x_w_bytes(int Ca, int Cb) { return ((size_t)16 * Ca * Cb * 2 + 255) & ~(size_t)255; }
@@ -365,14 +564,15 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
     const int w_bytes = 16 * Ca * Cb * 2;
     const __bf16* I = (const __bf16*)in;
     const __bf16* Wp = (const __bf16*)W;
+#define PG_BF16X_LAUNCH1(MR, NR, WM, WN, D, KB)                                                                              \
+    hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB>), grid, dim3(256), 0, st, I, ld_in, Wp, out, ld_out, slab_stride, g, \
+                       p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n)
 #define PG_BF16X_LAUNCH(MR, NR, WM, WN)                                                                                      \
     do {                                                                                                                     \
-        if (dir == 0)                                                                                                        \
-            hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, 0>), grid, dim3(256), 0, st, I, ld_in, Wp, out, ld_out, slab_stride, \
-                               g, p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n);                            \
-        else                                                                                                                 \
-            hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, 1>), grid, dim3(256), 0, st, I, ld_in, Wp, out, ld_out, slab_stride, \
-                               g, p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n);                            \
+        if (dir == 0 && !p->ring) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 0, 64);                                                   \
+        else if (dir == 0) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 0, 32);                                                          \
+        else if (!p->ring) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 1, 64);                                                          \
+        else PG_BF16X_LAUNCH1(MR, NR, WM, WN, 1, 32);                                                                        \
     } while (0)
     switch (p->tile) {
         case 0: PG_BF16X_LAUNCH(4, 2, 2, 2); break;
@@ -380,5 +580,69 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
         default: PG_BF16X_LAUNCH(2, 2, 4, 1); break;
     }
 #undef PG_BF16X_LAUNCH
+#undef PG_BF16X_LAUNCH1
+    return pg_launch_status();
+}
+
+// ---- weight gradient -------------------------------------------------------------------------------------------------------
+bool pg_bf16x_wgrad_geom_ok(int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride) {
+    (void)Hb; (void)Wb; (void)stride;
+    if (Ca % 32 != 0 || Cb % 32 != 0 || Ca < 64 || Cb < 32) return false;
+    if ((long)N * Hs * Ws >= (1L << 24)) return false;             // pixel decode by float reciprocals
+    return true;
+}
+
+pg_bf16x_plan pg_bf16x_wgrad_plan(int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride) {
+    (void)Hb; (void)Wb; (void)stride;
+    pg_bf16x_plan p;
+    static const int forced = getenv("PATCHGAN_BF16X_WTILE") ? atoi(getenv("PATCHGAN_BF16X_WTILE")) : -1;
+    // tiles (a x b): 0: 256 x 128, 1: 128 x 128, 2: 256 x 64, 3: 128 x 64
+    if (forced >= 0 && forced <= 3) p.tile = forced;
+    else if (Cb % 128 == 0) p.tile = (Ca % 256 == 0) ? 0 : 1;
+    else p.tile = (Ca % 256 == 0) ? 2 : 3;
+    p.bm = (p.tile == 0 || p.tile == 2) ? 256 : 128;
+    p.bn = (p.tile <= 1) ? 128 : 64;
+    p.tiles_m = (Ca + p.bm - 1) / p.bm;
+    p.tiles_n = (Cb + p.bn - 1) / p.bn;
+    p.ncls = 16;
+    const long M = (long)N * Hs * Ws;
+    p.nchunks = (int)((M + 63) / 64);
+    p.out_elems = 16L * Ca * Cb;
+    const long nb = (long)p.tiles_m * p.tiles_n * 16;
+    static const int target = getenv("PATCHGAN_BF16X_WTARGET") ? atoi(getenv("PATCHGAN_BF16X_WTARGET")) : 512;
+    long s = (nb >= target) ? 1 : (target + nb - 1) / nb;
+    const long smax = std::max<long>(1, p.nchunks / 4);
+    if (s > smax) s = smax;
+    p.split = (int)s;
+    p.cps = (p.nchunks + p.split - 1) / p.split;
+    p.split = (p.nchunks + p.cps - 1) / p.cps;
+    p.ring = 0;
+    return p;
+}
+
+const char* pg_bf16x_wgrad_kernel_name(int tile) {
+    static const char* const names[4] = {"k_wgrad_bf16x<4,2,2,2>", "k_wgrad_bf16x<2,2,2,2>", "k_wgrad_bf16x<2,2,4,1>", "k_wgrad_bf16x<1,2,4,1>"};
+    return names[tile < 0 || tile > 3 ? 0 : tile];
+}
+
+int pg_bf16x_wgrad(const void* small, int ld_small, long small_bytes, const void* big, int ld_big, long big_bytes, float* out,
+                   long slab_stride, int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, const pg_bf16x_plan* p,
+                   hipStream_t st) {
+    const XGeom g{N, Hb, Wb, Hs, Ws, Ca, Cb, stride};
+    const int ntiles = p->tiles_m * p->tiles_n;
+    const dim3 grid((unsigned)(ntiles * 16 * p->split), 1, 1);
+    const float inv_hw = 1.0f / (float)(Hs * Ws), inv_w = 1.0f / (float)Ws;
+    const __bf16* S = (const __bf16*)small;
+    const __bf16* B = (const __bf16*)big;
+#define PG_BF16X_WG(MR, NR, WM, WN)                                                                                          \
+    hipLaunchKernelGGL((k_wgrad_bf16x<MR, NR, WM, WN>), grid, dim3(256), 0, st, S, ld_small, B, ld_big, out, slab_stride, g, p->cps, \
+                       (int)small_bytes, (int)big_bytes, p->tiles_n, ntiles, inv_hw, inv_w)
+    switch (p->tile) {
+        case 0: PG_BF16X_WG(4, 2, 2, 2); break;
+        case 1: PG_BF16X_WG(2, 2, 2, 2); break;
+        case 2: PG_BF16X_WG(2, 2, 4, 1); break;
+        default: PG_BF16X_WG(1, 2, 4, 1); break;
+    }
+#undef PG_BF16X_WG
     return pg_launch_status();
 }

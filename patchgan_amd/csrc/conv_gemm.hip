@@ -1379,26 +1379,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 
 // ------------------------------------------------------------------------------------------------
-// big2small for image-facing layers with 1..3 big-side channels (enc0 forward, dec6 data gradient): the whole
-// contraction K = 16*CB <= 48 fits one LDS tile, so the kernel is one shot -- gather 128 pixels x K and 64 x K weights,
+// big2small for image-facing layers with 1..3 (5..8: 64-pixel tiles) big-side channels (enc0 / d0 forward, dec6 data gradient):
+// the whole contraction K = 16*CB <= 48 (128) fits one LDS tile, so the kernel is one shot -- gather 128 pixels x K and 64 x K weights,
 // one barrier, K/2 MFMAs per 32x32 tile, bias + activation, store -- and is bound by the HBM write of its output.
 // ------------------------------------------------------------------------------------------------
-template <int CB>
+template <int CB, int MI = 2>      // MI: 32-row MFMA tiles per wave: 128 (CB <= 4) or 64 (CB <= 8, K <= 128) pixels per workgroup
 __global__ __launch_bounds__(256) void k_b2s_tapk(const float* __restrict__ big, int ld_big, const float* __restrict__ P,
                                                   float* __restrict__ out, int ld_out, Geom g, const float* __restrict__ bias,
                                                   int act, int vec4) {
-    constexpr int K = 16 * CB, LDT = K + 4;
-    __shared__ __attribute__((aligned(16))) float smem[(128 + 64) * LDT];
+    constexpr int K = 16 * CB, LDT = K + 4, TM = 64 * MI;
+    __shared__ __attribute__((aligned(16))) float smem[(TM + 64) * LDT];
     float* As = smem;
-    float* Bs = smem + 128 * LDT;
+    float* Bs = smem + TM * LDT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane & 31, lh = lane >> 5;
     const int M = g.N * g.Hs * g.Ws;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64;
-    // A: 128 pixels x 16 taps, one (pixel, tap) item = CB consecutive floats; a thread owns one pixel and 8 taps
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * 64;
+    // A: TM pixels x 16 taps, one (pixel, tap) item = CB consecutive floats; a thread owns one pixel and 8 (4) taps
     {
-        const int r = tid & 127, t0 = (tid >> 7) * 8;
+        constexpr int TPT = 16 * TM / 256;
+        const int r = tid & (TM - 1), t0 = (tid / TM) * TPT;
         const int m = m0 + r;
         const int mm = min(m, M - 1);
         const int n = mm / (g.Hs * g.Ws);
@@ -1407,7 +1408,7 @@ __global__ __launch_bounds__(256) void k_b2s_tapk(const float* __restrict__ big,
         const int h0 = g.s * p - 1, w0 = g.s * q - 1;
         const float* base = big + ((long)(n * g.Hb + h0) * g.Wb + w0) * ld_big;
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
+        for (int tt = 0; tt < TPT; ++tt) {
             const int tap = t0 + tt, kh = tap >> 2, kw = tap & 3;
             const bool ok = m < M && (unsigned)(h0 + kh) < (unsigned)g.Hb && (unsigned)(w0 + kw) < (unsigned)g.Wb;
             const float* src = base + ((long)kh * g.Wb + kw) * ld_big;
@@ -1429,30 +1430,30 @@ __global__ __launch_bounds__(256) void k_b2s_tapk(const float* __restrict__ big,
         for (int c = 0; c < CB; ++c) Bs[a * LDT + tap * CB + c] = ok ? P[((long)tap * g.Ca + n0 + a) * CB + c] : 0.f;
     }
     __syncthreads();
-    f32x16 acc[2];
+    f32x16 acc[MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < K / 8; ++kk) {
-        f32x4 af[2], bf;
+        f32x4 af[MI], bf;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * 2 + i) * 32 + lrow) * LDT + kk * 8 + lh * 4]);
+        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MI + i) * 32 + lrow) * LDT + kk * 8 + lh * 4]);
         bf = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 + lrow) * LDT + kk * 8 + lh * 4]);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[e], acc[i], 0, 0, 0);
+            for (int i = 0; i < MI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[e], acc[i], 0, 0, 0);
     }
     const int col = n0 + wn * 32 + lrow;
     const float bv = (bias != nullptr && col < g.Ca) ? bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int m = m0 + (wm * 2 + i) * 32 + row;
+            const int m = m0 + (wm * MI + i) * 32 + row;
             if (m < M && col < g.Ca) out[(long)m * ld_out + col] = pg_act_epi(acc[i][r] + bv, act);
         }
 }
@@ -2592,6 +2593,7 @@ struct Tune {
     int mo1;        // stride-1 tile edge: 0 heuristic, 2 / 3 pinned
     int dma;        // stride-1 GEMM staging: 0 registers, 1 LDS-DMA ring for F(3x3,4x4), 2 also for 64-tile F(2x2,4x4)
     bool bf16x;     // PG_ALGO_BF16 on bf16 tensors: the LDS-DMA kernels of conv_bf16.hip (off: the register-staged k_*_bf16)
+    int bf16ring;   // ... their staging: 1 three-stage ring of 32-wide chunks, 0 one buffer of 64-wide chunks, -1 per-layer default
 };
 inline int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -2607,6 +2609,7 @@ inline Tune tune_of(int algo) {
         t.mo1 = env_int("PATCHGAN_WINO1_TILE", 0);
         t.dma = pg_wino_dma_mode();
         t.bf16x = env_int("PATCHGAN_NO_BF16X", 0) != 1;
+        t.bf16ring = env_int("PATCHGAN_BF16X_RING", -1);
         return t;
     }();
     Tune t = env;
@@ -2620,11 +2623,13 @@ inline Tune tune_of(int algo) {
     if (algo & PG_TUNE_WINO1_F3) t.mo1 = 3;
     if (algo & PG_TUNE_WINO_DMA) t.dma = 2;
     if (algo & PG_TUNE_BF16X_OFF) t.bf16x = false;
+    if (algo & PG_TUNE_BF16X_RING) t.bf16ring = 1;
+    if (algo & PG_TUNE_BF16X_FLAT) t.bf16ring = 0;
     if (force_generic()) t.wino = false;
     return t;
 }
 // every path on, for sizing a workspace that serves any tuning
-inline Tune tune_widest(int mo1) { return Tune{true, true, 1, 1, mo1, 0, true}; }
+inline Tune tune_widest(int mo1) { return Tune{true, true, 1, 1, mo1, 0, true, -1}; }
 
 // stride-1 layers only: forward is a pad-1 correlation big -> small, the data gradient a pad-2 correlation small -> big
 inline bool wino_b2s_ok(const Geom& g, const Tune& t) {
@@ -2669,8 +2674,12 @@ inline bool bf16x_ok(const Geom& g, int dir, int algo_full, const Tune& t) {
 }
 // packed bf16 weights (unless the caller owns them) followed by the split-K slabs
 inline size_t bf16x_ws(const Geom& g, int dir) {
-    const pg_bf16x_plan p = pg_bf16x_plan_of(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s);
+    const pg_bf16x_plan p = pg_bf16x_plan_of(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, -1);
     return pg_bf16x_w_bytes(g.Ca, g.Cb) + (p.split > 1 ? (size_t)p.split * p.out_elems * sizeof(float) : 0);
+}
+inline bool bf16x_wgrad_ok(const Geom& g, int algo_full, const Tune& t) {
+    if ((algo_full & PG_ALGO_MASK) != PG_ALGO_BF16 || !t.bf16x || force_generic() || (algo_full & PG_IO_MASK) != PG_IO_MASK) return false;
+    return pg_bf16x_wgrad_geom_ok(g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s);
 }
 inline bool aligned_bf_view(const void* p, int ld, bool bf) {
     return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % (bf ? 8 : 4)) == 0;
@@ -2680,7 +2689,7 @@ inline bool aligned_bf_view(const void* p, int ld, bool bf) {
 // eligible after all (alignment, workspace): the caller then falls through to the register-staged kernels.
 constexpr int BF16X_SKIP = -1000;
 int bf16x_run(int dir, const void* in, int ld_in, const float* P, const float* bias, void* out, int ld_out, const Geom& g, int act,
-              bool out_bf, void* ws, size_t ws_bytes, hipStream_t st, const pg_conv_extras& x) {
+              bool out_bf, void* ws, size_t ws_bytes, hipStream_t st, const pg_conv_extras& x, int ring) {
     const int Cin = dir == 0 ? g.Cb : g.Ca, Cout = dir == 0 ? g.Ca : g.Cb;
     const long in_pix = (long)g.N * (dir == 0 ? g.Hb * g.Wb : g.Hs * g.Ws), out_pix = (long)g.N * (dir == 0 ? g.Hs * g.Ws : g.Hb * g.Wb);
     const long in_bytes = tensor_bytes(in_pix, ld_in, Cin, true);
@@ -2701,7 +2710,7 @@ int bf16x_run(int dir, const void* in, int ld_in, const float* P, const float* b
         int rc = pg_bf16x_pack(P, W, g.Ca, g.Cb, dir, st);
         if (rc != PG_OK) return rc;
     }
-    pg_bf16x_plan p = pg_bf16x_plan_of(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s);
+    pg_bf16x_plan p = pg_bf16x_plan_of(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, ring);
     pg_bf16x_clamp(&p, avail);
     int rc;
     {
@@ -2749,6 +2758,10 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
         if (op == 1 && wino_s2b_ok(gq, t)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb, mo1));
     }
     if ((op == 0 || op == 1) && pg_bf16x_geom_ok(op, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s)) bytes = std::max(bytes, bf16x_ws(gq, op));
+    if (op == 2 && pg_bf16x_wgrad_geom_ok(gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s)) {
+        const pg_bf16x_plan wp = pg_bf16x_wgrad_plan(gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s);
+        if (wp.split > 1) bytes = std::max(bytes, (size_t)wp.split * wp.out_elems * sizeof(float));
+    }
     const Tune tw = tune_widest(0);
     const size_t colsum = ((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255;
     if (op == 0 && wino2_b2s_ok(gq, tw)) bytes = std::max(bytes, pg_wino2_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb));
@@ -2794,11 +2807,20 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
     clamp_split(p, ws_bytes, reserved);
     if (tile_id) *tile_id = p.t.id + ((op == 2) ? 10 * wgrad_mode(g) : 0) + fastcode;
     const Geom gq = to_geom(g);
+    // 1020 + tile: the LDS-DMA bf16 weight-gradient kernel (k_wgrad_bf16x), both operands bf16 tensors
+    if (op == 2 && bf16x_wgrad_ok(gq, algo_full, tune)) {
+        pg_bf16x_plan wp = pg_bf16x_wgrad_plan(gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s);
+        pg_bf16x_clamp(&wp, ws_bytes);
+        if (tile_id) *tile_id = 1020 + wp.tile;
+        if (split) *split = wp.split;
+        if (workgroups) *workgroups = (long)wp.tiles_m * wp.tiles_n * 16 * wp.split;
+        return PG_OK;
+    }
     // 1000 + 10 * dir + tile: the LDS-DMA bf16 kernels (k_conv_bf16x) on bf16 tensors
     if ((op == 0 || op == 1) && bf16x_ok(gq, op, algo_full, tune) && ws_bytes >= pg_bf16x_w_bytes(g->Ca, g->Cb)) {
-        pg_bf16x_plan bp = pg_bf16x_plan_of(op, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s);
+        pg_bf16x_plan bp = pg_bf16x_plan_of(op, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s, tune.bf16ring);
         pg_bf16x_clamp(&bp, ws_bytes - pg_bf16x_w_bytes(g->Ca, g->Cb));
-        if (tile_id) *tile_id = 1000 + 10 * op + bp.tile;
+        if (tile_id) *tile_id = 1000 + 100 * bp.ring + 10 * op + bp.tile;
         if (split) *split = bp.split;
         if (workgroups) *workgroups = (long)bp.tiles_m * bp.tiles_n * bp.ncls * bp.split;
         return PG_OK;
@@ -2823,11 +2845,12 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         if (tile_id) *tile_id += (mo1 == 3) ? 90 : (st ? 50 : 40);     // +90: F(3x3,4x4) variant k_wino_gemm<1,1,2,2,2,3>
     }
     // 81..83: one-shot k_b2s_tapk<Cb> for 1..3 big-side channels
-    if (op == 0 && g->Cb <= 3 && algo != PG_ALGO_BF16 && !force_generic() && tapk_enabled() &&
+    if (op == 0 && (g->Cb <= 3 || g->Cb == 5) && !(algo_full & PG_IO_MASK) && !force_generic() && tapk_enabled() &&
         !(b2s_tapn_ok(gq) && ws_bytes >= b2s_tapn_ws(gq))) {
         if (tile_id) *tile_id = 80 + g->Cb;
         if (split) *split = 1;
-        if (workgroups) *workgroups = (((long)g->N * g->Hs * g->Ws + 127) / 128) * ((g->Ca + 63) / 64);
+        const int tmk = g->Cb <= 3 ? 128 : 64;
+        if (workgroups) *workgroups = (((long)g->N * g->Hs * g->Ws + tmk - 1) / tmk) * ((g->Ca + 63) / 64);
         return PG_OK;
     }
     // 70 / 71: polyphase Winograd of a stride-2 layer (k_wino_bgemm<2,2,2,2> / <1,2,2,2>); 72 / 73: k_wino_bgemm_mz
@@ -2881,8 +2904,10 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     const double direct = 2.0 * g->N * g->Hs * g->Ws * 16.0 * g->Ca * g->Cb;
     double fl = direct;
     char buf[128];
-    if (code >= 1000) {
-        snprintf(buf, sizeof buf, "%s", pg_bf16x_kernel_name((code / 10) % 10, code % 10));
+    if (code >= 1020 && code < 1030) {
+        snprintf(buf, sizeof buf, "%s", pg_bf16x_wgrad_kernel_name(code - 1020));
+    } else if (code >= 1000) {
+        snprintf(buf, sizeof buf, "%s", pg_bf16x_kernel_name((code / 10) % 10, code % 10, (code / 100) % 10));
     } else if (algo == PG_ALGO_DIRECT) {
         snprintf(buf, sizeof buf, "%s", oc == 0 ? "k_big2small_direct" : oc == 1 ? "k_small2big_direct" : "k_wgrad_direct");
     } else if (mode == 6) {          // Winograd weight gradients: 60 / 63 stride 1 (F(4x4,2x2)), 61 / 62 polyphase stride 2
@@ -2974,7 +2999,7 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
                             part, x.v_keep, x.u_cache, x.u_valid);
     }
     if (bf16x_ok(g, 0, algo | io, tune) && !part && !x.v_keep) {
-        const int rc = bf16x_run(0, big, ld_big, P, bias, small, ld_small, g, act, io & PG_IO_SMALL_BF16, ws, ws_bytes, st, x);
+        const int rc = bf16x_run(0, big, ld_big, P, bias, small, ld_small, g, act, io & PG_IO_SMALL_BF16, ws, ws_bytes, st, x, tune.bf16ring);
         if (rc != BF16X_SKIP) return rc;
     }
     // only the Winograd paths have partial sums / transformed operands to hand over (the pg_conv_*_bytes / _chunks queries said 0)
@@ -2999,15 +3024,20 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
                            small, ld_small, g, act);
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
-    if (g.Cb <= 3 && algo != PG_ALGO_BF16 && !force_generic() && tapk_enabled()) {
+    if ((g.Cb <= 3 || g.Cb == 5) && !io && !force_generic() && tapk_enabled()) {     // (6..8 channels: measured slower than the generic kernel)
         // K = 16*Cb <= 48: one-shot kernel (with 4 channels the pipelined generic kernel is as fast: 46 TFLOP/s both)
         const int vec4 = (g.Cb == 4) && (ld_big % 4 == 0) && aligned16(big);
-        dim3 grid((unsigned)(((long)g.N * g.Hs * g.Ws + 127) / 128), (g.Ca + 63) / 64, 1);
+        const int tmk = g.Cb <= 3 ? 128 : 64;
+        dim3 grid((unsigned)(((long)g.N * g.Hs * g.Ws + tmk - 1) / tmk), (g.Ca + 63) / 64, 1);
         TimedLaunch timed(st);
         switch (g.Cb) {
             case 1: hipLaunchKernelGGL(k_b2s_tapk<1>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4); break;
             case 2: hipLaunchKernelGGL(k_b2s_tapk<2>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4); break;
             case 3: hipLaunchKernelGGL(k_b2s_tapk<3>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4); break;
+            case 5: hipLaunchKernelGGL((k_b2s_tapk<5, 1>), grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, 0); break;
+            case 6: hipLaunchKernelGGL((k_b2s_tapk<6, 1>), grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, 0); break;
+            case 7: hipLaunchKernelGGL((k_b2s_tapk<7, 1>), grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, 0); break;
+            case 8: hipLaunchKernelGGL((k_b2s_tapk<8, 1>), grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, 0); break;
             default: hipLaunchKernelGGL(k_b2s_tapk<4>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4); break;
         }
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
@@ -3111,7 +3141,7 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
                             x.u_cache, x.u_valid);
     }
     if (bf16x_ok(g, 1, algo | io, tune) && !part) {
-        const int rc = bf16x_run(1, small, ld_small, P, bias, big, ld_big, g, act, io & PG_IO_BIG_BF16, ws, ws_bytes, st, x);
+        const int rc = bf16x_run(1, small, ld_small, P, bias, big, ld_big, g, act, io & PG_IO_BIG_BF16, ws, ws_bytes, st, x, tune.bf16ring);
         if (rc != BF16X_SKIP) return rc;
     }
     if (part || x.u_cache) return PG_EINVAL;
@@ -3310,6 +3340,23 @@ static int wgrad_impl(const float* small, int ld_small, const float* big, int ld
                               e0, e1, v_pre);
     }
     if (v_pre) return PG_EINVAL;     // pg_conv_v_bytes said 0 for this call: there is no transformed operand to reuse
+    if (bf16x_wgrad_ok(g, algo | io, tune) && !dbias && aligned_bf_view(small, ld_small, true) && aligned_bf_view(big, ld_big, true) &&
+        aligned16(dP) && (!ws_bytes || aligned16(ws))) {
+        const long small_bytes = tensor_bytes(Kp, ld_small, g.Ca, true), big_bytes = tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb, true);
+        if (small_bytes < FAST_LIMIT && big_bytes < FAST_LIMIT) {
+            pg_bf16x_plan wp = pg_bf16x_wgrad_plan(g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s);
+            pg_bf16x_clamp(&wp, ws_bytes);
+            float* dst = wp.split == 1 ? dP : (float*)ws;
+            int rc;
+            {
+                TimedLaunch timed(st);
+                rc = pg_bf16x_wgrad(small, ld_small, small_bytes, big, ld_big, big_bytes, dst, wp.split == 1 ? 0L : wp.out_elems, g.N, g.Hb,
+                                    g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, &wp, st);
+            }
+            if (rc != PG_OK || wp.split == 1) return rc;
+            return launch_reduce(dst, wp.out_elems, wp.split, dP, g.Cb, 16L * g.Ca, g.Cb, nullptr, 0, st);
+        }
+    }
     Plan p = plan_wgrad(gg);
     clamp_split(p, ws_bytes, reserved);
     const bool in_bf = io != 0;

@@ -96,7 +96,8 @@ def test_lds_dma_bf16_kernels(geom):
     big, small, Wt, Hs, Ws = _mk(*geom)
     Wt = Wt.bfloat16().float()
     P = pack(Wt)
-    op = E.ConvOp(*geom, L.ALGO_BF16)
+    op = E.ConvOp(*geom, L.ALGO_BF16 | L.TUNE_BF16X_FLAT)
+    ring = E.ConvOp(*geom, L.ALGO_BF16 | L.TUNE_BF16X_RING)
     old = E.ConvOp(*geom, L.ALGO_BF16 | L.TUNE_BF16X_OFF)
 
     def check(got_view, want, out_bf):
@@ -116,7 +117,8 @@ def test_lds_dma_bf16_kernels(geom):
         if cin % 64:
             continue
         io_in = L.IO_BIG_BF16 if opcode == 0 else L.IO_SMALL_BF16
-        assert op.describe(opcode, io_in)[0].startswith('k_conv_bf16x'), op.describe(opcode, io_in)
+        assert op.describe(opcode, io_in)[0].startswith('k_conv_bf16x') and op.describe(opcode, io_in)[0].endswith(',64>')
+        assert ring.describe(opcode, io_in)[0].startswith('k_conv_bf16x') and ring.describe(opcode, io_in)[0].endswith(',32>')
         assert not old.describe(opcode, io_in)[0].startswith('k_conv_bf16x')
         bias = torch.randn(cout)
         if opcode == 0:
@@ -127,7 +129,7 @@ def test_lds_dma_bf16_kernels(geom):
             src, oshape = to_view_bf(small, ld=Ca + 16, off=8), (N, Hb, Wb, Cb)
         want = O.apply_act(lin, 'leakyrelu')
         for out_bf in (True, False):
-            for o in (op, old):
+            for o in (op, ring, old):
                 out = (empty_view_bf if out_bf else empty_view)(*oshape, ld=cout + 8, off=8)
                 run(opcode, o, src, out, bias.cuda(), 1)
                 check(out, want, out_bf)
@@ -141,6 +143,20 @@ def test_lds_dma_bf16_kernels(geom):
         torch.cuda.synchronize()
         check(out1, lin - bias.double().view(1, -1, 1, 1), True)
         assert torch.equal(out1.to_nchw(), out2.to_nchw())
+    # weight gradient (k_wgrad_bf16x: [pixel][channel] tiles by LDS-DMA, fragments by transposed LDS reads)
+    if Ca % 32 == 0 and Cb % 32 == 0 and Ca >= 64:
+        assert op.describe(2, L.IO_BIG_BF16 | L.IO_SMALL_BF16)[0].startswith('k_wgrad_bf16x'), op.describe(2, L.IO_BIG_BF16 | L.IO_SMALL_BF16)
+        Wr = Wt.double().clone().requires_grad_(True)
+        F.conv2d(big.double(), Wr, None, stride=s, padding=1).backward(small.double())
+        from tests.gpu_util import unpack
+        pow2 = (Hs & (Hs - 1)) == 0 and (Ws & (Ws - 1)) == 0
+        for o in (op, old):
+            if o is old and not (pow2 or (Ws >= 16 and Hs >= 2)):
+                continue            # the register-staged kernel's pixel decode does not cover this map size
+            dP = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+            o.wgrad(to_view_bf(small, ld=Ca + 16, off=8), to_view_bf(big, ld=Cb + 8, off=8), dP, 0)
+            torch.cuda.synchronize()
+            assert rel_err(unpack(dP, Ca, Cb), Wr.grad) < 2e-5, (o is op, rel_err(unpack(dP, Ca, Cb), Wr.grad))
 
 
 @pytest.mark.parametrize('shape', [(2, 64, 16, 16), (3, 6, 5, 7), (2, 512, 2, 2), (2, 64, 64, 64), (1, 136, 48, 48)])

@@ -28,12 +28,13 @@ for nb, tag in ((B, 'N'), (2 * B, '2N')):
     layers += [(f'd1/{tag}', nb, S // 2, S // 2, 128, 64, 2), (f'd2/{tag}', nb, S // 4, S // 4, 256, 128, 2),
                (f'd3/{tag}', nb, S // 8, S // 8, 512, 256, 1)]
 only = sys.argv[1:]
-print(f"{'layer':9s} {'geom':30s} {'GFLOP':>7s} | " + ' | '.join(f"{o:>44s}" for o in ('big2small  dma / regs', 'small2big  dma / regs', 'wgrad')))
-tot = [[0.0, 0.0], [0.0, 0.0], [0.0, 0.0]]
+print(f"{'layer':9s} {'geom':30s} {'GFLOP':>7s} | " + ' | '.join(f"{o:>50s}" for o in ('big2small  flat / ring / regs', 'small2big  flat / ring / regs', 'wgrad')))
+tot = [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]]
 for name, N, Hb, Wb, Ca, Cb, s in layers:
     if only and not any(name.startswith(o) for o in only):
         continue
-    ops = [E.ConvOp(N, Hb, Wb, Ca, Cb, s, L.ALGO_BF16), E.ConvOp(N, Hb, Wb, Ca, Cb, s, L.ALGO_BF16 | L.TUNE_BF16X_OFF)]
+    ops = [E.ConvOp(N, Hb, Wb, Ca, Cb, s, L.ALGO_BF16 | L.TUNE_BF16X_FLAT), E.ConvOp(N, Hb, Wb, Ca, Cb, s, L.ALGO_BF16 | L.TUNE_BF16X_RING),
+           E.ConvOp(N, Hb, Wb, Ca, Cb, s, L.ALGO_BF16 | L.TUNE_BF16X_OFF)]
     big = E.View.alloc(N, Hb, Wb, Cb, dev, bf=True)
     big.t.normal_()
     small = E.View.alloc(N, ops[0].Hs, ops[0].Ws, Ca, dev, bf=True)
@@ -45,7 +46,7 @@ for name, N, Hb, Wb, Ca, Cb, s in layers:
     for oc in (0, 1, 2):
         cell = []
         for k, op in enumerate(ops):
-            if oc == 2 and k == 1:
+            if oc == 2 and k >= 1:
                 continue
             fn = {0: lambda: op.big2small(big, P, 0, None, 0, small), 1: lambda: op.small2big(small, P, 0, None, 0, big),
                   2: lambda: op.wgrad(small, big, dP, 0)}[oc]
@@ -60,8 +61,8 @@ for name, N, Hb, Wb, Ca, Cb, s in layers:
             ms = e0.elapsed_time(e1) / REPS
             sym, split = op.describe(oc, io)
             tot[oc][k] += ms
-            tile = sym.split('<')[1][:-1].replace(',true', '').replace(',false', '')
-            cell.append(f"{ms * 1e3:5.0f}us {op.flops / ms / 1e9:4.0f}TF {tile}{'/' + str(split) if split > 1 else ''}")
-        cells.append(f"{'  '.join(cell):>44s}")
+            tile = sym.split('<')[1][:-1].replace(',true', '').replace(',false', '')[:7]
+            cell.append(f"{ms * 1e3:4.0f}us {op.flops / ms / 1e9:4.0f}TF" + (f" {tile}{'/' + str(split) if split > 1 else ''}" if k != 1 else ''))
+        cells.append(f"{'  '.join(cell):>50s}")
     print(f"{name:9s} {str((N, Hb, Wb, Ca, Cb, s)):30s} {ops[0].flops / 1e9:7.2f} | " + ' | '.join(cells), flush=True)
-print('sum ms: big2small dma %.3f regs %.3f | small2big dma %.3f regs %.3f | wgrad %.3f' % (tot[0][0], tot[0][1], tot[1][0], tot[1][1], tot[2][0]))
+print('sum ms: big2small flat %.3f ring %.3f regs %.3f | small2big flat %.3f ring %.3f regs %.3f | wgrad %.3f' % (*tot[0], *tot[1], tot[2][0]))
