@@ -5,7 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
-// direction: 0 = big -> small (Conv2d forward / ConvTranspose2d data gradient), 1 = small -> big
+// direction: 0 = big -> small (Conv2d forward / ConvTranspose2d data gradient), 1 = small -> big,
+// 2 = big -> small from an 8-channel-per-pixel `big` (Cb <= 8 real channels, ld 8: the image-facing layers),
+// 3 = row GEMM  out[m][n] = sum_a small[m][a] * W[n][a]  over the N*Hs*Ws pixels of `small`, n < Cb (callers pass Cb = 16 * real Cb:
+//     the taps-folded-into-N first half of a few-channel ConvTranspose2d; W = pack dir 1 of the real layer)
 struct pg_bf16x_plan {
     int tile;              // 0: 256x128 rows x channels per workgroup, 1: 128x128, 2: 256x64
     int bm, bn;
@@ -23,8 +26,8 @@ pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, i
 void pg_bf16x_clamp(pg_bf16x_plan* p, size_t slab_bytes_available);
 const char* pg_bf16x_kernel_name(int dir, int tile, int ring);
 
-// bf16 copy of the packed weights P[tap][a][b] (fp32): dir 0 keeps the layout, dir 1 transposes each tap to [tap][b][a]
-// (the GEMM's K index must be the contiguous one of both operands)
+// bf16 copy of the packed weights P[tap][a][b] (fp32): dir 0 keeps the layout, dir 1 / 3 transpose each tap to [tap][b][a]
+// (the GEMM's K index must be the contiguous one of both operands), dir 2 writes [a][tap][8] zero padded
 size_t pg_bf16x_w_bytes(int Ca, int Cb);
 int pg_bf16x_pack(const float* P, void* W, int Ca, int Cb, int dir, hipStream_t st);
 

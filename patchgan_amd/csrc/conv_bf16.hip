@@ -86,23 +86,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lrow = lane & 31, lh = lane >> 5;
 
     // direction-dependent view of the problem: rows = output pixels (of this parity class), Cin / Cout, local taps
+    // DRC 0: big -> small; 1: small -> big; 2: big -> small where `big` has 8 channels per pixel (ld_in == 8; an image-facing tensor
+    // padded to one 16-byte DMA piece per pixel): the 16 taps x 8 channels of an output pixel ARE its K = 128 row, one tap per
+    // LDS slot; 3: plain row GEMM out[m][n] = sum_k in[m][k] * W[n][k] over the N * Hs * Ws rows of `in` (K = Ca, n < Cb):
+    // the first half of the taps-folded-into-N ConvTranspose2d of the few-channel heads (second half: k_col2im_small2big)
+    constexpr bool B2S = (DRC == 0 || DRC == 2 || DRC == 3);
     const int ncls = (DRC == 1 && g.s == 2) ? 4 : 1;
     const int cls = blockIdx.z % ncls, slice = blockIdx.z / ncls;
     const int ah = (ncls == 4) ? (cls >> 1) : 0, aw = (ncls == 4) ? (cls & 1) : 0;
-    const int T = (DRC == 1 && g.s == 2) ? 2 : 4, Tsh = (T == 2) ? 1 : 2;
-    const int Hc = (DRC == 0) ? g.Hs : (g.s == 2 ? (g.Hb - ah + 1) / 2 : g.Hb);
-    const int Wc = (DRC == 0) ? g.Ws : (g.s == 2 ? (g.Wb - aw + 1) / 2 : g.Wb);
+    const int T = (DRC == 3) ? 1 : (DRC == 1 && g.s == 2) ? 2 : 4, Tsh = (T == 2) ? 1 : 2;
+    const int Hc = B2S ? g.Hs : (g.s == 2 ? (g.Hb - ah + 1) / 2 : g.Hb);
+    const int Wc = B2S ? g.Ws : (g.s == 2 ? (g.Wb - aw + 1) / 2 : g.Wb);
     const int Mc = g.N * Hc * Wc;
-    const int Cin = (DRC == 0) ? g.Cb : g.Ca, Cout = (DRC == 0) ? g.Ca : g.Cb;
-    const int Hin = (DRC == 0) ? g.Hb : g.Hs, Win = (DRC == 0) ? g.Wb : g.Ws;
+    const int Cin = (DRC == 0) ? g.Cb : (DRC == 2) ? 128 : g.Ca, Cout = (DRC == 0 || DRC == 2) ? g.Ca : g.Cb;
+    const int Hin = (DRC == 0 || DRC == 2) ? g.Hb : g.Hs, Win = (DRC == 0 || DRC == 2) ? g.Wb : g.Ws;
     const int kh0 = (DRC == 1 && g.s == 2) ? (1 - ah) : 0, kw0 = (DRC == 1 && g.s == 2) ? (1 - aw) : 0;
+    constexpr int TPC = KB / 8;                                    // DRC 2: taps per chunk
 
     const int wk = pg_xcd_remap(blockIdx.x, gridDim.x);
     const int tm = wk / tiles_n, tn = wk - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     if (m0 >= Mc) return;                                          // a smaller parity class (odd Hb / Wb): whole workgroup
     constexpr int CPB = BK / KB;                                   // kernel chunks per plan chunk
-    const int nchunks = T * T * Cin / KB;
+    const int nchunks = (DRC == 2) ? 128 / KB : T * T * Cin / KB;
     const int c_begin = slice * cps * CPB, c_end = min(nchunks, c_begin + cps * CPB);
 
     // ---- per-lane DMA sources: piece i of this wave covers tile rows (wave * AP + i) * RPP .. + RPP - 1, lane -> (row, slot);
@@ -119,13 +125,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int rem = mm - n * (Hc * Wc);
         const int ii = rem / Wc, jj = rem - ii * Wc;
         unsigned wv = 0, mask = 0;
-        if (DRC == 0) {                                            // tap (kh, kw) reads big pixel (s * ii - 1 + kh, s * jj - 1 + kw)
+        if (DRC == 3) {
+            a_off[i] = (mm * ld_in + cc * 8) * 2;
+            mask = 1u;
+        } else if (DRC == 0 || DRC == 2) {                         // tap (kh, kw) reads big pixel (s * ii - 1 + kh, s * jj - 1 + kw)
             const int h0 = g.s * ii - 1, w0 = g.s * jj - 1;
-            a_off[i] = (((n * Hin + h0) * Win + w0) * ld_in + cc * 8) * 2;
+            a_off[i] = (((n * Hin + h0) * Win + w0) * ld_in + (DRC == 2 ? 0 : cc * 8)) * 2;
 #pragma unroll
             for (int t = 0; t < 4; ++t) wv |= ((unsigned)(w0 + t) < (unsigned)Win) ? (1u << t) : 0u;
 #pragma unroll
             for (int t = 0; t < 4; ++t) mask |= ((unsigned)(h0 + t) < (unsigned)Hin) ? (wv << (4 * t)) : 0u;
+            if (DRC == 2) {                                        // slot cc of chunk c holds tap c * TPC + cc: the lane's own (kh, kw) offset
+                a_off[i] += (((cc >> 2) * Win + (cc & 3)) * ld_in) * 2;
+                mask >>= cc;
+            }
         } else {                                                   // local tap (th, tw) reads small pixel (ib - th, jb - tw)
             const int ib = (g.s == 2) ? ii + ah : ii + 1, jb = (g.s == 2) ? jj + aw : jj + 1;
             a_off[i] = (((n * Hin + ib) * Win + jb) * ld_in + cc * 8) * 2;
@@ -162,12 +175,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int tl = (c_begin * KB) / Cin;                                 // local tap and first input channel of the next chunk to load
-    int cin0 = c_begin * KB - tl * Cin;
+    int tl = (DRC == 2) ? c_begin * TPC : (c_begin * KB) / Cin;    // local tap and first input channel of the next chunk to load
+    int cin0 = (DRC == 2) ? 0 : c_begin * KB - tl * Cin;
     const int CC = Cout * Cin;
     auto issue = [&](int stage, bool on) {                         // DMA of that chunk into `stage`; off: zeros (keeps vmcnt counts)
         int a_uni, w_uni;
-        if (DRC == 0) {
+        if (DRC == 3) {
+            a_uni = cin0 * 2;
+            w_uni = cin0 * 2;
+        } else if (DRC == 2) {                                     // here tl = first tap of the chunk (a multiple of TPC)
+            a_uni = ((tl >> 2) * Win * ld_in) * 2;
+            w_uni = (tl * 8) * 2;
+        } else if (DRC == 0) {
             a_uni = (((tl >> 2) * Win + (tl & 3)) * ld_in + cin0) * 2;
             w_uni = (tl * CC + cin0) * 2;
         } else {
@@ -184,10 +203,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #pragma unroll
         for (int j = 0; j < BP; ++j) dma16(rw, b_dst + stage * STAGE + j * 1024, (int)((unsigned)(b_off[j] + w_uni) | kill));
-        cin0 += KB;
-        if (cin0 >= Cin) {
-            cin0 = 0;
-            ++tl;
+        if (DRC == 2) {
+            tl += TPC;
+        } else {
+            cin0 += KB;
+            if (cin0 >= Cin) {
+                cin0 = 0;
+                ++tl;
+            }
         }
     };
     auto multiply = [&](int stage) {
@@ -239,7 +262,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i < MR; ++i) {
         const int m = m0 + (wm * MR + i) * 32 + lrow;
         long orow;
-        if (DRC == 0) {
+        if (B2S) {
             orow = (long)m * ldo;
         } else {
             const int mm = min(m, Mc - 1);
@@ -307,7 +330,9 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* p, int second) {   // row
     return __builtin_bit_cast(bf16x8, both);
 }
 
-template <int MR, int NR, int WM, int WN>
+// TAPN: `big` has 8 channels per pixel (ld_big == 8, g.Cb <= 8 real ones): the 16 taps x 8 channels are the 128 b-columns of ONE GEMM
+// (no tap dimension in the grid); one DMA lane fetches one tap's pixel (16 bytes), its own (kh, kw) offset instead of the block's.
+template <int MR, int NR, int WM, int WN, bool TAPN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wgrad_bf16x(
     const __bf16* __restrict__ small, int ld_small, const __bf16* __restrict__ big, int ld_big, float* __restrict__ out, long slab_stride,
     XGeom g, int cps, int small_bytes, int big_bytes, int tiles_b, int ntiles, float inv_hw, float inv_w) {
@@ -329,9 +354,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lh = lane >> 5;
 
     const int wk = pg_xcd_remap(blockIdx.x, gridDim.x);
-    const int tap = wk & 15, tile = (wk >> 4) % ntiles, slice = (wk >> 4) / ntiles;
+    static_assert(!TAPN || BB == 128, "taps in N: 16 taps x 8 channels");
+    const int tap = TAPN ? 0 : (wk & 15), tile = TAPN ? wk % ntiles : (wk >> 4) % ntiles, slice = TAPN ? wk / ntiles : (wk >> 4) / ntiles;
     const int ta = tile / tiles_b, tb = tile - ta * tiles_b;
-    const int a0 = ta * BA, b0 = tb * BB;
+    const int a0 = ta * BA, b0 = TAPN ? 0 : tb * BB;
     const int kh = tap >> 2, kw = tap & 3;
     const int HW = g.Hs * g.Ws, M = g.N * HW;
     const int nchunks = (M + KP - 1) / KP;
@@ -357,8 +383,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int r = (wave * BP + j) * RPB + lane / LPR;
         const int ch = (lane % LPR) ^ swz(r, RBB);
         const int b = b0 + ch * 8;
-        b_row[j] = (b < g.Cb) ? r : 0x40000000;
-        b_col[j] = b * 2;
+        b_row[j] = (TAPN || b < g.Cb) ? r : 0x40000000;
+        b_col[j] = TAPN ? ch : b * 2;                              // TAPN: the lane's tap
     }
     char* const a_dst = As + wave * AP * 1024;
     char* const b_dst = Bs + wave * BP * 1024;
@@ -406,9 +432,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             int qq = rem - pp * g.Ws;
             pp += (qq >= g.Ws) - (qq < 0);
             qq = rem - pp * g.Ws;
-            const int h = g.s * pp - 1 + kh, w = g.s * qq - 1 + kw;
+            const int h = g.s * pp - 1 + (TAPN ? b_col[j] >> 2 : kh), w = g.s * qq - 1 + (TAPN ? b_col[j] & 3 : kw);
             const bool ok = m < M && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
-            const int off = ((n * g.Hb + h) * g.Wb + w) * ld_big * 2 + b_col[j];
+            const int off = ((n * g.Hb + h) * g.Wb + w) * ld_big * 2 + (TAPN ? 0 : b_col[j]);
             dma16(rb, b_dst + j * 1024, ok ? off : (int)0x80000000u);
         }
         wait_vmcnt<0>();
@@ -440,7 +466,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int b = bb + 8 * qd;
-                if (a < g.Ca && b < g.Cb) {
+                if (TAPN) {                                        // column b = tap * 8 + channel: dP[tap][a][channel < Cb]
+                    const int tp = b >> 3, c0 = b & 7;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (a < g.Ca && c0 + e < g.Cb) o[((long)tp * g.Ca + a) * g.Cb + c0 + e] = acc[i][j][4 * qd + e];
+                } else if (a < g.Ca && b < g.Cb) {
                     const f32x4 v = {acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
                     *reinterpret_cast<f32x4*>(o + (long)a * g.Cb + b) = v;
                 }
@@ -482,46 +513,68 @@ __global__ __launch_bounds__(256) void k_pack_w_bf16(const float* __restrict__ P
     }
 }
 
+// P[tap][a][b] (b < Cb <= 8) -> W8[a][tap][8] bf16, zero padded: the K = 128 row of output channel a in tap order
+__global__ __launch_bounds__(256) void k_pack_w8_bf16(const float* __restrict__ P, __bf16* __restrict__ W, int Ca, int Cb) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < 16L * Ca; i += (long)gridDim.x * 256) {
+        const int tap = (int)(i / Ca), a = (int)(i - (long)tap * Ca);
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (c < Cb) ? P[((long)tap * Ca + a) * Cb + c] : 0.f;
+        const u32x4 o = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        *reinterpret_cast<u32x4*>(W + ((long)a * 16 + tap) * 8) = o;
+    }
+}
+
 }  // namespace
 
 bool pg_bf16x_geom_ok(int dir, int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride) {
+    (void)stride;
+    if (dir == 2) {                    // big has <= 8 channels in 8-channel pixels
+        if (Cb > 8 || Ca % 8 != 0 || Ca < 32) return false;
+        return (long)N * Hs * Ws * Ca < 0x7fffffffL && (long)N * Hb * Wb * 16 < 0x60000000L;
+    }
+    if (dir == 3) {                    // rows of `small` (N*Hs*Ws x Ca) times W[Cb][Ca]
+        if (Ca % BK != 0 || Cb % 8 != 0) return false;
+        return (long)N * Hs * Ws * Cb < 0x7fffffffL && (long)Ca * Cb * 2 < 0x40000000L;
+    }
     const int Cin = dir == 0 ? Cb : Ca, Cout = dir == 0 ? Ca : Cb;
     if (Cin % BK != 0 || Cout % 8 != 0 || Cout < 32) return false;
     if (16L * Ca * Cb * 2 >= 0x40000000L) return false;
     const long pix = (long)N * (dir == 0 ? Hs * Ws : Hb * Wb);
     if (pix * Cout >= 0x7fffffffL) return false;
-    (void)stride;
     return true;
 }
 
 pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, int ring) {
     pg_bf16x_plan p;
-    const int Cin = dir == 0 ? Cb : Ca, Cout = dir == 0 ? Ca : Cb;
+    const int Cin = (dir == 0) ? Cb : Ca, Cout = (dir == 0 || dir == 2) ? Ca : Cb;
     p.ncls = (dir == 1 && stride == 2) ? 4 : 1;
-    const long Mc = (dir == 0) ? (long)N * Hs * Ws : (p.ncls == 4 ? (long)N * ((Hb + 1) / 2) * ((Wb + 1) / 2) : (long)N * Hb * Wb);
+    const long Mc = (dir != 1) ? (long)N * Hs * Ws : (p.ncls == 4 ? (long)N * ((Hb + 1) / 2) * ((Wb + 1) / 2) : (long)N * Hb * Wb);
     const int taps = (p.ncls == 4) ? 4 : 16;
-    p.nchunks = taps * Cin / BK;
-    p.out_elems = (long)N * (dir == 0 ? Hs * Ws : Hb * Wb) * Cout;
+    p.nchunks = (dir == 2) ? 2 : (dir == 3) ? Cin / BK : taps * Cin / BK;
+    p.out_elems = (long)N * (dir != 1 ? Hs * Ws : Hb * Wb) * Cout;
     auto blocks = [&](int bm, int bn) { return ((Mc + bm - 1) / bm) * ((Cout + bn - 1) / bn) * p.ncls; };
     static const int forced = getenv("PATCHGAN_BF16X_TILE") ? atoi(getenv("PATCHGAN_BF16X_TILE")) : -1;
+    static const int target = getenv("PATCHGAN_BF16X_TARGET") ? atoi(getenv("PATCHGAN_BF16X_TARGET")) : 512;
+    // Measured on the cfg4 layers (tools/layer_bench_bf16.py, one device): the 256 x 128 tile wins only where it alone fills the chip
+    // twice over (>= ~480 workgroups = two per CU) on a long K; one workgroup per CU loses to 128 x 128 tiles at two to four per CU,
+    // and a split-K pass (slab write + reduce) costs more than it returns once ~400 workgroups exist without it.
     if (forced >= 0 && forced <= 2) p.tile = forced;
     else if (Cout <= 64) p.tile = 2;
-    else if (blocks(256, 128) >= 200) p.tile = 0;
+    else if (blocks(256, 128) >= 480 && p.nchunks >= 32) p.tile = 0;
     else p.tile = 1;
     p.bm = (p.tile == 1) ? 128 : 256;
     p.bn = (p.tile == 2) ? 64 : 128;
     p.tiles_m = (int)((Mc + p.bm - 1) / p.bm);
     p.tiles_n = (Cout + p.bn - 1) / p.bn;
     const long nb = (long)p.tiles_m * p.tiles_n * p.ncls;
-    // two workgroups per CU overlap one's DMA wait with the other's MFMAs: split K until >= 512, at least 4 chunks per slice
-    static const int target = getenv("PATCHGAN_BF16X_TARGET") ? atoi(getenv("PATCHGAN_BF16X_TARGET")) : 512;
-    long s = (nb >= target) ? 1 : (target + nb - 1) / nb;
+    long s = (nb >= target * 25 / 32) ? 1 : (target + nb - 1) / nb;      // (400 of 512)
     const long smax = std::max<long>(1, p.nchunks / 4);
     if (s > smax) s = smax;
     p.split = (int)s;
     p.cps = (p.nchunks + p.split - 1) / p.split;
     p.split = (p.nchunks + p.cps - 1) / p.cps;
-    p.ring = (ring >= 0) ? (ring ? 1 : 0) : 0;
+    p.ring = (ring >= 0 && dir < 2) ? (ring ? 1 : 0) : 0;
     return p;
 }
 
@@ -533,23 +586,25 @@ void pg_bf16x_clamp(pg_bf16x_plan* p, size_t avail) {
 }
 
 const char* pg_bf16x_kernel_name(int dir, int tile, int ring) {
-    static const char* const names[2][2][3] = {
-        {{"k_conv_bf16x<4,2,2,2,0,64>", "k_conv_bf16x<2,2,2,2,0,64>", "k_conv_bf16x<2,2,4,1,0,64>"},
-         {"k_conv_bf16x<4,2,2,2,1,64>", "k_conv_bf16x<2,2,2,2,1,64>", "k_conv_bf16x<2,2,4,1,1,64>"}},
-        {{"k_conv_bf16x<4,2,2,2,0,32>", "k_conv_bf16x<2,2,2,2,0,32>", "k_conv_bf16x<2,2,4,1,0,32>"},
-         {"k_conv_bf16x<4,2,2,2,1,32>", "k_conv_bf16x<2,2,2,2,1,32>", "k_conv_bf16x<2,2,4,1,1,32>"}}};
-    return names[ring ? 1 : 0][dir ? 1 : 0][tile < 0 || tile > 2 ? 0 : tile];
+    static const char* const tiles[3] = {"4,2,2,2", "2,2,2,2", "2,2,4,1"};
+    static thread_local char buf[64];
+    snprintf(buf, sizeof buf, "k_conv_bf16x<%s,%d,%d>", tiles[tile < 0 || tile > 2 ? 0 : tile], dir, (ring && dir < 2) ? 32 : 64);
+    return buf;
 }
 
-size_t pg_bf16x_w_bytes(int Ca, int Cb) { return ((size_t)16 * Ca * Cb * 2 + 255) & ~(size_t)255; }
+size_t pg_bf16x_w_bytes(int Ca, int Cb) { return ((size_t)16 * Ca * std::max(Cb, 8) * 2 + 255) & ~(size_t)255; }
 
 int pg_bf16x_pack(const float* P, void* W, int Ca, int Cb, int dir, hipStream_t st) {
-    if (dir == 0) {
-        if ((Cb & 3) != 0) return PG_EINVAL;
+    if (dir == 2) {                    // W8[a][tap][8]: the Cb <= 8 channels of each tap, zero padded
+        const long total = 16L * Ca;
+        hipLaunchKernelGGL(k_pack_w8_bf16, dim3((int)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st, P, (__bf16*)W, Ca, Cb);
+    } else if (dir == 0 && (Cb & 3) == 0) {
         const long total4 = 4L * Ca * Cb;
         const int blocks = (int)std::min<long>((total4 + 255) / 256, 2048);
         hipLaunchKernelGGL(k_pack_w_bf16, dim3(blocks), dim3(256), 0, st, P, (__bf16*)W, Ca, Cb, 0);
-    } else {
+    } else if (dir == 0) {
+        return PG_EINVAL;
+    } else {                           // dir 1 and 3: each tap transposed to [b][a]
         const long tiles = 16L * ((Ca + 31) / 32) * ((Cb + 31) / 32);
         hipLaunchKernelGGL(k_pack_w_bf16, dim3((int)std::min<long>(tiles, 4096)), dim3(256), 0, st, P, (__bf16*)W, Ca, Cb, 1);
     }
@@ -561,7 +616,7 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
                   int act, int out_bf, hipStream_t st) {
     const XGeom g{N, Hb, Wb, Hs, Ws, Ca, Cb, stride};
     const dim3 grid((unsigned)(p->tiles_m * p->tiles_n), 1, (unsigned)(p->ncls * p->split));
-    const int w_bytes = 16 * Ca * Cb * 2;
+    const int w_bytes = (dir == 2) ? 16 * Ca * 8 * 2 : (dir == 3) ? Ca * Cb * 2 : 16 * Ca * Cb * 2;
     const __bf16* I = (const __bf16*)in;
     const __bf16* Wp = (const __bf16*)W;
 #define PG_BF16X_LAUNCH1(MR, NR, WM, WN, D, KB)                                                                              \
@@ -571,8 +626,10 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
     do {                                                                                                                     \
         if (dir == 0 && !p->ring) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 0, 64);                                                   \
         else if (dir == 0) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 0, 32);                                                          \
-        else if (!p->ring) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 1, 64);                                                          \
-        else PG_BF16X_LAUNCH1(MR, NR, WM, WN, 1, 32);                                                                        \
+        else if (dir == 1 && !p->ring) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 1, 64);                                              \
+        else if (dir == 1) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 1, 32);                                                          \
+        else if (dir == 2) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 2, 64);                                                          \
+        else PG_BF16X_LAUNCH1(MR, NR, WM, WN, 3, 64);                                                                        \
     } while (0)
     switch (p->tile) {
         case 0: PG_BF16X_LAUNCH(4, 2, 2, 2); break;
@@ -587,8 +644,9 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
 // ---- weight gradient -------------------------------------------------------------------------------------------------------
 bool pg_bf16x_wgrad_geom_ok(int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride) {
     (void)Hb; (void)Wb; (void)stride;
-    if (Ca % 32 != 0 || Cb % 32 != 0 || Ca < 64 || Cb < 32) return false;
     if ((long)N * Hs * Ws >= (1L << 24)) return false;             // pixel decode by float reciprocals
+    if (Cb <= 8) return Ca % 32 == 0 && Ca >= 64;                  // taps in N: `big` in 8-channel pixels (ld_big == 8, checked by the caller)
+    if (Ca % 32 != 0 || Cb % 32 != 0 || Ca < 64 || Cb < 32) return false;
     return true;
 }
 
@@ -597,8 +655,29 @@ pg_bf16x_plan pg_bf16x_wgrad_plan(int N, int Hb, int Wb, int Hs, int Ws, int Ca,
     pg_bf16x_plan p;
     static const int forced = getenv("PATCHGAN_BF16X_WTILE") ? atoi(getenv("PATCHGAN_BF16X_WTILE")) : -1;
     // tiles (a x b): 0: 256 x 128, 1: 128 x 128, 2: 256 x 64, 3: 128 x 64
+    if (Cb <= 8) {                     // taps in N: tiles 4 / 5 = 64 / 128 a-channels x (16 taps x 8)
+        p.tile = (Ca % 128 == 0) ? 5 : 4;
+        p.bm = (p.tile == 5) ? 128 : 64;
+        p.bn = 128;
+        p.tiles_m = (Ca + p.bm - 1) / p.bm;
+        p.tiles_n = 1;
+        p.ncls = 1;
+        const long Mp = (long)N * Hs * Ws;
+        p.nchunks = (int)((Mp + 63) / 64);
+        p.out_elems = 16L * Ca * Cb;
+        long sp = std::max<long>(1, 1024 / p.tiles_m);             // HBM-bound streaming of every pixel: many short slices
+        const long spmax = std::max<long>(1, p.nchunks / 8);
+        if (sp > spmax) sp = spmax;
+        p.split = (int)sp;
+        p.cps = (p.nchunks + p.split - 1) / p.split;
+        p.split = (p.nchunks + p.cps - 1) / p.cps;
+        p.ring = 0;
+        return p;
+    }
+    // (measured, tools/layer_bench_bf16.py: with <= 4096 pixels the 128 x 128 tile's shorter slices win: 20 vs 44 us on 1024 x 512 at 16 x 16)
+    const long Mpix = (long)N * Hs * Ws;
     if (forced >= 0 && forced <= 3) p.tile = forced;
-    else if (Cb % 128 == 0) p.tile = (Ca % 256 == 0) ? 0 : 1;
+    else if (Cb % 128 == 0) p.tile = (Ca % 256 == 0 && Mpix > 4096) ? 0 : 1;
     else p.tile = (Ca % 256 == 0) ? 2 : 3;
     p.bm = (p.tile == 0 || p.tile == 2) ? 256 : 128;
     p.bn = (p.tile <= 1) ? 128 : 64;
@@ -621,8 +700,9 @@ pg_bf16x_plan pg_bf16x_wgrad_plan(int N, int Hb, int Wb, int Hs, int Ws, int Ca,
 }
 
 const char* pg_bf16x_wgrad_kernel_name(int tile) {
-    static const char* const names[4] = {"k_wgrad_bf16x<4,2,2,2>", "k_wgrad_bf16x<2,2,2,2>", "k_wgrad_bf16x<2,2,4,1>", "k_wgrad_bf16x<1,2,4,1>"};
-    return names[tile < 0 || tile > 3 ? 0 : tile];
+    static const char* const names[6] = {"k_wgrad_bf16x<4,2,2,2>", "k_wgrad_bf16x<2,2,2,2>", "k_wgrad_bf16x<2,2,4,1>", "k_wgrad_bf16x<1,2,4,1>",
+                                         "k_wgrad_bf16x<2,1,1,4,true>", "k_wgrad_bf16x<4,1,1,4,true>"};
+    return names[tile < 0 || tile > 5 ? 0 : tile];
 }
 
 int pg_bf16x_wgrad(const void* small, int ld_small, long small_bytes, const void* big, int ld_big, long big_bytes, float* out,
@@ -630,18 +710,20 @@ int pg_bf16x_wgrad(const void* small, int ld_small, long small_bytes, const void
                    hipStream_t st) {
     const XGeom g{N, Hb, Wb, Hs, Ws, Ca, Cb, stride};
     const int ntiles = p->tiles_m * p->tiles_n;
-    const dim3 grid((unsigned)(ntiles * 16 * p->split), 1, 1);
+    const dim3 grid((unsigned)(ntiles * p->ncls * p->split), 1, 1);
     const float inv_hw = 1.0f / (float)(Hs * Ws), inv_w = 1.0f / (float)Ws;
     const __bf16* S = (const __bf16*)small;
     const __bf16* B = (const __bf16*)big;
-#define PG_BF16X_WG(MR, NR, WM, WN)                                                                                          \
-    hipLaunchKernelGGL((k_wgrad_bf16x<MR, NR, WM, WN>), grid, dim3(256), 0, st, S, ld_small, B, ld_big, out, slab_stride, g, p->cps, \
+#define PG_BF16X_WG(MR, NR, WM, WN, TN)                                                                                      \
+    hipLaunchKernelGGL((k_wgrad_bf16x<MR, NR, WM, WN, TN>), grid, dim3(256), 0, st, S, ld_small, B, ld_big, out, slab_stride, g, p->cps, \
                        (int)small_bytes, (int)big_bytes, p->tiles_n, ntiles, inv_hw, inv_w)
     switch (p->tile) {
-        case 0: PG_BF16X_WG(4, 2, 2, 2); break;
-        case 1: PG_BF16X_WG(2, 2, 2, 2); break;
-        case 2: PG_BF16X_WG(2, 2, 4, 1); break;
-        default: PG_BF16X_WG(1, 2, 4, 1); break;
+        case 0: PG_BF16X_WG(4, 2, 2, 2, false); break;
+        case 1: PG_BF16X_WG(2, 2, 2, 2, false); break;
+        case 2: PG_BF16X_WG(2, 2, 4, 1, false); break;
+        case 3: PG_BF16X_WG(1, 2, 4, 1, false); break;
+        case 4: PG_BF16X_WG(2, 1, 1, 4, true); break;
+        default: PG_BF16X_WG(4, 1, 1, 4, true); break;
     }
 #undef PG_BF16X_WG
     return pg_launch_status();

@@ -2140,7 +2140,15 @@ __global__ void k_slab_reduce4(const float* __restrict__ slabs, long slab_stride
         const int c = (int)(i - r * cq) << 2;
         const long off = r * cols + c;
         f32x4 v = *reinterpret_cast<const f32x4*>(slabs + off);
-        for (int z = 1; z < S; ++z) v += *reinterpret_cast<const f32x4*>(slabs + (long)z * slab_stride + off);
+        int z = 1;
+        for (; z + 8 <= S; z += 8) {        // eight independent loads in flight, summed in slab order
+            f32x4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(slabs + (long)(z + k) * slab_stride + off);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += t[k];
+        }
+        for (; z < S; ++z) v += *reinterpret_cast<const f32x4*>(slabs + (long)z * slab_stride + off);
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = pg_act_epi(v[e], act);
@@ -2192,6 +2200,7 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
 
 // float4 variant (C % 4 == 0, 16-byte aligned rows): 256 threads = 16 channel quads x 16 row lanes, four independent
 // loads in flight per lane; fixed-order combine.
+template <bool HB>      // HB: x holds bf16 elements (bf16 activation storage)
 __global__ __launch_bounds__(256) void k_colsum_partial4(const float* __restrict__ x, int ld, long rows, int C,
                                                          long rows_per_chunk, float* __restrict__ partial) {
     __shared__ f32x4 red[16][16];
@@ -2199,16 +2208,24 @@ __global__ __launch_bounds__(256) void k_colsum_partial4(const float* __restrict
     const int c = blockIdx.y * 64 + cl * 4;
     const long r_begin = blockIdx.x * rows_per_chunk;
     const long r_end = min(rows, r_begin + rows_per_chunk);
+    auto ld4 = [&](long idx) -> f32x4 {
+        if constexpr (HB) {
+            const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(x) + idx);
+            return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        } else {
+            return *reinterpret_cast<const f32x4*>(x + idx);
+        }
+    };
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     if (c < C) {
         long r = r_begin + rl;
         for (; r + 48 < r_end; r += 64) {
-            s0 += *reinterpret_cast<const f32x4*>(x + r * ld + c);
-            s1 += *reinterpret_cast<const f32x4*>(x + (r + 16) * ld + c);
-            s2 += *reinterpret_cast<const f32x4*>(x + (r + 32) * ld + c);
-            s3 += *reinterpret_cast<const f32x4*>(x + (r + 48) * ld + c);
+            s0 += ld4(r * ld + c);
+            s1 += ld4((r + 16) * ld + c);
+            s2 += ld4((r + 32) * ld + c);
+            s3 += ld4((r + 48) * ld + c);
         }
-        for (; r < r_end; r += 16) s0 += *reinterpret_cast<const f32x4*>(x + r * ld + c);
+        for (; r < r_end; r += 16) s0 += ld4(r * ld + c);
     }
     red[rl][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -2670,10 +2687,22 @@ inline bool wino_wgrad_ok(const Geom& g, const Tune& t) {
 inline bool bf16x_ok(const Geom& g, int dir, int algo_full, const Tune& t) {
     if ((algo_full & PG_ALGO_MASK) != PG_ALGO_BF16 || !t.bf16x || force_generic()) return false;
     if (!(algo_full & (dir == 0 ? PG_IO_BIG_BF16 : PG_IO_SMALL_BF16))) return false;
+    // big -> small from a few-channel `big`: the 8-channel-pixel form (dir 2; the caller also checks ld_big == 8)
+    if (dir == 0 && g.Cb <= 8) return pg_bf16x_geom_ok(2, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s);
     return pg_bf16x_geom_ok(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s);
+}
+// small -> big onto a few-channel `big` from a bf16 `small`: row GEMM on the bf16 kernels (dir 3) + k_col2im_small2big; fp32 output
+inline bool bf16x_s2b_tapn_ok(const Geom& g, int algo_full, const Tune& t) {
+    if ((algo_full & PG_ALGO_MASK) != PG_ALGO_BF16 || !t.bf16x || force_generic()) return false;
+    if ((algo_full & PG_IO_MASK) != PG_IO_SMALL_BF16 || g.Cb > 8) return false;
+    return pg_bf16x_geom_ok(3, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, 16 * g.Cb, g.s);
+}
+inline size_t bf16x_s2b_tapn_ws(const Geom& g) {
+    return pg_bf16x_w_bytes(g.Ca, g.Cb) + (size_t)g.N * g.Hs * g.Ws * 16 * g.Cb * sizeof(float);
 }
 // packed bf16 weights (unless the caller owns them) followed by the split-K slabs
 inline size_t bf16x_ws(const Geom& g, int dir) {
+    if (dir == 0 && g.Cb <= 8) dir = 2;
     const pg_bf16x_plan p = pg_bf16x_plan_of(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, -1);
     return pg_bf16x_w_bytes(g.Ca, g.Cb) + (p.split > 1 ? (size_t)p.split * p.out_elems * sizeof(float) : 0);
 }
@@ -2690,8 +2719,12 @@ inline bool aligned_bf_view(const void* p, int ld, bool bf) {
 constexpr int BF16X_SKIP = -1000;
 int bf16x_run(int dir, const void* in, int ld_in, const float* P, const float* bias, void* out, int ld_out, const Geom& g, int act,
               bool out_bf, void* ws, size_t ws_bytes, hipStream_t st, const pg_conv_extras& x, int ring) {
-    const int Cin = dir == 0 ? g.Cb : g.Ca, Cout = dir == 0 ? g.Ca : g.Cb;
-    const long in_pix = (long)g.N * (dir == 0 ? g.Hb * g.Wb : g.Hs * g.Ws), out_pix = (long)g.N * (dir == 0 ? g.Hs * g.Ws : g.Hb * g.Wb);
+    if (dir == 0 && g.Cb <= 8) {       // few-channel big: only in 8-channel pixels (16 bytes = one DMA piece per pixel)
+        if (ld_in != 8) return BF16X_SKIP;
+        dir = 2;
+    }
+    const int Cin = dir == 0 ? g.Cb : dir == 2 ? 8 : g.Ca, Cout = dir == 1 ? g.Cb : g.Ca;
+    const long in_pix = (long)g.N * (dir != 1 ? g.Hb * g.Wb : g.Hs * g.Ws), out_pix = (long)g.N * (dir != 1 ? g.Hs * g.Ws : g.Hb * g.Wb);
     const long in_bytes = tensor_bytes(in_pix, ld_in, Cin, true);
     if (!aligned_bf_view(in, ld_in, true) || !aligned_bf_view(out, ld_out, out_bf) || !aligned16(P) || (bias && !aligned16(bias)) ||
         in_bytes >= FAST_LIMIT)
@@ -2757,10 +2790,13 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
         if (op == 0 && wino_b2s_ok(gq, t)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Cb, gq.Ca, mo1));
         if (op == 1 && wino_s2b_ok(gq, t)) bytes = std::max(bytes, pg_wino_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb, mo1));
     }
-    if ((op == 0 || op == 1) && pg_bf16x_geom_ok(op, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s)) bytes = std::max(bytes, bf16x_ws(gq, op));
+    if ((op == 0 || op == 1) && pg_bf16x_geom_ok((op == 0 && gq.Cb <= 8) ? 2 : op, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s))
+        bytes = std::max(bytes, bf16x_ws(gq, op));
+    if (op == 1 && gq.Cb <= 8 && pg_bf16x_geom_ok(3, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, 16 * gq.Cb, gq.s)) bytes = std::max(bytes, bf16x_s2b_tapn_ws(gq) + 256);
     if (op == 2 && pg_bf16x_wgrad_geom_ok(gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s)) {
         const pg_bf16x_plan wp = pg_bf16x_wgrad_plan(gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s);
-        if (wp.split > 1) bytes = std::max(bytes, (size_t)wp.split * wp.out_elems * sizeof(float));
+        if (wp.split > 1)
+            bytes = std::max(bytes, (size_t)wp.split * wp.out_elems * sizeof(float) + (((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255));
     }
     const Tune tw = tune_widest(0);
     const size_t colsum = ((size_t)COLSUM_CHUNKS * g->Ca * sizeof(float) + 255) & ~(size_t)255;
@@ -2817,10 +2853,18 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         return PG_OK;
     }
     // 1000 + 10 * dir + tile: the LDS-DMA bf16 kernels (k_conv_bf16x) on bf16 tensors
+    if (op == 1 && bf16x_s2b_tapn_ok(gq, algo_full, tune) && ws_bytes >= bf16x_s2b_tapn_ws(gq)) {
+        const pg_bf16x_plan bp = pg_bf16x_plan_of(3, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, 16 * gq.Cb, gq.s, 0);
+        if (tile_id) *tile_id = 1030 + bp.tile;
+        if (split) *split = 1;
+        if (workgroups) *workgroups = (long)bp.tiles_m * bp.tiles_n;
+        return PG_OK;
+    }
     if ((op == 0 || op == 1) && bf16x_ok(gq, op, algo_full, tune) && ws_bytes >= pg_bf16x_w_bytes(g->Ca, g->Cb)) {
-        pg_bf16x_plan bp = pg_bf16x_plan_of(op, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s, tune.bf16ring);
+        const int xdir = (op == 0 && gq.Cb <= 8) ? 2 : op;
+        pg_bf16x_plan bp = pg_bf16x_plan_of(xdir, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s, tune.bf16ring);
         pg_bf16x_clamp(&bp, ws_bytes - pg_bf16x_w_bytes(g->Ca, g->Cb));
-        if (tile_id) *tile_id = 1000 + 100 * bp.ring + 10 * op + bp.tile;
+        if (tile_id) *tile_id = (xdir == 2) ? 1040 + bp.tile : 1000 + 100 * bp.ring + 10 * op + bp.tile;
         if (split) *split = bp.split;
         if (workgroups) *workgroups = (long)bp.tiles_m * bp.tiles_n * bp.ncls * bp.split;
         return PG_OK;
@@ -2906,6 +2950,10 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     char buf[128];
     if (code >= 1020 && code < 1030) {
         snprintf(buf, sizeof buf, "%s", pg_bf16x_wgrad_kernel_name(code - 1020));
+    } else if (code >= 1030 && code < 1040) {
+        snprintf(buf, sizeof buf, "%s+k_col2im_small2big", pg_bf16x_kernel_name(3, code - 1030, 0));
+    } else if (code >= 1040 && code < 1050) {
+        snprintf(buf, sizeof buf, "%s", pg_bf16x_kernel_name(2, code - 1040, 0));
     } else if (code >= 1000) {
         snprintf(buf, sizeof buf, "%s", pg_bf16x_kernel_name((code / 10) % 10, code % 10, (code / 100) % 10));
     } else if (algo == PG_ALGO_DIRECT) {
@@ -3140,6 +3188,27 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         return pg_wino2_s2b(small, ld_small, P, bias, big, ld_big, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, part,
                             x.u_cache, x.u_valid);
     }
+    if (bf16x_s2b_tapn_ok(g, algo | io, tune) && !part && !x.u_cache && ws && aligned16(ws) && ws_bytes >= bf16x_s2b_tapn_ws(g) &&
+        aligned_bf_view(small, ld_small, true) && aligned16(P) &&
+        tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca, true) < FAST_LIMIT) {
+        // D[small pixel][(tap, b)] = small . W' (bf16 row GEMM), then col2im: each big pixel sums the taps that reach it
+        const int Nc = 16 * g.Cb;
+        const size_t wb = pg_bf16x_w_bytes(g.Ca, g.Cb);
+        float* D = (float*)((char*)ws + wb);
+        int rc = pg_bf16x_pack(P, ws, g.Ca, g.Cb, 1, st);
+        if (rc != PG_OK) return rc;
+        const pg_bf16x_plan bp = pg_bf16x_plan_of(3, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, Nc, g.s, 0);
+        {
+            TimedLaunch timed(st);
+            rc = pg_bf16x_conv(3, small, ld_small, tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca, true), ws, D, Nc, 0L, g.N, g.Hb,
+                               g.Wb, g.Hs, g.Ws, g.Ca, Nc, g.s, &bp, nullptr, 0, 0, st);
+        }
+        if (rc != PG_OK) return rc;
+        const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
+        hipLaunchKernelGGL(k_col2im_small2big, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, D, bias,
+                           big, ld_big, g, act);
+        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+    }
     if (bf16x_ok(g, 1, algo | io, tune) && !part) {
         const int rc = bf16x_run(1, small, ld_small, P, bias, big, ld_big, g, act, io & PG_IO_BIG_BF16, ws, ws_bytes, st, x, tune.bf16ring);
         if (rc != BF16X_SKIP) return rc;
@@ -3287,7 +3356,8 @@ static int wgrad_impl(const float* small, int ld_small, const float* big, int ld
     const Tune tune = tune_of(algo);
     const int io = algo & PG_IO_MASK;                 // both activation operands bf16, or neither
     algo &= PG_ALGO_MASK;
-    if (io && (algo != PG_ALGO_BF16 || io != PG_IO_MASK || dbias)) return PG_EINVAL;
+    if (io && (algo != PG_ALGO_BF16 || io != PG_IO_MASK)) return PG_EINVAL;
+    if (io && dbias && !((g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned_io(small, true))) return PG_EINVAL;
     if (!ws) ws_bytes = 0;
     const long Kp = (long)g.N * g.Hs * g.Ws;
     size_t reserved = 0;
@@ -3298,8 +3368,11 @@ static int wgrad_impl(const float* small, int ld_small, const float* big, int ld
         int chunks = (int)std::min<long>(COLSUM_CHUNKS, Kp);
         long rpc = (Kp + chunks - 1) / chunks;
         chunks = (int)((Kp + rpc - 1) / rpc);
-        if ((g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned16(small) && aligned16(part))
-            hipLaunchKernelGGL(k_colsum_partial4, dim3(chunks, (g.Ca + 63) / 64), dim3(256), 0, st, small, ld_small, Kp, g.Ca,
+        if (io)
+            hipLaunchKernelGGL(k_colsum_partial4<true>, dim3(chunks, (g.Ca + 63) / 64), dim3(256), 0, st, small, ld_small, Kp, g.Ca,
+                               rpc, part);
+        else if ((g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned16(small) && aligned16(part))
+            hipLaunchKernelGGL(k_colsum_partial4<false>, dim3(chunks, (g.Ca + 63) / 64), dim3(256), 0, st, small, ld_small, Kp, g.Ca,
                                rpc, part);
         else
             hipLaunchKernelGGL(k_colsum_partial, dim3(chunks, (g.Ca + 63) / 64), dim3(256), 0, st, small, ld_small, Kp, g.Ca,
@@ -3340,13 +3413,14 @@ static int wgrad_impl(const float* small, int ld_small, const float* big, int ld
                               e0, e1, v_pre);
     }
     if (v_pre) return PG_EINVAL;     // pg_conv_v_bytes said 0 for this call: there is no transformed operand to reuse
-    if (bf16x_wgrad_ok(g, algo | io, tune) && !dbias && aligned_bf_view(small, ld_small, true) && aligned_bf_view(big, ld_big, true) &&
-        aligned16(dP) && (!ws_bytes || aligned16(ws))) {
-        const long small_bytes = tensor_bytes(Kp, ld_small, g.Ca, true), big_bytes = tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb, true);
+    if (bf16x_wgrad_ok(g, algo | io, tune) && (g.Cb > 8 || ld_big == 8) && aligned_bf_view(small, ld_small, true) &&
+        aligned_bf_view(big, ld_big, true) && aligned16(dP) && (ws_bytes <= reserved || aligned16(ws))) {
+        const long small_bytes = tensor_bytes(Kp, ld_small, g.Ca, true);
+        const long big_bytes = tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb > 8 ? g.Cb : 8, true);
         if (small_bytes < FAST_LIMIT && big_bytes < FAST_LIMIT) {
             pg_bf16x_plan wp = pg_bf16x_wgrad_plan(g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s);
-            pg_bf16x_clamp(&wp, ws_bytes);
-            float* dst = wp.split == 1 ? dP : (float*)ws;
+            pg_bf16x_clamp(&wp, ws_bytes > reserved ? ws_bytes - reserved : 0);
+            float* dst = wp.split == 1 ? dP : (float*)((char*)ws + reserved);
             int rc;
             {
                 TimedLaunch timed(st);

@@ -52,3 +52,16 @@ def empty_view_bf(N, H, W, C, ld=None, off=0):
     ld = ld or C
     buf = torch.full((N * H * W * ld + 64,), float('nan'), dtype=torch.bfloat16, device=DEV)
     return E.View(buf, off, ld, N, H, W, C, True)
+
+
+def to_view_bf8(x):
+    """NCHW CPU tensor with <= 8 channels -> bf16 NHWC View in 8-channel pixels (ld 8, pad channels zero): the layout the bf16
+    kernels take for image-facing tensors."""
+    from patchgan_amd import _lib as L
+    N, C, H, W = x.shape
+    assert C <= 8
+    src = to_view(x)
+    buf = torch.zeros(N * H * W * 8, dtype=torch.bfloat16, device=DEV)
+    v = E.View(buf, 0, 8, N, H, W, C, True)
+    L.check(L.load().pg_act_fwd_t(src.ptr(), src.ld, v.ptr(), v.ld, v.npix, C, L.ACT_NONE, 0.0, 0, None, 2), 'pg_act_fwd_t')
+    return v

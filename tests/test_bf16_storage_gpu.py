@@ -159,6 +159,59 @@ def test_lds_dma_bf16_kernels(geom):
             assert rel_err(unpack(dP, Ca, Cb), Wr.grad) < 2e-5, (o is op, rel_err(unpack(dP, Ca, Cb), Wr.grad))
 
 
+SEAMS = [(2, 64, 64, 64, 3, 2), (2, 32, 48, 64, 7, 2), (1, 33, 31, 128, 4, 2), (2, 31, 31, 64, 8, 1), (3, 16, 16, 128, 1, 2), (2, 128, 128, 64, 7, 2)]
+
+
+@pytest.mark.parametrize('geom', SEAMS, ids=lambda g: 'x'.join(map(str, g)))
+def test_bf16_kernels_on_image_facing_layers(geom):
+    """The few-channel layers next to the images (enc0, d0, the generator head) on the bf16 kernels: the few-channel tensor is a
+    bf16 tensor in 8-channel pixels (ld 8, zero pads -- one 16-byte DMA piece per pixel).  big2small = k_conv_bf16x<..,2,64> (the 16
+    taps of a pixel are its K = 128 row), weight gradient = k_wgrad_bf16x<..,true> (taps folded into N), small2big = bf16 row GEMM
+    k_conv_bf16x<..,3,64> + col2im with an fp32 result.  Against torch in float64 on bf16-representable operands: 2e-5 for fp32
+    results, one bf16 ulp for bf16 results."""
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view_bf, to_view_bf8, empty_view, empty_view_bf, pack, unpack, rel_err, DEV
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    Wt = Wt.bfloat16().float()
+    P = pack(Wt)
+    op = E.ConvOp(*geom, L.ALGO_BF16)
+    both = L.IO_BIG_BF16 | L.IO_SMALL_BF16
+    bias = torch.randn(Ca)
+    vb, vs = to_view_bf8(big), to_view_bf(small, ld=Ca + 8, off=8)
+    # forward
+    assert op.describe(0, L.IO_BIG_BF16)[0].startswith('k_conv_bf16x') and ',2,64>' in op.describe(0, L.IO_BIG_BF16)[0]
+    want = O.apply_act(F.conv2d(big.double(), Wt.double(), bias.double(), stride=s, padding=1), 'leakyrelu')
+    for out_bf in (True, False):
+        out = (empty_view_bf if out_bf else empty_view)(N, Hs, Ws, Ca, ld=Ca + 8, off=8)
+        op.big2small(vb, P, 0, bias.cuda(), 0, out, 1)
+        torch.cuda.synchronize()
+        got = out.to_nchw().double().cpu()
+        if out_bf:
+            ref = want.float().bfloat16().double()
+            assert ((got - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-5 * want.abs().max()).all(), rel_err(got, ref)
+        else:
+            assert rel_err(got, want) < 2e-5
+    # weight gradient (+ bias gradient from the bf16 dy)
+    assert op.describe(2, both)[0].startswith('k_wgrad_bf16x') and op.describe(2, both)[0].endswith(',true>')
+    Wr = Wt.double().clone().requires_grad_(True)
+    F.conv2d(big.double(), Wr, None, stride=s, padding=1).backward(small.double())
+    dP = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+    db = torch.full((Ca,), float('nan'), device=DEV)
+    op.wgrad(vs, vb, dP, 0, db, 0)
+    torch.cuda.synchronize()
+    assert rel_err(unpack(dP, Ca, Cb), Wr.grad) < 2e-5, rel_err(unpack(dP, Ca, Cb), Wr.grad)
+    assert rel_err(db.cpu(), small.double().sum((0, 2, 3))) < 2e-5
+    # data gradient / ConvTranspose2d forward onto the few-channel tensor (fp32 result)
+    assert 'k_conv_bf16x' in op.describe(1, L.IO_SMALL_BF16)[0] and ',3,64>' in op.describe(1, L.IO_SMALL_BF16)[0]
+    bias_b = torch.randn(Cb)
+    lin = torch.nn.grad.conv2d_input((N, Cb, Hb, Wb), Wt.double(), small.double(), stride=s, padding=1) + bias_b.double().view(1, -1, 1, 1)
+    out = empty_view(N, Hb, Wb, Cb, ld=Cb + 4, off=4)
+    op.small2big(vs, P, 0, bias_b.cuda(), 0, out, 3)
+    torch.cuda.synchronize()
+    assert rel_err(out.to_nchw(), torch.tanh(lin)) < 2e-5
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 16, 16), (3, 6, 5, 7), (2, 512, 2, 2), (2, 64, 64, 64), (1, 136, 48, 48)])
 @pytest.mark.parametrize('mix', ['all_bf16', 'y32_out16', 'g16_y32_dy32'])
 def test_instnorm_act_mixed_storage(shape, mix):
