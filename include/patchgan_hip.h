@@ -303,6 +303,10 @@ int pg_nhwc_to_nchw(const float* src, int ld_src, float* dst, int N, int C, int 
 /* dst[pix*ld_dst + c] = src[pix*ld_src + c] for c < C  (channel-slice copy; C need not be a multiple of 4) */
 int pg_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, long npix, int C, void* stream);
 int pg_fill(float* dst, long n, float value, void* stream);
+/* fp32 NHWC channel slice (C <= 8, pixel stride ld_src) -> bf16 tensor in 8-channel pixels (ld 8, channels C..7 zero, 16-byte-aligned
+ * dst): the form in which the PG_ALGO_BF16 kernels take the image-facing tensors (x, x | mask, dL/d(generator output)) -- one 16-byte
+ * LDS-DMA piece per pixel.  pg_conv4x4_big2small / _wgrad with PG_IO_BIG_BF16, Cb <= 8 and ld_big == 8 read that layout. */
+int pg_pad8_bf16(const float* src, int ld_src, void* dst, long npix, int C, void* stream);
 
 /* ---- input pipeline on the device (io.py:42-56: the dataset's `/ 255.` and one-hot mask) ----------------
  * dst[pix*ld_dst + c] = (float)src[pix*C + c] / div : decoded image bytes [npix][C] (HWC) into an NHWC channel slice */

@@ -95,6 +95,7 @@ SIGNATURES = {
     'pg_nhwc_to_nchw': (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     'pg_copy_channels': (_i, [_p, _i, _p, _i, _l, _i, _p]),
     'pg_fill': (_i, [_p, _l, _f, _p]),
+    'pg_pad8_bf16': (_i, [_p, _i, _p, _l, _i, _p]),
     'pg_u8_to_f32': (_i, [_p, _p, _i, _l, _i, _f, _p]),
     'pg_labels_to_onehot': (_i, [_p, _p, _i, _l, _p, _i, _i, _p]),
     'pg_tiles_count': (_i, [_i, _i, _i]),

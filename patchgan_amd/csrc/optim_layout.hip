@@ -98,6 +98,26 @@ __global__ void k_fill(float* __restrict__ dst, long n, float value) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = value;
 }
 
+// fp32 NHWC channel slice (C <= 8 channels, pixel stride ld_src) -> bf16 8-channel pixels: one 16-byte store per pixel, pads zero
+__global__ void k_pad8_bf16(const float* __restrict__ src, int ld_src, unsigned* __restrict__ dst, long npix, int C) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (c < C) ? src[i * ld_src + c] : 0.f;
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bf16x2 h;
+            h[0] = (__bf16)v[2 * k];
+            h[1] = (__bf16)v[2 * k + 1];
+            o[k] = __builtin_bit_cast(unsigned, h);
+        }
+        *reinterpret_cast<u32x4*>(dst + 4 * i) = o;
+    }
+}
+
 int blocks_for(long total) {
     long b = (total + 255) / 256;
     if (b > 8192) b = 8192;
@@ -126,6 +146,12 @@ int pg_nchw_to_nhwc(const float* src, float* dst, int ld_dst, int N, int C, int 
     const long HW = (long)H * W;
     hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(blocks_for((long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, src, dst,
                        ld_dst, N, C, HW);
+    return pg_launch_status();
+}
+
+int pg_pad8_bf16(const float* src, int ld_src, void* dst, long npix, int C, void* stream) {
+    if (!src || !dst || npix <= 0 || C <= 0 || C > 8 || ld_src < C || ((uintptr_t)dst & 15)) return PG_EINVAL;
+    hipLaunchKernelGGL(k_pad8_bf16, dim3(blocks_for(npix)), dim3(256), 0, (hipStream_t)stream, src, ld_src, (unsigned*)dst, npix, C);
     return pg_launch_status();
 }
 

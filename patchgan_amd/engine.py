@@ -49,6 +49,14 @@ class View:
     def ptr(self):
         return self.t.data_ptr() + self.off * (2 if self.bf else 4)
 
+    def padded8(self):
+        """This fp32 view (C <= 8) as a bf16 tensor in 8-channel pixels (ld 8, pad channels zero): the layout in which the bf16
+        kernels take the image-facing tensors (pg_pad8_bf16)."""
+        assert not self.bf and self.C <= 8
+        t = torch.empty(self.npix * 8, dtype=torch.bfloat16, device=self.t.device)
+        L.check(L.load().pg_pad8_bf16(self.ptr(), self.ld, t.data_ptr(), self.npix, self.C, _stream()), 'pg_pad8_bf16')
+        return View(t, 0, 8, self.N, self.H, self.W, self.C, True)
+
     def channels(self, c0, c):
         assert 0 <= c0 and c0 + c <= self.C
         return View(self.t, self.off + c0, self.ld, self.N, self.H, self.W, c, self.bf)
@@ -383,6 +391,7 @@ def conv_instnorm_act(op, opcode, src, flat, p_off, y, out, stats, act, drop_p=0
 FUSE_IN_STATS = os.environ.get('PATCHGAN_FUSE_IN_STATS', '1') != '0'      # A/B switches (same-device timing)
 KEEP_V = os.environ.get('PATCHGAN_KEEP_V', '1') != '0'
 CACHE_U = os.environ.get('PATCHGAN_CACHE_U', '1') != '0'
+SEAM8 = os.environ.get('PATCHGAN_SEAM8', '1') != '0'       # bf16 storage: image-facing tensors in 8-channel bf16 pixels
 
 
 def instnorm_act_bwd(g1, g2, y, stats, dy, act, drop_p=0.0, seed=0):
@@ -624,6 +633,10 @@ class GeneratorEngine:
         # the image-facing tensors (x, enc0's conv output, the generator output and its gradient) stay fp32 and the InstanceNorm /
         # activation kernels next to them read one type and write the other
         bf = c.bf = bool(self.act_bf)
+        # ... unless they fit 8-channel pixels: then x and dL/d(output) are padded to that bf16 layout (one small pass each) and the
+        # first / last layer run on the bf16 kernels as well (SEAM8)
+        seam8 = c.seam8 = bf and SEAM8 and self.nf % 8 == 0 and self.input_nc <= 8 and self.output_nc <= 8
+        c.xin8 = xin.padded8() if seam8 else None
         c.cat = [None] * 7
         for i in range(1, 7):
             op = dec_ops[i]
@@ -631,9 +644,9 @@ class GeneratorEngine:
         c.hidden = View.alloc(N, enc_ops[6].Hs, enc_ops[6].Ws, F[6], dev, bf=bf)
         c.y, c.stats, c.enc_out, c.v = [], [], [], []
         act = L.ACT_CODES[self.activation]
-        src = xin
+        src = c.xin8 if seam8 else xin
         for i, (l, op) in enumerate(zip(self.enc, enc_ops)):
-            y = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=bf and i > 0)
+            y = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=bf and (i > 0 or seam8))
             if i < 6:
                 cat = c.cat[6 - i]
                 out = cat.channels(cat.C - l.a, l.a)
@@ -654,7 +667,9 @@ class GeneratorEngine:
         src = c.hidden
         for i, (l, op) in enumerate(zip(self.dec, dec_ops)):
             if i == 6:
-                src = c.cat6_f32 = src.converted(False)      # the 1..4-channel head runs the fp32 row-GEMM path
+                # the 1..4-channel head: taps folded into N (row GEMM + col2im); fp32 kernels on an fp32 copy of its input, or the
+                # bf16 row GEMM straight from the bf16 tensor
+                src = c.cat6_f32 = src if seam8 else src.converted(False)
                 if self.final_act == 'softmax':
                     c.gen_raw = View.alloc(N, op.Hb, op.Wb, l.b, dev)
                     op.small2big(src, flat, l.p_off, None, 0, c.gen_raw)
@@ -695,7 +710,9 @@ class GeneratorEngine:
         else:
             act_bwd(g1, g2, c.gen_out, dy, L.ACT_CODES[self.final_act])
         bf = c.bf
-        dcat = View.alloc(N, op.Hs, op.Ws, l.a, dev)            # fp32 (the head's kernels); the blocks below read it as is
+        if c.seam8:
+            dy = dy.padded8()
+        dcat = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=c.seam8)  # fp32 with the head's fp32 kernels; the blocks below read it as is
         op.bwd_big(c.cat6_f32, dy, flat, gflat, l.p_off, dcat)    # weight gradient + data gradient of the ConvTranspose2d
         done(l)
         dskip = [None] * 7   # dskip[j]: gradient wrt enc_j output arriving through the skip connection
@@ -720,11 +737,11 @@ class GeneratorEngine:
         dx = None
         for j in range(6, -1, -1):
             l, op = self.enc[j], enc_ops[j]
-            dy = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=bf and j > 0)
+            dy = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=bf and (j > 0 or c.seam8))
             drop = 0.2 if (c.train and l.dropout) else 0.0
             instnorm_act_bwd(g_main, dskip[j] if j < 6 else None, c.y[j], c.stats[j], dy, act, drop,
                              _shift_seed(_mix_seed(c.seed, 1, j), c.sample0 * dy.HW * dy.C))
-            src = c.xin if j == 0 else c.enc_out[j - 1]
+            src = (c.xin8 if c.seam8 else c.xin) if j == 0 else c.enc_out[j - 1]
             op.wgrad(dy, src, gflat, l.p_off, v_pre=c.v[j] if ConvOp._aligned(dy, src) else None)
             done(l)
             if j > 0 or need_dx:
@@ -826,12 +843,14 @@ class DiscriminatorEngine:
         # layer's conv output (4-channel input: generic kernel) and the 1-channel head stay fp32
         bf = c.bf = bool(self.act_bf)
         last = len(self.layers) - 1
-        src = din
+        # the input in 8-channel bf16 pixels where it fits: the first layer then runs on the bf16 kernels too (GeneratorEngine.forward)
+        seam8 = c.seam8 = bf and SEAM8 and self.ndf % 8 == 0 and self.input_nc <= 8 and last > 0
+        src = din.padded8() if seam8 else din
         for li, (l, op) in enumerate(zip(self.layers, ops)):
             if li == last:
                 src = src.converted(False)
             c.src.append(src)
-            t = View.alloc(din.N, op.Hs, op.Ws, l.a, dev, bf=bf and 0 < li < last)
+            t = View.alloc(din.N, op.Hs, op.Ws, l.a, dev, bf=bf and (0 < li < last or (li == 0 and seam8)))
             bias = flat if l.bias_key is not None else None
             u, uv = self._ucache(ucache, li, 0, op, dev, src, t)
             vb = op.v_bytes() if (keep_v and KEEP_V and ConvOp._aligned(src, t)) else 0
@@ -843,7 +862,7 @@ class DiscriminatorEngine:
                 stats = torch.empty(din.N * l.a * 2, dtype=torch.float32, device=dev)
                 instnorm_act_fwd(t, a, stats, L.ACT_NONE)
             else:
-                if bf and li == 0:
+                if bf and li == 0 and not seam8:
                     t = t.converted(True)          # the next layer's kernel reads bf16
                 a, stats = t, None
             c.t.append(t)
@@ -863,7 +882,7 @@ class DiscriminatorEngine:
         bf, last = c.bf, len(self.layers) - 1
         for li in range(last, -1, -1):
             l, op = self.layers[li], ops[li]
-            inner = bf and 0 < li < last
+            inner = bf and (0 < li < last or (li == 0 and c.seam8))
             if l.norm:
                 dt = View.alloc(c.N, op.Hs, op.Ws, l.a, dev, bf=inner)
                 instnorm_act_bwd(g, None, c.t[li], c.stats[li], dt, L.ACT_NONE)
