@@ -74,10 +74,13 @@ extern "C" {
 #define PG_TUNE_BF16X_FLAT 0x8000 /* ... one LDS buffer of 64-wide K chunks */
 
 /* bf16 activation storage on the PG_ALGO_BF16 kernels: OR-ed into `algo` like the PG_TUNE_* bits.  The tensor named carries bf16
- * elements (NHWC, `ld` in bf16 elements, 8-byte-aligned base); weights, biases, weight gradients and split-K slabs stay fp32.
+ * elements (NHWC, `ld` in bf16 elements, 8-byte-aligned base; 16-byte-aligned base and ld % 8 == 0 for the LDS-DMA kernels); weights,
+ * biases, weight gradients and split-K slabs stay fp32.
  * pg_conv4x4_big2small: BIG = input, SMALL = output; pg_conv4x4_small2big: SMALL = input, BIG = output; pg_conv4x4_wgrad: both
- * or neither (no dbias).  Honoured on the fast bf16 kernels only (channels % 4 == 0 and >= 32 on the input side); any other
- * path returns PG_EINVAL. */
+ * or neither (dbias allowed with Ca % 4 == 0).  Honoured where a bf16 kernel covers the call -- input channels % 4 == 0 and >= 32 (the
+ * register-staged kernels), % 64 == 0 (the LDS-DMA kernels of conv_bf16.hip), or a <= 8-channel `big` in 8-channel pixels (ld_big == 8,
+ * pad channels zero: pg_pad8_bf16); pg_conv4x4_small2big onto <= 8 channels takes PG_IO_SMALL_BF16 alone and writes fp32.  Any other
+ * combination returns PG_EINVAL. */
 #define PG_IO_BIG_BF16 0x10000
 #define PG_IO_SMALL_BF16 0x20000
 #define PG_IO_MASK 0x30000
