@@ -169,7 +169,15 @@ typedef struct pg_conv_extras {
     const float* v_pre;
     float* u_cache;
     int u_valid;
+    /* small2big as a data gradient: out = conv(...) * f'(t), the activation backward of the layer BELOW folded into the epilogue
+     * (trainer.py:89,106: autograd's TanhBackward / LeakyReluBackward between two ConvolutionBackward nodes).  mul_t = that layer's
+     * activation OUTPUT [pixels of big][Cb], pixel stride mul_ld, storage type of `big`; mul_act = its PG_ACT_* (the derivative is
+     * expressed through the output).  Honoured where pg_conv_mul_ok() != 0; elsewhere PG_EINVAL. */
+    const void* mul_t;
+    int mul_ld;
+    int mul_act;
 } pg_conv_extras;
+int pg_conv_mul_ok(const pg_conv_geom* g, int algo, size_t ws_bytes);   /* small2big: the kernel of this call can apply mul_t */
 int pg_conv_stats_chunks(const pg_conv_geom* g, int op, int algo, size_t ws_bytes);   /* op 0 big2small, 1 small2big */
 size_t pg_conv_u_bytes(const pg_conv_geom* g, int op, int algo, size_t ws_bytes);      /* op 0 big2small, 1 small2big */
 size_t pg_conv_v_bytes(const pg_conv_geom* g, int algo, size_t ws_bytes);              /* big2small forward -> wgrad */

@@ -48,7 +48,7 @@ _G = ctypes.POINTER(ConvGeom)
 class ConvExtras(ctypes.Structure):
     """struct pg_conv_extras: optional hand-overs between calls on the same layer"""
     _fields_ = [('part', ctypes.c_void_p), ('v_keep', ctypes.c_void_p), ('v_pre', ctypes.c_void_p), ('u_cache', ctypes.c_void_p),
-                ('u_valid', ctypes.c_int)]
+                ('u_valid', ctypes.c_int), ('mul_t', ctypes.c_void_p), ('mul_ld', ctypes.c_int), ('mul_act', ctypes.c_int)]
 
 
 _X = ctypes.POINTER(ConvExtras)
@@ -58,6 +58,7 @@ SIGNATURES = {
     'pg_version': (_i, []),
     'pg_conv_workspace_bytes': (_sz, [_G, _i]),
     'pg_conv_describe': (_i, [_G, _i, _sz, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_l)]),
+    'pg_conv_mul_ok': (_i, [_G, _i, _sz]),
     'pg_conv_kernel': (_i, [_G, _i, _sz, ctypes.c_char_p, _sz, ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double)]),
     'pg_conv_time_next': (_i, [_p, _p]),
     'pg_conv_time_next2': (_i, [_p, _p, _p, _p]),

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "pg_common.h"
 
 // direction: 0 = big -> small (Conv2d forward / ConvTranspose2d data gradient), 1 = small -> big,
 // 2 = big -> small from an 8-channel-per-pixel `big` (Cb <= 8 real channels, ld 8: the image-facing layers),
@@ -35,7 +36,7 @@ int pg_bf16x_pack(const float* P, void* W, int Ca, int Cb, int dir, hipStream_t 
 // [split][pixels][Cout] for the caller's reduce pass
 int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void* W, void* out, int ld_out, long slab_stride,
                   int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, const pg_bf16x_plan* p, const float* bias,
-                  int act, int out_bf, hipStream_t st);
+                  int act, int out_bf, hipStream_t st, pg_epi_mul mul = pg_epi_mul{nullptr, 0, 0});
 
 // weight gradient on bf16 tensors (both operands), k_wgrad_bf16x: out = dP (slab_stride == 0, split 1) or fp32 slabs
 // [split][16 * Ca * Cb].  The plan's tile / tiles_m / tiles_n are over (Ca, Cb), nchunks in 64-pixel chunks.

@@ -65,10 +65,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 //          cover each other's DMA phase.
 // KB = 32: a ring of three stages of 64-byte rows: chunk c + 2 is in flight while chunk c is multiplied, one barrier per chunk,
 //          counted vmcnt (never 0 in the loop).
-template <int MR, int NR, int WM, int WN, int DRC, int KB>
+// MUL: the epilogue also multiplies by f'(t) (pg_epi_mul: the activation backward of the layer below a data gradient) -- its own
+// instantiation with unconditional, clamped loads of t (a conditional load inside the unrolled epilogue sends the accumulators to scratch)
+template <int MR, int NR, int WM, int WN, int DRC, int KB, bool MUL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv_bf16x(
     const __bf16* __restrict__ in, int ld_in, const __bf16* __restrict__ W, void* __restrict__ out, int ld_out, long slab_stride, XGeom g,
-    int cps, const float* __restrict__ bias, int act, int in_bytes, int w_bytes, int out_bf, int tiles_n) {
+    int cps, const float* __restrict__ bias, int act, int in_bytes, int w_bytes, int out_bf, int tiles_n, pg_epi_mul mul) {
     static_assert(WM * WN == 4, "four waves");
     static_assert(KB == 32 || KB == 64, "chunk width");
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
@@ -265,17 +267,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
         const int m = m0 + (wm * MR + i) * 32 + lrow;
-        long orow;
+        long opix;
         if (B2S) {
-            orow = (long)m * ldo;
+            opix = m;
         } else {
             const int mm = min(m, Mc - 1);
             const int n = mm / (Hc * Wc);
             const int rem = mm - n * (Hc * Wc);
             const int ii = rem / Wc, jj = rem - ii * Wc;
             const int h = (g.s == 2) ? 2 * ii + ah : ii, w = (g.s == 2) ? 2 * jj + aw : jj;
-            orow = (long)((n * g.Hb + h) * g.Wb + w) * ldo;
+            opix = (long)((n * g.Hb + h) * g.Wb + w);
         }
+        const long orow = opix * ldo;
         const bool mok = m < Mc;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
@@ -290,6 +293,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int e = 0; e < 4; ++e) {
                     const float x = acc[i][j][4 * q + e];
                     v[q][e] = fin ? act_epi(x + bv[e], act) : x;
+                }
+                if constexpr (MUL) {           // data gradient times the activation derivative of the layer below (t: its output)
+                    const long tidx = (mok ? opix : 0L) * mul.ld + min(ch, Cout - 4);
+                    f32x4 tv;
+                    if (obf) {
+                        const u32x2 h = *reinterpret_cast<const u32x2*>((const char*)mul.t + tidx * 2);
+                        tv = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
+                                   __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
+                    } else {
+                        tv = *reinterpret_cast<const f32x4*>((const char*)mul.t + tidx * 4);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[q][e] *= pg_act_grad_sel(tv[e], mul.act);
                 }
             }
             if (obf) {
@@ -617,7 +633,7 @@ int pg_bf16x_pack(const float* P, void* W, int Ca, int Cb, int dir, hipStream_t 
 
 int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void* W, void* out, int ld_out, long slab_stride,
                   int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, const pg_bf16x_plan* p, const float* bias,
-                  int act, int out_bf, hipStream_t st) {
+                  int act, int out_bf, hipStream_t st, pg_epi_mul mul) {
     const XGeom g{N, Hb, Wb, Hs, Ws, Ca, Cb, stride};
     const dim3 grid((unsigned)(p->tiles_m * p->tiles_n), 1, (unsigned)(p->ncls * p->split));
     const int w_bytes = (dir == 2) ? 16 * Ca * 8 * 2 : (dir == 3) ? Ca * Cb * 2 : 16 * Ca * Cb * 2;
@@ -625,11 +641,15 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
     const __bf16* Wp = (const __bf16*)W;
 #define PG_BF16X_LAUNCH1(MR, NR, WM, WN, D, KB)                                                                              \
     hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB>), grid, dim3(256), 0, st, I, ld_in, Wp, out, ld_out, slab_stride, g, \
-                       p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n)
+                       p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul)
+#define PG_BF16X_LAUNCHM(MR, NR, WM, WN)                                                                                     \
+    hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, 1, 64, true>), grid, dim3(256), 0, st, I, ld_in, Wp, out, ld_out, slab_stride, g, \
+                       p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul)
 #define PG_BF16X_LAUNCH(MR, NR, WM, WN)                                                                                      \
     do {                                                                                                                     \
         if (dir == 0 && !p->ring) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 0, 64);                                                   \
         else if (dir == 0) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 0, 32);                                                          \
+        else if (dir == 1 && mul.t) PG_BF16X_LAUNCHM(MR, NR, WM, WN);                                                        \
         else if (dir == 1 && !p->ring) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 1, 64);                                              \
         else if (dir == 1) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 1, 32);                                                          \
         else if (dir == 2) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 2, 64);                                                          \
@@ -642,6 +662,7 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
     }
 #undef PG_BF16X_LAUNCH
 #undef PG_BF16X_LAUNCH1
+#undef PG_BF16X_LAUNCHM
     return pg_launch_status();
 }
 

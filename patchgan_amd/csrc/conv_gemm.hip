@@ -2132,7 +2132,7 @@ __global__ void k_slab_reduce(const float* __restrict__ slabs, long slab_stride,
 }
 
 __global__ void k_slab_reduce4(const float* __restrict__ slabs, long slab_stride, int S, float* __restrict__ out,
-                               int ld_out, long rows, int cols, const float* __restrict__ bias, int act, int out_bf) {
+                               int ld_out, long rows, int cols, const float* __restrict__ bias, int act, int out_bf, pg_epi_mul mul) {
     const int cq = cols >> 2;
     const long total = rows * cq;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -2152,6 +2152,17 @@ __global__ void k_slab_reduce4(const float* __restrict__ slabs, long slab_stride
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = pg_act_epi(v[e], act);
+        if (mul.t) {
+            f32x4 tv;
+            if (out_bf) {
+                const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(mul.t) + r * mul.ld + c);
+                tv = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+            } else {
+                tv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(mul.t) + r * mul.ld + c);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= pg_act_grad_from_out(tv[e], mul.act);
+        }
         if (out_bf)
             *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + r * ld_out + c) = to_bf16(v);
         else
@@ -2499,8 +2510,8 @@ void clamp_split(Plan& p, size_t ws_bytes, size_t reserved) {
 }
 
 int launch_reduce(const float* slabs, long slab_stride, int S, float* out, int ld_out, long rows, int cols,
-                  const float* bias, int act, hipStream_t st, int out_bf = 0) {
-    if (S >= 64 && !bias && act == PG_ACT_NONE && rows * cols <= (1L << 22) && !out_bf) {
+                  const float* bias, int act, hipStream_t st, int out_bf = 0, pg_epi_mul mul = pg_epi_mul{nullptr, 0, 0}) {
+    if (S >= 64 && !bias && act == PG_ACT_NONE && rows * cols <= (1L << 22) && !out_bf && !mul.t) {
         const long total = rows * cols;
         hipLaunchKernelGGL(k_slab_reduce_z, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, slabs, slab_stride, S, out,
                            ld_out, rows, cols);
@@ -2512,9 +2523,10 @@ int launch_reduce(const float* slabs, long slab_stride, int S, float* out, int l
         int blocks = (int)std::min<long>((total4 + 255) / 256, 16384);
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(k_slab_reduce4, dim3(blocks), dim3(256), 0, st, slabs, slab_stride, S, out, ld_out, rows, cols,
-                           bias, act, out_bf);
+                           bias, act, out_bf, mul);
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
+    if (mul.t) return PG_EINVAL;       // (the callers that pass a multiplier satisfy the alignment of the vector form)
     const long total = rows * cols;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -2719,6 +2731,8 @@ inline bool aligned_bf_view(const void* p, int ld, bool bf) {
 constexpr int BF16X_SKIP = -1000;
 int bf16x_run(int dir, const void* in, int ld_in, const float* P, const float* bias, void* out, int ld_out, const Geom& g, int act,
               bool out_bf, void* ws, size_t ws_bytes, hipStream_t st, const pg_conv_extras& x, int ring) {
+    const pg_epi_mul mul{x.mul_t, x.mul_ld, x.mul_act};
+    if (mul.t && (dir != 1 || (reinterpret_cast<uintptr_t>(mul.t) & 15) || mul.ld % (out_bf ? 8 : 4))) return PG_EINVAL;
     if (dir == 0 && g.Cb <= 8) {       // few-channel big: only in 8-channel pixels (16 bytes = one DMA piece per pixel)
         if (ld_in != 8) return BF16X_SKIP;
         dir = 2;
@@ -2750,13 +2764,13 @@ int bf16x_run(int dir, const void* in, int ld_in, const float* P, const float* b
         TimedLaunch timed(st);
         if (p.split == 1)
             rc = pg_bf16x_conv(dir, in, ld_in, in_bytes, W, out, ld_out, 0L, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, &p, bias, act,
-                               out_bf ? 1 : 0, st);
+                               out_bf ? 1 : 0, st, mul);
         else
             rc = pg_bf16x_conv(dir, in, ld_in, in_bytes, W, rest, Cout, p.out_elems, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, &p,
                                nullptr, 0, 0, st);
     }
     if (rc != PG_OK || p.split == 1) return rc;
-    return launch_reduce((const float*)rest, p.out_elems, p.split, (float*)out, ld_out, out_pix, Cout, bias, act, st, out_bf ? 1 : 0);
+    return launch_reduce((const float*)rest, p.out_elems, p.split, (float*)out, ld_out, out_pix, Cout, bias, act, st, out_bf ? 1 : 0, mul);
 }
 
 }  // namespace
@@ -3003,7 +3017,7 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     return PG_OK;
 }
 
-static const pg_conv_extras NO_EXTRAS = {nullptr, nullptr, nullptr, nullptr, 0};
+static const pg_conv_extras NO_EXTRAS = {nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
 
 static int b2s_impl(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small,
                     const pg_conv_geom* gg, int act, int algo, void* ws, size_t ws_bytes, void* stream, const pg_conv_extras* xp) {
@@ -3153,6 +3167,8 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
     const pg_conv_extras& x = xp ? *xp : NO_EXTRAS;
     double* part = x.part;
     if ((x.u_cache && !aligned16(x.u_cache)) || x.v_keep || x.v_pre) return PG_EINVAL;
+    const pg_epi_mul mul{x.mul_t, x.mul_ld, x.mul_act};
+    if (mul.t && (mul.ld < gg->Cb || mul.act < PG_ACT_NONE || mul.act > PG_ACT_SIGMOID || part)) return PG_EINVAL;
     if (!geom_ok(gg) || !big || !P || !small || ld_big < gg->Cb || ld_small < gg->Ca) return PG_EINVAL;
     if (act < PG_ACT_NONE || act > PG_ACT_SIGMOID) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -3162,6 +3178,7 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
     algo &= PG_ALGO_MASK;
     if (io && algo != PG_ALGO_BF16) return PG_EINVAL;
     if (algo == PG_ALGO_DIRECT) {
+        if (mul.t) return PG_EINVAL;
         const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
         int blocks = (int)std::min<long>((total + 255) / 256, 65536);
         hipLaunchKernelGGL(k_small2big_direct, dim3(blocks), dim3(256), 0, st, small, ld_small, P, bias, big, ld_big, g,
@@ -3173,10 +3190,11 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         ws_bytes >= pg_wino_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1) &&
         pg_wino_eligible(g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, ld_small, small, tune.mo1)) {
         if (part) return PG_EINVAL;
+        if (mul.t && (!aligned16(mul.t) || mul.ld % 4)) return PG_EINVAL;
         int rc = pg_wino_prepare(small, ld_small, P, 1, g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, 2, ws, st, tune.mo1, x.u_cache, x.u_valid);
         if (rc != PG_OK) return rc;
         TimedLaunch timed(st);
-        return pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st, tune.mo1, tune.dma, x.u_cache);
+        return pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st, tune.mo1, tune.dma, x.u_cache, mul);
     }
     if (algo == PG_ALGO_AUTO && wino2_s2b_ok(g, tune) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
         aligned16(small) && aligned16(ws) && (!bias || aligned16(bias)) &&
@@ -3185,10 +3203,11 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         t_ev0 = nullptr;
         t_ev1 = nullptr;
         if (part && pg_wino2_s2b_stats_chunks(g.N, g.Hb, g.Wb, g.Cb) == 0) return PG_EINVAL;
+        if (mul.t && (!aligned16(mul.t) || mul.ld % 4)) return PG_EINVAL;
         return pg_wino2_s2b(small, ld_small, P, bias, big, ld_big, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, part,
-                            x.u_cache, x.u_valid);
+                            x.u_cache, x.u_valid, mul);
     }
-    if (bf16x_s2b_tapn_ok(g, algo | io, tune) && !part && !x.u_cache && ws && aligned16(ws) && ws_bytes >= bf16x_s2b_tapn_ws(g) &&
+    if (bf16x_s2b_tapn_ok(g, algo | io, tune) && !part && !x.u_cache && !mul.t && ws && aligned16(ws) && ws_bytes >= bf16x_s2b_tapn_ws(g) &&
         aligned_bf_view(small, ld_small, true) && aligned16(P) &&
         tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca, true) < FAST_LIMIT) {
         // D[small pixel][(tap, b)] = small . W' (bf16 row GEMM), then col2im: each big pixel sums the taps that reach it
@@ -3213,7 +3232,7 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         const int rc = bf16x_run(1, small, ld_small, P, bias, big, ld_big, g, act, io & PG_IO_BIG_BF16, ws, ws_bytes, st, x, tune.bf16ring);
         if (rc != BF16X_SKIP) return rc;
     }
-    if (part || x.u_cache) return PG_EINVAL;
+    if (part || x.u_cache || mul.t) return PG_EINVAL;
     if (!io && s2b_tapn_ok(g) && (ld_small % 4 == 0) && aligned16(small) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= s2b_tapn_ws(g) && tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT) {
         // D[small pixel][(tap, b)] = small . W' (row GEMM), then col2im: each big pixel sums the taps that reach it
@@ -3316,6 +3335,20 @@ size_t pg_conv_u_bytes(const pg_conv_geom* gg, int op, int algo, size_t ws_bytes
         return pg_wino_u_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1);
     if (wino2_s2b_ok(g, tune) && ws_bytes >= pg_wino2c_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb)) return pg_wino2_u_bytes(g.Ca, g.Cb);
     return 0;
+}
+
+int pg_conv_mul_ok(const pg_conv_geom* gg, int algo, size_t ws_bytes) {
+    if (!geom_ok(gg)) return 0;
+    const Geom g = to_geom(gg);
+    const Tune tune = tune_of(algo);
+    // mirrors the dispatch of s2b_impl for 16-byte-aligned tensors
+    if ((algo & PG_ALGO_MASK) == PG_ALGO_AUTO) {
+        if (wino_s2b_ok(g, tune) && ws_bytes >= pg_wino_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1)) return 1;
+        if (wino2_s2b_ok(g, tune) && ws_bytes >= pg_wino2c_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb)) return 1;
+        return 0;
+    }
+    if (bf16x_s2b_tapn_ok(g, algo, tune) && ws_bytes >= bf16x_s2b_tapn_ws(g)) return 0;
+    return bf16x_ok(g, 1, algo, tune) && ws_bytes >= bf16x_ws(g, 1) ? 1 : 0;
 }
 
 size_t pg_conv_v_bytes(const pg_conv_geom* gg, int algo, size_t ws_bytes) {

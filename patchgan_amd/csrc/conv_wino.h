@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "pg_common.h"
+
 
 // geometry + alignment gate; (in, out) = (big, small) forward, (small, big) data gradient
 // mo_forced: 0 = tile-edge heuristic, 2 / 3 = F(2x2,4x4) / F(3x3,4x4) pinned (PG_TUNE_WINO1_F2 / _F3)
@@ -23,7 +25,7 @@ size_t pg_wino2_u_bytes(int Ca, int Cb);     // both polyphase directions
 int pg_wino_dma_mode();   // process default (PATCHGAN_WINO_DMA): 0 register-staged k_wino_gemm only, 1: k_wino_gemm_dma<3,4,2> for F(3x3,4x4), 2: also <2,3,3> for 64-tile F(2x2,4x4)
 // the batched GEMM with fused output transform, bias and activation
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
-                 void* ws, hipStream_t st, int mo_forced, int dma_mode, const float* Uext);
+                 void* ws, hipStream_t st, int mo_forced, int dma_mode, const float* Uext, pg_epi_mul mul = pg_epi_mul{nullptr, 0, 0});
 
 // weight gradient of the same layers, F(4x4, 2x2): V (25*tiles*Cb) | DY (25*tiles*Ca) | S (slices*25*Ca*Cb) in ws
 bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
@@ -59,7 +61,7 @@ bool pg_wino2c_geom_ok(int N, int Hb, int Wb, int Ca, int Cb);
 size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb);
 int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                 double* part, float* Uext, int u_valid);
+                 double* part, float* Uext, int u_valid, pg_epi_mul mul = pg_epi_mul{nullptr, 0, 0});
 
 // weight gradient of the stride-2 layers, polyphase F(2x2, 3x3): V (16*tiles*4Cb) | DY (16*tiles*Ca) | S (slices*16*Ca*4Cb)
 bool pg_wino2_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);

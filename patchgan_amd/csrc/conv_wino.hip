@@ -157,11 +157,13 @@ __global__ __launch_bounds__(256) void k_wino_v(const float* __restrict__ in, in
 
 // 25 row GEMMs + fused output transform.  Workgroup = 4 waves (2 x 2), tile = 128 Winograd tiles x 64 output channels,
 // each wave 64 x 32 (two 32x32 MFMA tiles).  Requires Ci % 32 == 0.
-template <int MR, int NR, int WM, int WN, int WPE, int MO>
+// MUL: the epilogue also multiplies by f'(t) (pg_epi_mul) -- a separate instantiation, with unconditional (clamped) loads of t: a
+// conditional load inside the fully unrolled epilogue sends the accumulator arrays to scratch memory
+template <int MR, int NR, int WM, int WN, int WPE, int MO, bool MUL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_gemm(const float* __restrict__ V, const float* __restrict__ U,
                                                    const float* __restrict__ bias, float* __restrict__ out, int ld_out,
                                                    int T, int Ci, int Co, int TH, int TW, int Hout, int Wout, int act,
-                                                   int v_bytes, int u_bytes, int tiles_n) {
+                                                   int v_bytes, int u_bytes, int tiles_n, pg_epi_mul mul) {
     static_assert(NR == 1 && WM * WN == 4, "one 32-column MFMA tile per wave");
     constexpr int NP = MO + 3, NXI = NP * NP, NY = MO * MO;      // points, products, outputs per tile
     // K chunk: 64 floats for the F(3x3,4x4) instance (its workgroup tile is only 64 x 64: twice the MFMAs per barrier pair)
@@ -287,6 +289,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int m = m0 + (wm * MR + i) * 32 + row;
+            float tm[MUL ? NY : 1];
+            if constexpr (MUL) {               // every lane loads (clamped address), the store below stays conditional
+                const int mc = min(m, T - 1), colc = min(col, Co - 1);
+                const int n = mc / (TH * TW);
+                const int rem = mc - n * (TH * TW);
+                const int ti = rem / TW, tj = rem - ti * TW;
+#pragma unroll
+                for (int p = 0; p < NY; ++p) {
+                    const int y = min(MO * ti + p / MO, Hout - 1), x = min(MO * tj + p % MO, Wout - 1);
+                    tm[p] = pg_act_grad_sel(((const float*)mul.t)[((long)(n * Hout + y) * Wout + x) * mul.ld + colc], mul.act);
+                }
+            }
             if (m < T && col < Co) {
                 const int n = m / (TH * TW);
                 const int rem = m - n * (TH * TW);
@@ -294,8 +308,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
                 for (int p = 0; p < NY; ++p) {
                     const int y = MO * ti + p / MO, x = MO * tj + p % MO;
-                    if (y < Hout && x < Wout)
-                        out[((long)(n * Hout + y) * Wout + x) * ld_out + col] = act_epi(accy[p][i][r] + bv, act);
+                    if (y < Hout && x < Wout) {
+                        float v = act_epi(accy[p][i][r] + bv, act);
+                        if constexpr (MUL) v *= tm[p];
+                        out[((long)(n * Hout + y) * Wout + x) * ld_out + col] = v;
+                    }
                 }
             }
         }
@@ -961,7 +978,8 @@ __global__ __launch_bounds__(256) void k_wino_bgemm_mz(const float* __restrict__
 template <int MO, bool STATS = false>
 __device__ __forceinline__ void wino2_out_tile(const float* __restrict__ M, long zstride, long mbase, const float* __restrict__ bias,
                                                float* __restrict__ out, int ld_out, int n, int H, int W, int oy, int ox, int st,
-                                               int c0, int act, double* s1 = nullptr, double* s2 = nullptr) {
+                                               int c0, int act, double* s1 = nullptr, double* s2 = nullptr,
+                                               pg_epi_mul mul = pg_epi_mul{nullptr, 0, 0}) {
     constexpr int NP = MO + 1;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     f32x4 t[MO][NP];
@@ -990,6 +1008,11 @@ __device__ __forceinline__ void wino2_out_tile(const float* __restrict__ M, long
             for (int j = 0; j < NP; ++j) v += t[k][j] * w_at<MO>(l, j);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_epi(v[e], act);
+            if (mul.t) {        // data gradient: times the previous layer's activation derivative, expressed through its output t
+                const f32x4 tv = *reinterpret_cast<const f32x4*>((const float*)mul.t + ((long)(n * H + y) * W + x) * mul.ld + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= pg_act_grad_from_out(tv[e], mul.act);
+            }
             if (STATS) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1132,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_wino2c_v(const float* __restrict__ smal
 template <int MO>
 __global__ __launch_bounds__(256) void k_wino2c_out(const float* __restrict__ M, const float* __restrict__ bias,
                                                     float* __restrict__ out, int ld_out, int N, int Hb, int Wb, int Cb, int TH,
-                                                    int TW, int act) {
+                                                    int TW, int act, pg_epi_mul mul) {
     const int cq = Cb >> 2;
     const long T = (long)N * TH * TW;
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -1147,7 +1170,7 @@ __global__ __launch_bounds__(256) void k_wino2c_out(const float* __restrict__ M,
     const int ti = rem / TW, tj = rem - ti * TW;
     // class plane index i = MO*ti - r + al  ->  big row 2*i + r = 2*MO*ti - r + 2*al
     wino2_out_tile<MO>(M, 4L * T * Cb, tile * 4L * Cb + cls * Cb + c0, bias, out, ld_out, n, Hb, Wb, 2 * MO * ti - r,
-                       2 * MO * tj - sc, 2, c0, act);
+                       2 * MO * tj - sc, 2, c0, act, nullptr, nullptr, mul);
 }
 
 // grid (chunks, N): the same transform + per-sample partial sums of the output (see stats_block_reduce)
@@ -1343,7 +1366,7 @@ int pg_wino_dma_mode() {
 }
 
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
-                 void* ws, hipStream_t st, int forced, int dma_mode, const float* Uext) {
+                 void* ws, hipStream_t st, int forced, int dma_mode, const float* Uext, pg_epi_mul mul) {
     const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
     const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
     const float* U = Uext ? Uext : (const float*)ws;
@@ -1351,14 +1374,28 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
     const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cin, Cout, forced);
     const int v_bytes = (int)(X * T * Cin * 4), u_bytes = (int)(X * Cout * Cin * 4);
     const int tn = (Cout + 63) / 64;
-    if (mo == 3 && dma_mode) {
+    if (mul.t) {                       // the register-staged kernels' MUL instantiations
+        if (mo == 3) {
+            dim3 grid((unsigned)(((T + 63) / 64) * tn));
+            hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 2, 3, true>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
+                               TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul);
+        } else if (small_tile) {
+            dim3 grid((unsigned)(((T + 63) / 64) * tn));
+            hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 4, 2, true>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
+                               TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul);
+        } else {
+            dim3 grid((unsigned)(((T + 127) / 128) * tn));
+            hipLaunchKernelGGL((k_wino_gemm<2, 1, 2, 2, 2, 2, true>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
+                               TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul);
+        }
+    } else if (mo == 3 && dma_mode) {
         dim3 grid((unsigned)(((T + 63) / 64) * tn));
         hipLaunchKernelGGL((k_wino_gemm_dma<3, 4, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH, TW,
                            Hout, Wout, act, v_bytes, u_bytes, tn);
     } else if (mo == 3) {
         dim3 grid((unsigned)(((T + 63) / 64) * tn));
         hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 2, 3>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
-                           TW, Hout, Wout, act, v_bytes, u_bytes, tn);
+                           TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul);
     } else if (small_tile && dma_mode == 2) {
         dim3 grid((unsigned)(((T + 63) / 64) * tn));
         hipLaunchKernelGGL((k_wino_gemm_dma<2, 3, 3>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH, TW,
@@ -1366,11 +1403,11 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
     } else if (small_tile) {
         dim3 grid((unsigned)(((T + 63) / 64) * tn));
         hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 4, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
-                           TW, Hout, Wout, act, v_bytes, u_bytes, tn);
+                           TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul);
     } else {
         dim3 grid((unsigned)(((T + 127) / 128) * tn));
         hipLaunchKernelGGL((k_wino_gemm<2, 1, 2, 2, 2, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
-                           TW, Hout, Wout, act, v_bytes, u_bytes, tn);
+                           TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul);
     }
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
@@ -1592,7 +1629,7 @@ size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb) {
 template <int MO>
 static int wino2_s2b_run(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N,
                          int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0,
-                         hipEvent_t ev1, double* part, float* Uext, int u_valid) {
+                         hipEvent_t ev1, double* part, float* Uext, int u_valid, pg_epi_mul mul) {
     constexpr int X = (MO + 1) * (MO + 1);
     const int TH = ((Hb + 1) / 2 + 1 + MO - 1) / MO, TW = ((Wb + 1) / 2 + 1 + MO - 1) / MO, NC = 4 * Cb;
     const long T = (long)N * TH * TW;
@@ -1630,16 +1667,17 @@ static int wino2_s2b_run(const float* small, int ld_small, const float* P, const
                            big, ld_big, N, Hb, Wb, Cb, TH, TW, act, part);
     else
         hipLaunchKernelGGL(k_wino2c_out<MO>, dim3((unsigned)((T * Cb + 255) / 256)), dim3(256), 0, st, M, bias, big, ld_big, N, Hb,
-                           Wb, Cb, TH, TW, act);
+                           Wb, Cb, TH, TW, act, mul);
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
 
 int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                 double* part, float* Uext, int u_valid) {
+                 double* part, float* Uext, int u_valid, pg_epi_mul mul) {
+    if (part && mul.t) return PG_EINVAL;
     if (pg_wino2_mo() == 4)
-        return wino2_s2b_run<4>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part, Uext, u_valid);
-    return wino2_s2b_run<3>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part, Uext, u_valid);
+        return wino2_s2b_run<4>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part, Uext, u_valid, mul);
+    return wino2_s2b_run<3>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part, Uext, u_valid, mul);
 }
 
 // ---- weight gradient of the stride-2 layers (polyphase F(2x2, 3x3)) ----

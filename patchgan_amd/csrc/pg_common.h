@@ -26,6 +26,13 @@ __device__ __forceinline__ float pg_act_grad_from_out(float a, int act) {
     }
 }
 
+// the same values without a switch (selects only): for epilogues unrolled over many accumulators, where branches cost registers
+__device__ __forceinline__ float pg_act_grad_sel(float a, int act) {
+    const float pw = a > 0.f ? 1.f : (act == PG_ACT_LEAKY ? 0.2f : 0.f);
+    const float sm = act == PG_ACT_TANH ? 1.f - a * a : a * (1.f - a);
+    return act == PG_ACT_NONE ? 1.f : ((act == PG_ACT_LEAKY || act == PG_ACT_RELU) ? pw : sm);
+}
+
 // Counter-based dropout RNG: keep element e of stream `seed` iff a 64-bit mix of (seed, e) maps to u >= p.
 __device__ __forceinline__ uint64_t pg_mix64(uint64_t x) {
     x ^= x >> 30;
@@ -48,5 +55,13 @@ __device__ __forceinline__ int pg_xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
+
+// optional last step of a data-gradient epilogue: out *= f'(t[pixel * ld + c]), f' expressed through the activation OUTPUT t
+// (pg_act_grad_from_out) -- the standalone activation-backward pass folded into the kernel that produces its input.  t == nullptr: none.
+// t has the storage type of the output tensor.
+struct pg_epi_mul {
+    const void* t;
+    int ld, act;
+};
 
 static inline int pg_launch_status() { return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH; }

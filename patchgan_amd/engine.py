@@ -279,11 +279,23 @@ class ConvOp:
         return self._query(('v',), lambda: L.load().pg_conv_v_bytes(ctypes.byref(self.g), self.algo, max(self.ws_bytes, 1 << 20)))
 
     @staticmethod
-    def _extras(part=None, v_keep=None, v_pre=None, u_cache=None, u_valid=False):
-        if part is None and v_keep is None and v_pre is None and u_cache is None:
+    def _extras(part=None, v_keep=None, v_pre=None, u_cache=None, u_valid=False, mul=None):
+        if part is None and v_keep is None and v_pre is None and u_cache is None and mul is None:
             return None
         p = lambda t: t.data_ptr() if t is not None else None
-        return L.ConvExtras(p(part), p(v_keep), p(v_pre), p(u_cache), 1 if u_valid else 0)
+        mt, ml, ma = (mul[0].ptr(), mul[0].ld, mul[1]) if mul is not None else (None, 0, 0)
+        return L.ConvExtras(p(part), p(v_keep), p(v_pre), p(u_cache), 1 if u_valid else 0, mt, ml, ma)
+
+    def mul_ok(self, small, big, t):
+        """small2big(small -> big) can fold `big *= f'(t)` into its epilogue (pg_conv_extras.mul_t): the kernel of this call supports
+        it and the tensors satisfy its alignment; t must have big's shape and storage type."""
+        if t.bf != big.bf or (t.N, t.H, t.W, t.C) != (big.N, big.H, big.W, big.C):
+            return False
+        if not all(v.ptr() % 16 == 0 and v.ld % (8 if v.bf else 4) == 0 for v in (small, big, t)):
+            return False
+        io = self._io(big, small)
+        return bool(self._query(('mul', io), lambda: L.load().pg_conv_mul_ok(ctypes.byref(self.g), self.algo | io,
+                                                                              max(self.ws_bytes, 1 << 20))))
 
     def big2small(self, big, P, p_off, bias, b_off, small, act=L.ACT_NONE, part=None, v_keep=None, u_cache=None, u_valid=False):
         """part / v_keep / u_cache: the optional hand-overs of pg_conv_extras (sizes: stats_chunks(0), v_bytes(), u_bytes(0))."""
@@ -301,13 +313,15 @@ class ConvOp:
                 L.check(L.load().pg_conv4x4_big2small_x(*args, ctypes.byref(x)), 'pg_conv4x4_big2small_x')
         PROFILER.launch(self, 0, go, self._io(big, small)) if PROFILER is not None else go()
 
-    def small2big(self, small, P, p_off, bias, b_off, big, act=L.ACT_NONE, part=None, u_cache=None, u_valid=False):
+    def small2big(self, small, P, p_off, bias, b_off, big, act=L.ACT_NONE, part=None, u_cache=None, u_valid=False, mul=None):
+        """mul = (t, act code): big = conv(...) * f'(t), the activation backward of the layer below folded into the epilogue
+        (only where mul_ok(small, big, t))."""
         assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         wp, wn = self._ws(P.device)
         args = (small.ptr(), small.ld, L.ptr(P, p_off), L.ptr(bias, b_off) if bias is not None else None, big.ptr(), big.ld,
                 ctypes.byref(self.g), act, self.algo | self._io(big, small), wp, wn, _stream())
-        x = self._extras(part=part, u_cache=u_cache, u_valid=u_valid)
+        x = self._extras(part=part, u_cache=u_cache, u_valid=u_valid, mul=mul)
 
         def go():
             if x is None:
@@ -391,6 +405,7 @@ def conv_instnorm_act(op, opcode, src, flat, p_off, y, out, stats, act, drop_p=0
 FUSE_IN_STATS = os.environ.get('PATCHGAN_FUSE_IN_STATS', '1') != '0'      # A/B switches (same-device timing)
 KEEP_V = os.environ.get('PATCHGAN_KEEP_V', '1') != '0'
 CACHE_U = os.environ.get('PATCHGAN_CACHE_U', '1') != '0'
+FUSE_ACT_BWD = os.environ.get('PATCHGAN_FUSE_ACT_BWD', '1') != '0'   # activation backward in the data-gradient epilogue above it
 SEAM8 = os.environ.get('PATCHGAN_SEAM8', '1') != '0'       # bf16 storage: image-facing tensors in 8-channel bf16 pixels
 
 
@@ -880,15 +895,20 @@ class DiscriminatorEngine:
         g = gout
         dx = None
         bf, last = c.bf, len(self.layers) - 1
+        inner_of = lambda i: bf and (0 < i < last or (i == 0 and c.seam8))
+        fused = None        # dy of this layer, already produced by the data-gradient kernel of the layer above
         for li in range(last, -1, -1):
             l, op = self.layers[li], ops[li]
-            inner = bf and (0 < li < last or (li == 0 and c.seam8))
-            if l.norm:
-                dt = View.alloc(c.N, op.Hs, op.Ws, l.a, dev, bf=inner)
-                instnorm_act_bwd(g, None, c.t[li], c.stats[li], dt, L.ACT_NONE)
-                g = dt
-            dy = View.alloc(c.N, op.Hs, op.Ws, l.a, dev, bf=inner)
-            act_bwd(g, None, c.t[li], dy, L.ACT_CODES[l.act])
+            inner = inner_of(li)
+            if fused is not None:
+                dy, fused = fused, None
+            else:
+                if l.norm:
+                    dt = View.alloc(c.N, op.Hs, op.Ws, l.a, dev, bf=inner)
+                    instnorm_act_bwd(g, None, c.t[li], c.stats[li], dt, L.ACT_NONE)
+                    g = dt
+                dy = View.alloc(c.N, op.Hs, op.Ws, l.a, dev, bf=inner)
+                act_bwd(g, None, c.t[li], dy, L.ACT_CODES[l.act])
             src = c.src[li]
             if need_wgrad:
                 op.wgrad(dy, src, gflat, l.p_off, gflat if l.bias_key is not None else None, l.b_off,
@@ -896,7 +916,14 @@ class DiscriminatorEngine:
             if li > 0 or need_dx:
                 dsrc = View.alloc(c.N, op.Hb, op.Wb, l.b, dev, bf=bf and 0 < li < last)
                 u, uv = self._ucache(ucache, li, 1, op, dev, dy, dsrc)
-                op.small2big(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
+                # the activation backward of the layer below (no InstanceNorm in between) in this kernel's epilogue: dsrc is then its dy
+                below = self.layers[li - 1] if li > 0 else None
+                if (FUSE_ACT_BWD and below is not None and not below.norm and dsrc.bf == inner_of(li - 1)
+                        and op.mul_ok(dy, dsrc, c.t[li - 1])):
+                    op.small2big(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv, mul=(c.t[li - 1], L.ACT_CODES[below.act]))
+                    fused = dsrc
+                else:
+                    op.small2big(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
                 g = dsrc
                 if li == 0:
                     dx = dsrc

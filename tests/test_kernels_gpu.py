@@ -554,3 +554,57 @@ def test_conv_hand_overs_between_calls(geom, bits):
         plain.big2small(vb, P, 0, None, 0, empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=4), u_cache=torch.empty(1 << 20, dtype=torch.uint8, device=DEV))
     with pytest.raises(RuntimeError):
         plain.wgrad(vs, vb, torch.empty(16 * Ca * Cb, device=DEV), 0, v_pre=torch.empty(1 << 20, dtype=torch.uint8, device=DEV))
+
+
+def _act_grad_from_out(a, name):
+    """f'(x) through the activation output a = f(x) (what torch's in-place activations keep)."""
+    return 1 - a * a if name == 'tanh' else torch.where(a > 0, torch.ones_like(a), torch.full_like(a, 0.2))
+
+
+@pytest.mark.parametrize('act', ['tanh', 'leakyrelu'])
+@pytest.mark.parametrize('geom,bits,prec', [((9, 32, 32, 128, 64, 1), 0, 'fp32'), ((9, 32, 32, 128, 64, 1), 'f3', 'fp32'),
+                                            ((9, 32, 32, 128, 64, 1), 'f3_dma', 'fp32'), ((6, 62, 58, 256, 128, 2), 0, 'fp32'),
+                                            ((4, 32, 32, 128, 64, 2), 'w2', 'fp32'), ((2, 64, 64, 128, 64, 2), 0, 'bf16'),
+                                            ((2, 31, 31, 128, 256, 1), 0, 'bf16'), ((2, 8, 8, 512, 512, 2), 0, 'bf16')],
+                         ids=lambda v: 'x'.join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_activation_backward_in_data_gradient_epilogue(geom, bits, prec, act):
+    """pg_conv_extras.mul_t: small2big(dy) * f'(t) in one kernel (the Winograd output transforms, k_wino_gemm's epilogue, the bf16
+    LDS-DMA kernel and its split-K reduce) equals small2big followed by pg_act_bwd: bit for bit on fp32 tensors (the same fp32
+    product of the same two factors), within one bf16 ulp of the float64 value on bf16 tensors (the fused form rounds once)."""
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view, to_view_bf, empty_view, empty_view_bf, pack, rel_err
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    tune = {0: 0, 'f3': L.TUNE_WINO1_F3, 'f3_dma': L.TUNE_WINO1_F3 | L.TUNE_WINO_DMA, 'w2': L.TUNE_WINO2_ALL}[bits]
+    bf = prec == 'bf16'
+    op = E.ConvOp(*geom, (L.ALGO_BF16 if bf else L.ALGO_AUTO) | tune)
+    code = ACTS[act]
+    t = O.apply_act(torch.randn(N, Cb, Hb, Wb), act)               # an activation OUTPUT of the layer below
+    if bf:
+        small, t, Wt = small.bfloat16().float(), t.bfloat16().float(), Wt.bfloat16().float()
+    P = pack(Wt)
+    mk, em = (to_view_bf, empty_view_bf) if bf else (to_view, empty_view)
+    vs, vt = mk(small, ld=Ca + 8, off=8), mk(t, ld=Cb + 8, off=8)
+    fused, g, ref = em(N, Hb, Wb, Cb, ld=Cb + 8, off=8), em(N, Hb, Wb, Cb), em(N, Hb, Wb, Cb)
+    assert op.mul_ok(vs, fused, vt), op.describe(1, op._io(fused, vs))
+    op.small2big(vs, P, 0, None, 0, fused, mul=(vt, code))
+    op.small2big(vs, P, 0, None, 0, g)
+    E.act_bwd(g, None, vt, ref, code)
+    torch.cuda.synchronize()
+    if not bf:
+        if bits == 'f3_dma':      # with a multiplier the register-staged instance runs (one accumulation chain instead of two)
+            assert rel_err(fused.to_nchw(), ref.to_nchw()) < 1e-5
+        else:
+            assert torch.equal(fused.to_nchw(), ref.to_nchw())
+        lin = torch.nn.grad.conv2d_input((N, Cb, Hb, Wb), Wt, small, stride=s, padding=1)
+        assert rel_err(fused.to_nchw(), lin * _act_grad_from_out(t, act)) < 3e-5
+    else:
+        lin = torch.nn.grad.conv2d_input((N, Cb, Hb, Wb), Wt.double(), small.double(), stride=s, padding=1)
+        want = (lin * _act_grad_from_out(t.double(), act))
+        got, wr = fused.to_nchw().double().cpu(), want.float().bfloat16().double()
+        assert ((got - wr).abs() <= wr.abs() * 2.0 ** -7 + 1e-5 * want.abs().max()).all(), rel_err(got, wr)
+    # a call whose kernel cannot apply the multiplier refuses it
+    slow = E.ConvOp(*geom, L.ALGO_DIRECT)
+    assert not slow.mul_ok(to_view(small), empty_view(N, Hb, Wb, Cb), to_view(t))
+    with pytest.raises(RuntimeError):
+        slow.small2big(to_view(small), P, 0, None, 0, empty_view(N, Hb, Wb, Cb), mul=(to_view(t), code))
