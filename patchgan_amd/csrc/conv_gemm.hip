@@ -2179,8 +2179,17 @@ __global__ __launch_bounds__(256) void k_slab_reduce_z(const float* __restrict__
     const long i = (long)blockIdx.x * 32 + ol;
     const long total = rows * cols;
     float v = 0.f;
-    if (i < total)
-        for (int z = zl; z < S; z += 8) v += slabs[(long)z * slab_stride + i];
+    if (i < total) {
+        int z = zl;
+        for (; z + 56 < S; z += 64) {          // eight independent loads in flight, added in slab order
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = slabs[(long)(z + 8 * k) * slab_stride + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += t[k];
+        }
+        for (; z < S; z += 8) v += slabs[(long)z * slab_stride + i];
+    }
     red[zl][ol] = v;
     __syncthreads();
     if (zl == 0 && i < total) {

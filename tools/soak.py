@@ -6,9 +6,12 @@ import torch
 import patchgan_amd as pg
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+precision = sys.argv[2] if len(sys.argv) > 2 else 'fp32'        # tools/soak.py 1000 bf16: bf16 kernels + bf16 activation storage
 torch.manual_seed(0)
 g = pg.UNet(3, 1, 64, use_dropout=True, activation='leakyrelu', final_act='sigmoid').cuda()
 d = pg.Discriminator(4, 64, n_layers=3).cuda()
+g.set_precision(precision)
+d.set_precision(precision)
 t = pg.Trainer(g, d, tempfile.mkdtemp())
 t.setup_optimizers(2e-4, 2e-4)
 g.train(); d.train()
