@@ -67,10 +67,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 //          counted vmcnt (never 0 in the loop).
 // MUL: the epilogue also multiplies by f'(t) (pg_epi_mul: the activation backward of the layer below a data gradient) -- its own
 // instantiation with unconditional, clamped loads of t (a conditional load inside the unrolled epilogue sends the accumulators to scratch)
-template <int MR, int NR, int WM, int WN, int DRC, int KB, bool MUL = false>
+// STATS: the epilogue also emits per-channel sums / sums of squares of the values it STORES (bf16-rounded) for the InstanceNorm that
+// follows: part[((n * chunks + chunk) * Cout + c) * 2 + {0, 1}], fp64, one chunk per workgroup tile (the host guarantees
+// that a tile lies inside one sample and that the K loop is not split).  Per 32-channel column block: in-lane sums over the wave's
+// pixel tiles, a transpose through LDS (lane <-> value, fixed order), the waves that share the channels combined in wave order.
+template <int MR, int NR, int WM, int WN, int DRC, int KB, bool MUL = false, bool STATS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv_bf16x(
     const __bf16* __restrict__ in, int ld_in, const __bf16* __restrict__ W, void* __restrict__ out, int ld_out, long slab_stride, XGeom g,
-    int cps, const float* __restrict__ bias, int act, int in_bytes, int w_bytes, int out_bf, int tiles_n, pg_epi_mul mul) {
+    int cps, const float* __restrict__ bias, int act, int in_bytes, int w_bytes, int out_bf, int tiles_n, pg_epi_mul mul, double* __restrict__ part,
+    int chunks) {
     static_assert(WM * WN == 4, "four waves");
     static_assert(KB == 32 || KB == 64, "chunk width");
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
@@ -78,7 +83,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int RPP = 1024 / ROWB, SPR = ROWB / 16;              // rows per DMA piece, 16-byte slots per row
     constexpr int AP = BM / (4 * RPP), BP = BN / (4 * RPP);        // pieces per wave and chunk
     constexpr int NST = (KB == 32) ? 3 : 1, STAGE = (BM + BN) * ROWB;
-    __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
+    constexpr int STATB = STATS ? (4 * 64 * 33 + 4 * 64) * 4 : 0;   // STATS: [wave][lane][33] transpose area + [wave][64] results
+    __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE > STATB ? NST * STAGE : STATB];
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, w_bytes, 0x00020000);
 
@@ -264,25 +270,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ldo = fin ? ld_out : Cout;
     char* const obase = (char*)out + (fin ? 0L : (long)slice * slab_stride * 4);
     const bool obf = fin && out_bf;
+    long opix[MR];
+    bool mok[MR];
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
         const int m = m0 + (wm * MR + i) * 32 + lrow;
-        long opix;
         if (B2S) {
-            opix = m;
+            opix[i] = m;
         } else {
             const int mm = min(m, Mc - 1);
             const int n = mm / (Hc * Wc);
             const int rem = mm - n * (Hc * Wc);
             const int ii = rem / Wc, jj = rem - ii * Wc;
             const int h = (g.s == 2) ? 2 * ii + ah : ii, w = (g.s == 2) ? 2 * jj + aw : jj;
-            opix = (long)((n * g.Hb + h) * g.Wb + w);
+            opix[i] = (long)((n * g.Hb + h) * g.Wb + w);
         }
-        const long orow = opix * ldo;
-        const bool mok = m < Mc;
+        mok[i] = m < Mc;
+    }
+    if constexpr (STATS) __syncthreads();                          // the operand tiles in LDS are dead: the statistics reuse the space
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const int nb = n0 + (wn * NR + j) * 32;
+    for (int j = 0; j < NR; ++j) {
+        const int nb = n0 + (wn * NR + j) * 32;
+        float s1[STATS ? 16 : 1], s2[STATS ? 16 : 1];
+        if constexpr (STATS) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s1[k] = s2[k] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            const long orow = opix[i] * ldo;
             f32x4 v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     v[q][e] = fin ? act_epi(x + bv[e], act) : x;
                 }
                 if constexpr (MUL) {           // data gradient times the activation derivative of the layer below (t: its output)
-                    const long tidx = (mok ? opix : 0L) * mul.ld + min(ch, Cout - 4);
+                    const long tidx = (mok[i] ? opix[i] : 0L) * mul.ld + min(ch, Cout - 4);
                     f32x4 tv;
                     if (obf) {
                         const u32x2 h = *reinterpret_cast<const u32x2*>((const char*)mul.t + tidx * 2);
@@ -307,6 +323,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[q][e] *= pg_act_grad_sel(tv[e], mul.act);
                 }
+                if constexpr (STATS) {         // what InstanceNorm will read back: the bf16-rounded value
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r = mok[i] ? (float)(__bf16)v[q][e] : 0.f;
+                        s1[4 * q + e] += r;
+                        s2[4 * q + e] += r * r;
+                    }
+                }
             }
             if (obf) {
 #pragma unroll
@@ -317,15 +341,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const u32x2 hi = __builtin_amdgcn_permlane32_swap(pack2(v[q][2], v[q][3]), pack2(v[q + 1][2], v[q + 1][3]), false, false);
                     const int ch = nb + 8 * (q + lh);
                     const u32x4 o4 = {lo[0], hi[0], lo[1], hi[1]};
-                    if (mok && ch < Cout) *reinterpret_cast<u32x4*>(obase + (orow + ch) * 2) = o4;
+                    if (mok[i] && ch < Cout) *reinterpret_cast<u32x4*>(obase + (orow + ch) * 2) = o4;
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int ch = nb + 8 * q + 4 * lh;
-                    if (mok && ch < Cout) *reinterpret_cast<f32x4*>(obase + (orow + ch) * 4) = v[q];
+                    if (mok[i] && ch < Cout) *reinterpret_cast<f32x4*>(obase + (orow + ch) * 4) = v[q];
                 }
             }
+        }
+        if constexpr (STATS) {
+            // lane-major [lane][33] image of the 32 per-lane sums (s1 | s2), then lane L adds column L & 31 over the 32 lanes of its
+            // half in lane order: sums over the wave's MR * 32 pixels for channel nb + 8q + 4 * half + e, k = 4q + e = (L & 15)
+            float* const tr = reinterpret_cast<float*>(smem) + wave * 64 * 33;
+            float* const res = reinterpret_cast<float*>(smem) + 4 * 64 * 33 + wave * 64;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                tr[lane * 33 + k] = s1[k];
+                tr[lane * 33 + 16 + k] = s2[k];
+            }
+            __syncthreads();
+            float t = 0.f;
+#pragma unroll
+            for (int l = 0; l < 32; ++l) t += tr[(lh * 32 + l) * 33 + lrow];
+            res[lane] = t;
+            __syncthreads();
+            if (wm == 0) {                                         // the WM waves that share these channels, in wave order
+                float tot = t;
+#pragma unroll
+                for (int w2 = 1; w2 < WM; ++w2) tot += reinterpret_cast<const float*>(smem)[4 * 64 * 33 + (w2 * WN + wn) * 64 + lane];
+                const int which = lrow >> 4, k = lrow & 15;
+                const int ch = nb + 8 * (k >> 2) + 4 * lh + (k & 3);
+                // the tile's sample and chunk: every row of the tile lies in one sample (host-checked)
+                const int hw = Hc * Wc;
+                const int nsmp = m0 / hw, chunk = cls * (hw / BM) + (m0 - nsmp * hw) / BM;
+                if (ch < Cout) part[(((long)nsmp * chunks + chunk) * Cout + ch) * 2 + which] = (double)tot;
+            }
+            __syncthreads();
         }
     }
 }
@@ -605,6 +658,16 @@ void pg_bf16x_clamp(pg_bf16x_plan* p, size_t avail) {
     p->split = (p->nchunks + p->cps - 1) / p->cps;
 }
 
+// chunks per sample of the statistics the STATS epilogue emits for this plan; 0: not available (split K, tiles straddling samples)
+int pg_bf16x_stats_chunks(int dir, const pg_bf16x_plan* p, int N, int Hb, int Wb, int Hs, int Ws) {
+    (void)N;
+    if (dir > 1 || p->split != 1) return 0;
+    if (dir == 1 && p->ncls == 4 && ((Hb | Wb) & 1)) return 0;   // the four parity classes must have one size
+    const long hw = (dir == 0) ? (long)Hs * Ws : (p->ncls == 4 ? (long)(Hb / 2) * (Wb / 2) : (long)Hb * Wb);
+    if (hw % p->bm != 0) return 0;
+    return (int)(p->ncls * (hw / p->bm));
+}
+
 const char* pg_bf16x_kernel_name(int dir, int tile, int ring) {
     static const char* const tiles[3] = {"4,2,2,2", "2,2,2,2", "2,2,4,1"};
     static thread_local char buf[64];
@@ -633,7 +696,8 @@ int pg_bf16x_pack(const float* P, void* W, int Ca, int Cb, int dir, hipStream_t 
 
 int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void* W, void* out, int ld_out, long slab_stride,
                   int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, const pg_bf16x_plan* p, const float* bias,
-                  int act, int out_bf, hipStream_t st, pg_epi_mul mul) {
+                  int act, int out_bf, hipStream_t st, pg_epi_mul mul, double* part, int chunks) {
+    if (part && (mul.t || dir > 1 || p->split != 1 || !out_bf || slab_stride != 0)) return PG_EINVAL;
     const XGeom g{N, Hb, Wb, Hs, Ws, Ca, Cb, stride};
     const dim3 grid((unsigned)(p->tiles_m * p->tiles_n), 1, (unsigned)(p->ncls * p->split));
     const int w_bytes = (dir == 2) ? 16 * Ca * 8 * 2 : (dir == 3) ? Ca * Cb * 2 : 16 * Ca * Cb * 2;
@@ -641,13 +705,18 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
     const __bf16* Wp = (const __bf16*)W;
 #define PG_BF16X_LAUNCH1(MR, NR, WM, WN, D, KB)                                                                              \
     hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB>), grid, dim3(256), 0, st, I, ld_in, Wp, out, ld_out, slab_stride, g, \
-                       p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul)
+                       p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul, part, chunks)
 #define PG_BF16X_LAUNCHM(MR, NR, WM, WN)                                                                                     \
     hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, 1, 64, true>), grid, dim3(256), 0, st, I, ld_in, Wp, out, ld_out, slab_stride, g, \
-                       p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul)
+                       p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul, part, chunks)
+#define PG_BF16X_LAUNCHS(MR, NR, WM, WN, D)                                                                                  \
+    hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, 64, false, true>), grid, dim3(256), 0, st, I, ld_in, Wp, out, ld_out,   \
+                       slab_stride, g, p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul, part, chunks)
 #define PG_BF16X_LAUNCH(MR, NR, WM, WN)                                                                                      \
     do {                                                                                                                     \
-        if (dir == 0 && !p->ring) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 0, 64);                                                   \
+        if (part && dir == 0) PG_BF16X_LAUNCHS(MR, NR, WM, WN, 0);                                                           \
+        else if (part) PG_BF16X_LAUNCHS(MR, NR, WM, WN, 1);                                                                  \
+        else if (dir == 0 && !p->ring) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 0, 64);                                                   \
         else if (dir == 0) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 0, 32);                                                          \
         else if (dir == 1 && mul.t) PG_BF16X_LAUNCHM(MR, NR, WM, WN);                                                        \
         else if (dir == 1 && !p->ring) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 1, 64);                                              \
@@ -663,6 +732,7 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
 #undef PG_BF16X_LAUNCH
 #undef PG_BF16X_LAUNCH1
 #undef PG_BF16X_LAUNCHM
+#undef PG_BF16X_LAUNCHS
     return pg_launch_status();
 }
 

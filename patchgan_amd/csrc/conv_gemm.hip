@@ -2742,6 +2742,7 @@ int bf16x_run(int dir, const void* in, int ld_in, const float* P, const float* b
               bool out_bf, void* ws, size_t ws_bytes, hipStream_t st, const pg_conv_extras& x, int ring) {
     const pg_epi_mul mul{x.mul_t, x.mul_ld, x.mul_act};
     if (mul.t && (dir != 1 || (reinterpret_cast<uintptr_t>(mul.t) & 15) || mul.ld % (out_bf ? 8 : 4))) return PG_EINVAL;
+    if (x.part && (mul.t || bias || act != PG_ACT_NONE)) return PG_EINVAL;
     if (dir == 0 && g.Cb <= 8) {       // few-channel big: only in 8-channel pixels (16 bytes = one DMA piece per pixel)
         if (ld_in != 8) return BF16X_SKIP;
         dir = 2;
@@ -2768,12 +2769,14 @@ int bf16x_run(int dir, const void* in, int ld_in, const float* P, const float* b
     }
     pg_bf16x_plan p = pg_bf16x_plan_of(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, ring);
     pg_bf16x_clamp(&p, avail);
+    const int chunks = x.part ? pg_bf16x_stats_chunks(dir, &p, g.N, g.Hb, g.Wb, g.Hs, g.Ws) : 0;
+    if (x.part && (!chunks || !out_bf)) return PG_EINVAL;
     int rc;
     {
         TimedLaunch timed(st);
         if (p.split == 1)
             rc = pg_bf16x_conv(dir, in, ld_in, in_bytes, W, out, ld_out, 0L, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, &p, bias, act,
-                               out_bf ? 1 : 0, st, mul);
+                               out_bf ? 1 : 0, st, mul, x.part, chunks);
         else
             rc = pg_bf16x_conv(dir, in, ld_in, in_bytes, W, rest, Cout, p.out_elems, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, &p,
                                nullptr, 0, 0, st);
@@ -3069,7 +3072,7 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
         return pg_wino2_b2s(big, ld_big, P, bias, small, ld_small, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, nullptr,
                             part, x.v_keep, x.u_cache, x.u_valid);
     }
-    if (bf16x_ok(g, 0, algo | io, tune) && !part && !x.v_keep) {
+    if (bf16x_ok(g, 0, algo | io, tune) && !x.v_keep) {
         const int rc = bf16x_run(0, big, ld_big, P, bias, small, ld_small, g, act, io & PG_IO_SMALL_BF16, ws, ws_bytes, st, x, tune.bf16ring);
         if (rc != BF16X_SKIP) return rc;
     }
@@ -3237,7 +3240,7 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
                            big, ld_big, g, act);
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
-    if (bf16x_ok(g, 1, algo | io, tune) && !part) {
+    if (bf16x_ok(g, 1, algo | io, tune)) {
         const int rc = bf16x_run(1, small, ld_small, P, bias, big, ld_big, g, act, io & PG_IO_BIG_BF16, ws, ws_bytes, st, x, tune.bf16ring);
         if (rc != BF16X_SKIP) return rc;
     }
@@ -3375,6 +3378,11 @@ int pg_conv_stats_chunks(const pg_conv_geom* gg, int op, int algo, size_t ws_byt
     if (!geom_ok(gg) || (op != 0 && op != 1)) return 0;
     const Geom g = to_geom(gg);
     const Tune tune = tune_of(algo);
+    if ((algo & PG_IO_MASK) == PG_IO_MASK && bf16x_ok(g, op, algo, tune) && !(op == 0 && g.Cb <= 8) && ws_bytes >= bf16x_ws(g, op)) {
+        pg_bf16x_plan bp = pg_bf16x_plan_of(op, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, tune.bf16ring);
+        pg_bf16x_clamp(&bp, ws_bytes - pg_bf16x_w_bytes(g.Ca, g.Cb));
+        return pg_bf16x_stats_chunks(op, &bp, g.N, g.Hb, g.Wb, g.Hs, g.Ws);
+    }
     if ((algo & PG_ALGO_MASK) != PG_ALGO_AUTO) return 0;
     // mirrors the dispatch of b2s_impl / s2b_impl for 16-byte-aligned tensors: the stride-1 Winograd path comes first
     if (op == 0) {

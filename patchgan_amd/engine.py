@@ -261,10 +261,15 @@ class ConvOp:
     def stats_chunks(self, opcode, view_in, view_out):
         """Partial-sum chunks per sample the kernel of big2small (0) / small2big (1) can emit next to its output (K5: InstanceNorm
         statistics from the conv epilogue); 0 = not on this path (or the views are not 16-byte aligned)."""
-        if not self._aligned(view_in, view_out):
+        big, small = (view_in, view_out) if opcode == 0 else (view_out, view_in)
+        io = self._io(big, small)
+        if io:      # bf16 tensors: the LDS-DMA kernels' STATS epilogue (both tensors bf16, 16-byte-aligned views)
+            if io != L.IO_MASK or not all(v.ptr() % 16 == 0 and v.ld % 8 == 0 for v in (view_in, view_out)):
+                return 0
+        elif not self._aligned(view_in, view_out):
             return 0
-        return self._query(('chunks', opcode), lambda: L.load().pg_conv_stats_chunks(ctypes.byref(self.g), opcode, self.algo,
-                                                                                    max(self.ws_bytes, 1 << 20)))
+        return self._query(('chunks', opcode, io), lambda: L.load().pg_conv_stats_chunks(ctypes.byref(self.g), opcode, self.algo | io,
+                                                                                        max(self.ws_bytes, 1 << 20)))
 
     def u_bytes(self, opcode, io=0):
         """Bytes of the transformed weights the kernel of big2small (0) / small2big (1) works from (0: no weight transform on

@@ -159,6 +159,55 @@ def test_lds_dma_bf16_kernels(geom):
             assert rel_err(unpack(dP, Ca, Cb), Wr.grad) < 2e-5, (o is op, rel_err(unpack(dP, Ca, Cb), Wr.grad))
 
 
+@pytest.mark.parametrize('geom', [(16, 128, 128, 128, 64, 2), (8, 128, 128, 256, 128, 2), (2, 64, 64, 128, 64, 2)],
+                         ids=lambda g: 'x'.join(map(str, g)))
+def test_bf16_conv_emits_instancenorm_partials(geom):
+    """K5 on the bf16 kernels: k_conv_bf16x<.., STATS> writes, next to its bf16 output, per-sample partial sums / sums of squares of
+    the STORED (bf16-rounded) values, one chunk per workgroup tile; summed over the chunks they equal the sums of the output tensor
+    (fp32 in-tile sums: 1e-5 relative to sum |y|), and the InstanceNorm that consumes them equals the one that re-reads y."""
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view_bf, empty_view_bf, pack, rel_err, DEV
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    P = pack(Wt)
+    op = E.ConvOp(*geom, L.ALGO_BF16)
+    ran = 0
+    for opcode in (0, 1):
+        cin, cout = (Cb, Ca) if opcode == 0 else (Ca, Cb)
+        if cin % 64:
+            continue
+        src = to_view_bf(big if opcode == 0 else small, ld=cin + 8, off=8)
+        oshape = (N, Hs, Ws, Ca) if opcode == 0 else (N, Hb, Wb, Cb)
+        y = empty_view_bf(*oshape, ld=cout + 8, off=8)
+        chunks = op.stats_chunks(opcode, src, y)
+        if (oshape[1] * oshape[2]) % 256 == 0 and op.describe(opcode, L.IO_MASK)[1] == 1:
+            assert chunks > 0, (opcode, op.describe(opcode, L.IO_MASK))
+        if not chunks:
+            continue
+        ran += 1
+        part = torch.full((N * chunks * cout * 2,), float('nan'), dtype=torch.float64, device=DEV)
+        (op.big2small if opcode == 0 else op.small2big)(src, P, 0, None, 0, y, part=part)
+        torch.cuda.synchronize()
+        yv = y.to_nchw().double().cpu()
+        got = part.view(N, chunks, cout, 2).sum(1).cpu()
+        assert ((got[..., 0] - yv.sum((2, 3))).abs() <= 1e-5 * yv.abs().sum((2, 3)) + 1e-6).all()
+        assert ((got[..., 1] - (yv * yv).sum((2, 3))).abs() <= 1e-5 * (yv * yv).sum((2, 3)) + 1e-6).all()
+        # the same conv without the hand-over writes the same tensor; InstanceNorm from the partials = InstanceNorm from y
+        y2 = empty_view_bf(*oshape, ld=cout + 8, off=8)
+        (op.big2small if opcode == 0 else op.small2big)(src, P, 0, None, 0, y2)
+        torch.cuda.synchronize()
+        assert torch.equal(y.to_nchw(), y2.to_nchw())
+        o1, o2 = empty_view_bf(*oshape), empty_view_bf(*oshape)
+        st1, st2 = torch.empty(N * cout * 2, device=DEV), torch.empty(N * cout * 2, device=DEV)
+        E.instnorm_act_fwd(y2, o2, st2, 1)
+        L.check(L.load().pg_instnorm_act_fwd_parts_t(y.ptr(), y.ld, o1.ptr(), o1.ld, st1.data_ptr(), part.data_ptr(), chunks, N,
+                                                     oshape[1] * oshape[2], cout, 1, 1e-5, 0.0, 0, None, E._dt(y, o1)), 'parts')
+        torch.cuda.synchronize()
+        assert rel_err(st1.cpu(), st2.cpu()) < 1e-5
+        assert rel_err(o1.to_nchw(), o2.to_nchw()) < 2 ** -7
+    assert ran == (2 if N >= 8 else 0)          # the small geometry is split along K: no statistics from the kernel, chunks == 0
+
+
 SEAMS = [(2, 64, 64, 64, 3, 2), (2, 32, 48, 64, 7, 2), (1, 33, 31, 128, 4, 2), (2, 31, 31, 64, 8, 1), (3, 16, 16, 128, 1, 2), (2, 128, 128, 64, 7, 2)]
 
 
