@@ -60,11 +60,16 @@ def pmc_traffic(symbol):
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
         try:
-            k = json.load(open(f))['kernels'].get(symbol.replace(' ', ''))
+            ks = json.load(open(f))['kernels']
         except Exception:
-            k = None
-        if k:
-            best = k['hbm_bytes_per_launch']
+            continue
+        sym = symbol.replace(' ', '')
+        # the C ABI reports the kernel family of a call (k_conv_bf16x<2,2,2,2,0,64>); the profiler sees its instantiations, which
+        # carry further template flags (...,64,false,false>: without / with the epilogue multiplier, the statistics): take the
+        # instantiation with the most launches
+        cand = [v for n, v in ks.items() if n == sym or n.startswith(sym[:-1] + ',')]
+        if cand:
+            best = max(cand, key=lambda v: v.get('launches', 0))['hbm_bytes_per_launch']
     return best
 
 
