@@ -2287,6 +2287,66 @@ __global__ void k_big2small_direct(const float* __restrict__ big, int ld_big, co
     }
 }
 
+// small -> big from a ONE-channel `small` (the discriminator head's data gradient, disc.py:45: Conv2d(512, 1, 4, 1, 1) backward):
+// out[pixel][b] = sum over the <= 16 taps that reach the pixel of small[pixel'] * P[tap][0][b] -- 16 FMAs per output, bound by the
+// HBM write of `big`.  A thread owns 4 consecutive b (its 16 tap weights = 16 float4 in registers) and walks pixels; the tap
+// values of a pixel are the same address for every thread of the workgroup (one broadcast load each).  Output fp32 or bf16
+// (out_bf); mul: times f'(t) of the layer below (pg_epi_mul; t in the output's storage type).  Many short workgroups: the per-pixel
+// chain (16 loads, FMAs, store) is latency-bound, ~8 workgroups per CU hide it (64-pixel workgroups: 70 us, 7-pixel ones: 40 us;
+// a 4-pixel software pipeline per thread: slower, 64 more registers).
+__global__ __launch_bounds__(256) void k_s2b_ca1(const float* __restrict__ small, int ld_small, const float* __restrict__ P,
+                                                 const float* __restrict__ bias, float* __restrict__ big, int ld_big, Geom g, int act,
+                                                 int out_bf, pg_epi_mul mul, int pix_per_block) {
+    const int cq = g.Cb >> 2;                                      // channel quads
+    const int qd = threadIdx.x % cq, lane_p = threadIdx.x / cq, np = 256 / cq;     // host: 256 % cq == 0, cq <= 256
+    const int b = qd * 4;
+    f32x4 w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const f32x4*>(P + (long)t * g.Cb + b);      // Ca == 1: P[tap][0][b]
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + b);
+    const long total = (long)g.N * g.Hb * g.Wb;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    const long p1 = min(total, p0 + pix_per_block);
+    for (long m = p0 + lane_p; m < p1; m += np) {
+        const int n = (int)(m / (g.Hb * g.Wb));
+        const int rem = (int)(m - (long)n * g.Hb * g.Wb);
+        const int h = rem / g.Wb, wq = rem - h * g.Wb;
+        f32x4 acc = bv;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            const int hh = h + 1 - kh;
+            const int ih = (g.s == 2) ? hh >> 1 : hh;
+            const bool okh = hh >= 0 && !(g.s == 2 && (hh & 1)) && ih < g.Hs;
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int ww = wq + 1 - kw;
+                const int iw = (g.s == 2) ? ww >> 1 : ww;
+                const bool ok = okh && ww >= 0 && !(g.s == 2 && (ww & 1)) && iw < g.Ws;
+                const float x = ok ? small[(long)((n * g.Hs + ih) * g.Ws + iw) * ld_small] : 0.f;
+                acc += x * w[kh * 4 + kw];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = pg_act_epi(acc[e], act);
+        if (mul.t) {
+            f32x4 tv;
+            if (out_bf) {
+                const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(mul.t) + m * mul.ld + b);
+                tv = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            } else {
+                tv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(mul.t) + m * mul.ld + b);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] *= pg_act_grad_from_out(tv[e], mul.act);
+        }
+        if (out_bf)
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(big) + m * ld_big + b) = to_bf16(acc);
+        else
+            *reinterpret_cast<f32x4*>(big + m * ld_big + b) = acc;
+    }
+}
+
 __global__ void k_small2big_direct(const float* __restrict__ small, int ld_small, const float* __restrict__ P,
                                    const float* __restrict__ bias, float* __restrict__ big, int ld_big, Geom g,
                                    int act) {
@@ -2704,6 +2764,13 @@ inline bool wino_wgrad_ok(const Geom& g, const Tune& t) {
     return g.s == 1 && t.winow && t.wino && pg_wino_wgrad_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb);
 }
 
+// small -> big from a one-channel small (fp32) onto Cb % 4 == 0 channels, 256 % (Cb / 4) == 0: k_s2b_ca1; fp32 output under any
+// MFMA algo, bf16 output (PG_IO_BIG_BF16 alone) under PG_ALGO_BF16
+inline bool s2b_ca1_ok(const Geom& g, int algo_full) {
+    const int a = algo_full & PG_ALGO_MASK, io = algo_full & PG_IO_MASK;
+    if (g.Ca != 1 || g.Cb % 4 != 0 || g.Cb > 1024 || 256 % (g.Cb / 4) != 0 || a == PG_ALGO_DIRECT || force_generic()) return false;
+    return io == 0 || (io == PG_IO_BIG_BF16 && a == PG_ALGO_BF16);
+}
 // PG_ALGO_BF16 with the input activation stored as bf16: the LDS-DMA kernels of conv_bf16.hip (dir 0: big -> small, 1: small -> big)
 inline bool bf16x_ok(const Geom& g, int dir, int algo_full, const Tune& t) {
     if ((algo_full & PG_ALGO_MASK) != PG_ALGO_BF16 || !t.bf16x || force_generic()) return false;
@@ -2879,6 +2946,12 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         return PG_OK;
     }
     // 1000 + 10 * dir + tile: the LDS-DMA bf16 kernels (k_conv_bf16x) on bf16 tensors
+    if (op == 1 && s2b_ca1_ok(gq, algo_full)) {      // 1050: k_s2b_ca1
+        if (tile_id) *tile_id = 1050;
+        if (split) *split = 1;
+        if (workgroups) *workgroups = 2048;
+        return PG_OK;
+    }
     if (op == 1 && bf16x_s2b_tapn_ok(gq, algo_full, tune) && ws_bytes >= bf16x_s2b_tapn_ws(gq)) {
         const pg_bf16x_plan bp = pg_bf16x_plan_of(3, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, 16 * gq.Cb, gq.s, 0);
         if (tile_id) *tile_id = 1030 + bp.tile;
@@ -2974,7 +3047,9 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     const double direct = 2.0 * g->N * g->Hs * g->Ws * 16.0 * g->Ca * g->Cb;
     double fl = direct;
     char buf[128];
-    if (code >= 1020 && code < 1030) {
+    if (code == 1050) {
+        snprintf(buf, sizeof buf, "k_s2b_ca1");
+    } else if (code >= 1020 && code < 1030) {
         snprintf(buf, sizeof buf, "%s", pg_bf16x_wgrad_kernel_name(code - 1020));
     } else if (code >= 1030 && code < 1040) {
         snprintf(buf, sizeof buf, "%s+k_col2im_small2big", pg_bf16x_kernel_name(3, code - 1030, 0));
@@ -3198,6 +3273,19 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
     if (!ws) ws_bytes = 0;
+    if (s2b_ca1_ok(g, algo | io)) {
+        const bool out_bf = io & PG_IO_BIG_BF16;
+        const bool al = aligned16(P) && (!bias || aligned16(bias)) && aligned_bf_view(big, ld_big, out_bf) &&
+                        (!mul.t || aligned_bf_view(mul.t, mul.ld, out_bf));
+        if (al && !part && !x.u_cache) {
+            const long total = (long)g.N * g.Hb * g.Wb;
+            const int ppb = (int)std::min<long>(64, std::max<long>(4, total / 2048));
+            TimedLaunch timed(st);
+            hipLaunchKernelGGL(k_s2b_ca1, dim3((unsigned)((total + ppb - 1) / ppb)), dim3(256), 0, st, small, ld_small, P, bias, big, ld_big, g,
+                               act, out_bf ? 1 : 0, mul, ppb);
+            return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+        }
+    }
     if (algo == PG_ALGO_AUTO && wino_s2b_ok(g, tune) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= pg_wino_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1) &&
         pg_wino_eligible(g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, ld_small, small, tune.mo1)) {
@@ -3354,6 +3442,7 @@ int pg_conv_mul_ok(const pg_conv_geom* gg, int algo, size_t ws_bytes) {
     const Geom g = to_geom(gg);
     const Tune tune = tune_of(algo);
     // mirrors the dispatch of s2b_impl for 16-byte-aligned tensors
+    if (s2b_ca1_ok(g, algo)) return 1;
     if ((algo & PG_ALGO_MASK) == PG_ALGO_AUTO) {
         if (wino_s2b_ok(g, tune) && ws_bytes >= pg_wino_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1)) return 1;
         if (wino2_s2b_ok(g, tune) && ws_bytes >= pg_wino2c_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb)) return 1;

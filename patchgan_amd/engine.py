@@ -296,7 +296,8 @@ class ConvOp:
         it and the tensors satisfy its alignment; t must have big's shape and storage type."""
         if t.bf != big.bf or (t.N, t.H, t.W, t.C) != (big.N, big.H, big.W, big.C):
             return False
-        if not all(v.ptr() % 16 == 0 and v.ld % (8 if v.bf else 4) == 0 for v in (small, big, t)):
+        need = (big, t) if self.Ca == 1 else (small, big, t)       # (the one-channel kernel reads `small` by scalars)
+        if not all(v.ptr() % 16 == 0 and v.ld % (8 if v.bf else 4) == 0 for v in need):
             return False
         io = self._io(big, small)
         return bool(self._query(('mul', io), lambda: L.load().pg_conv_mul_ok(ctypes.byref(self.g), self.algo | io,
@@ -919,14 +920,19 @@ class DiscriminatorEngine:
                 op.wgrad(dy, src, gflat, l.p_off, gflat if l.bias_key is not None else None, l.b_off,
                          v_pre=c.v[li] if ConvOp._aligned(dy, src) else None)
             if li > 0 or need_dx:
-                dsrc = View.alloc(c.N, op.Hb, op.Wb, l.b, dev, bf=bf and 0 < li < last)
-                u, uv = self._ucache(ucache, li, 1, op, dev, dy, dsrc)
-                # the activation backward of the layer below (no InstanceNorm in between) in this kernel's epilogue: dsrc is then its dy
+                # the activation backward of the layer below (no InstanceNorm in between) in this kernel's epilogue: the tensor it
+                # writes is then that layer's dy (and has dy's storage type)
                 below = self.layers[li - 1] if li > 0 else None
-                if (FUSE_ACT_BWD and below is not None and not below.norm and dsrc.bf == inner_of(li - 1)
-                        and op.mul_ok(dy, dsrc, c.t[li - 1])):
+                dsrc = None
+                if FUSE_ACT_BWD and below is not None and not below.norm:
+                    cand = View.alloc(c.N, op.Hb, op.Wb, l.b, dev, bf=inner_of(li - 1))
+                    if op.mul_ok(dy, cand, c.t[li - 1]):
+                        dsrc = fused = cand
+                if dsrc is None:
+                    dsrc = View.alloc(c.N, op.Hb, op.Wb, l.b, dev, bf=bf and 0 < li < last)
+                u, uv = self._ucache(ucache, li, 1, op, dev, dy, dsrc)
+                if fused is not None:
                     op.small2big(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv, mul=(c.t[li - 1], L.ACT_CODES[below.act]))
-                    fused = dsrc
                 else:
                     op.small2big(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
                 g = dsrc

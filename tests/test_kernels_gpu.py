@@ -565,7 +565,8 @@ def _act_grad_from_out(a, name):
 @pytest.mark.parametrize('geom,bits,prec', [((9, 32, 32, 128, 64, 1), 0, 'fp32'), ((9, 32, 32, 128, 64, 1), 'f3', 'fp32'),
                                             ((9, 32, 32, 128, 64, 1), 'f3_dma', 'fp32'), ((6, 62, 58, 256, 128, 2), 0, 'fp32'),
                                             ((4, 32, 32, 128, 64, 2), 'w2', 'fp32'), ((2, 64, 64, 128, 64, 2), 0, 'bf16'),
-                                            ((2, 31, 31, 128, 256, 1), 0, 'bf16'), ((2, 8, 8, 512, 512, 2), 0, 'bf16')],
+                                            ((2, 31, 31, 128, 256, 1), 0, 'bf16'), ((2, 8, 8, 512, 512, 2), 0, 'bf16'),
+                                            ((3, 31, 29, 1, 512, 1), 0, 'fp32'), ((2, 32, 32, 1, 64, 2), 0, 'fp32'), ((3, 31, 29, 1, 512, 1), 0, 'head16')],
                          ids=lambda v: 'x'.join(map(str, v)) if isinstance(v, tuple) else str(v))
 def test_activation_backward_in_data_gradient_epilogue(geom, bits, prec, act):
     """pg_conv_extras.mul_t: small2big(dy) * f'(t) in one kernel (the Winograd output transforms, k_wino_gemm's epilogue, the bf16
@@ -576,7 +577,7 @@ def test_activation_backward_in_data_gradient_epilogue(geom, bits, prec, act):
     N, Hb, Wb, Ca, Cb, s = geom
     big, small, Wt, Hs, Ws = _mk(*geom)
     tune = {0: 0, 'f3': L.TUNE_WINO1_F3, 'f3_dma': L.TUNE_WINO1_F3 | L.TUNE_WINO_DMA, 'w2': L.TUNE_WINO2_ALL}[bits]
-    bf = prec == 'bf16'
+    bf = prec in ('bf16', 'head16')          # head16: fp32 one-channel small -> bf16 big (the discriminator head's data gradient in bf16 mode)
     op = E.ConvOp(*geom, (L.ALGO_BF16 if bf else L.ALGO_AUTO) | tune)
     code = ACTS[act]
     t = O.apply_act(torch.randn(N, Cb, Hb, Wb), act)               # an activation OUTPUT of the layer below
@@ -584,7 +585,9 @@ def test_activation_backward_in_data_gradient_epilogue(geom, bits, prec, act):
         small, t, Wt = small.bfloat16().float(), t.bfloat16().float(), Wt.bfloat16().float()
     P = pack(Wt)
     mk, em = (to_view_bf, empty_view_bf) if bf else (to_view, empty_view)
-    vs, vt = mk(small, ld=Ca + 8, off=8), mk(t, ld=Cb + 8, off=8)
+    vs, vt = (to_view if prec == 'head16' else mk)(small, ld=Ca + 8, off=8), mk(t, ld=Cb + 8, off=8)
+    if Ca == 1:
+        assert op.describe(1, op._io(em(N, Hb, Wb, Cb), vs))[0] == 'k_s2b_ca1'
     fused, g, ref = em(N, Hb, Wb, Cb, ld=Cb + 8, off=8), em(N, Hb, Wb, Cb), em(N, Hb, Wb, Cb)
     assert op.mul_ok(vs, fused, vt), op.describe(1, op._io(fused, vs))
     op.small2big(vs, P, 0, None, 0, fused, mul=(vt, code))
