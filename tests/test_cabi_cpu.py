@@ -58,7 +58,7 @@ def test_kernel_plan_of_the_benchmark_layers():
         (16, 64, 64, 512, 128, 2): ('k_wino_bgemm', 'k_wino_bgemm', 'k_wino_wgrad_gemm<1,1,2,2>'),            # dec4
         (16, 32, 32, 1024, 256, 2): ('k_wino_bgemm', 'k_wino_bgemm', 'k_wino_wgrad_gemm<2,2,2,2>'),           # dec3
         (32, 32, 32, 512, 256, 1): ('k_wino_gemm', 'k_wino_gemm', 'k_wino_wgrad_gemm'),                       # d3 at 2N
-        (32, 31, 31, 1, 512, 1): ('k_b2s_fast<1,1,4,1,true>+k_gather', 'k_small2big', 'k_wgrad_tapn'),        # D head
+        (32, 31, 31, 1, 512, 1): ('k_b2s_fast<1,1,4,1,true>+k_gather', 'k_s2b_ca1', 'k_wgrad_tapn'),        # D head
     }
     for geom, fams in want.items():
         auto, mfma = E.ConvOp(*geom, _lib.ALGO_AUTO), E.ConvOp(*geom, _lib.ALGO_MFMA)
