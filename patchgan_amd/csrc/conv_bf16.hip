@@ -740,7 +740,7 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
 bool pg_bf16x_wgrad_geom_ok(int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride) {
     (void)Hb; (void)Wb; (void)stride;
     if ((long)N * Hs * Ws >= (1L << 24)) return false;             // pixel decode by float reciprocals
-    if (Cb <= 8) return Ca % 32 == 0 && Ca >= 64;                  // taps in N: `big` in 8-channel pixels (ld_big == 8, checked by the caller)
+    if (Cb <= 8) return Ca % 32 == 0;                              // taps in N: `big` in 8-channel pixels (ld_big == 8, checked by the caller)
     if (Ca % 32 != 0 || Cb % 32 != 0 || Ca < 64 || Cb < 32) return false;
     return true;
 }

@@ -656,7 +656,8 @@ class GeneratorEngine:
         bf = c.bf = bool(self.act_bf)
         # ... unless they fit 8-channel pixels: then x and dL/d(output) are padded to that bf16 layout (one small pass each) and the
         # first / last layer run on the bf16 kernels as well (SEAM8)
-        seam8 = c.seam8 = bf and SEAM8 and self.nf % 8 == 0 and self.input_nc <= 8 and self.output_nc <= 8
+        # (nf % 32: the head's row GEMM contracts over 2 * nf channels in 64-wide chunks, the taps-in-N weight gradient tiles 32 channels)
+        seam8 = c.seam8 = bf and SEAM8 and self.nf % 32 == 0 and self.input_nc <= 8 and self.output_nc <= 8
         c.xin8 = xin.padded8() if seam8 else None
         c.cat = [None] * 7
         for i in range(1, 7):
@@ -865,7 +866,8 @@ class DiscriminatorEngine:
         bf = c.bf = bool(self.act_bf)
         last = len(self.layers) - 1
         # the input in 8-channel bf16 pixels where it fits: the first layer then runs on the bf16 kernels too (GeneratorEngine.forward)
-        seam8 = c.seam8 = bf and SEAM8 and self.ndf % 8 == 0 and self.input_nc <= 8 and last > 0
+        # (ndf % 64: the data gradient onto x | mask is a row GEMM contracting over ndf channels in 64-wide chunks)
+        seam8 = c.seam8 = bf and SEAM8 and self.ndf % 64 == 0 and self.input_nc <= 8 and last > 0
         src = din.padded8() if seam8 else din
         for li, (l, op) in enumerate(zip(self.layers, ops)):
             if li == last:

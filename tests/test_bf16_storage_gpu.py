@@ -356,3 +356,53 @@ def test_networks_bf16_storage_vs_fp32_storage(tmp_path):
     # a narrow network keeps fp32 activations (the fast bf16 kernels need >= 32 channels on every interior tensor)
     small = pg.UNet(3, 1, 4).cuda().set_precision('bf16')
     assert small.engine.act_bf is False
+
+
+@pytest.mark.parametrize('cfg', ['nf32_norm_n5_dropout_softmax', 'nf64_relu_mae_drop'])
+def test_bf16_storage_other_configurations(cfg, tmp_path):
+    """bf16 mode with bf16 activation storage away from the benchmark configuration: nf = ndf = 32 (32-channel layers stay on the
+    register-staged bf16 kernels, wider ones take the LDS-DMA kernels: both families in one network), a discriminator with
+    InstanceNorm and n_layers = 5 (Conv -> Tanh -> InstanceNorm: no activation-backward fusion there), a 3-class softmax head with
+    weighted BCE, ReLU + MAE, and dropout (same counter-based masks as the fp32 mode: compared against the HIP fp32 run of the same
+    seed).  Stated tolerance: every loss of two training steps within 5e-2 of the fp32-mode run, generator output within 3e-2
+    (measured 1.0e-2 and 2.2e-2)."""
+    import numpy as np
+    import patchgan_amd as pg
+    from tests.golden_util import LOSS_KEYS
+    if cfg.startswith('nf32'):
+        nf, out_nc, act, fact, loss, nl, norm, drop, B, S = 32, 3, 'leakyrelu', 'softmax', 'weighted_bce', 5, True, True, 2, 256
+    else:
+        nf, out_nc, act, fact, loss, nl, norm, drop, B, S = 64, 1, 'relu', 'sigmoid', 'MAE', 3, False, True, 1, 256
+    torch.manual_seed(99)
+    g0 = pg.UNet(3, out_nc, nf, use_dropout=drop, activation=act, final_act=fact)
+    d0 = pg.Discriminator(3 + out_nc, nf, n_layers=nl, norm=norm)
+    gw = {k: v.clone() for k, v in g0.state_dict().items()}
+    dw = {k: v.clone() for k, v in d0.state_dict().items()}
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(B, 3, S, S, generator=gen)
+    y = (torch.rand(B, out_nc, S, S, generator=gen) > 0.6).float()
+    curves, outs = {}, {}
+    for prec in ('fp32', 'bf16'):
+        torch.manual_seed(5)                # the dropout seed base
+        g = pg.UNet(3, out_nc, nf, use_dropout=drop, activation=act, final_act=fact)
+        d = pg.Discriminator(3 + out_nc, nf, n_layers=nl, norm=norm)
+        g.load_state_dict(gw)
+        d.load_state_dict(dw)
+        g.cuda().set_precision(prec)
+        d.cuda().set_precision(prec)
+        assert g.engine.act_bf == (prec == 'bf16') and d.engine.act_bf == (prec == 'bf16')
+        g.eval()
+        with torch.no_grad():
+            outs[prec] = g(x.cuda()).cpu()
+        g.train()
+        d.train()
+        t = pg.Trainer(g, d, str(tmp_path / prec))
+        t.loss_type = loss
+        t.setup_optimizers(1e-3, 1e-3)
+        curves[prec] = np.array([[r[k] for k in LOSS_KEYS] for r in (t.batch(x, y, train=True) for _ in range(2))])
+        assert np.isfinite(curves[prec]).all()
+    e_out = ((outs['bf16'] - outs['fp32']).abs().max() / outs['fp32'].abs().max()).item()
+    rel = np.abs(curves['bf16'] - curves['fp32']) / np.maximum(np.abs(curves['fp32']), 1e-3)
+    print(f'{cfg}: output bf16 vs fp32 mode {e_out:.1e}, losses {rel.max(axis=1)}')
+    assert e_out < 3e-2, e_out
+    assert rel.max() < 5e-2, rel
