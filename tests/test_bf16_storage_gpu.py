@@ -358,7 +358,7 @@ def test_networks_bf16_storage_vs_fp32_storage(tmp_path):
     assert small.engine.act_bf is False
 
 
-@pytest.mark.parametrize('cfg', ['nf32_norm_n5_dropout_softmax', 'nf64_relu_mae_drop'])
+@pytest.mark.parametrize('cfg', ['nf32_norm_n5_dropout_softmax', 'nf64_relu_mae_drop', 'nf48_tanh_tversky'])
 def test_bf16_storage_other_configurations(cfg, tmp_path):
     """bf16 mode with bf16 activation storage away from the benchmark configuration: nf = ndf = 32 (32-channel layers stay on the
     register-staged bf16 kernels, wider ones take the LDS-DMA kernels: both families in one network), a discriminator with
@@ -371,6 +371,8 @@ def test_bf16_storage_other_configurations(cfg, tmp_path):
     from tests.golden_util import LOSS_KEYS
     if cfg.startswith('nf32'):
         nf, out_nc, act, fact, loss, nl, norm, drop, B, S = 32, 3, 'leakyrelu', 'softmax', 'weighted_bce', 5, True, True, 2, 256
+    elif cfg.startswith('nf48'):     # channel counts 48 .. 384: neither % 64 nor % 32 everywhere, image-facing tensors stay fp32
+        nf, out_nc, act, fact, loss, nl, norm, drop, B, S = 48, 2, 'tanh', 'sigmoid', 'tversky', 3, False, False, 1, 256
     else:
         nf, out_nc, act, fact, loss, nl, norm, drop, B, S = 64, 1, 'relu', 'sigmoid', 'MAE', 3, False, True, 1, 256
     torch.manual_seed(99)
