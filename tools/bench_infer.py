@@ -8,7 +8,8 @@ from patchgan_amd.infer import predict_image
 from patchgan_amd import engine as E
 
 torch.manual_seed(0)
-g = pg.UNet(3, 1, 64, activation='leakyrelu', final_act='sigmoid').cuda().eval()
+precision = sys.argv[1] if len(sys.argv) > 1 else 'fp32'            # tools/bench_infer.py bf16: bf16 kernels + bf16 activation storage
+g = pg.UNet(3, 1, 64, activation='leakyrelu', final_act='sigmoid').cuda().eval().set_precision(precision)
 img = torch.rand(3, 1024, 1024).cuda()
 reps = int(os.environ.get('REPS', '10'))
 n = E.tiles_gather(img, 256, 0.9).N
@@ -30,7 +31,7 @@ ev[2].record()
 mask = E.tiles_blend(pred, (1024, 1024), 0.5, 0.9)
 ev[3].record()
 torch.cuda.synchronize()
-print(json.dumps({'metric': 'tiled inference, 1024x1024 -> 25 tiles of 256x256, UNet nf=64 fp32', 'tiles_per_s': round(n / dt, 1),
+print(json.dumps({'metric': f'tiled inference, 1024x1024 -> 25 tiles of 256x256, UNet nf=64 {precision}', 'tiles_per_s': round(n / dt, 1),
                   'images_per_s': round(1 / dt, 2), 'ms_per_image': round(dt * 1e3, 2),
                   'gather_ms': round(ev[0].elapsed_time(ev[1]), 3), 'forward_ms': round(ev[1].elapsed_time(ev[2]), 3),
                   'blend_ms': round(ev[2].elapsed_time(ev[3]), 3),
