@@ -656,8 +656,9 @@ class GeneratorEngine:
         bf = c.bf = bool(self.act_bf)
         # ... unless they fit 8-channel pixels: then x and dL/d(output) are padded to that bf16 layout (one small pass each) and the
         # first / last layer run on the bf16 kernels as well (SEAM8)
-        # (nf % 32: the head's row GEMM contracts over 2 * nf channels in 64-wide chunks, the taps-in-N weight gradient tiles 32 channels)
-        seam8 = c.seam8 = bf and SEAM8 and self.nf % 32 == 0 and self.input_nc <= 8 and self.output_nc <= 8
+        # (nf % 64: the row GEMMs next to the images -- the head's forward over 2 * nf channels, the data gradient onto x over nf --
+        # contract in 64-wide chunks)
+        seam8 = c.seam8 = bf and SEAM8 and self.nf % 64 == 0 and self.input_nc <= 8 and self.output_nc <= 8
         c.xin8 = xin.padded8() if seam8 else None
         c.cat = [None] * 7
         for i in range(1, 7):
