@@ -54,6 +54,7 @@ class FlatParamModule(nn.Module):
         algo = {'fp32': L.ALGO_AUTO, 'bf16': L.ALGO_BF16}[precision]
         self.engine.algo = algo | (self.engine.algo & ~L.ALGO_MASK)
         self.engine._ops = {}
+        self.engine._sok = {}
         # bf16 activation storage wherever every interior tensor can take it (channel counts % 4 == 0 and >= 32); otherwise the
         # bf16 kernels keep reading fp32 tensors and rounding them in flight
         self.engine.act_bf = bool(precision == 'bf16' and bf16_storage and self.engine.bf16_storage_ok())
@@ -67,6 +68,7 @@ class FlatParamModule(nn.Module):
         from . import _lib as L
         self.engine.algo = (self.engine.algo & L.ALGO_MASK) | int(bits)
         self.engine._ops = {}
+        self.engine._sok = {}
         return self
 
     def ensure_grad_flat(self):

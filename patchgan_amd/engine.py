@@ -368,6 +368,13 @@ class ConvOp:
         PROFILER.launch2(self, (2, 0), go, self._io(big, small)) if PROFILER is not None else go()
 
 
+def _bf16_tensors_ok(ops):
+    """Every one of these layers has bf16-tensor kernels for its three ops at this geometry (pg_conv_kernel names them): otherwise
+    the caller keeps fp32 activation storage for this extent (e.g. 7 x 7 maps on channel counts the LDS-DMA weight gradient does
+    not take: the register-staged kernel's pixel decode needs power-of-two or >= 16-wide maps)."""
+    return all('bf16' in op.describe(oc, L.IO_MASK)[0] for op in ops for oc in (0, 1, 2))
+
+
 def _dt(*views):
     """dtype mask of the *_t entry points: bit i = the i-th tensor argument is bf16."""
     m = 0
@@ -608,6 +615,13 @@ class GeneratorEngine:
         """Every interior tensor feeds / comes from a fast bf16 conv kernel: channel counts multiples of 4 and >= 32."""
         return self.nf % 4 == 0 and self.nf >= 32
 
+    def _storage_ok(self, key, interior_ops):
+        if not hasattr(self, '_sok'):
+            self._sok = {}
+        if key not in self._sok:
+            self._sok[key] = _bf16_tensors_ok(interior_ops)
+        return self._sok[key]
+
     def ops(self, N, H, W):
         """ConvOps for input extent (N, H, W); cached."""
         key = (N, H, W)
@@ -653,12 +667,13 @@ class GeneratorEngine:
         # bf16 activation storage: every interior activation (conv outputs, normalised outputs, their gradients) is a bf16 tensor;
         # the image-facing tensors (x, enc0's conv output, the generator output and its gradient) stay fp32 and the InstanceNorm /
         # activation kernels next to them read one type and write the other
-        bf = c.bf = bool(self.act_bf)
+        bf = c.bf = bool(self.act_bf) and self._storage_ok((N, H, W), enc_ops[1:] + dec_ops[:6])
         # ... unless they fit 8-channel pixels: then x and dL/d(output) are padded to that bf16 layout (one small pass each) and the
         # first / last layer run on the bf16 kernels as well (SEAM8)
         # (nf % 64: the row GEMMs next to the images -- the head's forward over 2 * nf channels, the data gradient onto x over nf --
         # contract in 64-wide chunks)
-        seam8 = c.seam8 = bf and SEAM8 and self.nf % 64 == 0 and self.input_nc <= 8 and self.output_nc <= 8
+        seam8 = c.seam8 = (bf and SEAM8 and self.nf % 64 == 0 and self.input_nc <= 8 and self.output_nc <= 8
+                           and enc_ops[0].describe(0, L.IO_MASK)[0].startswith('k_conv_bf16x'))      # (not with PG_TUNE_BF16X_OFF)
         c.xin8 = xin.padded8() if seam8 else None
         c.cat = [None] * 7
         for i in range(1, 7):
@@ -815,6 +830,13 @@ class DiscriminatorEngine:
     def bf16_storage_ok(self):
         return self.ndf % 4 == 0 and self.ndf >= 32
 
+    def _storage_ok(self, key, interior_ops):
+        if not hasattr(self, '_sok'):
+            self._sok = {}
+        if key not in self._sok:
+            self._sok[key] = _bf16_tensors_ok(interior_ops)
+        return self._sok[key]
+
     def ops(self, N, H, W):
         key = (N, H, W)
         if key not in self._ops:
@@ -864,11 +886,13 @@ class DiscriminatorEngine:
         c.t, c.stats, c.a, c.v, c.src = [], [], [], [], []
         # bf16 activation storage: the tensors between the first and the last layer are bf16; the input (x | mask), the first
         # layer's conv output (4-channel input: generic kernel) and the 1-channel head stay fp32
-        bf = c.bf = bool(self.act_bf)
         last = len(self.layers) - 1
+        bf = c.bf = bool(self.act_bf) and self._storage_ok((din.N, din.H, din.W), ops[1:last])
         # the input in 8-channel bf16 pixels where it fits: the first layer then runs on the bf16 kernels too (GeneratorEngine.forward)
         # (ndf % 64: the data gradient onto x | mask is a row GEMM contracting over ndf channels in 64-wide chunks)
-        seam8 = c.seam8 = bf and SEAM8 and self.ndf % 64 == 0 and self.input_nc <= 8 and last > 0
+        seam8 = c.seam8 = (bf and SEAM8 and self.ndf % 64 == 0 and self.input_nc <= 8 and last > 0
+                           and ops[0].describe(0, L.IO_MASK)[0].startswith('k_conv_bf16x'))
+
         src = din.padded8() if seam8 else din
         for li, (l, op) in enumerate(zip(self.layers, ops)):
             if li == last:
