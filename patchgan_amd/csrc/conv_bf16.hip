@@ -627,8 +627,8 @@ pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, i
     p.nchunks = (dir == 2) ? 2 : (dir == 3) ? Cin / BK : taps * Cin / BK;
     p.out_elems = (long)N * (dir != 1 ? Hs * Ws : Hb * Wb) * Cout;
     auto blocks = [&](int bm, int bn) { return ((Mc + bm - 1) / bm) * ((Cout + bn - 1) / bn) * p.ncls; };
-    static const int forced = getenv("PATCHGAN_BF16X_TILE") ? atoi(getenv("PATCHGAN_BF16X_TILE")) : -1;
-    static const int target = getenv("PATCHGAN_BF16X_TARGET") ? atoi(getenv("PATCHGAN_BF16X_TARGET")) : 512;
+    static const int forced = pg_exp_env("PATCHGAN_BF16X_TILE") ? atoi(pg_exp_env("PATCHGAN_BF16X_TILE")) : -1;
+    static const int target = pg_exp_env("PATCHGAN_BF16X_TARGET") ? atoi(pg_exp_env("PATCHGAN_BF16X_TARGET")) : 512;
     // Measured on the cfg4 layers (tools/layer_bench_bf16.py, one device): the 256 x 128 tile wins only where it alone fills the chip
     // twice over (>= ~480 workgroups = two per CU) on a long K; one workgroup per CU loses to 128 x 128 tiles at two to four per CU,
     // and a split-K pass (slab write + reduce) costs more than it returns once ~400 workgroups exist without it.
@@ -748,7 +748,7 @@ bool pg_bf16x_wgrad_geom_ok(int N, int Hb, int Wb, int Hs, int Ws, int Ca, int C
 pg_bf16x_plan pg_bf16x_wgrad_plan(int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride) {
     (void)Hb; (void)Wb; (void)stride;
     pg_bf16x_plan p;
-    static const int forced = getenv("PATCHGAN_BF16X_WTILE") ? atoi(getenv("PATCHGAN_BF16X_WTILE")) : -1;
+    static const int forced = pg_exp_env("PATCHGAN_BF16X_WTILE") ? atoi(pg_exp_env("PATCHGAN_BF16X_WTILE")) : -1;
     // tiles (a x b): 0: 256 x 128, 1: 128 x 128, 2: 256 x 64, 3: 128 x 64
     if (Cb <= 8) {                     // taps in N: tiles 4 / 5 = 64 / 128 a-channels x (16 taps x 8)
         p.tile = (Ca % 128 == 0) ? 5 : 4;
@@ -783,7 +783,7 @@ pg_bf16x_plan pg_bf16x_wgrad_plan(int N, int Hb, int Wb, int Hs, int Ws, int Ca,
     p.nchunks = (int)((M + 63) / 64);
     p.out_elems = 16L * Ca * Cb;
     const long nb = (long)p.tiles_m * p.tiles_n * 16;
-    static const int target = getenv("PATCHGAN_BF16X_WTARGET") ? atoi(getenv("PATCHGAN_BF16X_WTARGET")) : 512;
+    static const int target = pg_exp_env("PATCHGAN_BF16X_WTARGET") ? atoi(pg_exp_env("PATCHGAN_BF16X_WTARGET")) : 512;
     long s = (nb >= target) ? 1 : (target + nb - 1) / nb;
     const long smax = std::max<long>(1, p.nchunks / 4);
     if (s > smax) s = smax;

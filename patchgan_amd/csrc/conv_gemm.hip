@@ -2432,7 +2432,7 @@ inline bool aligned_io(const void* p, bool bf) { return (reinterpret_cast<uintpt
 constexpr long FAST_LIMIT = 0x60000000L;   // 1.5 GiB: keeps every 32-bit byte offset, incl. the +0x40000000 sentinel, < 2^32
 constexpr long FAST_P_LIMIT = 0x40000000L; // packed weights: the invalid-row sentinel (+1 GiB) must land beyond the block
 inline bool force_generic() {
-    static const bool v = getenv("PATCHGAN_GENERIC_KERNELS") != nullptr;   // debugging aid: disable the fast variants
+    static const bool v = pg_exp_env("PATCHGAN_GENERIC_KERNELS") != nullptr;   // debugging aid: disable the fast variants
     return v;
 }
 
@@ -2473,7 +2473,7 @@ constexpr int TARGET_BLOCKS = 512;
 int pick_split(long tiles, int nchunks, int min_chunks) {
     // one 4-wave workgroup per CU leaves the MFMA pipe idle while that workgroup stages its next tile
     // (measured 55 vs 80 TFLOP/s on the same kernel at 1 vs 2 workgroups per CU): split K until >= 512 workgroups
-    static const int target = getenv("PATCHGAN_SPLIT_TARGET") ? atoi(getenv("PATCHGAN_SPLIT_TARGET")) : TARGET_BLOCKS;
+    static const int target = pg_exp_env("PATCHGAN_SPLIT_TARGET") ? atoi(pg_exp_env("PATCHGAN_SPLIT_TARGET")) : TARGET_BLOCKS;
     if (tiles >= target) return 1;
     long s = (target + tiles - 1) / tiles;
     long smax = nchunks / min_chunks;
@@ -2492,7 +2492,7 @@ struct Plan {
 // A 128x128 tiling that yields 256..511 workgroups would need split-K 2 (slab write + reduce pass) to reach two
 // workgroups per CU; the 128x64 tile reaches the same occupancy without the slabs at the same MFMA efficiency.
 Tile refine_tile(Tile t, long rows, int cols, int ncls) {
-    static const bool off = getenv("PATCHGAN_TILE_REFINE") == nullptr;   // measured slower than split-K 2: off by default
+    static const bool off = pg_exp_env("PATCHGAN_TILE_REFINE") == nullptr;   // measured slower than split-K 2: off by default
     if (off || t.id != 0) return t;
     const long tiles = ((rows + 127) / 128) * ((cols + 127) / 128) * ncls;
     if (tiles >= 256 && tiles < TARGET_BLOCKS) return {1, 128, 64};
@@ -2557,7 +2557,7 @@ Plan plan_wgrad(const pg_conv_geom* g) {
     if (mode != 0) {
         // the taps-in-N kernels stream a huge K (every pixel) into one or two tiles: latency-bound per workgroup, so they
         // want far more, shorter slices than the MFMA-bound kernels (measured 83 us at 512 slices vs 187 us at 128)
-        static const int tt = getenv("PATCHGAN_TAPN_SPLIT") ? atoi(getenv("PATCHGAN_TAPN_SPLIT")) : 1024;
+        static const int tt = pg_exp_env("PATCHGAN_TAPN_SPLIT") ? atoi(pg_exp_env("PATCHGAN_TAPN_SPLIT")) : 1024;
         long want = tt / ((long)p.tiles_m * p.tiles_n);
         long smax = p.nchunks / 4;
         if (want > smax) want = smax;
@@ -2676,7 +2676,7 @@ inline size_t b2s_tapn_ws(const Geom& g) { return (size_t)g.N * g.Hb * g.Wb * 16
 
 inline bool tapk_enabled() {
     static const bool off = [] {
-        const char* e = getenv("PATCHGAN_NO_TAPK");
+        const char* e = pg_exp_env("PATCHGAN_NO_TAPK");
         return e && e[0] == '1';
     }();
     return !off;
@@ -2694,7 +2694,7 @@ struct Tune {
     int bf16ring;   // ... their staging: 1 three-stage ring of 32-wide chunks, 0 one buffer of 64-wide chunks, -1 per-layer default
 };
 inline int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
+    const char* e = pg_exp_env(name);
     return e ? atoi(e) : dflt;
 }
 inline Tune tune_of(int algo) {

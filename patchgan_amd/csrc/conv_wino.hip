@@ -1315,7 +1315,7 @@ bool pg_wino_eligible(int N, int Hin, int Win, int Cin, int Hout, int Wout, int 
 // 128-tile rows unless that leaves the 256 CUs short of two workgroups each
 bool pg_wino_small_tile(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced) {
     static const int forced = [] {
-        const char* e = getenv("PATCHGAN_WINO_TILE");
+        const char* e = pg_exp_env("PATCHGAN_WINO_TILE");
         return e ? atoi(e) : 0;
     }();
     if (pg_wino_mo(N, Hout, Wout, Cin, Cout, mo_forced) == 3) return true;          // nine output accumulator sets: 64-tile rows only
@@ -1359,7 +1359,7 @@ int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N,
 // whichever way the tile is staged), so the register-staged kernel stays the default.
 int pg_wino_dma_mode() {
     static const int mode = [] {
-        const char* e = getenv("PATCHGAN_WINO_DMA");
+        const char* e = pg_exp_env("PATCHGAN_WINO_DMA");
         return e ? atoi(e) : 0;
     }();
     return mode;
@@ -1424,7 +1424,7 @@ bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb) {
 // stride-1 weight gradient: 64x64 output tiles unless 128x128 ones alone give >= 768 workgroups (no K split then)
 bool pg_wino_wgrad_tile64(int Ca, int Cb) {
     static const int forced = [] {
-        const char* e = getenv("PATCHGAN_WINOW_TILE");
+        const char* e = pg_exp_env("PATCHGAN_WINOW_TILE");
         return e ? atoi(e) : 0;
     }();
     if (forced) return forced == 64;
@@ -1481,7 +1481,7 @@ int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big
 // batches per workgroup of k_wino_bgemm_mz (1 -> the single-batch kernel; PATCHGAN_BGEMM_MZ=0 forces that): the largest divisor of X that still leaves >= 768 workgroups (3 per CU)
 static int bgemm_zb(long tiles_mn, int X) {
     static const bool off = [] {
-        const char* e = getenv("PATCHGAN_BGEMM_MZ");
+        const char* e = pg_exp_env("PATCHGAN_BGEMM_MZ");
         return e && e[0] == '0';
     }();
     if (off) return 1;
@@ -1494,7 +1494,7 @@ static int bgemm_zb(long tiles_mn, int X) {
 // ---- stride-2 layers (polyphase / parity classes) ----
 int pg_wino2_mo() {     // output tile edge: 3 (default) or 4 (PATCHGAN_WINO2_TILE=4)
     static const int mo = [] {
-        const char* e = getenv("PATCHGAN_WINO2_TILE");
+        const char* e = pg_exp_env("PATCHGAN_WINO2_TILE");
         return (e && atoi(e) == 4) ? 4 : 3;
     }();
     return mo;
@@ -1694,7 +1694,7 @@ bool pg_wino2_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb) {
 // 128x128 output tiles when they alone fill the chip, else 64x64 tiles (4x the workgroups) so that fewer, longer K slices do
 bool pg_wino2_wgrad_tile64(int Ca, int Cb) {
     static const int forced = [] {
-        const char* e = getenv("PATCHGAN_WINO2W_TILE");
+        const char* e = pg_exp_env("PATCHGAN_WINO2W_TILE");
         return e ? atoi(e) : 0;
     }();
     if (forced) return forced == 64;

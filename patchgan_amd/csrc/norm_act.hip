@@ -524,7 +524,7 @@ ChunkPlan chunk_plan(int N, int HW, int C, int vecw) {
     p.groups = (units + G - 1) / G;
     int nchunk = 1;
     static const int chunk_min = [] {
-        const char* e = getenv("PATCHGAN_IN_CHUNK_MIN");
+        const char* e = pg_exp_env("PATCHGAN_IN_CHUNK_MIN");
         return e ? atoi(e) : 512;
     }();
     if (HW >= chunk_min) {

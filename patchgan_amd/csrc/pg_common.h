@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <algorithm>
 #include "patchgan_hip.h"
 
@@ -63,5 +64,13 @@ struct pg_epi_mul {
     const void* t;
     int ld, act;
 };
+
+// The PATCHGAN_* tuning variables (tile / split sweeps, kernel-family switches) exist for same-device A/B timing and
+// are honoured only when PATCHGAN_EXPERIMENT is set: a production process reads exactly one environment variable on this path.
+// (Callers and tests select kernels through the PG_TUNE_* bits of `algo`.)
+static inline const char* pg_exp_env(const char* name) {
+    static const bool on = getenv("PATCHGAN_EXPERIMENT") != nullptr;
+    return on ? getenv(name) : nullptr;
+}
 
 static inline int pg_launch_status() { return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH; }

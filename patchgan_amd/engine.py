@@ -415,11 +415,16 @@ def conv_instnorm_act(op, opcode, src, flat, p_off, y, out, stats, act, drop_p=0
         instnorm_act_fwd(y, out, stats, act, drop_p, seed)
 
 
-FUSE_IN_STATS = os.environ.get('PATCHGAN_FUSE_IN_STATS', '1') != '0'      # A/B switches (same-device timing)
-KEEP_V = os.environ.get('PATCHGAN_KEEP_V', '1') != '0'
-CACHE_U = os.environ.get('PATCHGAN_CACHE_U', '1') != '0'
-FUSE_ACT_BWD = os.environ.get('PATCHGAN_FUSE_ACT_BWD', '1') != '0'   # activation backward in the data-gradient epilogue above it
-SEAM8 = os.environ.get('PATCHGAN_SEAM8', '1') != '0'       # bf16 storage: image-facing tensors in 8-channel bf16 pixels
+def _exp_env(name, default='1'):
+    """A/B switches for same-device timing: honoured only when PATCHGAN_EXPERIMENT is set (like the C side's pg_exp_env)."""
+    return os.environ.get(name, default) if 'PATCHGAN_EXPERIMENT' in os.environ else default
+
+
+FUSE_IN_STATS = _exp_env('PATCHGAN_FUSE_IN_STATS') != '0'     # InstanceNorm sums from the producing conv
+KEEP_V = _exp_env('PATCHGAN_KEEP_V') != '0'                   # transformed input handed from forward to weight gradient
+CACHE_U = _exp_env('PATCHGAN_CACHE_U') != '0'                 # per-step cache of transformed / packed discriminator weights
+FUSE_ACT_BWD = _exp_env('PATCHGAN_FUSE_ACT_BWD') != '0'       # activation backward in the data-gradient epilogue above it
+SEAM8 = _exp_env('PATCHGAN_SEAM8') != '0'       # bf16 storage: image-facing tensors in 8-channel bf16 pixels
 
 
 def instnorm_act_bwd(g1, g2, y, stats, dy, act, drop_p=0.0, seed=0):

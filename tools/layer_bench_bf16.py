@@ -1,6 +1,7 @@
 """Per-layer timing of the PG_ALGO_BF16 conv kernels on bf16 tensors at the cfg4 shapes (512x512, nf = ndf = 64, B = 8), the
 LDS-DMA kernels of conv_bf16.hip next to the register-staged ones (PG_TUNE_BF16X_OFF), in one process on one device.
-    python tools/layer_bench_bf16.py [layer-name-prefix ...]        LB_BATCH / LB_REPS / LB_SIZE override 8 / 10 / 512"""
+    python tools/layer_bench_bf16.py [layer-name-prefix ...]        LB_BATCH / LB_REPS / LB_SIZE override 8 / 10 / 512
+Tile / split sweeps: PATCHGAN_EXPERIMENT=1 PATCHGAN_BF16X_TILE=0|1|2 PATCHGAN_BF16X_TARGET=<workgroups> (also _WTILE / _WTARGET)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

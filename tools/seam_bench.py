@@ -1,4 +1,4 @@
-"""Timing of the image-facing (few-channel) conv layers: tools/seam_bench.py  (PATCHGAN_NO_TAPK=1 for the generic kernels)"""
+"""Timing of the image-facing (few-channel) conv layers: tools/seam_bench.py  (PATCHGAN_EXPERIMENT=1 PATCHGAN_NO_TAPK=1 for the generic kernels)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
