@@ -2047,6 +2047,53 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const float* __restrict__ sm
 //   big2small:  D[big pixel][(tap, a)]    ->  small[n,p,q,a] = act(sum_{kh,kw in range} D[(s*p-1+kh, s*q-1+kw)] + bias[a])
 // and the weight re-layout the first needs: W'[(tap*Cb + b)][a] = P[tap][a][b] (a few KB).
 // ------------------------------------------------------------------------------------------------
+// The same gather for stride 2 with the D rows staged through LDS: a workgroup owns the 2*CT_H x 2*CT_W big pixels of one sample
+// that descend from a CT_H x CT_W block of small pixels, loads the (CT_H + 2) x (CT_W + 2) small pixels' D rows that reach them
+// once, coalesced (a row is 16 * Cb contiguous floats), and sums the four taps of every output from LDS.  (The kernel above reads
+// each D row in 16-byte pieces from four different pixels' threads: 1.3 - 2.3 TB/s at 512 x 512.)
+constexpr int CT_H = 4, CT_W = 16;
+__global__ __launch_bounds__(256) void k_col2im_s2_lds(const float* __restrict__ D, const float* __restrict__ bias, float* __restrict__ big,
+                                                       int ld_big, Geom g, int act, int tiles_h, int tiles_w) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];   // [(CT_H + 2) * (CT_W + 2)][Nc]
+    const int Nc = 16 * g.Cb, nq = Nc >> 2;
+    int t = blockIdx.x;
+    const int tw = t % tiles_w;
+    t /= tiles_w;
+    const int th = t % tiles_h, n = t / tiles_h;
+    const int a0 = th * CT_H, b0 = tw * CT_W;                     // first small pixel of the block; staged rows start one earlier
+    constexpr int RW = CT_W + 2, NR_ = (CT_H + 2) * RW;
+    for (int i = threadIdx.x; i < NR_ * nq; i += 256) {
+        const int r = i / nq, q = i - r * nq;
+        const int ih = a0 - 1 + r / RW, iw = b0 - 1 + r % RW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws)
+            v = *reinterpret_cast<const f32x4*>(D + (long)((n * g.Hs + ih) * g.Ws + iw) * Nc + 4 * q);
+        *reinterpret_cast<f32x4*>(rows + r * Nc + 4 * q) = v;
+    }
+    __syncthreads();
+    const int npx = 2 * CT_H * 2 * CT_W;
+    for (int i = threadIdx.x; i < npx * g.Cb; i += 256) {
+        const int b = i % g.Cb, p = i / g.Cb;
+        const int hl = p / (2 * CT_W), wl = p - hl * (2 * CT_W);
+        const int h = 2 * a0 + hl, w = 2 * b0 + wl;
+        if (h >= g.Hb || w >= g.Wb) continue;
+        // big row h = 2a + r: taps kh with (h + 1 - kh) even -> kh = 1 - r + 2j (j = 0, 1), small row a + r - j
+        const int rh = hl & 1, rw = wl & 1, al = hl >> 1, bl = wl >> 1;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kh = 1 - rh + 2 * j, ihl = al + rh - j + 1;             // + 1: the staged block starts at a0 - 1
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int kw = 1 - rw + 2 * k, iwl = bl + rw - k + 1;
+                acc += rows[(ihl * RW + iwl) * Nc + (kh * 4 + kw) * g.Cb + b];      // out-of-image small pixels were staged as zeros
+            }
+        }
+        if (bias) acc += bias[b];
+        big[((long)(n * g.Hb + h) * g.Wb + w) * ld_big + b] = pg_act_epi(acc, act);
+    }
+}
+
 __global__ void k_col2im_small2big(const float* __restrict__ D, const float* __restrict__ bias, float* __restrict__ big,
                                    int ld_big, Geom g, int act) {
     const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
@@ -3104,6 +3151,22 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     return PG_OK;
 }
 
+// the col2im half of the taps-folded-into-N small -> big paths
+static int launch_col2im(const float* D, const float* bias, float* big, int ld_big, const Geom& g, int act, hipStream_t st) {
+    const size_t lds = (size_t)(CT_H + 2) * (CT_W + 2) * 16 * g.Cb * sizeof(float);
+    if (g.s == 2) {                    // (a D row is 16 * Cb floats: always whole float4s)
+        if (lds <= 64 * 1024 && aligned16(D)) {
+            const int tiles_h = (g.Hs + CT_H) / CT_H, tiles_w = (g.Ws + CT_W) / CT_W;      // big rows reach one small row past Hs - 1
+            hipLaunchKernelGGL(k_col2im_s2_lds, dim3((unsigned)(g.N * tiles_h * tiles_w)), dim3(256), lds, st, D, bias, big, ld_big, g, act,
+                               tiles_h, tiles_w);
+            return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+        }
+    }
+    const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
+    hipLaunchKernelGGL(k_col2im_small2big, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, D, bias, big, ld_big, g, act);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+}
+
 static const pg_conv_extras NO_EXTRAS = {nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
 
 static int b2s_impl(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small,
@@ -3323,10 +3386,7 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
                                g.Wb, g.Hs, g.Ws, g.Ca, Nc, g.s, &bp, nullptr, 0, 0, st);
         }
         if (rc != PG_OK) return rc;
-        const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
-        hipLaunchKernelGGL(k_col2im_small2big, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, D, bias,
-                           big, ld_big, g, act);
-        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+        return launch_col2im(D, bias, big, ld_big, g, act, st);
     }
     if (bf16x_ok(g, 1, algo | io, tune)) {
         const int rc = bf16x_run(1, small, ld_small, P, bias, big, ld_big, g, act, io & PG_IO_BIG_BF16, ws, ws_bytes, st, x, tune.bf16ring);
@@ -3355,10 +3415,7 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
                              (int)tensor_bytes(Ms, ld_small, g.Ca), (int)((long)Nc * g.Ca * 4));
         }
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
-        const long total = (long)g.N * g.Hb * g.Wb * g.Cb;
-        hipLaunchKernelGGL(k_col2im_small2big, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, D, bias,
-                           big, ld_big, g, act);
-        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+        return launch_col2im(D, bias, big, ld_big, g, act, st);
     }
     Plan p = plan_s2b(gg);
     clamp_split(p, ws_bytes, 0);
