@@ -119,3 +119,79 @@ def test_two_rank_dropout_masks_are_those_of_the_global_batch(tmp_path):
     err = np.abs(res[0][1] - single) / np.maximum(np.abs(single), 1e-6)
     print('dp2 with dropout vs single process: max rel err per step', err.max(axis=1))
     assert err.max() < 1e-4, err
+
+
+def _worker_bf16(rank, world, port, q, gw, dw, x, y, nsteps):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(4)
+    import tempfile
+    import patchgan_amd as pg
+    from patchgan_amd.parallel import shard_batch
+    from tests.golden_util import LOSS_KEYS
+    g = pg.UNet(3, 4, 64, activation='leakyrelu', final_act='softmax', use_dropout=False)
+    d = pg.Discriminator(7, 64, n_layers=3)
+    g.load_state_dict(gw)
+    d.load_state_dict(dw)
+    g.cuda().set_precision('bf16')
+    d.cuda().set_precision('bf16')
+    t = pg.Trainer(g, d, tempfile.mkdtemp())
+    t.loss_type = 'weighted_bce'
+    t.setup_optimizers(1e-3, 1e-3)
+    g.train()
+    d.train()
+    xs, ys = shard_batch(x, y, rank, world)
+    curve = [[t.batch(xs, ys, train=True)[k] for k in LOSS_KEYS] for _ in range(nsteps)]
+    t.flush()
+    torch.cuda.synchronize()
+    q.put((rank, np.array(curve), g.flat.cpu().numpy(), d.flat.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_bf16_storage_tracks_single_process(tmp_path):
+    """BASELINE config 3 in miniature: the multi-class network (4-channel softmax head, weighted BCE) in bf16 mode with bf16
+    activation storage, nf = ndf = 64, two ranks with one 256 x 256 sample each against the single-process run on both samples.
+    The per-rank kernels see half the batch (other tile / split-K plans, other summation orders of bf16-rounded values), so the
+    statement is a bf16-level one: both ranks bit-identical to each other; step 1 (same weights) within 5e-3 on every loss; the
+    generator-side losses of all 3 steps within 2e-2; the discriminator's BCE terms -- small numbers that three Adam steps at 1e-3
+    drive apart from any bf16-level perturbation (measured 1e-3, 4e-2, 1.8e-1) -- within 0.5."""
+    import patchgan_amd as pg
+    from tests.golden_util import LOSS_KEYS
+    torch.manual_seed(77)
+    g = pg.UNet(3, 4, 64, activation='leakyrelu', final_act='softmax', use_dropout=False)
+    d = pg.Discriminator(7, 64, n_layers=3)
+    gw = {k: v.clone() for k, v in g.state_dict().items()}
+    dw = {k: v.clone() for k, v in d.state_dict().items()}
+    gen = torch.Generator().manual_seed(8)
+    x = torch.rand(2, 3, 256, 256, generator=gen)
+    y = (torch.rand(2, 4, 256, 256, generator=gen) > 0.7).float()
+    nsteps = 3
+    g.cuda().set_precision('bf16')
+    d.cuda().set_precision('bf16')
+    t = pg.Trainer(g, d, str(tmp_path / 'single'))
+    t.loss_type = 'weighted_bce'
+    t.setup_optimizers(1e-3, 1e-3)
+    g.train()
+    d.train()
+    single = np.array([[t.batch(x, y, train=True)[k] for k in LOSS_KEYS] for _ in range(nsteps)])
+    torch.cuda.synchronize()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, 2, port, q, gw, dw, x, y, nsteps)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, c0, g0, d0), (_, c1, g1, d1) = res
+    assert np.array_equal(g0, g1) and np.array_equal(d0, d1) and np.allclose(c0, c1, rtol=1e-6)
+    err = np.abs(c0 - single) / np.maximum(np.abs(single), 1e-3)
+    print('dp2 bf16 storage vs single process: max rel err per step', err.max(axis=1))
+    assert err[0].max() < 5e-3 and err[:, :3].max() < 2e-2 and err.max() < 0.5, err
