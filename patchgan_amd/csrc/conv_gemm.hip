@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 template <int CB, int MI = 2>      // MI: 32-row MFMA tiles per wave: 128 (CB <= 4) or 64 (CB <= 8, K <= 128) pixels per workgroup
 __global__ __launch_bounds__(256) void k_b2s_tapk(const float* __restrict__ big, int ld_big, const float* __restrict__ P,
                                                   float* __restrict__ out, int ld_out, Geom g, const float* __restrict__ bias,
-                                                  int act, int vec4) {
+                                                  int act, int vec4, int vec_out) {
     constexpr int K = 16 * CB, LDT = K + 4, TM = 64 * MI;
     __shared__ __attribute__((aligned(16))) float smem[(TM + 64) * LDT];
     float* As = smem;
@@ -1444,18 +1444,31 @@ __global__ __launch_bounds__(256) void k_b2s_tapk(const float* __restrict__ big,
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[e], acc[i], 0, 0, 0);
+            for (int i = 0; i < MI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[e], af[i][e], acc[i], 0, 0, 0);   // D[channel][pixel]
     }
-    const int col = n0 + wn * 32 + lrow;
-    const float bv = (bias != nullptr && col < g.Ca) ? bias[col] : 0.f;
+    // transposed product (weights as the A operand): a lane owns pixel lrow of its tile and, per accumulator quad, 4 consecutive
+    // channels -- one 16-byte store instead of four 4-byte ones (the kernel is bound by its output stores)
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + (wm * MI + i) * 32 + lrow;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int m = m0 + (wm * MI + i) * 32 + row;
-            if (m < M && col < g.Ca) out[(long)m * ld_out + col] = pg_act_epi(acc[i][r] + bv, act);
+        for (int q = 0; q < 4; ++q) {
+            const int ch = n0 + wn * 32 + 8 * q + 4 * lh;
+            if (m >= M || ch >= g.Ca) continue;
+            if (vec_out) {
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (bias != nullptr) bv = *reinterpret_cast<const f32x4*>(bias + ch);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = pg_act_epi(acc[i][4 * q + e] + bv[e], act);
+                *reinterpret_cast<f32x4*>(out + (long)m * ld_out + ch) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ch + e < g.Ca) out[(long)m * ld_out + ch + e] = pg_act_epi(acc[i][4 * q + e] + (bias != nullptr ? bias[ch + e] : 0.f), act);
+            }
         }
+    }
 }
 
 // ================================================================================================
@@ -3035,11 +3048,11 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         if (tile_id) *tile_id += (mo1 == 3) ? 90 : (st ? 50 : 40);     // +90: F(3x3,4x4) variant k_wino_gemm<1,1,2,2,2,3>
     }
     // 81..83: one-shot k_b2s_tapk<Cb> for 1..3 big-side channels
-    if (op == 0 && (g->Cb <= 3 || g->Cb == 5) && !(algo_full & PG_IO_MASK) && !force_generic() && tapk_enabled() &&
+    if (op == 0 && g->Cb <= 5 && !(algo_full & PG_IO_MASK) && !force_generic() && tapk_enabled() &&
         !(b2s_tapn_ok(gq) && ws_bytes >= b2s_tapn_ws(gq))) {
         if (tile_id) *tile_id = 80 + g->Cb;
         if (split) *split = 1;
-        const int tmk = g->Cb <= 3 ? 128 : 64;
+        const int tmk = g->Cb <= 4 ? 128 : 64;
         if (workgroups) *workgroups = (((long)g->N * g->Hs * g->Ws + tmk - 1) / tmk) * ((g->Ca + 63) / 64);
         return PG_OK;
     }
@@ -3236,21 +3249,22 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
                            small, ld_small, g, act);
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
-    if ((g.Cb <= 3 || g.Cb == 5) && !io && !force_generic() && tapk_enabled()) {     // (6..8 channels: measured slower than the generic kernel)
+    if (g.Cb <= 5 && !io && !force_generic() && tapk_enabled()) {     // (6..8 channels: measured slower than the generic kernel)
         // K = 16*Cb <= 48: one-shot kernel (with 4 channels the pipelined generic kernel is as fast: 46 TFLOP/s both)
         const int vec4 = (g.Cb == 4) && (ld_big % 4 == 0) && aligned16(big);
-        const int tmk = g.Cb <= 3 ? 128 : 64;
+        const int vec_out = (g.Ca % 4 == 0) && (ld_small % 4 == 0) && aligned16(small) && (!bias || aligned16(bias));
+        const int tmk = g.Cb <= 4 ? 128 : 64;
         dim3 grid((unsigned)(((long)g.N * g.Hs * g.Ws + tmk - 1) / tmk), (g.Ca + 63) / 64, 1);
         TimedLaunch timed(st);
         switch (g.Cb) {
-            case 1: hipLaunchKernelGGL(k_b2s_tapk<1>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4); break;
-            case 2: hipLaunchKernelGGL(k_b2s_tapk<2>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4); break;
-            case 3: hipLaunchKernelGGL(k_b2s_tapk<3>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4); break;
-            case 5: hipLaunchKernelGGL((k_b2s_tapk<5, 1>), grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, 0); break;
-            case 6: hipLaunchKernelGGL((k_b2s_tapk<6, 1>), grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, 0); break;
-            case 7: hipLaunchKernelGGL((k_b2s_tapk<7, 1>), grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, 0); break;
-            case 8: hipLaunchKernelGGL((k_b2s_tapk<8, 1>), grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, 0); break;
-            default: hipLaunchKernelGGL(k_b2s_tapk<4>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4); break;
+            case 1: hipLaunchKernelGGL(k_b2s_tapk<1>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4, vec_out); break;
+            case 2: hipLaunchKernelGGL(k_b2s_tapk<2>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4, vec_out); break;
+            case 3: hipLaunchKernelGGL(k_b2s_tapk<3>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4, vec_out); break;
+            case 5: hipLaunchKernelGGL((k_b2s_tapk<5, 1>), grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, 0, vec_out); break;
+            case 6: hipLaunchKernelGGL((k_b2s_tapk<6, 1>), grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, 0, vec_out); break;
+            case 7: hipLaunchKernelGGL((k_b2s_tapk<7, 1>), grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, 0, vec_out); break;
+            case 8: hipLaunchKernelGGL((k_b2s_tapk<8, 1>), grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, 0, vec_out); break;
+            default: hipLaunchKernelGGL(k_b2s_tapk<4>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4, vec_out); break;
         }
         return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
     }
