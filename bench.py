@@ -240,8 +240,11 @@ def main():
     last = None
     host_ms = 0.0
     for _ in range(args.steps):
-        last = t.batch(x, y, train=True)
+        cur = t.batch(x, y, train=True)
         host_ms += t.host_ms
+        if last is not None:
+            last['gen']            # as Trainer.train's epoch loop: step i's losses are read once step i + 1 is enqueued
+        last = cur
     t.flush()                      # the last step's (deferred, data-parallel) discriminator update belongs to the timed work
     sync()
     elapsed = time.perf_counter() - t0
