@@ -20,8 +20,10 @@ blocks, t0, ok = [], time.perf_counter(), True
 for s in range(1, steps + 1):
     x = torch.rand(16, 3, 256, 256, device='cuda', generator=gen)
     y = (x.mean(1, keepdim=True) > 0.5).float()          # a learnable target
-    l = t.batch(x, y, train=True)
-    ok = ok and all(math.isfinite(v) for v in l.values())
+    cur = t.batch(x, y, train=True)
+    if s > 1:
+        ok = ok and all(math.isfinite(v) for v in l.values())     # step s - 1, read once step s is enqueued (as Trainer.train does)
+    l = cur
     if s % 100 == 0:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
