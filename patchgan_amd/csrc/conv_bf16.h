@@ -36,7 +36,8 @@ int pg_bf16x_pack(const float* P, void* W, int Ca, int Cb, int dir, hipStream_t 
 // [split][pixels][Cout] for the caller's reduce pass
 int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void* W, void* out, int ld_out, long slab_stride,
                   int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, const pg_bf16x_plan* p, const float* bias,
-                  int act, int out_bf, hipStream_t st, pg_epi_mul mul = pg_epi_mul{nullptr, 0, 0}, double* part = nullptr, int chunks = 0);
+                  int act, int out_bf, hipStream_t st, pg_epi_mul mul = pg_epi_mul{nullptr, 0, 0}, double* part = nullptr, int chunks = 0, int bt = 0);
+// bt (dir 1): W is the dir-0 pack ([tap][a][b]): the kernel stages the weight tile [a][b] and reads it transposed
 // part (dir 0 / 1, unsplit K, bf16 output): the epilogue also writes per-sample partial sums / sums of squares of the stored values,
 // part[((n * chunks + chunk) * Cout + c) * 2 + {0, 1}] (fp64), chunks = pg_bf16x_stats_chunks(...) (0: not available)
 int pg_bf16x_stats_chunks(int dir, const pg_bf16x_plan* p, int N, int Hb, int Wb, int Hs, int Ws);

@@ -56,6 +56,16 @@ __device__ __forceinline__ unsigned pack2(float x, float y) {
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds, int byte_off) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (void __attribute__((address_space(3)))*)lds, 16, byte_off, 0, 0, 0);
 }
+// 8 consecutive K rows of one column as an MFMA bf16 fragment from a [K][column] LDS image: two transposing reads
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_frag2(const char* p, int second) {   // rows p and p + second (4 pixel rows further)
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + second));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -71,7 +81,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // follows: part[((n * chunks + chunk) * Cout + c) * 2 + {0, 1}], fp64, one chunk per workgroup tile (the host guarantees
 // that a tile lies inside one sample and that the K loop is not split).  Per 32-channel column block: in-lane sums over the wave's
 // pixel tiles, a transpose through LDS (lane <-> value, fixed order), the waves that share the channels combined in wave order.
-template <int MR, int NR, int WM, int WN, int DRC, int KB, bool MUL = false, bool STATS = false>
+// BT (dir 1): the weights come in the SAME packed layout as dir 0 ([tap][a][b], b contiguous): the B tile is staged [k = a][n = b] and its
+// fragments come out of transposing reads, so one bf16 copy of a layer's weights serves both directions.
+template <int MR, int NR, int WM, int WN, int DRC, int KB, bool MUL = false, bool STATS = false, bool BT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv_bf16x(
     const __bf16* __restrict__ in, int ld_in, const __bf16* __restrict__ W, void* __restrict__ out, int ld_out, long slab_stride, XGeom g,
     int cps, const float* __restrict__ bias, int act, int in_bytes, int w_bytes, int out_bf, int tiles_n, pg_epi_mul mul, double* __restrict__ part,
@@ -157,13 +169,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         a_mask[i] = (m < Mc) ? mask : 0u;
     }
+    static_assert(!BT || (DRC == 1 && KB == 64), "transposed B staging: small -> big, 64-wide chunks");
+    constexpr int RBB = BN * 2, RPB = 1024 / RBB, LPRB = RBB / 16;        // BT: B rows = the chunk's 64 input channels, BN * 2 bytes each
+    auto swzT = [](int r) { return RBB >= 256 ? (r & 3) << 2 : ((r >> 1) & 1) << 2; };
     int b_off[BP];
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
-        const int r = (wave * BP + j) * RPP + lane / SPR;
-        const int cc = (lane % SPR) ^ swz(r);
-        const int n = n0 + r;
-        b_off[j] = (n < Cout) ? (n * Cin + cc * 8) * 2 : (int)0x80000000u;
+        if constexpr (BT) {
+            const int r = (wave * BP + j) * RPB + lane / LPRB;     // (BP == 64 / RPB / 4 for both tile widths)
+            const int ch = (lane % LPRB) ^ swzT(r);
+            const int b = n0 + ch * 8;
+            b_off[j] = (b < Cout) ? (r * Cout + b) * 2 : (int)0x80000000u;
+        } else {
+            const int r = (wave * BP + j) * RPP + lane / SPR;
+            const int cc = (lane % SPR) ^ swz(r);
+            const int n = n0 + r;
+            b_off[j] = (n < Cout) ? (n * Cin + cc * 8) * 2 : (int)0x80000000u;
+        }
     }
     char* const a_dst = smem + wave * AP * 1024;
     char* const b_dst = smem + BM * ROWB + wave * BP * 1024;
@@ -174,6 +196,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int ks = 0; ks < KB / 16; ++ks) slot[ks] = lrow * ROWB + (((ks * 2 + lh) ^ swz(lrow)) << 4);
     const char* const a_rd = smem + wm * MR * 32 * ROWB;
     const char* const b_rd = smem + BM * ROWB + wn * NR * 32 * ROWB;
+    int b_rdt[BT ? NR : 1];                                        // BT: transposed-read addresses (as k_wgrad_bf16x)
+    if constexpr (BT) {
+        const int q4 = (lane & 15) >> 2, g4 = lane >> 4;
+        const int chl = (g4 & 1) * 2 + ((lane & 3) >> 1), half8 = (lane & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) b_rdt[j] = (lh * 8 + q4) * RBB + ((((wn * NR + j) * 4 + chl) ^ swzT(q4)) << 4) + half8;
+    }
 
     f32x16 acc[MR][NR];
 #pragma unroll
@@ -204,7 +233,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         } else {
             const int th = tl >> Tsh, tw = tl & (T - 1);
             a_uni = (cin0 - (th * Win + tw) * ld_in) * 2;
-            w_uni = (((kh0 + g.s * th) * 4 + (kw0 + g.s * tw)) * CC + cin0) * 2;
+            w_uni = BT ? (((kh0 + g.s * th) * 4 + (kw0 + g.s * tw)) * CC + cin0 * Cout) * 2
+                       : (((kh0 + g.s * th) * 4 + (kw0 + g.s * tw)) * CC + cin0) * 2;
         }
         const unsigned kill = on ? 0u : 0x80000000u;
 #pragma unroll
@@ -232,7 +262,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_rd + stage * STAGE + i * 32 * ROWB + slot[ks]);
 #pragma unroll
-            for (int j = 0; j < NR; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(b_rd + stage * STAGE + j * 32 * ROWB + slot[ks]);
+            for (int j = 0; j < NR; ++j) {
+                if constexpr (BT)
+                    bf[j] = tr_frag2(smem + BM * ROWB + stage * STAGE + ks * 16 * RBB + b_rdt[j], 4 * RBB);
+                else
+                    bf[j] = *reinterpret_cast<const bf16x8*>(b_rd + stage * STAGE + j * 32 * ROWB + slot[ks]);
+            }
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -394,15 +429,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Output transposed (D[b][a]): a lane owns 4 consecutive b of one a per accumulator quad = one 16-byte fp32 store.
 // Grid: flat, XCD-remapped so that the 16 taps of one (tile, K slice) run back to back on one XCD: they share the `small` tile and
 // read shifted windows of the same `big` pixels from that XCD's L2.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ bf16x8 tr_frag2(const char* p, int second) {   // rows p and p + second (4 pixel rows further)
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + second));
-    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, both);
-}
-
 // TAPN: `big` has 8 channels per pixel (ld_big == 8, g.Cb <= 8 real ones): the 16 taps x 8 channels are the 128 b-columns of ONE GEMM
 // (no tap dimension in the grid); one DMA lane fetches one tap's pixel (16 bytes), its own (kh, kw) offset instead of the block's.
 template <int MR, int NR, int WM, int WN, bool TAPN = false>
@@ -696,33 +722,31 @@ int pg_bf16x_pack(const float* P, void* W, int Ca, int Cb, int dir, hipStream_t 
 
 int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void* W, void* out, int ld_out, long slab_stride,
                   int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, const pg_bf16x_plan* p, const float* bias,
-                  int act, int out_bf, hipStream_t st, pg_epi_mul mul, double* part, int chunks) {
+                  int act, int out_bf, hipStream_t st, pg_epi_mul mul, double* part, int chunks, int bt) {
     if (part && (mul.t || dir > 1 || p->split != 1 || !out_bf || slab_stride != 0)) return PG_EINVAL;
     const XGeom g{N, Hb, Wb, Hs, Ws, Ca, Cb, stride};
     const dim3 grid((unsigned)(p->tiles_m * p->tiles_n), 1, (unsigned)(p->ncls * p->split));
     const int w_bytes = (dir == 2) ? 16 * Ca * 8 * 2 : (dir == 3) ? Ca * Cb * 2 : 16 * Ca * Cb * 2;
     const __bf16* I = (const __bf16*)in;
     const __bf16* Wp = (const __bf16*)W;
-#define PG_BF16X_LAUNCH1(MR, NR, WM, WN, D, KB)                                                                              \
-    hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB>), grid, dim3(256), 0, st, I, ld_in, Wp, out, ld_out, slab_stride, g, \
-                       p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul, part, chunks)
-#define PG_BF16X_LAUNCHM(MR, NR, WM, WN)                                                                                     \
-    hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, 1, 64, true>), grid, dim3(256), 0, st, I, ld_in, Wp, out, ld_out, slab_stride, g, \
-                       p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul, part, chunks)
-#define PG_BF16X_LAUNCHS(MR, NR, WM, WN, D)                                                                                  \
-    hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, 64, false, true>), grid, dim3(256), 0, st, I, ld_in, Wp, out, ld_out,   \
-                       slab_stride, g, p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul, part, chunks)
+#define PG_BF16X_ARGS I, ld_in, Wp, out, ld_out, slab_stride, g, p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul, part, chunks
+#define PG_BF16X_K(MR, NR, WM, WN, D, KB, MUL, ST, BT) \
+    hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB, MUL, ST, BT>), grid, dim3(256), 0, st, PG_BF16X_ARGS)
 #define PG_BF16X_LAUNCH(MR, NR, WM, WN)                                                                                      \
     do {                                                                                                                     \
-        if (part && dir == 0) PG_BF16X_LAUNCHS(MR, NR, WM, WN, 0);                                                           \
-        else if (part) PG_BF16X_LAUNCHS(MR, NR, WM, WN, 1);                                                                  \
-        else if (dir == 0 && !p->ring) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 0, 64);                                                   \
-        else if (dir == 0) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 0, 32);                                                          \
-        else if (dir == 1 && mul.t) PG_BF16X_LAUNCHM(MR, NR, WM, WN);                                                        \
-        else if (dir == 1 && !p->ring) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 1, 64);                                              \
-        else if (dir == 1) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 1, 32);                                                          \
-        else if (dir == 2) PG_BF16X_LAUNCH1(MR, NR, WM, WN, 2, 64);                                                          \
-        else PG_BF16X_LAUNCH1(MR, NR, WM, WN, 3, 64);                                                                        \
+        if (dir == 1 && !p->ring && bt) {                                                                                    \
+            if (part) PG_BF16X_K(MR, NR, WM, WN, 1, 64, false, true, true);                                                  \
+            else if (mul.t) PG_BF16X_K(MR, NR, WM, WN, 1, 64, true, false, true);                                            \
+            else PG_BF16X_K(MR, NR, WM, WN, 1, 64, false, false, true);                                                      \
+        } else if (part && dir == 0) PG_BF16X_K(MR, NR, WM, WN, 0, 64, false, true, false);                                  \
+        else if (part) PG_BF16X_K(MR, NR, WM, WN, 1, 64, false, true, false);                                                \
+        else if (dir == 0 && !p->ring) PG_BF16X_K(MR, NR, WM, WN, 0, 64, false, false, false);                               \
+        else if (dir == 0) PG_BF16X_K(MR, NR, WM, WN, 0, 32, false, false, false);                                           \
+        else if (dir == 1 && mul.t) PG_BF16X_K(MR, NR, WM, WN, 1, 64, true, false, false);                                   \
+        else if (dir == 1 && !p->ring) PG_BF16X_K(MR, NR, WM, WN, 1, 64, false, false, false);                               \
+        else if (dir == 1) PG_BF16X_K(MR, NR, WM, WN, 1, 32, false, false, false);                                           \
+        else if (dir == 2) PG_BF16X_K(MR, NR, WM, WN, 2, 64, false, false, false);                                           \
+        else PG_BF16X_K(MR, NR, WM, WN, 3, 64, false, false, false);                                                         \
     } while (0)
     switch (p->tile) {
         case 0: PG_BF16X_LAUNCH(4, 2, 2, 2); break;
@@ -730,9 +754,8 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
         default: PG_BF16X_LAUNCH(2, 2, 4, 1); break;
     }
 #undef PG_BF16X_LAUNCH
-#undef PG_BF16X_LAUNCH1
-#undef PG_BF16X_LAUNCHM
-#undef PG_BF16X_LAUNCHS
+#undef PG_BF16X_K
+#undef PG_BF16X_ARGS
     return pg_launch_status();
 }
 

@@ -2767,7 +2767,7 @@ inline Tune tune_of(int algo) {
         t.mo1 = env_int("PATCHGAN_WINO1_TILE", 0);
         t.dma = pg_wino_dma_mode();
         t.bf16x = env_int("PATCHGAN_NO_BF16X", 0) != 1;
-        t.bf16ring = env_int("PATCHGAN_BF16X_RING", -1);
+        t.bf16ring = -1;      // (pinned only per call: PG_TUNE_BF16X_RING / _FLAT)
         return t;
     }();
     Tune t = env;
@@ -2890,8 +2890,12 @@ int bf16x_run(int dir, const void* in, int ld_in, const float* P, const float* b
         rest += wb;
         avail -= wb;
     }
+    // small -> big reads the SAME packed copy as big -> small (transposed staging in the kernel): one pack per layer serves both
+    // (not the ring-staged variant, PG_TUNE_BF16X_RING: it keeps the per-tap transposed pack; callers that share one cache entry
+    // between the two directions of a layer must not set that bit -- engine._ucache checks it)
+    const int bt = (dir == 1 && !(ring > 0)) ? 1 : 0;
     if (!(x.u_cache && x.u_valid)) {
-        int rc = pg_bf16x_pack(P, W, g.Ca, g.Cb, dir, st);
+        int rc = pg_bf16x_pack(P, W, g.Ca, g.Cb, bt ? 0 : dir, st);
         if (rc != PG_OK) return rc;
     }
     pg_bf16x_plan p = pg_bf16x_plan_of(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, ring);
@@ -2903,10 +2907,10 @@ int bf16x_run(int dir, const void* in, int ld_in, const float* P, const float* b
         TimedLaunch timed(st);
         if (p.split == 1)
             rc = pg_bf16x_conv(dir, in, ld_in, in_bytes, W, out, ld_out, 0L, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, &p, bias, act,
-                               out_bf ? 1 : 0, st, mul, x.part, chunks);
+                               out_bf ? 1 : 0, st, mul, x.part, chunks, bt);
         else
             rc = pg_bf16x_conv(dir, in, ld_in, in_bytes, W, rest, Cout, p.out_elems, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, &p,
-                               nullptr, 0, 0, st);
+                               nullptr, 0, 0, st, pg_epi_mul{nullptr, 0, 0}, nullptr, 0, bt);
     }
     if (rc != PG_OK || p.split == 1) return rc;
     return launch_reduce((const float*)rest, p.out_elems, p.split, (float*)out, ld_out, out_pix, Cout, bias, act, st, out_bf ? 1 : 0, mul);

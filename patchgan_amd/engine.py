@@ -375,6 +375,30 @@ def _bf16_tensors_ok(ops):
     return all('bf16' in op.describe(oc, L.IO_MASK)[0] for op in ops for oc in (0, 1, 2))
 
 
+def _ucache(ucache, li, opcode, op, dev, src, dst):
+    """(buffer, valid) of the transformed / packed weights of layer li / direction opcode in the caller's per-step cache (a dict that
+    lives exactly as long as the weights stay unchanged).  On bf16 tensors one packed bf16 copy serves both directions of a layer (the
+    small -> big kernel stages it transposed), so the two directions share an entry."""
+    if ucache is None or not CACHE_U:
+        return None, False
+    big, small = (src, dst) if opcode == 0 else (dst, src)
+    io = ConvOp._io(big, small)
+    if io:      # bf16 tensors: the LDS-DMA kernels' packed bf16 weights (16-byte-aligned views)
+        if not all(v.ptr() % 16 == 0 and v.ld % (8 if v.bf else 4) == 0 for v in (src, dst)):
+            return None, False
+    elif not ConvOp._aligned(src, dst):
+        return None, False
+    nb = op.u_bytes(opcode, io)
+    if not nb:
+        return None, False
+    shared = io == L.IO_MASK and op.Cb > 8 and not (op.algo & L.TUNE_BF16X_RING)
+    key = (li, 'w', nb) if shared else (li, opcode, nb)         # nb separates the F(2x2,4x4) / F(3x3,4x4) transforms of the stride-1 layer
+    if key in ucache:
+        return ucache[key], True
+    ucache[key] = torch.empty(nb, dtype=torch.uint8, device=dev)
+    return ucache[key], False
+
+
 def _dt(*views):
     """dtype mask of the *_t entry points: bit i = the i-th tensor argument is bf16."""
     m = 0
@@ -394,12 +418,14 @@ def instnorm_act_fwd(y, out, stats, act, drop_p=0.0, seed=0):
             'pg_instnorm_act_fwd')
 
 
-def conv_instnorm_act(op, opcode, src, flat, p_off, y, out, stats, act, drop_p=0.0, seed=0, v_keep=None):
+def conv_instnorm_act(op, opcode, src, flat, p_off, y, out, stats, act, drop_p=0.0, seed=0, v_keep=None, u_cache=None, u_valid=False):
     """Conv2d / ConvTranspose2d (no bias) -> InstanceNorm2d -> activation -> dropout (unet.py:19-30,53-67).  Where the conv's
     kernel can emit the per-sample sums of its output (polyphase Winograd output transform) the InstanceNorm statistics come
     from those partials and the separate statistics pass over y is skipped; otherwise conv, then pg_instnorm_act_fwd."""
     conv = op.big2small if opcode == 0 else op.small2big
     kw = {'v_keep': v_keep} if v_keep is not None else {}
+    if u_cache is not None:
+        kw.update(u_cache=u_cache, u_valid=u_valid)
     if y.HW <= 1:
         raise ValueError(f"Expected more than 1 spatial element when training, got input size "
                          f"torch.Size([{y.N}, {y.C}, {y.H}, {y.W}])")
@@ -656,12 +682,14 @@ class GeneratorEngine:
             self._ops[key] = (enc_ops, dec_ops)
         return self._ops[key]
 
-    def forward(self, flat, xin, gen_out, train, seed=0, sample0=0, keep_v=False):
+    def forward(self, flat, xin, gen_out, train, seed=0, sample0=0, keep_v=False, ucache=None):
         """xin: View [N,H,W,input_nc]; gen_out: View [N,H,W,output_nc] to receive final_act(dec6).
         train selects dropout (InstanceNorm always uses instance statistics, unet.py:77).  sample0 = index of this
         batch's first sample in the global batch (data parallelism: the dropout masks are those of the global batch).
         keep_v: a backward pass follows -- encoder layers on the polyphase Winograd path keep their transformed input for the
-        weight gradient (pg_conv_extras.v_keep / v_pre) instead of transforming it again."""
+        weight gradient (pg_conv_extras.v_keep / v_pre) instead of transforming it again.
+        ucache: a dict the caller keeps for as long as `flat` is unchanged (Trainer.batch: forward + backward of one step): on bf16
+        tensors a layer's packed bf16 weights are built once and serve both its forward and its data gradient."""
         N, H, W = xin.N, xin.H, xin.W
         dev = flat.device
         enc_ops, dec_ops = self.ops(N, H, W)
@@ -699,8 +727,9 @@ class GeneratorEngine:
             drop = 0.2 if (train and l.dropout) else 0.0
             vb = op.v_bytes() if (keep_v and KEEP_V and ConvOp._aligned(src, y)) else 0
             vk = torch.empty(vb, dtype=torch.uint8, device=dev) if vb else None
+            u, uv = _ucache(ucache, ('e', i), 0, op, dev, src, y) if bf else (None, False)
             conv_instnorm_act(op, 0, src, flat, l.p_off, y, out, stats, act, drop, _shift_seed(_mix_seed(seed, 1, i), sample0 * y.HW * y.C),
-                              v_keep=vk)
+                              v_keep=vk, u_cache=u, u_valid=uv)
             c.v.append(vk)
             c.y.append(y)
             c.stats.append(stats)
@@ -726,15 +755,16 @@ class GeneratorEngine:
                 yd = View.alloc(N, op.Hb, op.Wb, l.b, dev, bf=bf)
                 stats = torch.empty(N * l.b * 2, dtype=torch.float32, device=dev)
                 drop = 0.2 if (train and l.dropout) else 0.0
+                u, uv = _ucache(ucache, ('d', i), 1, op, dev, src, yd) if bf else (None, False)
                 conv_instnorm_act(op, 1, src, flat, l.p_off, yd, out, stats, act, drop,
-                                  _shift_seed(_mix_seed(seed, 2, i), sample0 * yd.HW * yd.C))
+                                  _shift_seed(_mix_seed(seed, 2, i), sample0 * yd.HW * yd.C), u_cache=u, u_valid=uv)
                 c.yd[i], c.statsd[i] = yd, stats
             else:
                 op.small2big(src, flat, l.p_off, None, 0, out, act)
             src = cat
         return c
 
-    def backward(self, flat, gflat, c, g1, g2=None, need_dx=False, on_ready=None):
+    def backward(self, flat, gflat, c, g1, g2=None, need_dx=False, on_ready=None, ucache=None):
         """g1 (+ g2): Views of dL/d(gen_out).  Writes every weight gradient into `gflat` (packed layout);
         returns dL/dx as a View if need_dx.  on_ready(lo, hi) is called after each layer's weight gradient has been
         enqueued with that layer's range of the flat buffer (last layer first): the hook data parallelism uses to
@@ -772,7 +802,12 @@ class GeneratorEngine:
                 act_bwd(g, None, c.cat[i + 1].channels(0, l.b), dy, act)
             src = c.hidden if i == 0 else c.cat[i]
             dsrc = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=bf)
-            op.bwd_big(src, dy, flat, gflat, l.p_off, dsrc)
+            u, uv = _ucache(ucache, ('d', i), 0, op, dev, dy, dsrc) if bf else (None, False)
+            if u is not None:      # bf16 tensors: the two halves as two calls, the data gradient on the forward's packed weights
+                op.wgrad(src, dy, gflat, l.p_off)
+                op.big2small(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
+            else:
+                op.bwd_big(src, dy, flat, gflat, l.p_off, dsrc)
             done(l)
             dcat = dsrc
         # ---- encoder, last to first; dcat is now dL/d(hidden)
@@ -789,7 +824,8 @@ class GeneratorEngine:
             done(l)
             if j > 0 or need_dx:
                 dsrc = View.alloc(N, op.Hb, op.Wb, l.b, dev, bf=bf and j > 0)
-                op.small2big(dy, flat, l.p_off, None, 0, dsrc)
+                u, uv = _ucache(ucache, ('e', j), 1, op, dev, dy, dsrc) if bf else (None, False)
+                op.small2big(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
                 if j == 0:
                     dx = dsrc
                 g_main = dsrc
@@ -858,27 +894,6 @@ class DiscriminatorEngine:
         op = self.ops(N, H, W)[-1]
         return (N, 1, op.Hs, op.Ws)
 
-    @staticmethod
-    def _ucache(ucache, li, opcode, op, dev, src, dst):
-        """(buffer, valid) of the transformed / packed weights of layer li / direction opcode in the caller's per-step cache."""
-        if ucache is None or not CACHE_U:
-            return None, False
-        big, small = (src, dst) if opcode == 0 else (dst, src)
-        io = ConvOp._io(big, small)
-        if io:      # bf16 tensors: the LDS-DMA kernels' packed bf16 weights (16-byte-aligned views)
-            if not all(v.ptr() % 16 == 0 and v.ld % (8 if v.bf else 4) == 0 for v in (src, dst)):
-                return None, False
-        elif not ConvOp._aligned(src, dst):
-            return None, False
-        nb = op.u_bytes(opcode, io)
-        if not nb:
-            return None, False
-        key = (li, opcode, nb)         # nb separates the F(2x2,4x4) / F(3x3,4x4) transforms of the stride-1 layer
-        if key in ucache:
-            return ucache[key], True
-        ucache[key] = torch.empty(nb, dtype=torch.uint8, device=dev)
-        return ucache[key], False
-
     def forward(self, flat, din, ucache=None, keep_v=False):
         """din: View [N,H,W,input_nc].  Returns a context; ctx.out is the sigmoid patch map View [N,h,w,1].
         ucache: a dict owned by the caller that lives exactly as long as the weights in `flat` stay unchanged (Trainer.batch: one
@@ -905,7 +920,7 @@ class DiscriminatorEngine:
             c.src.append(src)
             t = View.alloc(din.N, op.Hs, op.Ws, l.a, dev, bf=bf and (0 < li < last or (li == 0 and seam8)))
             bias = flat if l.bias_key is not None else None
-            u, uv = self._ucache(ucache, li, 0, op, dev, src, t)
+            u, uv = _ucache(ucache, li, 0, op, dev, src, t)
             vb = op.v_bytes() if (keep_v and KEEP_V and ConvOp._aligned(src, t)) else 0
             vk = torch.empty(vb, dtype=torch.uint8, device=dev) if vb else None
             c.v.append(vk)
@@ -962,7 +977,7 @@ class DiscriminatorEngine:
                         dsrc = fused = cand
                 if dsrc is None:
                     dsrc = View.alloc(c.N, op.Hb, op.Wb, l.b, dev, bf=bf and 0 < li < last)
-                u, uv = self._ucache(ucache, li, 1, op, dev, dy, dsrc)
+                u, uv = _ucache(ucache, li, 1, op, dev, dy, dsrc)
                 if fused is not None:
                     op.small2big(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv, mul=(c.t[li - 1], L.ACT_CODES[below.act]))
                 else:

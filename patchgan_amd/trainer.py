@@ -201,7 +201,8 @@ class Trainer:
 
         # ---- generator step
         seed = E._mix_seed(G._seed_base, self._step) if G.training else 0
-        gc = ge.forward(G.flat, xin, gen, G.training, seed, sample0=dist.rank * N, keep_v=train)   # trainer.py:63
+        gcache = {} if train else None     # G's weights are constant from here to its Adam step: packed bf16 copies are shared by forward and backward
+        gc = ge.forward(G.flat, xin, gen, G.training, seed, sample0=dist.rank * N, keep_v=train, ucache=gcache)   # trainer.py:63
         self.flush()          # D's deferred all-reduce + Adam from the previous step ran under this G forward
         # seg loss, phase 1 (per-sample reductions); under data parallelism its two batch-global terms are summed across
         # ranks on the comm stream while the discriminator's forward pass over the fake batch runs
@@ -226,7 +227,7 @@ class Trainer:
                 # gen_img.detach() is the pre-update output, trainer.py:98)
                 g_reducer = GradReducer(dist, gflat, self.bucket_bytes)
             ge.backward(G.flat, gflat, gc, gseg, ddin.channels(Cin, Cout),                    # trainer.py:88-89
-                        on_ready=g_reducer.ready if g_reducer is not None else None)
+                        on_ready=g_reducer.ready if g_reducer is not None else None, ucache=gcache)
             if g_reducer is None:
                 self._adam_step('g')                                                          # trainer.py:90
         del dc
