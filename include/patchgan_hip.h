@@ -189,6 +189,20 @@ int pg_conv4x4_small2big_x(const float* small, int ld_small, const float* P, con
                            const pg_conv_extras* x);
 int pg_conv4x4_wgrad_x(const float* small, int ld_small, const float* big, int ld_big, float* dP, float* dbias,
                        const pg_conv_geom* g, int algo, void* ws, size_t ws_bytes, void* stream, const pg_conv_extras* x);
+/* The weight preparations (Winograd weight transforms; packed bf16 weights) of SEVERAL layers in one launch per kernel family: item i
+ * fills items[i].u with exactly what the call `op` (0 big2small, 1 small2big) on that geometry / algo / workspace size would write into
+ * pg_conv_extras.u_cache with u_valid == 0 (pg_conv_u_bytes(...) bytes; PG_EINVAL, nothing launched, if that is 0 for any item).
+ * The caller then passes u_valid = 1.  A network's weights change once per step (trainer.py:90,107 optimizer.step()): one call per
+ * network and step instead of one small transform kernel per layer, direction and step. */
+typedef struct pg_conv_prep_item {
+    pg_conv_geom g;
+    int op;
+    int algo;
+    size_t ws_bytes;
+    const float* P;
+    void* u;
+} pg_conv_prep_item;
+int pg_conv_prep_batch(int n, const pg_conv_prep_item* items, void* stream);
 /* pg_instnorm_act_fwd with the statistics pass replaced by the producer's partial sums: merge (fixed order) + normalise. */
 int pg_instnorm_act_fwd_parts(const float* y, int ld_y, float* out, int ld_out, float* stats, const double* part, int chunks,
                               int N, int HW, int C, int act, float eps, float drop_p, uint64_t seed, void* stream);
@@ -222,6 +236,11 @@ int pg_act_bwd_t(const void* g1, int ld_g1, const void* g2, int ld_g2, const voi
  * call is exactly the two calls above.  Bit-identical to them either way.  ws: pg_conv_workspace_bytes(g, 3). */
 int pg_conv4x4_bwd_big(const float* small, int ld_small, const float* big, int ld_big, const float* P, float* dP,
                        float* dsmall, int ld_dsmall, const pg_conv_geom* g, int algo, void* ws, size_t ws_bytes, void* stream);
+/* ... with the data gradient's transformed weights in a caller-owned cache (x->u_cache / u_valid as for pg_conv4x4_big2small_x,
+ * size pg_conv_u_bytes(g, 0, ...); every other field of x must be NULL / 0). */
+int pg_conv4x4_bwd_big_x(const float* small, int ld_small, const float* big, int ld_big, const float* P, float* dP,
+                         float* dsmall, int ld_dsmall, const pg_conv_geom* g, int algo, void* ws, size_t ws_bytes, void* stream,
+                         const pg_conv_extras* x);
 
 /* As pg_conv_time_next, for pg_conv4x4_bwd_big: the first pair goes around its weight-gradient GEMM, the second around its
  * data-gradient GEMM. */

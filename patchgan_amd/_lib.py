@@ -53,6 +53,13 @@ class ConvExtras(ctypes.Structure):
 
 _X = ctypes.POINTER(ConvExtras)
 
+
+class ConvPrepItem(ctypes.Structure):
+    """struct pg_conv_prep_item: one layer / direction of pg_conv_prep_batch"""
+    _fields_ = [('g', ConvGeom), ('op', ctypes.c_int), ('algo', ctypes.c_int), ('ws_bytes', ctypes.c_size_t), ('P', ctypes.c_void_p),
+                ('u', ctypes.c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/patchgan_hip.h one to one
 SIGNATURES = {
     'pg_version': (_i, []),
@@ -63,6 +70,7 @@ SIGNATURES = {
     'pg_conv_time_next': (_i, [_p, _p]),
     'pg_conv_time_next2': (_i, [_p, _p, _p, _p]),
     'pg_conv4x4_bwd_big': (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _G, _i, _p, _sz, _p]),
+    'pg_conv4x4_bwd_big_x': (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _G, _i, _p, _sz, _p, _X]),
     'pg_conv4x4_big2small': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p]),
     'pg_conv4x4_small2big': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p]),
     'pg_conv4x4_wgrad': (_i, [_p, _i, _p, _i, _p, _p, _G, _i, _p, _sz, _p]),
@@ -72,6 +80,7 @@ SIGNATURES = {
     'pg_conv4x4_big2small_x': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p, _X]),
     'pg_conv4x4_small2big_x': (_i, [_p, _i, _p, _p, _p, _i, _G, _i, _i, _p, _sz, _p, _X]),
     'pg_conv4x4_wgrad_x': (_i, [_p, _i, _p, _i, _p, _p, _G, _i, _p, _sz, _p, _X]),
+    'pg_conv_prep_batch': (_i, [_i, ctypes.POINTER(ConvPrepItem), _p]),
     'pg_instnorm_act_fwd_parts': (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p]),
     'pg_instnorm_workspace_bytes': (_sz, [_i, _i, _i]),
     'pg_instnorm_act_fwd': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _f, _u64, _p, _sz, _p]),

@@ -31,6 +31,14 @@ const char* pg_bf16x_kernel_name(int dir, int tile, int ring);
 // (the GEMM's K index must be the contiguous one of both operands), dir 2 writes [a][tap][8] zero padded
 size_t pg_bf16x_w_bytes(int Ca, int Cb);
 int pg_bf16x_pack(const float* P, void* W, int Ca, int Cb, int dir, hipStream_t st);
+// the packs of several layers in one launch (pg_conv_prep_batch); at most PG_BF16X_PACK_MAX items per call
+#define PG_BF16X_PACK_MAX 24
+struct pg_bf16x_pack_item {
+    const float* P;
+    void* W;
+    int Ca, Cb, dir;
+};
+int pg_bf16x_pack_batch(int n, const pg_bf16x_pack_item* items, hipStream_t st);
 
 // out: the destination tensor (bf16 if out_bf, else fp32; bias and activation applied) when slab_stride == 0, else fp32 slabs
 // [split][pixels][Cout] for the caller's reduce pass

@@ -579,21 +579,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-// P[tap][a][b] fp32 -> bf16, optionally transposing each tap to [b][a] (32 x 32 tiles through LDS)
-__global__ __launch_bounds__(256) void k_pack_w_bf16(const float* __restrict__ P, __bf16* __restrict__ W, int Ca, int Cb, int transpose) {
+// P[tap][a][b] fp32 -> bf16, optionally transposing each tap to [b][a] (32 x 32 tiles through LDS).  blk / nblk: this workgroup's index
+// in / the size of the (grid-stride) block range that covers the layer -- the whole grid, or one item's share of k_pack_batch's
+__device__ __forceinline__ void pack_w_body(const float* __restrict__ P, __bf16* __restrict__ W, int Ca, int Cb, int transpose, int blk,
+                                            int nblk, float (*tile)[33]) {
     if (!transpose) {
         const long total4 = 4L * Ca * Cb;                           // float4 groups
-        for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        for (long i = blk * 256L + threadIdx.x; i < total4; i += (long)nblk * 256) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(P + 4 * i);
             u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
             *reinterpret_cast<u32x2*>(W + 4 * i) = o;
         }
         return;
     }
-    __shared__ float tile[32][33];
     const int tb = (Cb + 31) / 32, ta = (Ca + 31) / 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
-    for (long t = blockIdx.x; t < 16L * ta * tb; t += gridDim.x) {
+    for (long t = blk; t < 16L * ta * tb; t += nblk) {
         const int tap = (int)(t / (ta * tb));
         const int rem = (int)(t - (long)tap * ta * tb);
         const int a0 = (rem / tb) * 32, b0 = (rem % tb) * 32;
@@ -611,10 +612,14 @@ __global__ __launch_bounds__(256) void k_pack_w_bf16(const float* __restrict__ P
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(256) void k_pack_w_bf16(const float* __restrict__ P, __bf16* __restrict__ W, int Ca, int Cb, int transpose) {
+    __shared__ float tile[32][33];
+    pack_w_body(P, W, Ca, Cb, transpose, blockIdx.x, gridDim.x, tile);
+}
 
 // P[tap][a][b] (b < Cb <= 8) -> W8[a][tap][8] bf16, zero padded: the K = 128 row of output channel a in tap order
-__global__ __launch_bounds__(256) void k_pack_w8_bf16(const float* __restrict__ P, __bf16* __restrict__ W, int Ca, int Cb) {
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < 16L * Ca; i += (long)gridDim.x * 256) {
+__device__ __forceinline__ void pack_w8_body(const float* __restrict__ P, __bf16* __restrict__ W, int Ca, int Cb, int blk, int nblk) {
+    for (long i = blk * 256L + threadIdx.x; i < 16L * Ca; i += (long)nblk * 256) {
         const int tap = (int)(i / Ca), a = (int)(i - (long)tap * Ca);
         float v[8];
 #pragma unroll
@@ -622,6 +627,31 @@ __global__ __launch_bounds__(256) void k_pack_w8_bf16(const float* __restrict__ 
         const u32x4 o = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
         *reinterpret_cast<u32x4*>(W + ((long)a * 16 + tap) * 8) = o;
     }
+}
+__global__ __launch_bounds__(256) void k_pack_w8_bf16(const float* __restrict__ P, __bf16* __restrict__ W, int Ca, int Cb) {
+    pack_w8_body(P, W, Ca, Cb, blockIdx.x, gridDim.x);
+}
+
+// The packs of several layers in ONE launch (pg_bf16x_pack_batch): item i owns the blocks [block0_i, block0_{i+1})
+struct PackItem {
+    const float* P;
+    __bf16* W;
+    int Ca, Cb, dir, block0, nblk;
+};
+struct PackBatch {
+    int n;
+    PackItem it[PG_BF16X_PACK_MAX];
+};
+__global__ __launch_bounds__(256) void k_pack_batch(const PackBatch b) {
+    __shared__ float tile[32][33];
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].block0) ++i;
+    const PackItem& t = b.it[i];
+    const int blk = blockIdx.x - t.block0;
+    if (t.dir == 2)
+        pack_w8_body(t.P, t.W, t.Ca, t.Cb, blk, t.nblk);
+    else
+        pack_w_body(t.P, t.W, t.Ca, t.Cb, t.dir != 0, blk, t.nblk, tile);
 }
 
 }  // namespace
@@ -703,20 +733,37 @@ const char* pg_bf16x_kernel_name(int dir, int tile, int ring) {
 
 size_t pg_bf16x_w_bytes(int Ca, int Cb) { return ((size_t)16 * Ca * std::max(Cb, 8) * 2 + 255) & ~(size_t)255; }
 
+// workgroups of one layer's pack (0: this layout / channel count has no pack)
+static int pack_blocks(int Ca, int Cb, int dir) {
+    if (dir == 2) return (int)std::min<long>((16L * Ca + 255) / 256, 2048);        // W8[a][tap][8]: the Cb <= 8 channels of each tap, zero padded
+    if (dir == 0) return (Cb & 3) ? 0 : (int)std::min<long>((4L * Ca * Cb + 255) / 256, 2048);
+    return (int)std::min<long>(16L * ((Ca + 31) / 32) * ((Cb + 31) / 32), 4096);    // dir 1 and 3: each tap transposed to [b][a]
+}
+
 int pg_bf16x_pack(const float* P, void* W, int Ca, int Cb, int dir, hipStream_t st) {
-    if (dir == 2) {                    // W8[a][tap][8]: the Cb <= 8 channels of each tap, zero padded
-        const long total = 16L * Ca;
-        hipLaunchKernelGGL(k_pack_w8_bf16, dim3((int)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st, P, (__bf16*)W, Ca, Cb);
-    } else if (dir == 0 && (Cb & 3) == 0) {
-        const long total4 = 4L * Ca * Cb;
-        const int blocks = (int)std::min<long>((total4 + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_pack_w_bf16, dim3(blocks), dim3(256), 0, st, P, (__bf16*)W, Ca, Cb, 0);
-    } else if (dir == 0) {
-        return PG_EINVAL;
-    } else {                           // dir 1 and 3: each tap transposed to [b][a]
-        const long tiles = 16L * ((Ca + 31) / 32) * ((Cb + 31) / 32);
-        hipLaunchKernelGGL(k_pack_w_bf16, dim3((int)std::min<long>(tiles, 4096)), dim3(256), 0, st, P, (__bf16*)W, Ca, Cb, 1);
+    const int blocks = pack_blocks(Ca, Cb, dir);
+    if (blocks == 0) return PG_EINVAL;
+    if (dir == 2)
+        hipLaunchKernelGGL(k_pack_w8_bf16, dim3(blocks), dim3(256), 0, st, P, (__bf16*)W, Ca, Cb);
+    else
+        hipLaunchKernelGGL(k_pack_w_bf16, dim3(blocks), dim3(256), 0, st, P, (__bf16*)W, Ca, Cb, dir == 0 ? 0 : 1);
+    return pg_launch_status();
+}
+
+int pg_bf16x_pack_batch(int n, const pg_bf16x_pack_item* items, hipStream_t st) {
+    if (n <= 0) return PG_OK;
+    if (n > PG_BF16X_PACK_MAX || !items) return PG_EINVAL;
+    PackBatch b;
+    b.n = n;
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const pg_bf16x_pack_item& s = items[i];
+        const int nb = (s.P && s.W && s.Ca > 0 && s.Cb > 0 && s.dir >= 0 && s.dir <= 3) ? pack_blocks(s.Ca, s.Cb, s.dir) : 0;
+        if (nb == 0) return PG_EINVAL;
+        b.it[i] = PackItem{s.P, (__bf16*)s.W, s.Ca, s.Cb, s.dir, (int)blocks, nb};
+        blocks += nb;
     }
+    hipLaunchKernelGGL(k_pack_batch, dim3((unsigned)blocks), dim3(256), 0, st, b);
     return pg_launch_status();
 }
 

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <alloca.h>
 #include <new>
+#include <vector>
 #include "patchgan_hip.h"
 #include "pg_common.h"
 #include "conv_wino.h"
@@ -3512,6 +3513,48 @@ size_t pg_conv_u_bytes(const pg_conv_geom* gg, int op, int algo, size_t ws_bytes
     return 0;
 }
 
+int pg_conv_prep_batch(int n, const pg_conv_prep_item* items, void* stream) {
+    if (n < 0 || (n > 0 && !items)) return PG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<pg_wino_prep> wv;
+    std::vector<pg_bf16x_pack_item> bv;
+    for (int i = 0; i < n; ++i) {      // mirrors pg_conv_u_bytes / the dispatch of b2s_impl and s2b_impl
+        const pg_conv_prep_item& it = items[i];
+        if (!geom_ok(&it.g) || (it.op != 0 && it.op != 1) || !it.P || !it.u || !aligned16(it.P) || !aligned16(it.u)) return PG_EINVAL;
+        const Geom g = to_geom(&it.g);
+        const Tune tune = tune_of(it.algo);
+        const int op = it.op;
+        if ((it.algo & PG_ALGO_MASK) == PG_ALGO_AUTO) {
+            if (op == 0 && wino_b2s_ok(g, tune) && it.ws_bytes >= pg_wino_ws_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1))
+                wv.push_back(pg_wino_prep{it.P, (float*)it.u, g.Ca, g.Cb, 0, pg_wino_mo(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1), 0});
+            else if (op == 0 && wino2_b2s_ok(g, tune) && it.ws_bytes >= pg_wino2_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb))
+                wv.push_back(pg_wino_prep{it.P, (float*)it.u, g.Ca, g.Cb, 1, 0, 0});
+            else if (op == 1 && wino_s2b_ok(g, tune) && it.ws_bytes >= pg_wino_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1))
+                wv.push_back(pg_wino_prep{it.P, (float*)it.u, g.Cb, g.Ca, 0, pg_wino_mo(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1), 1});
+            else if (op == 1 && wino2_s2b_ok(g, tune) && it.ws_bytes >= pg_wino2c_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb))
+                wv.push_back(pg_wino_prep{it.P, (float*)it.u, g.Ca, g.Cb, 2, 0, 0});
+            else
+                return PG_EINVAL;
+        } else if (bf16x_ok(g, op, it.algo, tune)) {
+            // big -> small: [tap][a][b] (8-channel-pixel form for a few-channel big); small -> big: the same pack (transposed staging in
+            // the kernel) unless the ring-staged variant is pinned (bf16x_run)
+            const int dir = (op == 0) ? (g.Cb <= 8 ? 2 : 0) : (tune.bf16ring > 0 ? 1 : 0);
+            bv.push_back(pg_bf16x_pack_item{it.P, it.u, g.Ca, g.Cb, dir});
+        } else {
+            return PG_EINVAL;
+        }
+    }
+    for (size_t o = 0; o < wv.size(); o += PG_WINO_PREP_MAX) {
+        const int rc = pg_wino_prep_batch((int)std::min<size_t>(PG_WINO_PREP_MAX, wv.size() - o), wv.data() + o, st);
+        if (rc != PG_OK) return rc;
+    }
+    for (size_t o = 0; o < bv.size(); o += PG_BF16X_PACK_MAX) {
+        const int rc = pg_bf16x_pack_batch((int)std::min<size_t>(PG_BF16X_PACK_MAX, bv.size() - o), bv.data() + o, st);
+        if (rc != PG_OK) return rc;
+    }
+    return PG_OK;
+}
+
 int pg_conv_mul_ok(const pg_conv_geom* gg, int algo, size_t ws_bytes) {
     if (!geom_ok(gg)) return 0;
     const Geom g = to_geom(gg);
@@ -3715,7 +3758,17 @@ int pg_conv4x4_wgrad_x(const float* small, int ld_small, const float* big, int l
 
 int pg_conv4x4_bwd_big(const float* small, int ld_small, const float* big, int ld_big, const float* P, float* dP,
                        float* dsmall, int ld_dsmall, const pg_conv_geom* gg, int algo, void* ws, size_t ws_bytes, void* stream) {
+    return pg_conv4x4_bwd_big_x(small, ld_small, big, ld_big, P, dP, dsmall, ld_dsmall, gg, algo, ws, ws_bytes, stream, nullptr);
+}
+
+int pg_conv4x4_bwd_big_x(const float* small, int ld_small, const float* big, int ld_big, const float* P, float* dP,
+                         float* dsmall, int ld_dsmall, const pg_conv_geom* gg, int algo, void* ws, size_t ws_bytes, void* stream,
+                         const pg_conv_extras* x) {
     if (!geom_ok(gg) || !small || !big || !P || !dP || !dsmall) return PG_EINVAL;
+    if (x && (x->part || x->v_keep || x->v_pre || x->mul_t)) return PG_EINVAL;      // only the data gradient's u_cache / u_valid
+    float* const Uext = x ? x->u_cache : nullptr;
+    const int u_valid = x ? x->u_valid : 0;
+    if (Uext && !aligned16(Uext)) return PG_EINVAL;
     if (ld_small < gg->Ca || ld_big < gg->Cb || ld_dsmall < gg->Ca) return PG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const Geom g = to_geom(gg);
@@ -3734,6 +3787,12 @@ int pg_conv4x4_bwd_big(const float* small, int ld_small, const float* big, int l
         if (rc != PG_OK) return rc;
         t_ev0 = e2;
         t_ev1 = e3;
+        if (Uext) {
+            pg_conv_extras xu{};
+            xu.u_cache = Uext;
+            xu.u_valid = u_valid;
+            return pg_conv4x4_big2small_x(big, ld_big, P, nullptr, dsmall, ld_dsmall, gg, PG_ACT_NONE, algo, ws, ws_bytes, stream, &xu);
+        }
         return pg_conv4x4_big2small(big, ld_big, P, nullptr, dsmall, ld_dsmall, gg, PG_ACT_NONE, algo, ws, ws_bytes, stream);
     }
     t_ev0 = t_ev1 = t_ev2 = t_ev3 = nullptr;
@@ -3745,7 +3804,7 @@ int pg_conv4x4_bwd_big(const float* small, int ld_small, const float* big, int l
     rc = pg_wino2_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, rest, st, e0, e1, V);
     if (rc != PG_OK) return rc;
     return pg_wino2_b2s(big, ld_big, P, nullptr, dsmall, ld_dsmall, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, PG_ACT_NONE, rest, st, e2,
-                        e3, V, nullptr, nullptr, nullptr, 0);
+                        e3, V, nullptr, nullptr, Uext, u_valid);
 }
 
 }  // extern "C"

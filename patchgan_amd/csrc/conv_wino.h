@@ -22,6 +22,16 @@ int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N,
 // holds the transform of the current weights and the transform kernel is skipped
 size_t pg_wino_u_bytes(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced);
 size_t pg_wino2_u_bytes(int Ca, int Cb);     // both polyphase directions
+// Weight transforms of several layers in one launch (pg_conv_prep_batch): kind 0 = stride-1 layer (Ca = Cout, Cb = Cin of the correlation,
+// mo = 2 / 3, flip as pg_wino_prepare), 1 = polyphase big -> small (k_wino2_u), 2 = polyphase small -> big (k_wino2c_u); U as the
+// Uext of the corresponding call.  At most PG_WINO_PREP_MAX items per call.
+#define PG_WINO_PREP_MAX 24
+struct pg_wino_prep {
+    const float* P;
+    float* U;
+    int Ca, Cb, kind, mo, flip;
+};
+int pg_wino_prep_batch(int n, const pg_wino_prep* items, hipStream_t st);
 int pg_wino_dma_mode();   // process default (PATCHGAN_WINO_DMA): 0 register-staged k_wino_gemm only, 1: k_wino_gemm_dma<3,4,2> for F(3x3,4x4), 2: also <2,3,3> for 64-tile F(2x2,4x4)
 // the batched GEMM with fused output transform, bias and activation
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,

@@ -75,9 +75,9 @@ template <int MO> __device__ __forceinline__ float s1_at(int k, int i) { return 
 // U[xi][co][ci] = sum_{k,l} G[xi_i][k] G[xi_j][l] w(k, l, co, ci);  flip = 0: w = P[(k*4+l)][co][ci] (forward),
 // flip = 1: w = P[((3-k)*4 + (3-l))][ci][co] (data gradient).  One thread per (co, ci).
 template <int MO>
-__global__ void k_wino_u(const float* __restrict__ P, float* __restrict__ U, int Co, int Ci, int flip) {
+__device__ __forceinline__ void wino_u_body(const float* __restrict__ P, float* __restrict__ U, int Co, int Ci, int flip, long block) {
     constexpr int NP = MO + 3;
-    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long idx = block * 256 + threadIdx.x;
     if (idx >= (long)Co * Ci) return;
     const int ci = (int)(idx % Ci), co = (int)(idx / Ci);
     float g[4][4];
@@ -106,6 +106,10 @@ __global__ void k_wino_u(const float* __restrict__ P, float* __restrict__ U, int
             for (int l = 0; l < 4; ++l) s += t[a][l] * s1_g<MO>(b, l);
             U[((long)(a * NP + b) * Co + co) * Ci + ci] = s;
         }
+}
+template <int MO>
+__global__ __launch_bounds__(256) void k_wino_u(const float* __restrict__ P, float* __restrict__ U, int Co, int Ci, int flip) {
+    wino_u_body<MO>(P, U, Co, Ci, flip, blockIdx.x);
 }
 
 // V[xi][tile][ci] = (B^T d B)[xi], d[i][j] = in[n, 2*Ti - pad + i, 2*Tj - pad + j, ci] (0 outside).  One thread per
@@ -674,9 +678,9 @@ template <int MO> __device__ __forceinline__ float w_g(int a, int u) { return MO
 template <int MO> __device__ __forceinline__ float w_at(int k, int i) { return MO == 4 ? c_A4Tp[k][i] : c_A3T[k][i]; }
 
 template <int MO>
-__global__ void k_wino2_u(const float* __restrict__ P, float* __restrict__ U, int Ca, int Cb) {
+__device__ __forceinline__ void wino2_u_body(const float* __restrict__ P, float* __restrict__ U, int Ca, int Cb, long block) {
     constexpr int NP = MO + 1;
-    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long idx = block * 256 + threadIdx.x;
     if (idx >= (long)Ca * Cb) return;
     const int b = (int)(idx % Cb), a = (int)(idx / Cb);
     float w[4][4];
@@ -700,6 +704,10 @@ __global__ void k_wino2_u(const float* __restrict__ P, float* __restrict__ U, in
                 for (int j = 0; j < NP; ++j)
                     U[((long)(i * NP + j) * Ca + a) * K + (r * 2 + sph) * Cb + b] = t[i][0] * w_g<MO>(j, 0) + t[i][1] * w_g<MO>(j, 1);
         }
+}
+template <int MO>
+__global__ __launch_bounds__(256) void k_wino2_u(const float* __restrict__ P, float* __restrict__ U, int Ca, int Cb) {
+    wino2_u_body<MO>(P, U, Ca, Cb, blockIdx.x);
 }
 
 // shared by both directions: window origin (oy, ox) + step `st` pixels between window entries; writes V[(xi*nb + bi)][tile][c]
@@ -1098,11 +1106,11 @@ __global__ __launch_bounds__(256) void k_wino2_out_stats(const float* __restrict
 // LDS so that both the reads and the writes are 64-byte runs.  grid (ceil(Cb/16), ceil(Ca/16)), 256 threads (32 x 32 tiles with
 // 1024 threads and 66 KB of LDS gave 128 workgroups on a 512 x 256 layer: half the chip idle, 12 us for 22 MB).
 template <int MO>
-__global__ __launch_bounds__(256) void k_wino2c_u(const float* __restrict__ P, float* __restrict__ U, int Ca, int Cb) {
+__device__ __forceinline__ void wino2c_u_body(const float* __restrict__ P, float* __restrict__ U, int Ca, int Cb, int bx, int by,
+                                              float (*tile)[16][17]) {
     constexpr int NP = MO + 1;
-    __shared__ float tile[16][16][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int b0 = blockIdx.x * 16, a0 = blockIdx.y * 16;
+    const int b0 = bx * 16, a0 = by * 16;
     {   // read: b fastest
         const int a = a0 + ty, b = b0 + tx;
         const bool ok = a < Ca && b < Cb;
@@ -1136,6 +1144,39 @@ __global__ __launch_bounds__(256) void k_wino2c_u(const float* __restrict__ P, f
                 for (int j = 0; j < NP; ++j)
                     U[(((long)(i * NP + j) * 4 + r * 2 + sc) * Cb + b) * Ca + a] = t[i][0] * w_g<MO>(j, 0) + t[i][1] * w_g<MO>(j, 1);
         }
+}
+template <int MO>
+__global__ __launch_bounds__(256) void k_wino2c_u(const float* __restrict__ P, float* __restrict__ U, int Ca, int Cb) {
+    __shared__ float tile[16][16][17];
+    wino2c_u_body<MO>(P, U, Ca, Cb, blockIdx.x, blockIdx.y, tile);
+}
+
+// Several layers' weight transforms in ONE launch (pg_conv_prep_batch): block ranges [block0, next block0) per item, the item's own
+// kernel body on its local block index.  Items are few (one per layer and direction of a network): a linear scan, uniform per block.
+struct WinoPrepItem {
+    const float* P;
+    float* U;
+    int Ca, Cb, kind, flip, gx, block0;      // kind: 2 / 3 = stride-1 F(2x2,4x4) / F(3x3,4x4) (Ca = Co, Cb = Ci), 10 + MO = big -> small, 20 + MO = small -> big
+};
+struct WinoPrepBatch {
+    int n;
+    WinoPrepItem it[PG_WINO_PREP_MAX];
+};
+__global__ __launch_bounds__(256) void k_wino_prep_batch(const WinoPrepBatch b) {
+    __shared__ float tile[16][16][17];
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].block0) ++i;
+    const WinoPrepItem& t = b.it[i];
+    const int blk = blockIdx.x - t.block0;
+    switch (t.kind) {
+        case 2: wino_u_body<2>(t.P, t.U, t.Ca, t.Cb, t.flip, blk); break;
+        case 3: wino_u_body<3>(t.P, t.U, t.Ca, t.Cb, t.flip, blk); break;
+        case 13: wino2_u_body<3>(t.P, t.U, t.Ca, t.Cb, blk); break;
+        case 14: wino2_u_body<4>(t.P, t.U, t.Ca, t.Cb, blk); break;
+        case 23: wino2c_u_body<3>(t.P, t.U, t.Ca, t.Cb, blk % t.gx, blk / t.gx, tile); break;
+        case 24: wino2c_u_body<4>(t.P, t.U, t.Ca, t.Cb, blk % t.gx, blk / t.gx, tile); break;
+        default: break;
+    }
 }
 
 template <int MO>
@@ -1582,6 +1623,43 @@ int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias
     return wino2_b2s_run<3>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, Vpre, part, Vkeep,
                             Uext, u_valid);
 }
+int pg_wino_prep_batch(int n, const pg_wino_prep* items, hipStream_t st) {
+    if (n <= 0) return PG_OK;
+    if (n > PG_WINO_PREP_MAX || !items) return PG_EINVAL;
+    WinoPrepBatch b;
+    b.n = n;
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const pg_wino_prep& s = items[i];
+        WinoPrepItem& t = b.it[i];
+        if (!s.P || !s.U || s.Ca < 1 || s.Cb < 1) return PG_EINVAL;
+        t.P = s.P;
+        t.U = s.U;
+        t.Ca = s.Ca;
+        t.Cb = s.Cb;
+        t.flip = s.flip;
+        t.gx = 1;
+        t.block0 = (int)blocks;
+        if (s.kind == 0) {
+            if (s.mo != 2 && s.mo != 3) return PG_EINVAL;
+            t.kind = s.mo;
+            blocks += ((long)s.Ca * s.Cb + 255) / 256;
+        } else if (s.kind == 1) {
+            t.kind = 10 + pg_wino2_mo();
+            blocks += ((long)s.Ca * s.Cb + 255) / 256;
+        } else if (s.kind == 2) {
+            t.kind = 20 + pg_wino2_mo();
+            t.gx = (s.Cb + 15) / 16;
+            blocks += (long)t.gx * ((s.Ca + 15) / 16);
+        } else {
+            return PG_EINVAL;
+        }
+        if (blocks > 0x7fffffffL) return PG_EINVAL;
+    }
+    hipLaunchKernelGGL(k_wino_prep_batch, dim3((unsigned)blocks), dim3(256), 0, st, b);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+}
+
 size_t pg_wino2_u_bytes(int Ca, int Cb) { return align256((size_t)wino2_nxi() * Ca * 4 * Cb * 4); }
 
 // chunks of per-sample partial sums the output transforms emit (0: channel count not a power-of-two multiple of 4 up to 1024)

@@ -352,9 +352,10 @@ class ConvOp:
                 L.check(L.load().pg_conv4x4_wgrad_x(*args, ctypes.byref(x)), 'pg_conv4x4_wgrad_x')
         PROFILER.launch(self, 2, go, self._io(big, small)) if PROFILER is not None else go()
 
-    def bwd_big(self, small, big, P, dP, p_off, dsmall):
+    def bwd_big(self, small, big, P, dP, p_off, dsmall, u_cache=None, u_valid=False):
         """Weight gradient (small = x, big = dy) and data gradient (big -> small) of a ConvTranspose2d layer in one call; where
-        both run the polyphase Winograd path the transformed dy is computed once and shared (pg_conv4x4_bwd_big)."""
+        both run the polyphase Winograd path the transformed dy is computed once and shared (pg_conv4x4_bwd_big).
+        u_cache / u_valid: the data gradient's transformed weights, as for big2small."""
         assert (big.N, big.H, big.W, big.C) == (self.N, self.Hb, self.Wb, self.Cb), 'big view mismatch'
         assert (small.N, small.H, small.W, small.C) == (self.N, self.Hs, self.Ws, self.Ca), 'small view mismatch'
         assert (dsmall.N, dsmall.H, dsmall.W, dsmall.C) == (self.N, self.Hs, self.Ws, self.Ca), 'dsmall view mismatch'
@@ -362,9 +363,13 @@ class ConvOp:
 
         def go():
             assert small.bf == big.bf == dsmall.bf, 'bwd_big: one storage type for the three activation tensors'
-            L.check(L.load().pg_conv4x4_bwd_big(small.ptr(), small.ld, big.ptr(), big.ld, L.ptr(P, p_off), L.ptr(dP, p_off),
-                                                dsmall.ptr(), dsmall.ld, ctypes.byref(self.g), self.algo | self._io(big, small), wp, wn,
-                                                _stream()), 'pg_conv4x4_bwd_big')
+            args = (small.ptr(), small.ld, big.ptr(), big.ld, L.ptr(P, p_off), L.ptr(dP, p_off), dsmall.ptr(), dsmall.ld,
+                    ctypes.byref(self.g), self.algo | self._io(big, small), wp, wn, _stream())
+            if u_cache is None:
+                L.check(L.load().pg_conv4x4_bwd_big(*args), 'pg_conv4x4_bwd_big')
+            else:
+                x = self._extras(u_cache=u_cache, u_valid=u_valid)
+                L.check(L.load().pg_conv4x4_bwd_big_x(*args, ctypes.byref(x)), 'pg_conv4x4_bwd_big_x')
         PROFILER.launch2(self, (2, 0), go, self._io(big, small)) if PROFILER is not None else go()
 
 
@@ -375,7 +380,16 @@ def _bf16_tensors_ok(ops):
     return all('bf16' in op.describe(oc, L.IO_MASK)[0] for op in ops for oc in (0, 1, 2))
 
 
-def _ucache(ucache, li, opcode, op, dev, src, dst):
+class UCache(dict):
+    """A network's transformed / packed weights for ONE weight version: key -> device buffer (see _ucache).  `log` records how each
+    entry was made -- (key, op, opcode, io, p_off, bytes) -- so that the engine can fill the same set in one launch next time."""
+
+    def __init__(self):
+        super().__init__()
+        self.log = []
+
+
+def _ucache(ucache, li, opcode, op, dev, src, dst, p_off=None):
     """(buffer, valid) of the transformed / packed weights of layer li / direction opcode in the caller's per-step cache (a dict that
     lives exactly as long as the weights stay unchanged).  On bf16 tensors one packed bf16 copy serves both directions of a layer (the
     small -> big kernel stages it transposed), so the two directions share an entry."""
@@ -396,7 +410,28 @@ def _ucache(ucache, li, opcode, op, dev, src, dst):
     if key in ucache:
         return ucache[key], True
     ucache[key] = torch.empty(nb, dtype=torch.uint8, device=dev)
+    if p_off is not None and isinstance(ucache, UCache):
+        ucache.log.append((key, op, opcode, io, p_off, nb))
     return ucache[key], False
+
+
+def prefill_ucache(plan, flat, dev):
+    """A UCache holding every entry of `plan` (the log of an earlier UCache of the same network, input extent and storage mode),
+    filled from the CURRENT weights `flat` by ONE pg_conv_prep_batch call: one launch per kernel family instead of one small weight
+    transform / pack kernel per layer and direction.  Entries that end up unused cost a few microseconds; entries that are
+    missing are made lazily by the conv calls as before."""
+    uc = UCache()
+    if not plan or not PREP_BATCH:
+        return uc
+    items = (L.ConvPrepItem * len(plan))()
+    for it, (key, op, opcode, io, p_off, nb) in zip(items, plan):
+        buf = torch.empty(nb, dtype=torch.uint8, device=dev)
+        uc[key] = buf
+        it.g, it.op, it.algo, it.ws_bytes = op.g, opcode, op.algo | io, max(op.ws_bytes, 1 << 20)
+        it.P, it.u = L.ptr(flat, p_off), buf.data_ptr()
+    uc.log = list(plan)
+    L.check(L.load().pg_conv_prep_batch(len(plan), items, _stream()), 'pg_conv_prep_batch')
+    return uc
 
 
 def _dt(*views):
@@ -449,6 +484,7 @@ def _exp_env(name, default='1'):
 FUSE_IN_STATS = _exp_env('PATCHGAN_FUSE_IN_STATS') != '0'     # InstanceNorm sums from the producing conv
 KEEP_V = _exp_env('PATCHGAN_KEEP_V') != '0'                   # transformed input handed from forward to weight gradient
 CACHE_U = _exp_env('PATCHGAN_CACHE_U') != '0'                 # per-step cache of transformed / packed discriminator weights
+PREP_BATCH = _exp_env('PATCHGAN_PREP_BATCH') != '0'           # one batched weight-preparation launch per network and step
 FUSE_ACT_BWD = _exp_env('PATCHGAN_FUSE_ACT_BWD') != '0'       # activation backward in the data-gradient epilogue above it
 SEAM8 = _exp_env('PATCHGAN_SEAM8') != '0'       # bf16 storage: image-facing tensors in 8-channel bf16 pixels
 
@@ -631,7 +667,23 @@ class GenContext:
     pass
 
 
-class GeneratorEngine:
+class _WeightPrep:
+    """Per-step weight preparation of a network (mixed into the two engines).  ucache_begin() opens the cache for one weight version:
+    from the second step of a given kind on it comes back already filled by one batched launch (prefill_ucache) with what the previous
+    such step used; ucache_end() remembers what this step used."""
+
+    def ucache_begin(self, flat, N, H, W, tag=None):
+        key = (N, H, W, tag, self.algo, bool(self.act_bf))
+        uc = prefill_ucache(self.__dict__.setdefault('_uplan', {}).get(key), flat, flat.device)
+        uc.plan_key = key
+        return uc
+
+    def ucache_end(self, uc):
+        if isinstance(uc, UCache) and getattr(uc, 'plan_key', None) is not None:
+            self.__dict__.setdefault('_uplan', {})[uc.plan_key] = list(uc.log)
+
+
+class GeneratorEngine(_WeightPrep):
     def __init__(self, input_nc, output_nc, nf, activation, final_act, use_dropout, algo=None):
         self.input_nc, self.output_nc, self.nf = input_nc, output_nc, nf
         self.activation, self.final_act, self.use_dropout = activation, final_act, use_dropout
@@ -727,7 +779,7 @@ class GeneratorEngine:
             drop = 0.2 if (train and l.dropout) else 0.0
             vb = op.v_bytes() if (keep_v and KEEP_V and ConvOp._aligned(src, y)) else 0
             vk = torch.empty(vb, dtype=torch.uint8, device=dev) if vb else None
-            u, uv = _ucache(ucache, ('e', i), 0, op, dev, src, y) if bf else (None, False)
+            u, uv = _ucache(ucache, ('e', i), 0, op, dev, src, y, l.p_off)
             conv_instnorm_act(op, 0, src, flat, l.p_off, y, out, stats, act, drop, _shift_seed(_mix_seed(seed, 1, i), sample0 * y.HW * y.C),
                               v_keep=vk, u_cache=u, u_valid=uv)
             c.v.append(vk)
@@ -755,7 +807,7 @@ class GeneratorEngine:
                 yd = View.alloc(N, op.Hb, op.Wb, l.b, dev, bf=bf)
                 stats = torch.empty(N * l.b * 2, dtype=torch.float32, device=dev)
                 drop = 0.2 if (train and l.dropout) else 0.0
-                u, uv = _ucache(ucache, ('d', i), 1, op, dev, src, yd) if bf else (None, False)
+                u, uv = _ucache(ucache, ('d', i), 1, op, dev, src, yd, l.p_off)
                 conv_instnorm_act(op, 1, src, flat, l.p_off, yd, out, stats, act, drop,
                                   _shift_seed(_mix_seed(seed, 2, i), sample0 * yd.HW * yd.C), u_cache=u, u_valid=uv)
                 c.yd[i], c.statsd[i] = yd, stats
@@ -802,12 +854,12 @@ class GeneratorEngine:
                 act_bwd(g, None, c.cat[i + 1].channels(0, l.b), dy, act)
             src = c.hidden if i == 0 else c.cat[i]
             dsrc = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=bf)
-            u, uv = _ucache(ucache, ('d', i), 0, op, dev, dy, dsrc) if bf else (None, False)
-            if u is not None:      # bf16 tensors: the two halves as two calls, the data gradient on the forward's packed weights
+            u, uv = _ucache(ucache, ('d', i), 0, op, dev, dy, dsrc, l.p_off)
+            if u is not None and bf:      # bf16 tensors: the two halves as two calls, the data gradient on the forward's packed weights
                 op.wgrad(src, dy, gflat, l.p_off)
                 op.big2small(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
             else:
-                op.bwd_big(src, dy, flat, gflat, l.p_off, dsrc)
+                op.bwd_big(src, dy, flat, gflat, l.p_off, dsrc, u_cache=u, u_valid=uv)
             done(l)
             dcat = dsrc
         # ---- encoder, last to first; dcat is now dL/d(hidden)
@@ -824,7 +876,7 @@ class GeneratorEngine:
             done(l)
             if j > 0 or need_dx:
                 dsrc = View.alloc(N, op.Hb, op.Wb, l.b, dev, bf=bf and j > 0)
-                u, uv = _ucache(ucache, ('e', j), 1, op, dev, dy, dsrc) if bf else (None, False)
+                u, uv = _ucache(ucache, ('e', j), 1, op, dev, dy, dsrc, l.p_off)
                 op.small2big(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
                 if j == 0:
                     dx = dsrc
@@ -859,7 +911,7 @@ class DiscContext:
     pass
 
 
-class DiscriminatorEngine:
+class DiscriminatorEngine(_WeightPrep):
     def __init__(self, input_nc, ndf, n_layers, norm, algo=None):
         self.input_nc, self.ndf, self.n_layers, self.norm = input_nc, ndf, n_layers, norm
         self.layers = disc_layers(input_nc, ndf, n_layers, norm)
@@ -920,7 +972,7 @@ class DiscriminatorEngine:
             c.src.append(src)
             t = View.alloc(din.N, op.Hs, op.Ws, l.a, dev, bf=bf and (0 < li < last or (li == 0 and seam8)))
             bias = flat if l.bias_key is not None else None
-            u, uv = _ucache(ucache, li, 0, op, dev, src, t)
+            u, uv = _ucache(ucache, li, 0, op, dev, src, t, l.p_off)
             vb = op.v_bytes() if (keep_v and KEEP_V and ConvOp._aligned(src, t)) else 0
             vk = torch.empty(vb, dtype=torch.uint8, device=dev) if vb else None
             c.v.append(vk)
@@ -977,7 +1029,7 @@ class DiscriminatorEngine:
                         dsrc = fused = cand
                 if dsrc is None:
                     dsrc = View.alloc(c.N, op.Hb, op.Wb, l.b, dev, bf=bf and 0 < li < last)
-                u, uv = _ucache(ucache, li, 1, op, dev, dy, dsrc)
+                u, uv = _ucache(ucache, li, 1, op, dev, dy, dsrc, l.p_off)
                 if fused is not None:
                     op.small2big(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv, mul=(c.t[li - 1], L.ACT_CODES[below.act]))
                 else:

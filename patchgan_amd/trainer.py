@@ -201,7 +201,9 @@ class Trainer:
 
         # ---- generator step
         seed = E._mix_seed(G._seed_base, self._step) if G.training else 0
-        gcache = {} if train else None     # G's weights are constant from here to its Adam step: packed bf16 copies are shared by forward and backward
+        # G's weights are constant from here to its Adam step: its Winograd-transformed / packed bf16 weights for this step are made by
+        # one batched launch (from the second step on; engine._WeightPrep), shared by forward and backward where one copy serves both
+        gcache = ge.ucache_begin(G.flat, N, H, W) if train else None
         gc = ge.forward(G.flat, xin, gen, G.training, seed, sample0=dist.rank * N, keep_v=train, ucache=gcache)   # trainer.py:63
         self.flush()          # D's deferred all-reduce + Adam from the previous step ran under this G forward
         # seg loss, phase 1 (per-sample reductions); under data parallelism its two batch-global terms are summed across
@@ -209,7 +211,7 @@ class Trainer:
         seg_pending = E.loss_begin(gen, yv, 0.0, self.tversky_beta, allred)
         # D's weights do not change until the Adam step at the end of this call: its Winograd-transformed weights are computed
         # once per (layer, direction) and shared by the passes below through this per-step cache
-        ucache = {}
+        ucache = de.ucache_begin(D.flat, N, H, W, tag=bool(train))
         dc = de.forward(D.flat, fake, ucache=ucache)                                          # trainer.py:66
         gseg = E.View.alloc(N, H, W, Cout, dev) if train else None
         E.loss_finish(seg_pending, _LOSS_MODES[self.loss_type], float(self.seg_alpha), gseg, losses, 0, Bglobal,
@@ -228,6 +230,7 @@ class Trainer:
                 g_reducer = GradReducer(dist, gflat, self.bucket_bytes)
             ge.backward(G.flat, gflat, gc, gseg, ddin.channels(Cin, Cout),                    # trainer.py:88-89
                         on_ready=g_reducer.ready if g_reducer is not None else None, ucache=gcache)
+            ge.ucache_end(gcache)
             if g_reducer is None:
                 self._adam_step('g')                                                          # trainer.py:90
         del dc
@@ -258,6 +261,7 @@ class Trainer:
                 self._pending_d = dist.all_reduce_side(dflat)
             else:
                 self._adam_step('d')                                                          # trainer.py:107
+        de.ucache_end(ucache)
         if wait_losses is not None:
             wait_losses()
         self._last_gen = gen

@@ -611,3 +611,72 @@ def test_activation_backward_in_data_gradient_epilogue(geom, bits, prec, act):
     assert not slow.mul_ok(to_view(small), empty_view(N, Hb, Wb, Cb), to_view(t))
     with pytest.raises(RuntimeError):
         slow.small2big(to_view(small), P, 0, None, 0, empty_view(N, Hb, Wb, Cb), mul=(to_view(t), code))
+
+
+def test_weight_prep_batch_equals_per_layer_transforms():
+    """pg_conv_prep_batch: the Winograd weight transforms (stride-1 F(2x2,4x4) / F(3x3,4x4), both polyphase directions) and the packed
+    bf16 weights (plain, 8-channel-pixel form) of several layers made by ONE call are bit-identical to what each convolution call
+    writes into its own pg_conv_extras.u_cache; a batch with an item that has no weight preparation is refused as a whole; the data
+    gradient inside pg_conv4x4_bwd_big_x reads such a cache."""
+    import ctypes
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view, to_view_bf, to_view_bf8, empty_view, empty_view_bf, pack, DEV
+    cases = [((6, 62, 58, 256, 128, 2), L.ALGO_AUTO, 0), ((9, 32, 32, 128, 64, 1), L.ALGO_AUTO, 0),
+             ((9, 32, 32, 128, 64, 1), L.ALGO_AUTO | L.TUNE_WINO1_F3, 0), ((4, 70, 74, 96, 40, 2), L.ALGO_AUTO | L.TUNE_WINO2_ALL, 0),
+             ((2, 64, 64, 128, 64, 2), L.ALGO_BF16, L.IO_MASK), ((2, 31, 31, 128, 256, 1), L.ALGO_BF16, L.IO_MASK),
+             ((2, 64, 64, 128, 64, 2), L.ALGO_BF16 | L.TUNE_BF16X_RING, L.IO_MASK), ((2, 64, 64, 64, 4, 2), L.ALGO_BF16, L.IO_MASK)]
+    plan, want, flat_parts, off = [], [], [], 0
+    for ci, (geom, algo, io) in enumerate(cases):
+        N, Hb, Wb, Ca, Cb, s = geom
+        big, small, Wt, Hs, Ws = _mk(*geom, seed=ci)
+        op = E.ConvOp(*geom, algo)
+        P = pack(Wt)
+        for opcode in (0, 1):
+            if Cb <= 8 and opcode == 1:
+                continue                               # (the taps-in-N row GEMM onto a few channels owns no cache)
+            nb = op.u_bytes(opcode, io)
+            assert nb > 0, (geom, opcode)
+            u = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+            if io:
+                vb = to_view_bf8(big) if Cb <= 8 else to_view_bf(big)
+                vs = to_view_bf(small)
+                ob, os_ = empty_view_bf(N, Hb, Wb, Cb), empty_view_bf(N, Hs, Ws, Ca)
+            else:
+                vb, vs = to_view(big, ld=Cb + 4), to_view(small, ld=Ca + 4, off=4)
+                ob, os_ = empty_view(N, Hb, Wb, Cb, ld=Cb + 8, off=4), empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=4)
+            if opcode == 0:
+                op.big2small(vb, P, 0, None, 0, os_, u_cache=u, u_valid=False)
+            else:
+                op.small2big(vs, P, 0, None, 0, ob, u_cache=u, u_valid=False)
+            plan.append(((ci, opcode, nb), op, opcode, io, off, nb))
+            want.append(u)
+        flat_parts.append(P)
+        off += P.numel()
+    flat = torch.cat(flat_parts)
+    uc = E.prefill_ucache(plan, flat, flat.device)
+    torch.cuda.synchronize()
+    assert len(uc) == len(plan)
+    for (key, op, opcode, io, p_off, nb), w in zip(plan, want):
+        # (the buffers are torch.empty: compare the bytes the transform defines -- the whole buffer but its 256-byte round-up)
+        got = uc[key]
+        used = nb - 256
+        assert torch.equal(got[:used], w[:used]), (key, op.g.key(), opcode)
+    # all or nothing: one item without a weight preparation -> PG_EINVAL, nothing launched
+    plain = E.ConvOp(6, 62, 58, 256, 128, 2, L.ALGO_MFMA)
+    assert plain.u_bytes(0) == 0
+    with pytest.raises(RuntimeError):
+        E.prefill_ucache(plan[:2] + [(('x',), plain, 0, 0, 0, 1 << 20)], flat, flat.device)
+    # pg_conv4x4_bwd_big_x: the data gradient on a prepared cache, bit-identical to the plain call
+    geom = cases[0][0]
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom, seed=0)
+    op, P = plan[0][1], flat_parts[0]
+    vs, vb = to_view(small, ld=Ca + 4, off=4), to_view(big, ld=Cb + 8, off=4)
+    outs = []
+    for kw in ({}, {'u_cache': uc[plan[0][0]], 'u_valid': True}):
+        dP = torch.full((16 * Ca * Cb,), float('nan'), device=DEV)
+        ds = empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=0)
+        op.bwd_big(vs, vb, P, dP, 0, ds, **kw)
+        outs.append((dP, ds.to_nchw()))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -577,3 +577,34 @@ def test_full_size_cfg2_matches_oracle(tmp_path, tuning):
                         'decoder.5.model.UpConv5.weight'):
                 got_g, want_g = g.get_parameter(key).grad.cpu().double(), r['grads64'][0][key].double()
                 assert ((got_g - want_g).norm() / want_g.norm()).item() < 2e-2, key
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_batched_weight_preparation_is_bitwise_the_per_layer_one(tmp_path, prec, monkeypatch):
+    """Trainer.batch prepares a network's Winograd-transformed / packed bf16 weights with one pg_conv_prep_batch launch per step (from the
+    second step on, from the set the first step used) instead of one small kernel per layer and direction: same bytes, so three steps at
+    the benchmark width give bit-identical losses and weights either way -- and the batched path really is taken."""
+    import patchgan_amd as pg
+    from patchgan_amd import engine as E
+    gen = torch.Generator().manual_seed(11)
+    x = torch.rand(2, 3, 256, 256, generator=gen)
+    y = (torch.rand(2, 1, 256, 256, generator=gen) > 0.6).float()
+    outs, plans = [], []
+    for batched in (True, False):
+        monkeypatch.setattr(E, 'PREP_BATCH', batched)
+        torch.manual_seed(5)
+        g = pg.UNet(3, 1, 64, use_dropout=False, activation='leakyrelu', final_act='sigmoid').cuda()
+        d = pg.Discriminator(4, 64, n_layers=3).cuda()
+        if prec == 'bf16':
+            g.set_precision('bf16')
+            d.set_precision('bf16')
+        t = pg.Trainer(g, d, str(tmp_path / f'b{int(batched)}'))
+        t.setup_optimizers(1e-3, 1e-3)
+        g.train()
+        d.train()
+        ls = [t.batch(x, y, train=True) for _ in range(3)]
+        outs.append((ls, g.flat.clone(), d.flat.clone()))
+        plans.append((sum(len(p) for p in g.engine._uplan.values()), sum(len(p) for p in d.engine._uplan.values())))
+    assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert plans[0][0] >= 4 and plans[0][1] >= 2, plans        # prepared (layer, direction) entries of G and D (more at larger batches)
