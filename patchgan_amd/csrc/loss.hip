@@ -48,6 +48,51 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ p
     }
 }
 
+// C == 4: a block owns (n, z) and all four channels of its pixels -- every byte of a fetched line is used by the block that fetched
+// it, instead of four blocks each touching 4 of every 16 (28) bytes.  Same output layout as k_loss_reduce with gridDim.x = N * 4.
+__global__ __launch_bounds__(256) void k_loss_reduce_c4(const float* __restrict__ p, int ld_p, const float* __restrict__ y, int ld_y,
+                                                        float tconst, int HW, int N, double* __restrict__ S) {
+    __shared__ double red[20][256];
+    const int tid = threadIdx.x, n = blockIdx.x;
+    const float* pb = p + (long)n * HW * ld_p;
+    const float* yb = y ? y + (long)n * HW * ld_y : nullptr;
+    double s[4][5];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s[c][k] = 0.0;
+    for (int i = blockIdx.y * 256 + tid; i < HW; i += 256 * gridDim.y) {
+        float pv4[4], yv4[4];       // (the generator output is a 4-channel slice of the 7-channel discriminator input: scalar loads)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            pv4[c] = pb[(long)i * ld_p + c];
+            yv4[c] = yb ? yb[(long)i * ld_y + c] : tconst;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float pv = pv4[c], yv = yv4[c];
+            const float lp = fmaxf(logf(pv), -100.f), lq = fmaxf(log1pf(-pv), -100.f);
+            s[c][0] += (double)(yv * pv);
+            s[c][1] += (double)yv;
+            s[c][2] += (double)pv;
+            s[c][3] += (double)(-(yv * lp + (1.f - yv) * lq));
+            s[c][4] += (double)fabsf(pv - yv);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) red[c * 5 + k][tid] = s[c][k];
+    for (int off = 128; off > 0; off >>= 1) {
+        __syncthreads();
+        if (tid < off) {
+#pragma unroll
+            for (int k = 0; k < 20; ++k) red[k][tid] += red[k][tid + off];
+        }
+    }
+    if (tid < 20) S[((long)blockIdx.y * N * 4 + (long)n * 4) * 5 + tid] = red[tid][0];
+}
+
 __global__ void k_loss_combine(const double* __restrict__ Spart, int nsplit, int n5, double* __restrict__ S) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n5) return;
@@ -152,12 +197,14 @@ __global__ void k_loss_grad(const float* __restrict__ p, int ld_p, const float* 
     }
 }
 
-// pixel splits per (n, c) so that a loss over a large map runs on >= ~256 workgroups
+// pixel splits per (n, c) -- per n for the four-channel kernel -- so that a loss over a large map runs on >= ~256 workgroups
+inline bool loss_c4(int HW, int C) { return C == 4 && HW >= 4096; }
 int loss_nsplit(int N, int HW, int C) {
-    int ns = 256 / (N * C);
+    const bool c4 = loss_c4(HW, C);
+    int ns = c4 ? 1024 / N : 256 / (N * C);      // (the four-channel kernel is VALU-bound -- two logs, 20 fp64 sums per pixel: 4 blocks per CU)
     const int maxs = HW / 1024;
     if (ns > maxs) ns = maxs;
-    if (ns > 64) ns = 64;
+    if (ns > (c4 ? 128 : 64)) ns = c4 ? 128 : 64;
     return ns < 1 ? 1 : ns;
 }
 
@@ -176,6 +223,13 @@ int pg_loss_reduce(const float* p, int ld_p, const float* y, int ld_y, float tco
     if (!p || !S || N <= 0 || HW <= 0 || C <= 0 || ld_p < C || (y && ld_y < C)) return PG_EINVAL;
     // S must hold (1 + nsplit) * N*C*5 doubles when nsplit > 1 (pg_loss_reduce_doubles): partials behind the result
     const int nsplit = loss_nsplit(N, HW, C);
+    if (loss_c4(HW, C) && nsplit > 1) {
+        double* part = S + (long)N * C * 5;
+        hipLaunchKernelGGL(k_loss_reduce_c4, dim3(N, nsplit), dim3(256), 0, (hipStream_t)stream, p, ld_p, y, ld_y, tconst, HW, N, part);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        hipLaunchKernelGGL(k_loss_combine, dim3((N * C * 5 + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, nsplit, N * C * 5, S);
+        return pg_launch_status();
+    }
     if (nsplit == 1) {
         hipLaunchKernelGGL(k_loss_reduce, dim3(N * C, 1), dim3(256), 0, (hipStream_t)stream, p, ld_p, y, ld_y, tconst, HW, C, S);
         return pg_launch_status();

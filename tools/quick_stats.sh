@@ -8,3 +8,4 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/qs_$TAG -o s --output-format c
 cd $R
 cp $(find gpurun_out/qs_$TAG -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_stats.csv
 python3 tools/stats_table.py gpurun_out/${TAG}_stats.csv 13 200 | grep -i "total\|pack\|prep\|wino.*_u" 
+python3 tools/stats_table.py gpurun_out/${TAG}_stats.csv 13 200 | grep -i "loss" 
