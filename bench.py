@@ -235,6 +235,16 @@ def main():
     pd = parallel.current()
     if pd.on:
         pd.timing = []             # (start, end, bytes) HIP events on the comm stream around every collective
+    if os.environ.get('PATCHGAN_BENCH_TRACE'):
+        import gc
+        _gc_t = [0.0]
+
+        def _gc_cb(phase, info):
+            if phase == 'start':
+                _gc_t[0] = time.perf_counter()
+            elif info.get('generation') == 2:
+                sys.stderr.write(f'gc gen2 {1e3 * (time.perf_counter() - _gc_t[0]):.2f} ms collected {info.get("collected")}\n')
+        gc.callbacks.append(_gc_cb)
     sync()
     t0 = time.perf_counter()
     last = None
@@ -242,6 +252,8 @@ def main():
     for _ in range(args.steps):
         cur = t.batch(x, y, train=True)
         host_ms += t.host_ms
+        if os.environ.get('PATCHGAN_BENCH_TRACE'):
+            sys.stderr.write(f'step host_ms {t.host_ms:.3f} reserved_MiB {torch.cuda.memory_reserved() >> 20} segments {torch.cuda.memory_stats().get("segment.all.allocated", -1)}\n')
         if last is not None:
             last['gen']            # as Trainer.train's epoch loop: step i's losses are read once step i + 1 is enqueued
         last = cur

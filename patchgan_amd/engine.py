@@ -384,9 +384,18 @@ class UCache(dict):
     """A network's transformed / packed weights for ONE weight version: key -> device buffer (see _ucache).  `log` records how each
     entry was made -- (key, op, opcode, io, p_off, bytes) -- so that the engine can fill the same set in one launch next time."""
 
-    def __init__(self):
+    def __init__(self, pool=None):
         super().__init__()
         self.log = []
+        self.pool = pool if pool is not None else {}      # key -> device buffer, reused from step to step (see _WeightPrep)
+
+    def buffer(self, key, nb, dev):
+        """The device buffer of entry `key`: the pool's (same stream as every reader and writer of it, so reusing it for the next
+        weight version needs no synchronisation), allocated on first use -- no allocator traffic per step."""
+        buf = self.pool.get(key)
+        if buf is None or buf.numel() != nb or buf.device != dev:
+            buf = self.pool[key] = torch.empty(nb, dtype=torch.uint8, device=dev)
+        return buf
 
 
 def _ucache(ucache, li, opcode, op, dev, src, dst, p_off=None):
@@ -409,24 +418,26 @@ def _ucache(ucache, li, opcode, op, dev, src, dst, p_off=None):
     key = (li, 'w', nb) if shared else (li, opcode, nb)         # nb separates the F(2x2,4x4) / F(3x3,4x4) transforms of the stride-1 layer
     if key in ucache:
         return ucache[key], True
-    ucache[key] = torch.empty(nb, dtype=torch.uint8, device=dev)
-    if p_off is not None and isinstance(ucache, UCache):
-        ucache.log.append((key, op, opcode, io, p_off, nb))
+    if isinstance(ucache, UCache):
+        ucache[key] = ucache.buffer(key, nb, dev)
+        if p_off is not None:
+            ucache.log.append((key, op, opcode, io, p_off, nb))
+    else:
+        ucache[key] = torch.empty(nb, dtype=torch.uint8, device=dev)
     return ucache[key], False
 
 
-def prefill_ucache(plan, flat, dev):
+def prefill_ucache(plan, flat, dev, pool=None):
     """A UCache holding every entry of `plan` (the log of an earlier UCache of the same network, input extent and storage mode),
     filled from the CURRENT weights `flat` by ONE pg_conv_prep_batch call: one launch per kernel family instead of one small weight
     transform / pack kernel per layer and direction.  Entries that end up unused cost a few microseconds; entries that are
     missing are made lazily by the conv calls as before."""
-    uc = UCache()
+    uc = UCache(pool)
     if not plan or not PREP_BATCH:
         return uc
     items = (L.ConvPrepItem * len(plan))()
     for it, (key, op, opcode, io, p_off, nb) in zip(items, plan):
-        buf = torch.empty(nb, dtype=torch.uint8, device=dev)
-        uc[key] = buf
+        buf = uc[key] = uc.buffer(key, nb, dev)
         it.g, it.op, it.algo, it.ws_bytes = op.g, opcode, op.algo | io, max(op.ws_bytes, 1 << 20)
         it.P, it.u = L.ptr(flat, p_off), buf.data_ptr()
     uc.log = list(plan)
@@ -674,7 +685,8 @@ class _WeightPrep:
 
     def ucache_begin(self, flat, N, H, W, tag=None):
         key = (N, H, W, tag, self.algo, bool(self.act_bf))
-        uc = prefill_ucache(self.__dict__.setdefault('_uplan', {}).get(key), flat, flat.device)
+        pool = self.__dict__.setdefault('_upool', {}).setdefault(key, {})
+        uc = prefill_ucache(self.__dict__.setdefault('_uplan', {}).get(key), flat, flat.device, pool)
         uc.plan_key = key
         return uc
 
