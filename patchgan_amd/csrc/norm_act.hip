@@ -370,30 +370,60 @@ __global__ void k_in_merge(const double* __restrict__ part, int nchunk, int NC, 
     }
 }
 
+// grid (blocks per sample, N).  Where the channel units divide 256 (every power-of-two channel count) a thread keeps ONE channel unit
+// for the whole launch -- its statistics / coefficients live in registers and the pixel index advances by a constant: no division and
+// no per-element reload of the statistics in the loop (the flat form spent two 64-bit divisions and 16 scalar-indexed loads per
+// 16 bytes of payload and ran at 3 TB/s).  Other channel counts: the flat form within the sample, 32-bit.
 template <int VEC, bool BWD>
-__global__ void k_in_apply(TPtr y, int ld_y, TPtr g1, int ld_g1,
+__global__ __launch_bounds__(256) void k_in_apply(TPtr y, int ld_y, TPtr g1, int ld_g1,
                            TPtr g2, int ld_g2, const float* __restrict__ stats,
                            const float* __restrict__ coef, TPtr out, int ld_out, int N, int HW, int C,
                            int act, float drop_p, uint64_t seed) {
     const int cq = C / VEC;
-    const long total = (long)N * HW * cq;
+    const int n = blockIdx.y;
+    const long nb = (long)n * HW;
     const float keep_scale = 1.f / (1.f - drop_p);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long pix = i / cq;
-        const int c0 = (int)(i - pix * cq) * VEC;
-        const int n = (int)(pix / HW);
+    const bool fixed = cq <= 256 && 256 % cq == 0;
+    const int PL = fixed ? 256 / cq : 1;
+    int c0 = fixed ? (int)(threadIdx.x % cq) * VEC : 0;
+    float mf[VEC], rs[VEC], cf0[VEC], cf1[VEC];
+    auto load_coef = [&]() {
         const float* st = stats + ((long)n * C + c0) * 2;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            mf[k] = st[2 * k];
+            rs[k] = st[2 * k + 1];
+        }
+        if (BWD) {
+            const float* cf = coef + ((long)n * C + c0) * 2;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                cf0[k] = cf[2 * k];
+                cf1[k] = cf[2 * k + 1];
+            }
+        }
+    };
+    if (fixed) load_coef();
+    const int first = fixed ? blockIdx.x * PL + (int)(threadIdx.x / cq) : blockIdx.x * 256 + (int)threadIdx.x;
+    const int step = fixed ? gridDim.x * PL : gridDim.x * 256;
+    const int limit = fixed ? HW : HW * cq;
+    for (int i = first; i < limit; i += step) {
+        int p = i;
+        if (!fixed) {
+            p = i / cq;
+            c0 = (i - p * cq) * VEC;
+            load_coef();
+        }
+        const long pix = nb + p;
         Vec<VEC> v = vload<VEC>(y + (long)(pix * ld_y + c0)), o;
         if (!BWD) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float mf = st[2 * k], rs = st[2 * k + 1];
-                float a = pg_act(__fadd_rn(__fmul_rn(v.v[k], rs), -mf * rs), act);
+                float a = pg_act(__fadd_rn(__fmul_rn(v.v[k], rs[k]), -mf[k] * rs[k]), act);
                 if (drop_p > 0.f) a = pg_dropout_keep(seed, (uint64_t)pix * C + c0 + k, drop_p) ? a * keep_scale : 0.f;
                 o.v[k] = a;
             }
         } else {
-            const float* cf = coef + ((long)n * C + c0) * 2;
             Vec<VEC> g = vload<VEC>(g1 + (long)(pix * ld_g1 + c0));
             if (g2) {
                 Vec<VEC> h = vload<VEC>(g2 + (long)(pix * ld_g2 + c0));
@@ -402,16 +432,25 @@ __global__ void k_in_apply(TPtr y, int ld_y, TPtr g1, int ld_g1,
             }
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float mf = st[2 * k], rs = st[2 * k + 1];
                 float gg = g.v[k];
                 if (drop_p > 0.f) gg = pg_dropout_keep(seed, (uint64_t)pix * C + c0 + k, drop_p) ? gg * keep_scale : 0.f;
-                const float z = __fadd_rn(__fmul_rn(v.v[k], rs), -mf * rs);
+                const float z = __fadd_rn(__fmul_rn(v.v[k], rs[k]), -mf[k] * rs[k]);
                 const float dz = gg * pg_norm_act_grad(z, act);
-                o.v[k] = (dz - cf[2 * k] - (v.v[k] - mf) * cf[2 * k + 1]) * rs;
+                o.v[k] = (dz - cf0[k] - (v.v[k] - mf[k]) * cf1[k]) * rs[k];
             }
         }
         vstore<VEC>(out + (long)(pix * ld_out + c0), o);
     }
+}
+
+// blocks per sample of k_in_apply: ~4096 workgroups in all, at least 4 (fixed form: pixel rows of 256 / cq) iterations per thread where
+// the plane allows
+inline dim3 in_apply_grid(int N, int HW, int units) {
+    const long per_sample = ((long)HW * units + 255) / 256;
+    long gx = (4096 + N - 1) / N;
+    if (gx > (per_sample + 3) / 4) gx = (per_sample + 3) / 4;
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, (unsigned)N);
 }
 
 template <int VEC>
@@ -587,10 +626,10 @@ int pg_instnorm_act_fwd_t(const void* y, int ld_y, void* out, int ld_out, float*
                            stats, (float*)nullptr);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         if (vec)
-            hipLaunchKernelGGL((k_in_apply<4, false>), dim3(ew_blocks((long)N * HW * (C / 4))), dim3(256), 0, st, ty, ld_y, none, 0,
+            hipLaunchKernelGGL((k_in_apply<4, false>), in_apply_grid(N, HW, C / 4), dim3(256), 0, st, ty, ld_y, none, 0,
                                none, 0, stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
         else
-            hipLaunchKernelGGL((k_in_apply<1, false>), dim3(ew_blocks((long)N * HW * C)), dim3(256), 0, st, ty, ld_y, none, 0, none, 0,
+            hipLaunchKernelGGL((k_in_apply<1, false>), in_apply_grid(N, HW, C), dim3(256), 0, st, ty, ld_y, none, 0, none, 0,
                                stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
         return pg_launch_status();
     }
@@ -622,10 +661,10 @@ int pg_instnorm_act_fwd_parts_t(const void* y, int ld_y, void* out, int ld_out, 
                        (float*)nullptr);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     if (vec)
-        hipLaunchKernelGGL((k_in_apply<4, false>), dim3(ew_blocks((long)N * HW * (C / 4))), dim3(256), 0, st, ty, ld_y, none, 0, none,
+        hipLaunchKernelGGL((k_in_apply<4, false>), in_apply_grid(N, HW, C / 4), dim3(256), 0, st, ty, ld_y, none, 0, none,
                            0, stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
     else
-        hipLaunchKernelGGL((k_in_apply<1, false>), dim3(ew_blocks((long)N * HW * C)), dim3(256), 0, st, ty, ld_y, none, 0, none, 0,
+        hipLaunchKernelGGL((k_in_apply<1, false>), in_apply_grid(N, HW, C), dim3(256), 0, st, ty, ld_y, none, 0, none, 0,
                            stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
     return pg_launch_status();
 }
@@ -661,10 +700,10 @@ int pg_instnorm_act_bwd_t(const void* g1, int ld_g1, const void* g2, int ld_g2, 
                            const_cast<float*>(stats), coef);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         if (vec)
-            hipLaunchKernelGGL((k_in_apply<4, true>), dim3(ew_blocks((long)N * HW * (C / 4))), dim3(256), 0, st, ty, ld_y, tg1,
+            hipLaunchKernelGGL((k_in_apply<4, true>), in_apply_grid(N, HW, C / 4), dim3(256), 0, st, ty, ld_y, tg1,
                                ld_g1, tg2, ld_g2, stats, coef, tdy, ld_dy, N, HW, C, act, drop_p, seed);
         else
-            hipLaunchKernelGGL((k_in_apply<1, true>), dim3(ew_blocks((long)N * HW * C)), dim3(256), 0, st, ty, ld_y, tg1, ld_g1,
+            hipLaunchKernelGGL((k_in_apply<1, true>), in_apply_grid(N, HW, C), dim3(256), 0, st, ty, ld_y, tg1, ld_g1,
                                tg2, ld_g2, stats, coef, tdy, ld_dy, N, HW, C, act, drop_p, seed);
         return pg_launch_status();
     }
