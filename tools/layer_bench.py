@@ -50,6 +50,6 @@ for name, N, Hb, Wb, Ca, Cb, s, _ in layers:
         ms = e0.elapsed_time(e1) / REPS
         sym, split = op.describe(oc)
         tot[oc] += ms
-        cells.append(f"{ms*1e3:7.0f}us {op.flops/ms/1e9:6.1f}TF {sym.split('<')[1][:-1]}{'/' + str(split) if split > 1 else '':4s}")
+        cells.append(f"{ms*1e3:7.0f}us {op.flops/ms/1e9:6.1f}TF {(sym.split('<')[1][:-1] if '<' in sym else sym[-6:])}{'/' + str(split) if split > 1 else '':4s}")
     print(f"{name:10s} {str((N, Hb, Wb, Ca, Cb, s)):34s} {op.flops/1e9:8.2f} | " + ' | '.join(cells), flush=True)
 print('sum ms', tot)
