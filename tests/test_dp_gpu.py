@@ -11,6 +11,30 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+def _collect(q, procs, timeout=300.0):
+    """One result per worker from the queue; fails AT ONCE when a worker died (a crashed rank leaves its peer blocked in a collective
+    and the queue empty: waiting out the timeout would only hide the exit code), and never leaves a rank behind on the GPU."""
+    import queue
+    import time
+    out, t0 = [], time.monotonic()
+    try:
+        while len(out) < len(procs):
+            try:
+                out.append(q.get(timeout=1.0))
+                continue
+            except queue.Empty:
+                pass
+            dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+            assert not dead, f'worker(s) died (rank, exit code): {dead}'
+            assert time.monotonic() - t0 < timeout, 'workers still running after the timeout'
+    except BaseException:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        raise
+    return sorted(out, key=lambda r: r[0])
+
+
 def _worker(rank, world, port, q, name, nsteps, dropout=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -62,7 +86,7 @@ def test_two_rank_step_matches_single_process_golden(name):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, name, nsteps)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    res = _collect(q, procs)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -112,7 +136,7 @@ def test_two_rank_dropout_masks_are_those_of_the_global_batch(tmp_path):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, name, nsteps, True)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    res = _collect(q, procs)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -186,7 +210,7 @@ def test_two_rank_bf16_storage_tracks_single_process(tmp_path):
     procs = [ctx.Process(target=_worker_bf16, args=(r, 2, port, q, gw, dw, x, y, nsteps)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    res = _collect(q, procs)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
