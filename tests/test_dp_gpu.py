@@ -219,3 +219,85 @@ def test_two_rank_bf16_storage_tracks_single_process(tmp_path):
     err = np.abs(c0 - single) / np.maximum(np.abs(single), 1e-3)
     print('dp2 bf16 storage vs single process: max rel err per step', err.max(axis=1))
     assert err[0].max() < 5e-3 and err[:, :3].max() < 2e-2 and err.max() < 0.5, err
+
+
+def _worker_n(rank, world, port, q, gw, dw, x, y, nsteps, cfg):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import tempfile
+    import patchgan_amd as pg
+    from patchgan_amd.parallel import shard_batch
+    from tests.golden_util import LOSS_KEYS
+    g = pg.UNet(3, cfg['out_nc'], cfg['nf'], activation='leakyrelu', final_act=cfg['final_act'], use_dropout=True)
+    d = pg.Discriminator(3 + cfg['out_nc'], cfg['nf'], n_layers=3, norm=cfg['norm'])
+    g.load_state_dict(gw)
+    d.load_state_dict(dw)
+    g.cuda()
+    d.cuda()
+    g._seed_base = 99
+    t = pg.Trainer(g, d, tempfile.mkdtemp())
+    t.loss_type = cfg['loss_type']
+    t.bucket_bytes = 256 << 10
+    t.setup_optimizers(1e-3, 1e-3)
+    g.train()
+    d.train()
+    xs, ys = shard_batch(x, y, rank, world)
+    curve = [[t.batch(xs, ys, train=True)[k] for k in LOSS_KEYS] for _ in range(nsteps)]
+    t.flush()
+    torch.cuda.synchronize()
+    q.put((rank, np.array(curve), g.flat.cpu().numpy(), d.flat.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('cfg', [dict(out_nc=1, nf=8, final_act='sigmoid', norm=False, loss_type='tversky'),
+                                 dict(out_nc=3, nf=8, final_act='softmax', norm=True, loss_type='weighted_bce')],
+                         ids=['tversky', 'wbce_norm'])
+def test_four_ranks_equal_the_single_process_large_batch(tmp_path, cfg):
+    """World size 4 (one sample per rank, all four on the one GPU, gloo): nothing in the data-parallel step may depend on there being two
+    ranks -- the global batch factor of the batch-non-linear loss terms (focal-Tversky's mean under the power, weighted BCE's sum(y)),
+    the dropout offsets r * N * HW * C, the bucket order of the gradient reducer, the deferred discriminator update.  Four steps with
+    dropout on against the single-process run on the whole batch of four: every loss within 1e-4 (fp32 reduction-order noise), the four
+    ranks bit-identical to each other."""
+    import patchgan_amd as pg
+    from tests.golden_util import LOSS_KEYS
+    torch.manual_seed(31)
+    g = pg.UNet(3, cfg['out_nc'], cfg['nf'], activation='leakyrelu', final_act=cfg['final_act'], use_dropout=True)
+    d = pg.Discriminator(3 + cfg['out_nc'], cfg['nf'], n_layers=3, norm=cfg['norm'])
+    gw = {k: v.clone() for k, v in g.state_dict().items()}
+    dw = {k: v.clone() for k, v in d.state_dict().items()}
+    gen = torch.Generator().manual_seed(32)
+    x = torch.rand(4, 3, 128, 128, generator=gen)
+    y = (torch.rand(4, cfg['out_nc'], 128, 128, generator=gen) > 0.6).float()
+    nsteps = 4
+    g.cuda()
+    d.cuda()
+    g._seed_base = 99
+    t = pg.Trainer(g, d, str(tmp_path / 'single'))
+    t.loss_type = cfg['loss_type']
+    t.setup_optimizers(1e-3, 1e-3)
+    g.train()
+    d.train()
+    single = np.array([[t.batch(x, y, train=True)[k] for k in LOSS_KEYS] for _ in range(nsteps)])
+    torch.cuda.synchronize()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_n, args=(r, 4, port, q, gw, dw, x, y, nsteps, cfg)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = _collect(q, procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in res[1:]:
+        assert np.array_equal(r[2], res[0][2]) and np.array_equal(r[3], res[0][3])
+        assert np.allclose(r[1], res[0][1], rtol=1e-6)
+    err = np.abs(res[0][1] - single) / np.maximum(np.abs(single), 1e-6)
+    print('dp4 vs single process: max rel err per step', err.max(axis=1))
+    assert err.max() < 1e-4, err
