@@ -3126,7 +3126,7 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
         snprintf(buf, sizeof buf, "%s", oc == 0 ? "k_big2small_direct" : oc == 1 ? "k_small2big_direct" : "k_wgrad_direct");
     } else if (mode == 6) {          // Winograd weight gradients: 60 / 63 stride 1 (F(4x4,2x2)), 61 / 62 polyphase stride 2
         snprintf(buf, sizeof buf, "k_wino_wgrad_gemm<%s>", (tid == 2 || tid == 3) ? "1,1,2,2" : "2,2,2,2");
-        fl = (g->stride == 1) ? 2.0 * 25 * g->N * cd(g->Hs, 2) * cd(g->Ws, 2) * g->Ca * g->Cb
+        fl = (g->stride == 1) ? pg_wino_wgrad_flops(g->N, g->Hs, g->Ws, g->Ca, g->Cb)
                               : 2.0 * 16 * g->N * cd(g->Hs, 3) * cd(g->Ws, 3) * g->Ca * 4.0 * g->Cb;
     } else if (mode == 8) {
         snprintf(buf, sizeof buf, "k_b2s_tapk<%d>", tid);

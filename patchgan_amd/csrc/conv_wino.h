@@ -37,8 +37,10 @@ int pg_wino_dma_mode();   // process default (PATCHGAN_WINO_DMA): 0 register-sta
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
                  void* ws, hipStream_t st, int mo_forced, int dma_mode, const float* Uext, pg_epi_mul mul = pg_epi_mul{nullptr, 0, 0});
 
-// weight gradient of the same layers, F(4x4, 2x2): V (25*tiles*Cb) | DY (25*tiles*Ca) | S (slices*25*Ca*Cb) in ws
+// weight gradient of the same layers, F(4x4, 2x2) or F(4x4, 3x3) (X = 25 / 36 points): V (X*tiles*Cb) | DY (X*tiles*Ca) | S (slices*X*Ca*Cb) in ws
 bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
+int pg_wino_wgrad_r(int N, int Hs, int Ws);      // dy-tile edge: 2 = F(4x4,2x2), 3 = F(4x4,3x3)
+double pg_wino_wgrad_flops(int N, int Hs, int Ws, int Ca, int Cb);      // FLOPs its GEMM executes
 int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb);
 bool pg_wino_wgrad_tile64(int Ca, int Cb);      // k_wino_wgrad_gemm<1,1,2,2> instead of <2,2,2,2>
 size_t pg_wino_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);

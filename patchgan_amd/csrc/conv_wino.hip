@@ -473,8 +473,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 __device__ __constant__ float c_G2[5][2] = {{0.5f, 0.f}, {-0.5f, -0.5f}, {-1.f / 6, 1.f / 6}, {1.f / 6, 1.f / 3}, {0.f, 1.f}};
 __device__ __constant__ float c_A4T[4][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 2, 0}, {0, 1, 1, 4, 0}, {0, 1, -1, 8, 1}};
 
+// F(4x4, 3x3): 3x3 tiles of dy against 6x6 windows of x on the six points of the forward's F(3x3,4x4) (0, 1, -1, 1/2, -2, inf: the
+// same B^T, i.e. the same k_wino_v<3>): 36 instead of 144 multiplies per tile and channel pair, 1.56x fewer than F(4x4,2x2), transformed
+// operands 0.64x the size; simulated fp32 error 3e-6 (F(4x4,2x2): 4e-6).  G rows = (1, p, p^2) / N_p with the Lagrange denominators of c_G34.
+__device__ __constant__ float c_G43[6][3] = {{1.f, 0.f, 0.f},           {1.f / 3, 1.f / 3, 1.f / 3},       {-1.f / 3, 1.f / 3, -1.f / 3},
+                                             {-16.f / 15, -8.f / 15, -4.f / 15}, {1.f / 15, -2.f / 15, 4.f / 15}, {0.f, 0.f, 1.f}};
+__device__ __constant__ float c_A4T6[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 0.5f, -2, 0}, {0, 1, 1, 0.25f, 4, 0}, {0, 1, -1, 0.125f, -8, 1}};
+template <int R> __device__ __forceinline__ float wg_g(int a, int u) {
+    if constexpr (R == 2) return c_G2[a][u];
+    else return c_G43[a][u];
+}
+template <int R> __device__ __forceinline__ float wg_at(int k, int i) {
+    if constexpr (R == 2) return c_A4T[k][i];
+    else return c_A4T6[k][i];
+}
+
+template <int R>      // R x R tiles of dy (2: F(4x4,2x2), 3: F(4x4,3x3)); NP = R + 3 points
 __global__ __launch_bounds__(256) void k_wino_dy(const float* __restrict__ dy, int ld, float* __restrict__ DY, int N, int Hs,
                                                  int Ws, int Ca, int TH, int TW) {
+    constexpr int NP = R + 3;
     const int cq = Ca >> 2;
     const long T = (long)N * TH * TW;
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -485,24 +502,33 @@ __global__ __launch_bounds__(256) void k_wino_dy(const float* __restrict__ dy, i
     const int rem = (int)(tile - (long)n * TH * TW);
     const int ti = rem / TW, tj = rem - ti * TW;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 d[2][2];
+    f32x4 d[R][R];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < R; ++u)
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            const int y = 2 * ti + u, x = 2 * tj + v;
+        for (int v = 0; v < R; ++v) {
+            const int y = R * ti + u, x = R * tj + v;
             d[u][v] = (y < Hs && x < Ws) ? *reinterpret_cast<const f32x4*>(dy + ((long)(n * Hs + y) * Ws + x) * ld + c0) : z;
         }
-    f32x4 t[5][2];
+    f32x4 t[NP][R];
 #pragma unroll
-    for (int a = 0; a < 5; ++a)
+    for (int a = 0; a < NP; ++a)
 #pragma unroll
-        for (int v = 0; v < 2; ++v) t[a][v] = c_G2[a][0] * d[0][v] + c_G2[a][1] * d[1][v];
+        for (int v = 0; v < R; ++v) {
+            f32x4 sum = wg_g<R>(a, 0) * d[0][v];
 #pragma unroll
-    for (int a = 0; a < 5; ++a)
+            for (int u = 1; u < R; ++u) sum += wg_g<R>(a, u) * d[u][v];
+            t[a][v] = sum;
+        }
 #pragma unroll
-        for (int b = 0; b < 5; ++b)
-            *reinterpret_cast<f32x4*>(DY + ((long)(a * 5 + b) * T + tile) * Ca + c0) = t[a][0] * c_G2[b][0] + t[a][1] * c_G2[b][1];
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+        for (int b = 0; b < NP; ++b) {
+            f32x4 sum = t[a][0] * wg_g<R>(b, 0);
+#pragma unroll
+            for (int v = 1; v < R; ++v) sum += t[a][v] * wg_g<R>(b, v);
+            *reinterpret_cast<f32x4*>(DY + ((long)(a * NP + b) * T + tile) * Ca + c0) = sum;
+        }
 }
 
 // 1-D grid of tilesA * tilesB * NX * slices workgroups; work index = ((slice * NX + xi) * tilesA + tile_a) * tilesB + tile_b,
@@ -607,28 +633,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
 }
 
-// one thread per (a, b): sums the slices in order, then the 25 -> 16 output transform
+// one thread per (a, b): sums the slices in order, then the NP^2 -> 16 output transform
+template <int R>
 __global__ void k_wino_wgrad_out(const float* __restrict__ S, int slices, float* __restrict__ dP, int Ca, int Cb) {
+    constexpr int NP = R + 3;
     const long ab = (long)Ca * Cb;
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (idx >= ab) return;
-    float m[5][5];
+    float m[NP][NP];
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < NP; ++i)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NP; ++j) {
             float v = 0.f;
-            for (int s = 0; s < slices; ++s) v += S[((long)s * 25 + i * 5 + j) * ab + idx];
+            for (int s = 0; s < slices; ++s) v += S[((long)s * NP * NP + i * NP + j) * ab + idx];
             m[i][j] = v;
         }
-    float t[4][5];
+    float t[4][NP];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NP; ++j) {
             float v = 0.f;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) v += c_A4T[k][i] * m[i][j];
+            for (int i = 0; i < NP; ++i) v += wg_at<R>(k, i) * m[i][j];
             t[k][j] = v;
         }
 #pragma unroll
@@ -637,7 +665,7 @@ __global__ void k_wino_wgrad_out(const float* __restrict__ S, int slices, float*
         for (int l = 0; l < 4; ++l) {
             float v = 0.f;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) v += t[k][j] * c_A4T[l][j];
+            for (int j = 0; j < NP; ++j) v += t[k][j] * wg_at<R>(l, j);
             dP[(long)(k * 4 + l) * ab + idx] = v;
         }
 }
@@ -1455,11 +1483,32 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
 }
 
 // ---- weight gradient ----
+// dy-tile edge: 3 (F(4x4,3x3), 36 points) where that still leaves >= 1024 tiles (32 K chunks), else 2 (F(4x4,2x2), 25 points);
+// PATCHGAN_WINOW_R=2|3 pins it (experiment switch)
+int pg_wino_wgrad_r(int N, int Hs, int Ws) {
+    static const int forced = [] {
+        const char* e = pg_exp_env("PATCHGAN_WINOW_R");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 2 || forced == 3) return forced;
+    return (long)N * ((Hs + 2) / 3) * ((Ws + 2) / 3) >= 1024 ? 3 : 2;
+}
+static long wgrad_tiles(int N, int Hs, int Ws) {
+    const int r = pg_wino_wgrad_r(N, Hs, Ws);
+    return (long)N * ((Hs + r - 1) / r) * ((Ws + r - 1) / r);
+}
+static int wgrad_nxi(int N, int Hs, int Ws) {
+    const int np = pg_wino_wgrad_r(N, Hs, Ws) + 3;
+    return np * np;
+}
+double pg_wino_wgrad_flops(int N, int Hs, int Ws, int Ca, int Cb) {
+    return 2.0 * wgrad_nxi(N, Hs, Ws) * wgrad_tiles(N, Hs, Ws) * Ca * Cb;
+}
 bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb) {
     if (Ca % 4 != 0 || Cb % 4 != 0 || Ca < 64 || Cb < 64) return false;
-    const long T = (long)N * ((Hs + 1) / 2) * ((Ws + 1) / 2);
-    if (T < 2048) return false;
-    if (25.0 * T * Ca * 4 >= 1.5e9 || 25.0 * T * Cb * 4 >= 1.5e9) return false;
+    if ((long)N * ((Hs + 1) / 2) * ((Ws + 1) / 2) < 2048) return false;
+    const double xt = (double)wgrad_nxi(N, Hs, Ws) * wgrad_tiles(N, Hs, Ws);
+    if (xt * Ca * 4 >= 1.5e9 || xt * Cb * 4 >= 1.5e9) return false;
     return true;
 }
 
@@ -1473,9 +1522,9 @@ bool pg_wino_wgrad_tile64(int Ca, int Cb) {
     return 25L * ((Ca + 127) / 128) * ((Cb + 127) / 128) < 768;
 }
 int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb) {
-    const long T = (long)N * ((Hs + 1) / 2) * ((Ws + 1) / 2);
+    const long T = wgrad_tiles(N, Hs, Ws);
     const int tt = pg_wino_wgrad_tile64(Ca, Cb) ? 64 : 128;
-    const long wgs = 25L * ((Ca + tt - 1) / tt) * ((Cb + tt - 1) / tt);
+    const long wgs = (long)wgrad_nxi(N, Hs, Ws) * ((Ca + tt - 1) / tt) * ((Cb + tt - 1) / tt);
     long s = (768 + wgs - 1) / wgs;                 // three workgroups per CU
     const long nchunks = (T + KC - 1) / KC;
     if (s > nchunks / 16) s = nchunks / 16;          // at least 16 chunks per slice
@@ -1483,23 +1532,29 @@ int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb) {
 }
 
 size_t pg_wino_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb) {
-    const long T = (long)N * ((Hs + 1) / 2) * ((Ws + 1) / 2);
-    return align256((size_t)25 * T * Cb * 4) + align256((size_t)25 * T * Ca * 4) +
-           align256((size_t)pg_wino_wgrad_slices(N, Hs, Ws, Ca, Cb) * 25 * Ca * Cb * 4);
+    const long T = wgrad_tiles(N, Hs, Ws), X = wgrad_nxi(N, Hs, Ws);
+    return align256((size_t)X * T * Cb * 4) + align256((size_t)X * T * Ca * 4) +
+           align256((size_t)pg_wino_wgrad_slices(N, Hs, Ws, Ca, Cb) * X * Ca * Cb * 4);
 }
 
 int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
                   int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-    const int TH = (Hs + 1) / 2, TW = (Ws + 1) / 2;
+    const int R = pg_wino_wgrad_r(N, Hs, Ws), X = (R + 3) * (R + 3);
+    const int TH = (Hs + R - 1) / R, TW = (Ws + R - 1) / R;
     const long T = (long)N * TH * TW;
     float* V = (float*)ws;
-    float* DY = (float*)((char*)ws + align256((size_t)25 * T * Cb * 4));
-    float* S = (float*)((char*)DY + align256((size_t)25 * T * Ca * 4));
-    hipLaunchKernelGGL(k_wino_v<2>, dim3((unsigned)((T * (Cb / 4) + 255) / 256)), dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb,
-                       TH, TW, 1);
-    if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
-    hipLaunchKernelGGL(k_wino_dy, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, small, ld_small, DY, N, Hs, Ws,
-                       Ca, TH, TW);
+    float* DY = (float*)((char*)ws + align256((size_t)X * T * Cb * 4));
+    float* S = (float*)((char*)DY + align256((size_t)X * T * Ca * 4));
+    const dim3 gv((unsigned)((T * (Cb / 4) + 255) / 256)), gd((unsigned)((T * (Ca / 4) + 255) / 256));
+    if (R == 3) {
+        hipLaunchKernelGGL(k_wino_v<3>, gv, dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb, TH, TW, 1);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        hipLaunchKernelGGL(k_wino_dy<3>, gd, dim3(256), 0, st, small, ld_small, DY, N, Hs, Ws, Ca, TH, TW);
+    } else {
+        hipLaunchKernelGGL(k_wino_v<2>, gv, dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb, TH, TW, 1);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        hipLaunchKernelGGL(k_wino_dy<2>, gd, dim3(256), 0, st, small, ld_small, DY, N, Hs, Ws, Ca, TH, TW);
+    }
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
     const int slices = pg_wino_wgrad_slices(N, Hs, Ws, Ca, Cb);
     const int nchunks = (int)((T + KC - 1) / KC);
@@ -1507,16 +1562,20 @@ int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big
     if (ev0) (void)hipEventRecord(ev0, st);
     if (pg_wino_wgrad_tile64(Ca, Cb)) {
         const int tilesA = (Ca + 63) / 64, tilesB = (Cb + 63) / 64;
-        hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB * 25 * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                           Cb, cps, tilesA, tilesB, 25, (int)(25L * T * Ca * 4), (int)(25L * T * Cb * 4));
+        hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB * X * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                           Cb, cps, tilesA, tilesB, X, (int)((long)X * T * Ca * 4), (int)((long)X * T * Cb * 4));
     } else {
         const int tilesA = (Ca + 127) / 128, tilesB = (Cb + 127) / 128;
-        hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB * 25 * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                           Cb, cps, tilesA, tilesB, 25, (int)(25L * T * Ca * 4), (int)(25L * T * Cb * 4));
+        hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB * X * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                           Cb, cps, tilesA, tilesB, X, (int)((long)X * T * Ca * 4), (int)((long)X * T * Cb * 4));
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
-    hipLaunchKernelGGL(k_wino_wgrad_out, dim3((unsigned)(((long)Ca * Cb + 255) / 256)), dim3(256), 0, st, S, slices, dP, Ca, Cb);
+    const dim3 go((unsigned)(((long)Ca * Cb + 255) / 256));
+    if (R == 3)
+        hipLaunchKernelGGL(k_wino_wgrad_out<3>, go, dim3(256), 0, st, S, slices, dP, Ca, Cb);
+    else
+        hipLaunchKernelGGL(k_wino_wgrad_out<2>, go, dim3(256), 0, st, S, slices, dP, Ca, Cb);
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
 
