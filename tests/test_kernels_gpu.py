@@ -154,9 +154,12 @@ def test_winograd_stride1(geom, tile):
         outs.append(vb.to_nchw())
     torch.cuda.synchronize()
     assert rel_err(outs[0], want) < 1e-5 and rel_err(outs[1], want) < 1e-5 and rel_err(outs[0], outs[1]) < 1e-5
-    # weight (+ bias) gradient: F(4x4, 2x2)
+    # weight (+ bias) gradient: F(4x4, 3x3) on 3x3 tiles of dy where that leaves >= 1024 tiles, else F(4x4, 2x2) (the third geometry)
     from tests.gpu_util import unpack, DEV
     assert auto.describe(2)[0].startswith('k_wino_wgrad_gemm') and not mfma.describe(2)[0].startswith('k_wino')
+    t3 = N * ((Hs + 2) // 3) * ((Ws + 2) // 3)
+    r = 3 if t3 >= 1024 else 2
+    assert auto.kernel_flops(2) == 2.0 * (r + 3) ** 2 * N * ((Hs + r - 1) // r) * ((Ws + r - 1) // r) * Ca * Cb, (r, auto.kernel_flops(2))
     Wr = Wt.clone().requires_grad_(True)
     br = torch.zeros(Ca, requires_grad=True)
     F.conv2d(big, Wr, br, stride=1, padding=1).backward(small)
