@@ -3211,11 +3211,14 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
     if (algo == PG_ALGO_AUTO && wino_b2s_ok(g, tune) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= pg_wino_ws_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1) &&
         pg_wino_eligible(g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, ld_big, big, tune.mo1)) {
-        if (part || x.v_keep) return PG_EINVAL;
-        int rc = pg_wino_prepare(big, ld_big, P, 0, g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, 1, ws, st, tune.mo1, x.u_cache, x.u_valid);
+        if (part) return PG_EINVAL;
+        if (x.v_keep && !(wino_wgrad_ok(g, tune) && pg_wino_wgrad_v_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb, tune.mo1))) return PG_EINVAL;
+        int rc = pg_wino_prepare(big, ld_big, P, 0, g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, 1, ws, st, tune.mo1, x.u_cache, x.u_valid,
+                                 x.v_keep);
         if (rc != PG_OK) return rc;
         TimedLaunch timed(st);
-        return pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st, tune.mo1, tune.dma, x.u_cache);
+        return pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st, tune.mo1, tune.dma, x.u_cache,
+                            pg_epi_mul{nullptr, 0, 0}, x.v_keep);
     }
     if (algo == PG_ALGO_AUTO && wino2_b2s_ok(g, tune) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
         aligned16(small) && aligned16(ws) && (!bias || aligned16(bias)) &&
@@ -3571,9 +3574,14 @@ int pg_conv_mul_ok(const pg_conv_geom* gg, int algo, size_t ws_bytes) {
 }
 
 size_t pg_conv_v_bytes(const pg_conv_geom* gg, int algo, size_t ws_bytes) {
-    if (!geom_ok(gg) || (algo & PG_ALGO_MASK) != PG_ALGO_AUTO || pg_wino2_mo() != 3) return 0;
+    if (!geom_ok(gg) || (algo & PG_ALGO_MASK) != PG_ALGO_AUTO) return 0;
     const Geom g = to_geom(gg);
     const Tune tune = tune_of(algo);
+    // stride-1 layer: forward on F(3x3,4x4), weight gradient on F(4x4,3x3) -- one transformed input
+    if (wino_b2s_ok(g, tune) && wino_wgrad_ok(g, tune) && ws_bytes >= pg_wino_ws_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1) &&
+        ws_bytes >= (((size_t)COLSUM_CHUNKS * g.Ca * sizeof(float) + 255) & ~(size_t)255) + pg_wino_wgrad_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb))
+        return pg_wino_wgrad_v_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb, tune.mo1);
+    if (pg_wino2_mo() != 3) return 0;
     const size_t colsum = ((size_t)COLSUM_CHUNKS * g.Ca * sizeof(float) + 255) & ~(size_t)255;
     if (wino2_b2s_ok(g, tune) && ws_bytes >= pg_wino2_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb) && wino2_wgrad_ok(g, tune) &&
         ws_bytes >= colsum + pg_wino2_wgrad_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb))
@@ -3657,9 +3665,9 @@ static int wgrad_impl(const float* small, int ld_small, const float* big, int ld
         hipEvent_t e0 = t_ev0, e1 = t_ev1;
         t_ev0 = nullptr;
         t_ev1 = nullptr;
-        if (v_pre) return PG_EINVAL;
+        if (v_pre && !pg_wino_wgrad_v_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb, tune.mo1)) return PG_EINVAL;
         return pg_wino_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, (char*)ws + reserved, st,
-                             e0, e1);
+                             e0, e1, v_pre);
     }
     if (algo == PG_ALGO_AUTO && wino2_wgrad_ok(g, tune) && (ld_small % 4 == 0) && (ld_big % 4 == 0) && aligned16(small) &&
         aligned16(big) && aligned16(ws) && aligned16(dP) && ws_bytes >= reserved + pg_wino2_wgrad_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) {

@@ -17,7 +17,7 @@ bool pg_wino_small_tile(int N, int Hout, int Wout, int Cin, int Cout, int mo_for
 size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced);
 // weight transform + input transform into ws
 int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N, int Hin, int Win, int Cin, int Hout,
-                    int Wout, int Cout, int pad, void* ws, hipStream_t st, int mo_forced, float* Uext, int u_valid);
+                    int Wout, int Cout, int pad, void* ws, hipStream_t st, int mo_forced, float* Uext, int u_valid, float* Vext = nullptr);
 // Uext (optional, all paths with a weight transform): caller-owned cache of the transformed weights; u_valid != 0: it already
 // holds the transform of the current weights and the transform kernel is skipped
 size_t pg_wino_u_bytes(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced);
@@ -35,7 +35,10 @@ int pg_wino_prep_batch(int n, const pg_wino_prep* items, hipStream_t st);
 int pg_wino_dma_mode();   // process default (PATCHGAN_WINO_DMA): 0 register-staged k_wino_gemm only, 1: k_wino_gemm_dma<3,4,2> for F(3x3,4x4), 2: also <2,3,3> for 64-tile F(2x2,4x4)
 // the batched GEMM with fused output transform, bias and activation
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
-                 void* ws, hipStream_t st, int mo_forced, int dma_mode, const float* Uext, pg_epi_mul mul = pg_epi_mul{nullptr, 0, 0});
+                 void* ws, hipStream_t st, int mo_forced, int dma_mode, const float* Uext, pg_epi_mul mul = pg_epi_mul{nullptr, 0, 0},
+                 const float* Vext = nullptr);
+// Vext (both): the transformed input lives in a caller-owned buffer (pg_wino_wgrad_v_bytes) instead of the workspace -- the forward
+// call keeps it for the layer's weight gradient (Vpre of pg_wino_wgrad), F(3x3,4x4) forward + F(4x4,3x3) weight gradient only
 
 // weight gradient of the same layers, F(4x4, 2x2) or F(4x4, 3x3) (X = 25 / 36 points): V (X*tiles*Cb) | DY (X*tiles*Ca) | S (slices*X*Ca*Cb) in ws
 bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
@@ -46,7 +49,8 @@ bool pg_wino_wgrad_tile64(int Ca, int Cb);      // k_wino_wgrad_gemm<1,1,2,2> in
 size_t pg_wino_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
 // ev0 / ev1 (optional) are recorded around the GEMM kernel
 int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
-                  int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+                  int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const float* Vpre = nullptr);
+size_t pg_wino_wgrad_v_bytes(int N, int Hs, int Ws, int Ca, int Cb, int fwd_mo_forced);     // 0: the two calls do not share a transform
 
 // stride-2 layers, polyphase F(MO x MO, 2x2), MO = pg_wino2_mo() (3, or 4 with PATCHGAN_WINO2_TILE=4), X = (MO+1)^2:
 // big -> small: U (X*Ca*4Cb) | V (X*tiles*4Cb) | M (X*tiles*Ca) in ws

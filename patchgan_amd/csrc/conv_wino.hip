@@ -1403,11 +1403,11 @@ size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout, int forced
 }
 
 int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N, int Hin, int Win, int Cin, int Hout,
-                    int Wout, int Cout, int pad, void* ws, hipStream_t st, int forced, float* Uext, int u_valid) {
+                    int Wout, int Cout, int pad, void* ws, hipStream_t st, int forced, float* Uext, int u_valid, float* Vext) {
     const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
     const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
     float* U = Uext ? Uext : (float*)ws;       // Uext: caller-owned cache of the transformed weights (u_valid: already filled)
-    float* V = (float*)((char*)ws + align256((size_t)X * Cout * Cin * 4));
+    float* V = Vext ? Vext : (float*)((char*)ws + align256((size_t)X * Cout * Cin * 4));      // Vext: caller-owned (kept for the weight gradient)
     const dim3 gu((unsigned)(((long)Cout * Cin + 255) / 256)), gv((unsigned)((T * (Cin / 4) + 255) / 256));
     if (!(Uext && u_valid)) {
         if (mo == 3)
@@ -1436,11 +1436,11 @@ int pg_wino_dma_mode() {
 }
 
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
-                 void* ws, hipStream_t st, int forced, int dma_mode, const float* Uext, pg_epi_mul mul) {
+                 void* ws, hipStream_t st, int forced, int dma_mode, const float* Uext, pg_epi_mul mul, const float* Vext) {
     const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
     const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
     const float* U = Uext ? Uext : (const float*)ws;
-    const float* V = (const float*)((const char*)ws + align256((size_t)X * Cout * Cin * 4));
+    const float* V = Vext ? Vext : (const float*)((const char*)ws + align256((size_t)X * Cout * Cin * 4));
     const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cin, Cout, forced);
     const int v_bytes = (int)(X * T * Cin * 4), u_bytes = (int)(X * Cout * Cin * 4);
     const int tn = (Cout + 63) / 64;
@@ -1537,21 +1537,28 @@ size_t pg_wino_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb) {
            align256((size_t)pg_wino_wgrad_slices(N, Hs, Ws, Ca, Cb) * X * Ca * Cb * 4);
 }
 
+// the transformed input the forward F(3x3,4x4) leaves (same 6 x 6 windows at 3t - 1, same B^T) is the V of F(4x4,3x3)
+size_t pg_wino_wgrad_v_bytes(int N, int Hs, int Ws, int Ca, int Cb, int fwd_forced) {
+    if (pg_wino_wgrad_r(N, Hs, Ws) != 3 || pg_wino_mo(N, Hs, Ws, Cb, Ca, fwd_forced) != 3) return 0;
+    return align256((size_t)36 * wgrad_tiles(N, Hs, Ws) * Cb * 4);
+}
+
 int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
-                  int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+                  int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const float* Vpre) {
     const int R = pg_wino_wgrad_r(N, Hs, Ws), X = (R + 3) * (R + 3);
     const int TH = (Hs + R - 1) / R, TW = (Ws + R - 1) / R;
     const long T = (long)N * TH * TW;
-    float* V = (float*)ws;
+    if (Vpre && R != 3) return PG_EINVAL;
+    const float* V = Vpre ? Vpre : (const float*)ws;
     float* DY = (float*)((char*)ws + align256((size_t)X * T * Cb * 4));
     float* S = (float*)((char*)DY + align256((size_t)X * T * Ca * 4));
     const dim3 gv((unsigned)((T * (Cb / 4) + 255) / 256)), gd((unsigned)((T * (Ca / 4) + 255) / 256));
     if (R == 3) {
-        hipLaunchKernelGGL(k_wino_v<3>, gv, dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb, TH, TW, 1);
+        if (!Vpre) hipLaunchKernelGGL(k_wino_v<3>, gv, dim3(256), 0, st, big, ld_big, (float*)ws, N, Hb, Wb, Cb, TH, TW, 1);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         hipLaunchKernelGGL(k_wino_dy<3>, gd, dim3(256), 0, st, small, ld_small, DY, N, Hs, Ws, Ca, TH, TW);
     } else {
-        hipLaunchKernelGGL(k_wino_v<2>, gv, dim3(256), 0, st, big, ld_big, V, N, Hb, Wb, Cb, TH, TW, 1);
+        hipLaunchKernelGGL(k_wino_v<2>, gv, dim3(256), 0, st, big, ld_big, (float*)ws, N, Hb, Wb, Cb, TH, TW, 1);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         hipLaunchKernelGGL(k_wino_dy<2>, gd, dim3(256), 0, st, small, ld_small, DY, N, Hs, Ws, Ca, TH, TW);
     }

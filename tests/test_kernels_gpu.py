@@ -500,7 +500,7 @@ def test_conv_emits_instancenorm_partials(geom):
 
 
 @pytest.mark.parametrize('geom,bits', [((6, 62, 58, 256, 128, 2), 0), ((16, 32, 32, 288, 160, 2), 0), ((9, 32, 32, 128, 64, 1), 0),
-                                       ((4, 70, 74, 96, 40, 2), 'all')],
+                                       ((4, 70, 74, 96, 40, 2), 'all'), ((9, 32, 32, 128, 64, 1), 'f3'), ((10, 31, 31, 64, 128, 1), 'f3')],
                          ids=lambda v: 'x'.join(map(str, v)) if isinstance(v, tuple) else str(v))
 def test_conv_hand_overs_between_calls(geom, bits):
     """pg_conv_extras: (1) the forward call keeps its polyphase-transformed input (v_keep) and the layer's weight gradient reads
@@ -512,10 +512,12 @@ def test_conv_hand_overs_between_calls(geom, bits):
     from tests.gpu_util import to_view, empty_view, pack, unpack, DEV
     N, Hb, Wb, Ca, Cb, s = geom
     big, small, Wt, Hs, Ws = _mk(*geom)
-    algo = L.ALGO_AUTO | ((L.TUNE_WINO2_ALL | L.TUNE_WINO2W_ALL) if bits == 'all' else 0)
+    algo = L.ALGO_AUTO | ((L.TUNE_WINO2_ALL | L.TUNE_WINO2W_ALL) if bits == 'all' else L.TUNE_WINO1_F3 if bits == 'f3' else 0)
     op = E.ConvOp(*geom, algo)
     P = pack(Wt)
     vb, vs = to_view(big, ld=Cb + 4, off=0), to_view(small, ld=Ca + 4, off=4)
+    # the stride-1 layer shares a transform only between the F(3x3,4x4) forward and the F(4x4,3x3) weight gradient (>= 1024 3x3 tiles)
+    shares = s == 2 or (bits == 'f3' and N * ((Hs + 2) // 3) * ((Ws + 2) // 3) >= 1024)
 
     def fwd(**kw):
         out = empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=4)
@@ -528,7 +530,7 @@ def test_conv_hand_overs_between_calls(geom, bits):
         return out.to_nchw()
 
     ref = fwd()
-    if s == 2:                                       # (1) v_keep -> v_pre
+    if shares:                                       # (1) v_keep -> v_pre
         assert op.v_bytes() > 0
         vk = torch.empty(op.v_bytes(), dtype=torch.uint8, device=DEV)
         assert torch.equal(fwd(v_keep=vk), ref)
