@@ -2817,9 +2817,11 @@ inline bool wino2_wgrad_ok(const Geom& g, const Tune& t) {
     if (g.s != 2 || t.wino2w == 0 || !t.wino || !pg_wino2_wgrad_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) return false;
     if (t.wino2w == 1) return true;
     // measured on the cfg2 layers (64x64 output tiles unless 128x128 ones alone fill the chip): 256x128 ch -16 %, 512x256 -20 %,
-    // 512x128 -17 %, 256x64 -15 %, 1024x256 +-0; 128 small-side channels: slower than the implicit GEMM (+35 %)
+    // 512x128 -17 %, 256x64 -15 %, 1024x256 +-0; 128 small-side channels: +35 % in round 1, -8 ... -13 % since the XCD-contiguous
+    // 4-waves-per-SIMD form of the GEMM (enc1 184 -> 170, d1 at 2N 319 -> 277 us, before counting the V it now gets from the forward
+    // call) -- taken where the K dimension is long (>= 4096 tiles)
     const long T = (long)g.N * ((g.Hs + 2) / 3) * ((g.Ws + 2) / 3);
-    return T >= 512 && g.Ca >= 256 && g.Cb >= 64;
+    return g.Cb >= 64 && ((T >= 512 && g.Ca >= 256) || (T >= 4096 && g.Ca >= 128));
 }
 inline bool wino_wgrad_ok(const Geom& g, const Tune& t) {
     return g.s == 1 && t.winow && t.wino && pg_wino_wgrad_geom_ok(g.N, g.Hs, g.Ws, g.Ca, g.Cb);

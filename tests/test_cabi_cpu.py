@@ -52,7 +52,7 @@ def test_kernel_plan_of_the_benchmark_layers():
         pytest.skip('kernel-selection switches set in the environment')
     want = {   # (N, Hb, Wb, Ca, Cb, stride): (big2small, small2big, wgrad) kernel families under PG_ALGO_AUTO
         (16, 256, 256, 64, 3, 2): ('k_b2s_tapk', 'k_b2s_fast<2,1,2,2,true>+k_col2im', 'k_wgrad_tapn'),     # enc0
-        (16, 128, 128, 128, 64, 2): ('k_wino_bgemm', 'k_wino_bgemm', 'k_wgrad_fast'),                        # enc1
+        (16, 128, 128, 128, 64, 2): ('k_wino_bgemm', 'k_wino_bgemm', 'k_wino_wgrad_gemm<1,1,2,2>'),           # enc1
         (16, 64, 64, 256, 128, 2): ('k_wino_bgemm', 'k_wino_bgemm', 'k_wino_wgrad_gemm<1,1,2,2>'),            # enc2
         (16, 16, 16, 512, 512, 2): ('k_b2s_fast', 'k_s2b_fast', 'k_wgrad_fast'),                              # enc4: too few tiles
         (16, 64, 64, 512, 128, 2): ('k_wino_bgemm', 'k_wino_bgemm', 'k_wino_wgrad_gemm<1,1,2,2>'),            # dec4
