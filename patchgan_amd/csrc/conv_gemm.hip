@@ -3218,9 +3218,16 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
         int rc = pg_wino_prepare(big, ld_big, P, 0, g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, 1, ws, st, tune.mo1, x.u_cache, x.u_valid,
                                  x.v_keep);
         if (rc != PG_OK) return rc;
-        TimedLaunch timed(st);
-        return pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st, tune.mo1, tune.dma, x.u_cache,
-                            pg_epi_mul{nullptr, 0, 0}, x.v_keep);
+        const int nsl = pg_wino_gemm_slices(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1);
+        {
+            TimedLaunch timed(st);
+            rc = pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st, tune.mo1, tune.dma, x.u_cache,
+                              pg_epi_mul{nullptr, 0, 0}, x.v_keep);
+        }
+        if (rc != PG_OK || nsl == 1) return rc;
+        const long pix = (long)g.N * g.Hs * g.Ws;
+        return launch_reduce(pg_wino_gemm_slabs(ws, g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1), pix * g.Ca, nsl, small, ld_small, pix, g.Ca, bias,
+                             act, st);
     }
     if (algo == PG_ALGO_AUTO && wino2_b2s_ok(g, tune) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
         aligned16(small) && aligned16(ws) && (!bias || aligned16(bias)) &&
@@ -3380,8 +3387,15 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         if (mul.t && (!aligned16(mul.t) || mul.ld % 4)) return PG_EINVAL;
         int rc = pg_wino_prepare(small, ld_small, P, 1, g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, 2, ws, st, tune.mo1, x.u_cache, x.u_valid);
         if (rc != PG_OK) return rc;
-        TimedLaunch timed(st);
-        return pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st, tune.mo1, tune.dma, x.u_cache, mul);
+        const int nsl = pg_wino_gemm_slices(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1);
+        {
+            TimedLaunch timed(st);
+            rc = pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st, tune.mo1, tune.dma, x.u_cache, mul);
+        }
+        if (rc != PG_OK || nsl == 1) return rc;
+        const long pix = (long)g.N * g.Hb * g.Wb;
+        return launch_reduce(pg_wino_gemm_slabs(ws, g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1), pix * g.Cb, nsl, big, ld_big, pix, g.Cb, bias, act,
+                             st, 0, mul);
     }
     if (algo == PG_ALGO_AUTO && wino2_s2b_ok(g, tune) && (ld_big % 4 == 0) && (ld_small % 4 == 0) && aligned16(big) && aligned16(P) &&
         aligned16(small) && aligned16(ws) && (!bias || aligned16(bias)) &&

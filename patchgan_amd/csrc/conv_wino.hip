@@ -167,7 +167,9 @@ template <int MR, int NR, int WM, int WN, int WPE, int MO, bool MUL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_gemm(const float* __restrict__ V, const float* __restrict__ U,
                                                    const float* __restrict__ bias, float* __restrict__ out, int ld_out,
                                                    int T, int Ci, int Co, int TH, int TW, int Hout, int Wout, int act,
-                                                   int v_bytes, int u_bytes, int tiles_n, pg_epi_mul mul) {
+                                                   int v_bytes, int u_bytes, int tiles_n, pg_epi_mul mul, int nsl, long slab_stride) {
+    // nsl > 1: the input-channel (K) range is split over nsl workgroups per output tile; workgroup `slice` writes its partial OUTPUTS
+    // (the output transform is linear) to out + slice * slab_stride, the caller reduces the slabs in order (bias / act / mul there)
     static_assert(NR == 1 && WM * WN == 4, "one 32-column MFMA tile per wave");
     constexpr int NP = MO + 3, NXI = NP * NP, NY = MO * MO;      // points, products, outputs per tile
     // K chunk: 64 floats for the F(3x3,4x4) instance (its workgroup tile is only 64 x 64: twice the MFMAs per barrier pair)
@@ -185,9 +187,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     // 1-D grid: work index w = tile block * tiles_n + channel block, each XCD a contiguous run of w -- the tiles_n workgroups
     // that read one slab of V sit next to each other on one XCD (one fabric fetch of V instead of tiles_n), and every XCD walks
     // xi in step, so the current U[xi] slab (Co*Ci floats) stays in its L2
-    const int w = pg_xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (w / tiles_n) * BM, n0 = (w % tiles_n) * BN;
-    const int nch = Ci / KCL, total = NXI * nch;
+    int w = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (w % tiles_n) * BN;
+    w /= tiles_n;
+    const int slice = w % nsl;
+    const int m0 = (w / nsl) * BM;
+    const int nch = Ci / KCL / nsl, total = NXI * nch, ch0 = slice * nch;      // this slice's chunks [ch0, ch0 + nch) of every xi
+    out += slice * slab_stride;
     const int kq = tid % QR, r0 = tid / QR;
 
     int a_off[AI], b_off[BI];
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     f32x4 ra[AI], rb[BI];
     int ld_xi = 0, ld_ch = 0;                    // (xi, chunk) of the NEXT load
     auto issue_loads = [&](bool on) {
-        const int av = ld_xi * v_xi + ld_ch * KCL, bu = ld_xi * u_xi + ld_ch * KCL;
+        const int av = ld_xi * v_xi + (ch0 + ld_ch) * KCL, bu = ld_xi * u_xi + (ch0 + ld_ch) * KCL;
 #pragma unroll
         for (int i = 0; i < AI; ++i) ra[i] = bload4(rV, voff(a_off[i] + av, on && a_ok[i]));
 #pragma unroll
@@ -1353,11 +1359,38 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // (PG_TUNE_WINO1_F2 / _F3, PATCHGAN_WINO1_TILE), 0 = heuristic.
 // F(3x3,4x4) keeps nine output accumulator sets per lane, so its workgroup tile is 64 tiles x 64 channels at 2 waves per SIMD:
 // it is used when that grid still fills the chip (>= 240 workgroups), F(2x2,4x4) otherwise.
+static bool wino1_split_off() {      // PATCHGAN_WINO1_SPLIT=0: no K split in the stride-1 GEMM (experiment switch)
+    static const bool off = [] {
+        const char* e = pg_exp_env("PATCHGAN_WINO1_SPLIT");
+        return e && e[0] == '0';
+    }();
+    return off;
+}
 int pg_wino_mo(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
     if (Cin % 64 != 0) return 2;                 // the F(3x3,4x4) instance walks K in chunks of 64
     if (forced == 2 || forced == 3) return forced;
     const long T3 = (long)N * ((Hout + 2) / 3) * ((Wout + 2) / 3);
-    return ((T3 + 63) / 64) * ((Cout + 63) / 64) >= 240 ? 3 : 2;
+    const long wg = ((T3 + 63) / 64) * ((Cout + 63) / 64);
+    if (wg >= 240) return 3;
+    // fewer workgroups than CUs: with the input channels split over 2 / 4 workgroups per tile (k_wino_gemm's nsl) the F(3x3,4x4)
+    // instance still fills the chip (data gradient of the 512 -> 256 layer at batch 16: 124 tiles x 4 slices)
+    const int nch = Cin / 64;
+    const int smax = wino1_split_off() ? 1 : (nch % 4 == 0 ? 4 : nch % 2 == 0 ? 2 : 1);
+    return wg * smax >= 240 ? 3 : 2;
+}
+// K slices of the F(3x3,4x4) GEMM: the fewest of 1 / 2 / 4 that give >= 400 workgroups (two per CU on most of the chip)
+int pg_wino_gemm_slices(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
+    if (pg_wino_mo(N, Hout, Wout, Cin, Cout, forced) != 3 || wino1_split_off()) return 1;
+    const long T3 = (long)N * ((Hout + 2) / 3) * ((Wout + 2) / 3);
+    const long wg = ((T3 + 63) / 64) * ((Cout + 63) / 64);
+    const int nch = Cin / 64;
+    static const long want = [] {
+        const char* e = pg_exp_env("PATCHGAN_WINO1_SPLIT_WG");
+        return e ? atol(e) : 400L;
+    }();
+    if (wg >= want) return 1;
+    if (nch % 2 == 0 && (wg * 2 >= want || nch % 4 != 0)) return 2;
+    return nch % 4 == 0 ? 4 : 1;
 }
 static long wino1_tiles(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
     const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced);
@@ -1399,7 +1432,13 @@ size_t pg_wino_u_bytes(int N, int Hout, int Wout, int Cin, int Cout, int forced)
 }
 size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
     const long T = wino1_tiles(N, Hout, Wout, Cin, Cout, forced), X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
-    return align256((size_t)X * Cout * Cin * 4) + align256((size_t)X * T * Cin * 4);
+    const int nsl = pg_wino_gemm_slices(N, Hout, Wout, Cin, Cout, forced);
+    return align256((size_t)X * Cout * Cin * 4) + align256((size_t)X * T * Cin * 4) +
+           (nsl > 1 ? align256((size_t)nsl * N * Hout * Wout * Cout * 4) : 0);      // U | V | partial-output slabs of the K split
+}
+float* pg_wino_gemm_slabs(void* ws, int N, int Hout, int Wout, int Cin, int Cout, int forced) {
+    const long T = wino1_tiles(N, Hout, Wout, Cin, Cout, forced), X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
+    return (float*)((char*)ws + align256((size_t)X * Cout * Cin * 4) + align256((size_t)X * T * Cin * 4));
 }
 
 int pg_wino_prepare(const float* in, int ld_in, const float* P, int flip, int N, int Hin, int Win, int Cin, int Hout,
@@ -1444,19 +1483,27 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
     const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cin, Cout, forced);
     const int v_bytes = (int)(X * T * Cin * 4), u_bytes = (int)(X * Cout * Cin * 4);
     const int tn = (Cout + 63) / 64;
+    const int nsl = pg_wino_gemm_slices(N, Hout, Wout, Cin, Cout, forced);
+    if (nsl > 1) {       // partial outputs into dense [pixel][Cout] slabs behind U | V; the caller reduces them (bias / act / mul there)
+        float* slabs = pg_wino_gemm_slabs(ws, N, Hout, Wout, Cin, Cout, forced);
+        dim3 grid((unsigned)(((T + 63) / 64) * tn * nsl));
+        hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 2, 3>), grid, dim3(256), 0, st, V, U, (const float*)nullptr, slabs, Cout, (int)T, Cin, Cout,
+                           TH, TW, Hout, Wout, PG_ACT_NONE, v_bytes, u_bytes, tn, pg_epi_mul{nullptr, 0, 0}, nsl, (long)N * Hout * Wout * Cout);
+        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+    }
     if (mul.t) {                       // the register-staged kernels' MUL instantiations
         if (mo == 3) {
             dim3 grid((unsigned)(((T + 63) / 64) * tn));
             hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 2, 3, true>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
-                               TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul);
+                               TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul, 1, 0L);
         } else if (small_tile) {
             dim3 grid((unsigned)(((T + 63) / 64) * tn));
             hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 4, 2, true>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
-                               TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul);
+                               TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul, 1, 0L);
         } else {
             dim3 grid((unsigned)(((T + 127) / 128) * tn));
             hipLaunchKernelGGL((k_wino_gemm<2, 1, 2, 2, 2, 2, true>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
-                               TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul);
+                               TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul, 1, 0L);
         }
     } else if (mo == 3 && dma_mode) {
         dim3 grid((unsigned)(((T + 63) / 64) * tn));
@@ -1465,7 +1512,7 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
     } else if (mo == 3) {
         dim3 grid((unsigned)(((T + 63) / 64) * tn));
         hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 2, 3>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
-                           TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul);
+                           TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul, 1, 0L);
     } else if (small_tile && dma_mode == 2) {
         dim3 grid((unsigned)(((T + 63) / 64) * tn));
         hipLaunchKernelGGL((k_wino_gemm_dma<2, 3, 3>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH, TW,
@@ -1473,11 +1520,11 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
     } else if (small_tile) {
         dim3 grid((unsigned)(((T + 63) / 64) * tn));
         hipLaunchKernelGGL((k_wino_gemm<1, 1, 2, 2, 4, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
-                           TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul);
+                           TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul, 1, 0L);
     } else {
         dim3 grid((unsigned)(((T + 127) / 128) * tn));
         hipLaunchKernelGGL((k_wino_gemm<2, 1, 2, 2, 2, 2>), grid, dim3(256), 0, st, V, U, bias, out, ld_out, (int)T, Cin, Cout, TH,
-                           TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul);
+                           TW, Hout, Wout, act, v_bytes, u_bytes, tn, mul, 1, 0L);
     }
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
