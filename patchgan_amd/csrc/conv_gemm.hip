@@ -3144,6 +3144,7 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
         const int dm = tune.dma;
         if (mode == 9 && dm) snprintf(buf, sizeof buf, "k_wino_gemm_dma<3,4,2>");
         else if (mode == 5 && dm == 2) snprintf(buf, sizeof buf, "k_wino_gemm_dma<2,3,3>");
+        else if (mode == 9 && pg_wino_row_on()) snprintf(buf, sizeof buf, "k_wino_gemm_row<4>");
         else snprintf(buf, sizeof buf, "k_wino_gemm<%s>", mode == 9 ? "1,1,2,2,2,3" : mode == 4 ? "2,1,2,2,2,2" : "1,1,2,2,4,2");
         const int ho = oc == 0 ? g->Hs : g->Hb, wo = oc == 0 ? g->Ws : g->Wb;
         fl = 2.0 * (mo + 3) * (mo + 3) * g->N * cd(ho, mo) * cd(wo, mo) * (double)g->Ca * g->Cb;
@@ -3218,7 +3219,8 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
         int rc = pg_wino_prepare(big, ld_big, P, 0, g.N, g.Hb, g.Wb, g.Cb, g.Hs, g.Ws, g.Ca, 1, ws, st, tune.mo1, x.u_cache, x.u_valid,
                                  x.v_keep);
         if (rc != PG_OK) return rc;
-        const int nsl = pg_wino_gemm_slices(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1);
+        const int nsl = pg_wino_gemm_rows(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1, tune.dma, small, ld_small, bias, pg_epi_mul{nullptr, 0, 0})
+                            ? 1 : pg_wino_gemm_slices(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1);
         {
             TimedLaunch timed(st);
             rc = pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st, tune.mo1, tune.dma, x.u_cache,
@@ -3387,7 +3389,8 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         if (mul.t && (!aligned16(mul.t) || mul.ld % 4)) return PG_EINVAL;
         int rc = pg_wino_prepare(small, ld_small, P, 1, g.N, g.Hs, g.Ws, g.Ca, g.Hb, g.Wb, g.Cb, 2, ws, st, tune.mo1, x.u_cache, x.u_valid);
         if (rc != PG_OK) return rc;
-        const int nsl = pg_wino_gemm_slices(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1);
+        const int nsl = pg_wino_gemm_rows(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1, tune.dma, big, ld_big, bias, mul)
+                            ? 1 : pg_wino_gemm_slices(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1);
         {
             TimedLaunch timed(st);
             rc = pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st, tune.mo1, tune.dma, x.u_cache, mul);

@@ -35,6 +35,10 @@ int pg_wino_prep_batch(int n, const pg_wino_prep* items, hipStream_t st);
 // K slices of the F(3x3,4x4) GEMM (1: none).  > 1: pg_wino_gemm writes nsl partial outputs, dense [pixel][Cout], to pg_wino_gemm_slabs(ws, ...)
 // (inside pg_wino_ws_bytes) WITHOUT bias / activation / multiplier, and the caller reduces them in slice order
 int pg_wino_gemm_slices(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced);
+// true: pg_wino_gemm runs the row-split pair k_wino_gemm_row + k_wino_t_out (complete output, no slab reduce to follow)
+bool pg_wino_gemm_rows(int N, int Hout, int Wout, int Cin, int Cout, int mo_forced, int dma_mode, const float* out, int ld_out,
+                       const float* bias, pg_epi_mul mul);
+bool pg_wino_row_on();
 float* pg_wino_gemm_slabs(void* ws, int N, int Hout, int Wout, int Cin, int Cout, int mo_forced);
 int pg_wino_dma_mode();   // process default (PATCHGAN_WINO_DMA): 0 register-staged k_wino_gemm only, 1: k_wino_gemm_dma<3,4,2> for F(3x3,4x4), 2: also <2,3,3> for 64-tile F(2x2,4x4)
 // the batched GEMM with fused output transform, bias and activation

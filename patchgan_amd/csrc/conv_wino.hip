@@ -329,6 +329,164 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 }
 
 
+// F(3x3,4x4) with the output transform cut in two (round 2, second half).  k_wino_gemm<..,3> keeps all nine output sets of a tile
+// in registers (220 VGPRs, 2 waves per SIMD, 0.53-0.56 of the MFMA peak).  Here a workgroup owns ONE ROW i of the 6 x 6 products of its
+// 64 tiles x 64 channels and folds only the column transform, T_i[c] = sum_j M_ij * AT[c][j]: three accumulator sets + M, 4 waves per
+// SIMD, six times the workgroups (no K split needed at batch 16).  T (18 planes, half of what an unfused M would be) goes through
+// memory once; k_wino_t_out finishes Y[r][c] = sum_i AT[r][i] * T_i[c] with bias, activation and the data-gradient multiplier.
+template <int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_gemm_row(
+    const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ Tout, int T, int Ci, int Co, int v_bytes, int u_bytes,
+    int tiles_n) {
+    constexpr int NP = 6, KCL = 64, LDL = KCL + 4, QR = KCL / 4, RP = 256 / QR, BM = 64, BN = 64, AI = BM / RP, BI = BN / RP;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDL];
+    float* As = smem;
+    float* Bs = smem + BM * LDL;
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, v_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, u_bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lh = lane >> 5;
+    // work index = (tile block * 6 + row) * tiles_n + channel block, each XCD a contiguous run: the tiles_n workgroups that share the
+    // V slabs of one (tile block, row) are neighbours, and an XCD stays on one row of U for a stretch
+    int w = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (w % tiles_n) * BN;
+    w /= tiles_n;
+    const int xrow = w % NP;
+    const int m0 = (w / NP) * BM;
+    const int nch = Ci / KCL, total = NP * nch;
+    const int kq = tid % QR, r0 = tid / QR;
+    int a_off[AI], b_off[BI];
+    bool a_ok[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + r0 + RP * i;
+        a_ok[i] = m < T;
+        a_off[i] = min(m, T - 1) * Ci + kq * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int co = n0 + r0 + RP * i;
+        b_off[i] = (co < Co) ? co * Ci + kq * 4 : 0x10000000;
+    }
+    const int v_xi = T * Ci, u_xi = Co * Ci;
+    f32x4 ra[AI], rb[BI];
+    int ld_j = 0, ld_ch = 0;
+    auto issue_loads = [&](bool on) {
+        const int xi = xrow * NP + ld_j;
+        const int av = xi * v_xi + ld_ch * KCL, bu = xi * u_xi + ld_ch * KCL;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) ra[i] = bload4(rV, voff(a_off[i] + av, on && a_ok[i]));
+#pragma unroll
+        for (int i = 0; i < BI; ++i) rb[i] = bload4(rU, voff(b_off[i] + bu, on));
+        const bool wrap = ld_ch + 1 >= nch;
+        ld_ch = wrap ? 0 : ld_ch + 1;
+        ld_j = wrap ? ld_j + 1 : ld_j;
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + RP * i) * LDL + kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(r0 + RP * i) * LDL + kq * 4]) = rb[i];
+    };
+    f32x16 accm, acct[3];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        accm[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acct[c][r] = 0.f;
+    }
+    issue_loads(true);
+    store_chunk();
+    __syncthreads();
+    int j = 0, ch = 0;
+    for (int it = 0; it < total; ++it) {
+        const bool more = it + 1 < total;
+        issue_loads(more);
+        __builtin_amdgcn_sched_barrier(0x386);
+#pragma unroll
+        for (int kk = 0; kk < KCL / 8; ++kk) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + lrow) * LDL + kk * 8 + lh * 4]);
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 + lrow) * LDL + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accm = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], accm, 0, 0, 0);
+        }
+        if (ch == nch - 1) {
+            const float c0 = c_AT34[0][j], c1 = c_AT34[1][j], c2 = c_AT34[2][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float mv = accm[r];
+                acct[0][r] += c0 * mv;
+                acct[1][r] += c1 * mv;
+                acct[2][r] += c2 * mv;
+                accm[r] = 0.f;
+            }
+        }
+        const bool wrap = ch + 1 >= nch;
+        ch = wrap ? 0 : ch + 1;
+        j = wrap ? j + 1 : j;
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+    const int col = n0 + wn * 32 + lrow;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + wm * 32 + row;
+        if (m < T && col < Co) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Tout[((long)(xrow * 3 + c) * T + m) * Co + col] = acct[c][r];
+        }
+    }
+}
+
+// Y[r][c] = sum_i AT[r][i] * T_i[c] per (tile, four channels), + bias, activation, optional multiplier f'(t); one thread per item
+template <bool MUL>
+__global__ __launch_bounds__(256) void k_wino_t_out(const float* __restrict__ Tt, const float* __restrict__ bias, float* __restrict__ out,
+                                                    int ld_out, int T, int Co, int TH, int TW, int Hout, int Wout, int act, pg_epi_mul mul) {
+    const int cq = Co >> 2;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)T * cq) return;
+    const int c0 = (int)(idx % cq) << 2;
+    const int m = (int)(idx / cq);
+    const int n = m / (TH * TW);
+    const int rem = m - n * (TH * TW);
+    const int ti = rem / TW, tj = rem - ti * TW;
+    f32x4 t[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[i][c] = *reinterpret_cast<const f32x4*>(Tt + ((long)(i * 3 + c) * T + m) * Co + c0);
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) bv = *reinterpret_cast<const f32x4*>(bias + c0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int y = 3 * ti + r;
+        if (y >= Hout) continue;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int x = 3 * tj + c;
+            if (x >= Wout) continue;
+            f32x4 v = c_AT34[r][0] * t[0][c];
+#pragma unroll
+            for (int i = 1; i < 6; ++i) v += c_AT34[r][i] * t[i][c];
+            const long pix = (long)(n * Hout + y) * Wout + x;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = act_epi(v[e] + bv[e], act);
+            if constexpr (MUL) {
+                const f32x4 tm = *reinterpret_cast<const f32x4*>((const float*)mul.t + pix * mul.ld + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] *= pg_act_grad_sel(tm[e], mul.act);
+            }
+            *reinterpret_cast<f32x4*>(out + pix * ld_out + c0) = o;
+        }
+    }
+}
+
 // The same batched GEMM + fused output transform for the 64-tile x 64-channel workgroup tile, with the operand tiles brought
 // in by LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS without staging registers) into a ring of NSTAGE stages of
 // 128 rows x 32 k, so the loads of chunk c + NSTAGE - 1 are in flight while chunk c is multiplied.  The register-staged
@@ -1366,6 +1524,13 @@ static bool wino1_split_off() {      // PATCHGAN_WINO1_SPLIT=0: no K split in th
     }();
     return off;
 }
+bool pg_wino_row_on() {      // F(3x3,4x4) as k_wino_gemm_row + k_wino_t_out (default) or the fully fused k_wino_gemm (PATCHGAN_WINO1_ROW=0)
+    static const bool on = [] {
+        const char* e = pg_exp_env("PATCHGAN_WINO1_ROW");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
 int pg_wino_mo(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
     if (Cin % 64 != 0) return 2;                 // the F(3x3,4x4) instance walks K in chunks of 64
     if (forced == 2 || forced == 3) return forced;
@@ -1433,8 +1598,16 @@ size_t pg_wino_u_bytes(int N, int Hout, int Wout, int Cin, int Cout, int forced)
 size_t pg_wino_ws_bytes(int N, int Hout, int Wout, int Cin, int Cout, int forced) {
     const long T = wino1_tiles(N, Hout, Wout, Cin, Cout, forced), X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
     const int nsl = pg_wino_gemm_slices(N, Hout, Wout, Cin, Cout, forced);
-    return align256((size_t)X * Cout * Cin * 4) + align256((size_t)X * T * Cin * 4) +
-           (nsl > 1 ? align256((size_t)nsl * N * Hout * Wout * Cout * 4) : 0);      // U | V | partial-output slabs of the K split
+    const size_t slabs = nsl > 1 ? align256((size_t)nsl * N * Hout * Wout * Cout * 4) : 0;
+    const size_t trow = (X == 36) ? align256((size_t)18 * T * Cout * 4) : 0;          // T of the row-split form
+    return align256((size_t)X * Cout * Cin * 4) + align256((size_t)X * T * Cin * 4) + std::max(slabs, trow);   // U | V | slabs or T
+}
+// the row-split form runs (and then NO slab reduce follows): F(3x3,4x4), register-staged, 16-byte-aligned output / bias / multiplier
+bool pg_wino_gemm_rows(int N, int Hout, int Wout, int Cin, int Cout, int forced, int dma_mode, const float* out, int ld_out,
+                       const float* bias, pg_epi_mul mul) {
+    if (!pg_wino_row_on() || dma_mode || pg_wino_mo(N, Hout, Wout, Cin, Cout, forced) != 3 || (Cout & 3) || (ld_out & 3)) return false;
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return al(out) && (!bias || al(bias)) && (!mul.t || (al(mul.t) && (mul.ld & 3) == 0));
 }
 float* pg_wino_gemm_slabs(void* ws, int N, int Hout, int Wout, int Cin, int Cout, int forced) {
     const long T = wino1_tiles(N, Hout, Wout, Cin, Cout, forced), X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
@@ -1483,6 +1656,18 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
     const bool small_tile = pg_wino_small_tile(N, Hout, Wout, Cin, Cout, forced);
     const int v_bytes = (int)(X * T * Cin * 4), u_bytes = (int)(X * Cout * Cin * 4);
     const int tn = (Cout + 63) / 64;
+    if (pg_wino_gemm_rows(N, Hout, Wout, Cin, Cout, forced, dma_mode, out, ld_out, bias, mul)) {
+        float* Tt = pg_wino_gemm_slabs(ws, N, Hout, Wout, Cin, Cout, forced);
+        hipLaunchKernelGGL(k_wino_gemm_row<4>, dim3((unsigned)(((T + 63) / 64) * tn * 6)), dim3(256), 0, st, V, U, Tt, (int)T, Cin, Cout,
+                           v_bytes, u_bytes, tn);
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        const dim3 go((unsigned)((T * (Cout / 4) + 255) / 256));
+        if (mul.t)
+            hipLaunchKernelGGL(k_wino_t_out<true>, go, dim3(256), 0, st, Tt, bias, out, ld_out, (int)T, Cout, TH, TW, Hout, Wout, act, mul);
+        else
+            hipLaunchKernelGGL(k_wino_t_out<false>, go, dim3(256), 0, st, Tt, bias, out, ld_out, (int)T, Cout, TH, TW, Hout, Wout, act, mul);
+        return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+    }
     const int nsl = pg_wino_gemm_slices(N, Hout, Wout, Cin, Cout, forced);
     if (nsl > 1) {       // partial outputs into dense [pixel][Cout] slabs behind U | V; the caller reduces them (bias / act / mul there)
         float* slabs = pg_wino_gemm_slabs(ws, N, Hout, Wout, Cin, Cout, forced);
