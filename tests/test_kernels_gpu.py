@@ -685,3 +685,31 @@ def test_weight_prep_batch_equals_per_layer_transforms():
         outs.append((dP, ds.to_nchw()))
     torch.cuda.synchronize()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize('geom', [(9, 32, 32, 128, 64, 1), (16, 32, 32, 512, 256, 1)], ids=lambda g: 'x'.join(map(str, g)))
+def test_winograd_stride1_fused_kernel_on_unaligned_outputs(geom):
+    """F(3x3,4x4) normally runs as k_wino_gemm_row + k_wino_t_out (16-byte stores); an output view that is only 8-byte aligned takes the
+    fully fused nine-accumulator kernel k_wino_gemm<..,3> -- with its input channels split over 2 / 4 workgroups per tile and the slab
+    reduce where the grid is small (both geometries in one direction or the other) -- and must give the same convolution."""
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view, empty_view, pack, rel_err
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    op = E.ConvOp(*geom, L.ALGO_AUTO | L.TUNE_WINO1_F3)
+    assert op.describe(0)[0].startswith('k_wino_gemm') and op.describe(1)[0].startswith('k_wino_gemm')
+    P = pack(Wt)
+    bias_a, bias_b = torch.randn(Ca), torch.randn(Cb)
+    outs = []
+    for off in (4, 2):                 # 16-byte aligned (row-split pair) / 8-byte aligned (fused kernel)
+        vs = empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=off)
+        op.big2small(to_view(big, ld=Cb + 4, off=0), P, 0, bias_a.cuda(), 0, vs, ACTS['leakyrelu'])
+        vb = empty_view(N, Hb, Wb, Cb, ld=Cb + 8, off=off)
+        op.small2big(to_view(small, ld=Ca + 4, off=4), P, 0, bias_b.cuda(), 0, vb)
+        outs.append((vs.to_nchw(), vb.to_nchw()))
+    torch.cuda.synchronize()
+    want_f = O.apply_act(F.conv2d(big, Wt, bias_a, stride=1, padding=1), 'leakyrelu')
+    want_d = F.conv_transpose2d(small, Wt, bias_b, stride=1, padding=1)
+    for f, d in outs:
+        assert rel_err(f, want_f) < 1e-5 and rel_err(d, want_d) < 1e-5, (rel_err(f, want_f), rel_err(d, want_d))
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-5 and rel_err(outs[0][1], outs[1][1]) < 1e-5      # (other association, split-K order)
