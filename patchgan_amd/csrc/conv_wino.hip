@@ -347,13 +347,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane & 31, lh = lane >> 5;
-    // work index = (tile block * 6 + row) * tiles_n + channel block, each XCD a contiguous run: the tiles_n workgroups that share the
-    // V slabs of one (tile block, row) are neighbours, and an XCD stays on one row of U for a stretch
+    // work index = (row * tile blocks + tile block) * tiles_n + channel block, each XCD a contiguous run of it: the tiles_n workgroups
+    // that share the V slabs of one (tile block, row) are neighbours, and everything resident on an XCD works on the SAME row, i.e.
+    // walks the same six U slabs in step (512 KB each: L2-resident; with the row index fastest an XCD cycled through all 36)
     int w = pg_xcd_remap(blockIdx.x, gridDim.x);
     const int n0 = (w % tiles_n) * BN;
     w /= tiles_n;
-    const int xrow = w % NP;
-    const int m0 = (w / NP) * BM;
+    const int tiles_m = (T + BM - 1) / BM;
+    const int xrow = w / tiles_m;
+    const int m0 = (w % tiles_m) * BM;
     const int nch = Ci / KCL, total = NP * nch;
     const int kq = tid % QR, r0 = tid / QR;
     int a_off[AI], b_off[BI];
