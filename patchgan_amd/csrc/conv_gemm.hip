@@ -3144,7 +3144,7 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
         const int dm = tune.dma;
         if (mode == 9 && dm) snprintf(buf, sizeof buf, "k_wino_gemm_dma<3,4,2>");
         else if (mode == 5 && dm == 2) snprintf(buf, sizeof buf, "k_wino_gemm_dma<2,3,3>");
-        else if (mode == 9 && pg_wino_row_on()) snprintf(buf, sizeof buf, "k_wino_gemm_row<4>");
+        else if (mode == 9 && pg_wino_row_on()) snprintf(buf, sizeof buf, "k_wino_gemm_row<4,1>");
         else snprintf(buf, sizeof buf, "k_wino_gemm<%s>", mode == 9 ? "1,1,2,2,2,3" : mode == 4 ? "2,1,2,2,2,2" : "1,1,2,2,4,2");
         const int ho = oc == 0 ? g->Hs : g->Hb, wo = oc == 0 ? g->Ws : g->Wb;
         fl = 2.0 * (mo + 3) * (mo + 3) * g->N * cd(ho, mo) * cd(wo, mo) * (double)g->Ca * g->Cb;
