@@ -71,7 +71,13 @@ def predict_image(generator, image, size, overlap, threshold):
     tiles = E.tiles_gather(image, size, overlap)
     pred = E.View.alloc(tiles.N, size, size, eng.output_nc, image.device)
     eng.forward(generator.flat, tiles, pred, False, 0)
-    return E.tiles_blend(pred, tuple(image.shape[1:]), threshold, overlap).cpu().numpy()
+    mask = E.tiles_blend(pred, tuple(image.shape[1:]), threshold, overlap)
+    # device -> host through a pinned block of torch's caching host allocator (the numpy array keeps it alive; it returns to the cache when
+    # the caller drops the mask): a pageable .cpu() of the 8-MB float64 mask took 0.3-1.2 ms of the 3-ms image, this one 0.15
+    host = torch.empty(mask.shape, dtype=mask.dtype, pin_memory=True)
+    host.copy_(mask, non_blocking=True)
+    torch.cuda.current_stream(mask.device).synchronize()
+    return host.numpy()
 
 
 def patchgan_infer(argv=None):
