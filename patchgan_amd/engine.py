@@ -1062,7 +1062,7 @@ class LossBuffers:
 
     def __init__(self, N, C, device, HW=1):
         self.S = torch.empty(int(L.load().pg_loss_reduce_doubles(N, HW, C)), dtype=torch.float64, device=device)
-        self.sums = torch.zeros(2, dtype=torch.float64, device=device)
+        self.sums = torch.empty(2, dtype=torch.float64, device=device)      # (written by pg_loss_prepare where it is read at all)
         self.coef = torch.empty(N * C * 2, dtype=torch.float32, device=device)
 
 
@@ -1071,7 +1071,7 @@ class PendingLoss:
     __slots__ = ('buf', 'wait', 'args')
 
 
-def loss_begin(p, y, tconst, beta=0.75, allreduce=None):
+def loss_begin(p, y, tconst, beta=0.75, allreduce=None, need_sums=True):
     """Phase 1 of a loss term over prediction View p against target View y (or the constant tconst): the per-sample
     reductions and the two batch-global terms.  `allreduce(tensor)` starts their SUM across ranks under data parallelism
     and returns a wait() callable; anything enqueued between loss_begin and loss_finish overlaps that exchange."""
@@ -1080,10 +1080,11 @@ def loss_begin(p, y, tconst, beta=0.75, allreduce=None):
     st = _stream()
     L.check(lib.pg_loss_reduce(p.ptr(), p.ld, y.ptr() if y is not None else None, y.ld if y is not None else 0,
                                float(tconst), p.N, p.HW, p.C, buf.S.data_ptr(), st), 'pg_loss_reduce')
-    L.check(lib.pg_loss_prepare(buf.S.data_ptr(), p.N, p.C, beta, buf.sums.data_ptr(), st), 'pg_loss_prepare')
+    if need_sums:      # the two batch-global terms: only focal-Tversky and weighted BCE read them (pg_loss_finalize)
+        L.check(lib.pg_loss_prepare(buf.S.data_ptr(), p.N, p.C, beta, buf.sums.data_ptr(), st), 'pg_loss_prepare')
     h = PendingLoss()
     h.buf, h.args = buf, (p, y, tconst, beta)
-    h.wait = allreduce(buf.sums) if allreduce is not None else None
+    h.wait = allreduce(buf.sums) if (allreduce is not None and need_sums) else None
     return h
 
 
@@ -1111,5 +1112,5 @@ def loss_value_and_grad(p, y, tconst, mode, alpha, grad_out, loss_out, loss_slot
     """Evaluate one loss term over prediction View p against target View y (or the constant tconst), write its
     value into loss_out[loss_slot] and, if grad_out is not None, its gradient wrt p into View grad_out.
     `allreduce(tensor)` starts the SUM of the two global reduction terms across ranks and returns wait()."""
-    h = loss_begin(p, y, tconst, beta, allreduce)
+    h = loss_begin(p, y, tconst, beta, allreduce, need_sums=mode in (L.LOSS_TVERSKY, L.LOSS_WBCE))
     return loss_finish(h, mode, alpha, grad_out, loss_out, loss_slot, bglobal, gamma)
