@@ -54,10 +54,12 @@ def make_inputs(batch, rank):
 
 
 def pmc_traffic(symbol):
-    """HBM bytes per launch of `symbol` from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json: FETCH_SIZE
-    and WRITE_SIZE collected in separate passes, gfx950 corrections applied); None if that kernel was not profiled."""
+    """(HBM bytes per launch of `symbol`, the file it came from) from the committed rocprofv3 --pmc passes
+    (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, gfx950 corrections applied; the
+    newest file that has the kernel); (None, None) if that kernel was not profiled.  NOT measured in this run: PMC counters
+    need the profiler."""
     import glob
-    best = None
+    best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
         try:
             ks = json.load(open(f))['kernels']
@@ -70,7 +72,8 @@ def pmc_traffic(symbol):
         cand = [v for n, v in ks.items() if n == sym or n.startswith(sym[:-1] + ',')]
         if cand:
             best = max(cand, key=lambda v: v.get('launches', 0))['hbm_bytes_per_launch']
-    return best
+            src = 'profiles/' + os.path.basename(f)
+    return best, src
 
 
 def usable_cpus():
@@ -110,12 +113,20 @@ def cpu_baseline(max_seconds=25.0):
             'sample': f'{n} G+D steps of the same workload (bs {BATCH_PER_GPU}, {SIZE}x{SIZE}) after 1 warm-up step; {dt / n:.2f} s/step'}
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, script=None, timeout=None, grace=5.0):
     """`python bench.py --gpus N` without a launcher: start N fresh worker processes (one rank per GPU) from THIS process,
     which has not touched the GPU and does not import torch (a process that has initialised HIP must never exec or be
-    replaced), wait for all of them, forward rank 0's JSON line, and fail if any rank failed."""
+    replaced), and supervise them: every child is polled; the FIRST rank that exits non-zero (or the overall `timeout`,
+    default PATCHGAN_SPAWN_TIMEOUT_S / 900 s) ends the job at once -- its siblings, which would otherwise sit in a collective
+    or in the rendezvous until the RCCL watchdog fires while holding their GPUs, are terminated (SIGTERM, SIGKILL after
+    `grace` seconds: exactly the PIDs started here), the failed rank is named and the exit status is non-zero.  Rank 0's
+    stdout is drained by a reader thread (so polling cannot deadlock on a full pipe) and forwarded.  `script` (tests): the
+    program the ranks run instead of this file."""
     import socket
     import subprocess
+    import threading
+    if timeout is None:
+        timeout = float(os.environ.get('PATCHGAN_SPAWN_TIMEOUT_S', '900'))
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
@@ -126,15 +137,41 @@ def spawn_ranks(n, argv):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cpus() // n)))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + timeout
+    failure = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failure = f"rank {bad[0][0]} exited with status {bad[0][1]} (all failed so far, (rank, status): {bad})"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            failure = f"still running after {timeout:.0f} s (ranks alive: {[r for r, c in enumerate(codes) if c is None]})"
+            break
+        time.sleep(0.05)
+    if failure is not None:
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.terminate()
+        t_end = time.monotonic() + grace
+        for p in alive:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=10.0)
+    sys.stdout.write(b''.join(c for c in chunks if c).decode(errors='replace'))
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+    if failure is not None:
+        raise SystemExit(f"bench.py: {failure}; the other ranks were terminated")
 
 
 def main():
@@ -183,10 +220,14 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
+        # bounded rendezvous / collective timeout: a rank whose peer never arrives (or died) gives up instead of waiting out
+        # the 10-30 min default while holding its GPU (spawn_ranks ends the job sooner when it is the launcher)
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get('PATCHGAN_DIST_TIMEOUT_S', '300')))
         if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {args.gpus}")
 
@@ -199,6 +240,7 @@ def main():
         D.set_precision('bf16', bf16_storage=not args.fp32_activations)
     t = pg.Trainer(G, D, tempfile.mkdtemp(prefix='pgbench_'))
     t.loss_type, t.seg_alpha = CFG['loss_type'], 200
+    t.gc_freeze = True            # as the patchgan_train entry point does (trainer._settle_gc): opt-in, process-global
     t.setup_optimizers(1e-3, 1e-3)
     G.train()
     D.train()
@@ -235,6 +277,7 @@ def main():
     pd = parallel.current()
     if pd.on:
         pd.timing = []             # (start, end, bytes) HIP events on the comm stream around every collective
+        pd.exposed = []            # (before, after, bytes) HIP events on the consuming stream around each wait for one
     if os.environ.get('PATCHGAN_BENCH_TRACE'):
         import gc
         _gc_t = [0.0]
@@ -264,12 +307,23 @@ def main():
     comm = None
     if pd.on:
         recs, pd.timing = pd.timing, None
+        waits, pd.exposed = pd.exposed, None
+        per = max(1, len(recs) // args.steps)          # collectives of one step, in issue order (the same every step)
+        by_slot = [[r for r in recs[i::per]] for i in range(per)] if len(recs) == per * args.steps else []
         comm = {'backend': dist.get_backend(), 'ranks_in_group': dist.get_world_size(),
                 'collectives_per_step': len(recs) / args.steps,
                 'allreduce_ms_per_step': round(sum(e0.elapsed_time(e1) for e0, e1, _ in recs) / args.steps, 4),
                 'allreduce_MB_per_step': round(sum(b for _, _, b in recs) / args.steps / 1e6, 2),
+                # per collective of a step, in issue order: payload and mean duration on the comm stream
+                'per_collective': [{'MB': round(rs[0][2] / 1e6, 3),
+                                    'ms': round(sum(e0.elapsed_time(e1) for e0, e1, _ in rs) / len(rs), 4)} for rs in by_slot],
+                # EXPOSED communication: time the consuming (compute) stream stood still waiting on a collective's `done`
+                # event -- everything else of allreduce_ms_per_step ran under compute kernels
+                'exposed_ms_per_step': round(sum(a.elapsed_time(b) for a, b, _ in waits) / args.steps, 4),
+                'waits_per_step': len(waits) / args.steps,
                 'note': 'HIP events on the second (comm) stream around each gradient / loss-term all-reduce; they run '
-                        'under the backward and discriminator kernels of the compute stream'}
+                        'under the backward and discriminator kernels of the compute stream; exposed_ms_per_step = event '
+                        'pairs on the compute stream around each wait for a collective'}
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -294,9 +348,12 @@ def main():
         # direct-convolution count; crediting it with those would "exceed" the peak)
         achieved = d['kflops'] / (d['ms'] * 1e-3) / 1e12
         peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == 'f32' else 2500.0     # dense MFMA peak of the multiply dtype
+        traffic, traffic_src = pmc_traffic(sym)
         roofline = {'bound': 'mfma', 'kernel': sym,
                     'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / peak, 4), 'traffic': pmc_traffic(sym),
+                    'frac': round(achieved / peak, 4), 'traffic': traffic,
+                    'traffic_source': (f'{traffic_src} (committed rocprofv3 --pmc pass of the same command; not measured '
+                                       'in this run)') if traffic_src else None,
                     'launches_per_step': d['launches'] / timed_steps, 'launches_timed': d['launches'],
                     'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                     'achieved_in_direct_conv_flops': round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2),

@@ -55,6 +55,7 @@ class FlatParamModule(nn.Module):
         self.engine.algo = algo | (self.engine.algo & ~L.ALGO_MASK)
         self.engine._ops = {}
         self.engine._sok = {}
+        self.engine.clear_weight_caches()
         # bf16 activation storage wherever every interior tensor can take it (channel counts % 4 == 0 and >= 32); otherwise the
         # bf16 kernels keep reading fp32 tensors and rounding them in flight
         self.engine.act_bf = bool(precision == 'bf16' and bf16_storage and self.engine.bf16_storage_ok())
@@ -69,6 +70,7 @@ class FlatParamModule(nn.Module):
         self.engine.algo = (self.engine.algo & L.ALGO_MASK) | int(bits)
         self.engine._ops = {}
         self.engine._sok = {}
+        self.engine.clear_weight_caches()
         return self
 
     def ensure_grad_flat(self):

@@ -216,9 +216,16 @@ class ConvOp:
         self.ws_bytes = max(int(lib.pg_conv_workspace_bytes(ctypes.byref(self.g), op)) for op in (0, 1, 2, 3))
         self._desc = {}
 
+    @property
+    def ws_arg(self):
+        """The workspace size every query (pg_conv_kernel, pg_conv_u_bytes, pg_conv_stats_chunks, ...) AND every launch of this
+        op passes to the C ABI: the SAME number on both sides, so a hand-over sized by a query can never meet a launch that
+        planned with a different workspace (the device buffer itself is shared and may be larger)."""
+        return max(self.ws_bytes, 1 << 20)
+
     def _ws(self, device):
-        ws = _workspace(self.ws_bytes, device)
-        return ws.data_ptr(), ws.numel()
+        ws = _workspace(self.ws_bytes, device)          # (at least ws_arg bytes: _workspace never allocates less than 1 MiB)
+        return ws.data_ptr(), self.ws_arg
 
     @property
     def flops(self):
@@ -240,7 +247,7 @@ class ConvOp:
         if key not in self._desc:
             name = ctypes.create_string_buffer(128)
             s, fl = ctypes.c_int(0), ctypes.c_double(0)
-            L.check(L.load().pg_conv_kernel(ctypes.byref(self.g), opcode + 16 * (self.algo | io), max(self.ws_bytes, 1 << 20), name, 128,
+            L.check(L.load().pg_conv_kernel(ctypes.byref(self.g), opcode + 16 * (self.algo | io), self.ws_arg, name, 128,
                                             ctypes.byref(s), ctypes.byref(fl)), 'pg_conv_kernel')
             self._desc[key] = (name.value.decode(), s.value, fl.value)
         return self._desc[key]
@@ -269,19 +276,19 @@ class ConvOp:
         elif not self._aligned(view_in, view_out):
             return 0
         return self._query(('chunks', opcode, io), lambda: L.load().pg_conv_stats_chunks(ctypes.byref(self.g), opcode, self.algo | io,
-                                                                                        max(self.ws_bytes, 1 << 20)))
+                                                                                        self.ws_arg))
 
     def u_bytes(self, opcode, io=0):
         """Bytes of the transformed weights the kernel of big2small (0) / small2big (1) works from (0: no weight transform on
         this path): what a caller-owned cache for pg_conv_extras.u_cache must hold.  io: the PG_IO_* bits of the call (the bf16
         kernels on bf16 tensors work from a packed bf16 copy of the weights)."""
         return self._query(('u', opcode, io), lambda: L.load().pg_conv_u_bytes(ctypes.byref(self.g), opcode, self.algo | io,
-                                                                               max(self.ws_bytes, 1 << 20)))
+                                                                               self.ws_arg))
 
     def v_bytes(self):
         """Bytes of the polyphase-transformed `big` tensor that big2small can keep (v_keep) for the weight gradient of the
         same layer (v_pre); 0 when the two calls do not both take the polyphase Winograd path."""
-        return self._query(('v',), lambda: L.load().pg_conv_v_bytes(ctypes.byref(self.g), self.algo, max(self.ws_bytes, 1 << 20)))
+        return self._query(('v',), lambda: L.load().pg_conv_v_bytes(ctypes.byref(self.g), self.algo, self.ws_arg))
 
     @staticmethod
     def _extras(part=None, v_keep=None, v_pre=None, u_cache=None, u_valid=False, mul=None):
@@ -301,7 +308,7 @@ class ConvOp:
             return False
         io = self._io(big, small)
         return bool(self._query(('mul', io), lambda: L.load().pg_conv_mul_ok(ctypes.byref(self.g), self.algo | io,
-                                                                              max(self.ws_bytes, 1 << 20))))
+                                                                              self.ws_arg)))
 
     def big2small(self, big, P, p_off, bias, b_off, small, act=L.ACT_NONE, part=None, v_keep=None, u_cache=None, u_valid=False):
         """part / v_keep / u_cache: the optional hand-overs of pg_conv_extras (sizes: stats_chunks(0), v_bytes(), u_bytes(0))."""
@@ -438,7 +445,7 @@ def prefill_ucache(plan, flat, dev, pool=None):
     items = (L.ConvPrepItem * len(plan))()
     for it, (key, op, opcode, io, p_off, nb) in zip(items, plan):
         buf = uc[key] = uc.buffer(key, nb, dev)
-        it.g, it.op, it.algo, it.ws_bytes = op.g, opcode, op.algo | io, max(op.ws_bytes, 1 << 20)
+        it.g, it.op, it.algo, it.ws_bytes = op.g, opcode, op.algo | io, op.ws_arg
         it.P, it.u = L.ptr(flat, p_off), buf.data_ptr()
     uc.log = list(plan)
     L.check(L.load().pg_conv_prep_batch(len(plan), items, _stream()), 'pg_conv_prep_batch')
@@ -681,18 +688,43 @@ class GenContext:
 class _WeightPrep:
     """Per-step weight preparation of a network (mixed into the two engines).  ucache_begin() opens the cache for one weight version:
     from the second step of a given kind on it comes back already filled by one batched launch (prefill_ucache) with what the previous
-    such step used; ucache_end() remembers what this step used."""
+    such step used; ucache_end() remembers what this step used.
+
+    Memory: the transformed / packed weights depend on the layer, the direction and the transform (all three are in the entry key,
+    which carries the byte count), NOT on the input extent -- so the device buffers live in ONE pool per network keyed by entry,
+    shared by every extent and mode (a ragged last batch or a second image size adds no device memory).  The per-(extent, mode)
+    fill plans are small host lists, kept for the MAX_PLANS most recently used kinds of step.  clear_weight_caches() (called by
+    set_precision / set_tuning) drops both."""
+
+    MAX_PLANS = 8
 
     def ucache_begin(self, flat, N, H, W, tag=None):
         key = (N, H, W, tag, self.algo, bool(self.act_bf))
-        pool = self.__dict__.setdefault('_upool', {}).setdefault(key, {})
-        uc = prefill_ucache(self.__dict__.setdefault('_uplan', {}).get(key), flat, flat.device, pool)
+        pool = self.__dict__.setdefault('_upool', {})
+        plans = self.__dict__.setdefault('_uplan', {})
+        plan = plans.pop(key, None)
+        if plan is not None:
+            plans[key] = plan          # most recently used last
+        uc = prefill_ucache(plan, flat, flat.device, pool)
         uc.plan_key = key
         return uc
 
     def ucache_end(self, uc):
         if isinstance(uc, UCache) and getattr(uc, 'plan_key', None) is not None:
-            self.__dict__.setdefault('_uplan', {})[uc.plan_key] = list(uc.log)
+            plans = self.__dict__.setdefault('_uplan', {})
+            plans.pop(uc.plan_key, None)
+            plans[uc.plan_key] = list(uc.log)
+            while len(plans) > self.MAX_PLANS:
+                plans.pop(next(iter(plans)))
+            # buffers no remembered plan refers to any more (entries of evicted plans) go back to the allocator
+            pool = self.__dict__.get('_upool', {})
+            live = {e[0] for p in plans.values() for e in p} | set(uc.keys())
+            for k in [k for k in pool if k not in live]:
+                del pool[k]
+
+    def clear_weight_caches(self):
+        self.__dict__.pop('_upool', None)
+        self.__dict__.pop('_uplan', None)
 
 
 class GeneratorEngine(_WeightPrep):

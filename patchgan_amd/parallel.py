@@ -37,6 +37,7 @@ class Dist:
         self.backend = dist.get_backend() if ready else None
         self._comm = None
         self.timing = None          # list of (start_event, end_event, nbytes) when bench.py asks for it
+        self.exposed = None         # list of (before_wait, after_wait, nbytes): see all_reduce_side
 
     def all_reduce(self, t, async_op=False):
         if self.on:
@@ -74,7 +75,22 @@ class Dist:
                 self.timing.append((e0, e1, t.numel() * t.element_size()))
         done = torch.cuda.Event()
         done.record(comm)
-        return lambda: torch.cuda.current_stream().wait_event(done)
+        if self.timing is None:
+            return lambda: torch.cuda.current_stream().wait_event(done)
+        nbytes = t.numel() * t.element_size()
+
+        def wait_timed():
+            # EXPOSED communication: how long the consuming stream really stood still for this collective = the time between an
+            # event recorded just before the wait and one recorded just after it (~0 when the collective had already finished
+            # under the kernels that were enqueued in between)
+            cur = torch.cuda.current_stream()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(cur)
+            cur.wait_event(done)
+            b.record(cur)
+            if self.exposed is not None:
+                self.exposed.append((a, b, nbytes))
+        return wait_timed
 
 
 _CURRENT = None

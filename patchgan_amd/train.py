@@ -73,8 +73,12 @@ def patchgan_train(argv=None):
     device = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
+        import datetime
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=device)
+        # bounded rendezvous / collective timeout: a rank whose peer died fails within minutes instead of holding its GPU for
+        # the backend's 10-30 min default (torch.distributed.run then tears the job down)
+        dist.init_process_group('nccl', device_id=device,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get('PATCHGAN_DIST_TIMEOUT_S', '600'))))
 
     with open(args.config_file, 'r') as infile:
         config = yaml.safe_load(infile)
@@ -131,6 +135,7 @@ def patchgan_train(argv=None):
 
     checkpoint_path = config.get('checkpoint_path', './checkpoints/')
     trainer = Trainer(generator, discriminator, savefolder=checkpoint_path)
+    trainer.gc_freeze = True      # this process is the training job: keep generation-2 collections out of the step loop
     if dataset_kwargs.get('device_pipeline', False):
         trainer.label_values = [int(v) for v in np.sort(dataset_kwargs['labels'])]
     if config.get('load_last_checkpoint', False):

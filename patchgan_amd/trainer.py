@@ -38,12 +38,15 @@ _GC_FREEZES = 0
 
 
 def _settle_gc(step):
-    """Keep CPython's cyclic collector out of the step loop's way.  A full (generation-2) collection walks every live container object
-    of the process -- ~0.5 M after `import torch` -- and takes 40-70 ms here: four to fifteen G+D steps of GPU time during which the
-    host enqueues nothing (measured: one such pause inside a 20-step bench window moved bf16 cfg2 from 4.3 to 6.2 ms per step).
-    After the first and after the third training step of the process -- by then the engines' kernel plans, workspaces and weight
-    caches exist -- collect once and move everything alive into the permanent generation (gc.freeze()): later collections only
-    look at what the steps themselves create.  PATCHGAN_GC_FREEZE=0 leaves the collector alone."""
+    """Keep CPython's cyclic collector out of the step loop's way -- OPT-IN (Trainer.gc_freeze; bench.py and the patchgan_train
+    entry point set it, a program that embeds Trainer is left alone: gc.freeze() is process-global and would move the host
+    application's own objects to the permanent generation as well).  A full (generation-2) collection walks every live container
+    object of the process -- ~0.5 M after `import torch` -- and takes 40-70 ms here: four to fifteen G+D steps of GPU time during
+    which the host enqueues nothing (measured: one such pause inside a 20-step bench window moved bf16 cfg2 from 4.3 to 6.2 ms per
+    step).  After the first and after the third training step of the process -- by then the engines' kernel plans, workspaces and
+    weight caches exist -- collect once and move everything alive into the permanent generation (gc.freeze()): later collections
+    only look at what the steps themselves create.  Trainer.train() undoes it (gc.unfreeze()) when it returns.
+    PATCHGAN_GC_FREEZE=0 switches it off everywhere."""
     global _GC_FREEZES
     if _GC_FREEZES >= 2 or step not in (1, 3) or os.environ.get('PATCHGAN_GC_FREEZE', '1') == '0':
         return
@@ -51,6 +54,15 @@ def _settle_gc(step):
     gc.collect()
     gc.freeze()
     _GC_FREEZES += 1
+
+
+def _unsettle_gc():
+    """Hand the objects frozen by _settle_gc back to the collector (end of Trainer.train)."""
+    global _GC_FREEZES
+    if _GC_FREEZES:
+        import gc
+        gc.unfreeze()
+        _GC_FREEZES = 0
 
 
 class StepLosses(dict):
@@ -137,6 +149,7 @@ class Trainer:
 
     neptune_config = None
     label_values = None      # label list of the dataset, only for the uint8 (device-side) input path of batch()
+    gc_freeze = False        # opt-in: gc.collect() + gc.freeze() after training steps 1 and 3 (_settle_gc; process-global)
 
     def __init__(self, generator, discriminator, savefolder, device='cuda'):
         generator.apply(weights_init)
@@ -284,7 +297,7 @@ class Trainer:
         if wait_losses is not None:
             wait_losses()
         self._last_gen = gen
-        if train:
+        if train and self.gc_freeze:
             _settle_gc(self._step)
         self.host_ms = (time.perf_counter() - t_host0) * 1e3       # host time to enqueue the whole step (bench.py reports it)
         # the step's one device-to-host copy, asynchronous into a pinned slot: the returned dict waits for it on first access
@@ -375,6 +388,8 @@ class Trainer:
             if epoch % save_freq == 0:
                 self.save(epoch)
         self.flush()
+        if self.gc_freeze:
+            _unsettle_gc()
         return history['gen'], history['disc']
 
     def _run_epoch(self, data, train, epoch, desc, **bar_kwargs):
@@ -446,16 +461,23 @@ class Trainer:
 
 
 class _Plateau:
-    """torch ReduceLROnPlateau defaults (mode min, factor 0.1, patience 10, rel threshold 1e-4) on a scalar LR."""
+    """torch.optim.lr_scheduler.ReduceLROnPlateau with its defaults, as the reference constructs it (trainer.py:175-178: mode
+    'min', factor 0.1, patience 10, relative threshold 1e-4, cooldown 0, min_lr 0, eps 1e-8), on a scalar learning rate:
+    step(metric) after every epoch (trainer.py:271-273) returns the learning rate for the next one.
+    tests/test_trainer_cpu.py holds it against torch's class."""
 
     def __init__(self, lr):
         self.lr, self.best, self.bad = lr, float('inf'), 0
 
     def step(self, metric):
+        metric = float(metric)
         if metric < self.best * (1 - 1e-4):
             self.best, self.bad = metric, 0
         else:
             self.bad += 1
         if self.bad > 10:
-            self.lr, self.bad = max(self.lr * 0.1, 0.0), 0
+            new_lr = max(self.lr * 0.1, 0.0)
+            if self.lr - new_lr > 1e-8:        # torch ignores updates smaller than eps
+                self.lr = new_lr
+            self.bad = 0
         return self.lr

@@ -1,5 +1,6 @@
 """CPU-side checks of the boundary: the shared library loads and exports every symbol include/patchgan_hip.h
 declares (no compute calls: there is no GPU here), and the host mirror keeps the reference's surface."""
+import ctypes
 import os
 import re
 
@@ -128,3 +129,66 @@ def test_transfer_and_errors():
         g.load_transfer_data(sd)
     with pytest.raises(ValueError):
         pg.UNet(3, 1, 4, activation='gelu')
+
+
+def test_queries_do_not_depend_on_a_larger_workspace():
+    """The engine sizes hand-over buffers from queries (pg_conv_kernel, pg_conv_u_bytes, pg_conv_v_bytes, pg_conv_stats_chunks,
+    pg_conv_mul_ok) and then launches; both sides must see the same plan.  ConvOp passes ONE workspace size to both
+    (ConvOp.ws_arg), and -- checked here on every layer geometry of cfg2, cfg4 and cfg1 -- the C side's answers do not change
+    with any workspace at least as large as pg_conv_workspace_bytes reports (the device buffer the launches share may be larger)."""
+    import patchgan_amd as pg
+    from patchgan_amd import _lib, engine as E
+    lib = _lib.load()
+    geoms = set()
+    for nf, ndf, nl, out_nc, size, B in ((64, 64, 3, 1, 256, 16), (64, 64, 3, 4, 512, 8), (32, 16, 5, 7, 256, 4)):
+        g, d = E.GeneratorEngine(3, out_nc, nf, 'leakyrelu', 'sigmoid', False), E.DiscriminatorEngine(3 + out_nc, ndf, nl, False)
+        enc, dec = g.ops(B, size, size)
+        for op in enc + dec + d.ops(B, size, size) + d.ops(2 * B, size, size):
+            geoms.add(op.g.key())
+    assert len(geoms) > 40
+    for key in sorted(geoms):
+        for algo, ios in ((_lib.ALGO_AUTO, (0,)), (_lib.ALGO_BF16, (0, _lib.IO_MASK))):
+            op = E.ConvOp(key[0], key[1], key[2], key[5], key[6], key[7], algo)
+            assert op._ws(torch.device('cpu'))[1] == op.ws_arg       # what a launch passes == what the queries pass
+            for io in ios:
+                a = algo | io
+
+                def answers(ws):
+                    out = []
+                    for oc in (0, 1, 2):
+                        name, s, fl = ctypes.create_string_buffer(128), ctypes.c_int(0), ctypes.c_double(0)
+                        assert lib.pg_conv_kernel(ctypes.byref(op.g), oc + 16 * a, ws, name, 128, ctypes.byref(s), ctypes.byref(fl)) == 0
+                        out.append((name.value, s.value, fl.value))
+                    out += [lib.pg_conv_u_bytes(ctypes.byref(op.g), oc, a, ws) for oc in (0, 1)]
+                    out += [lib.pg_conv_stats_chunks(ctypes.byref(op.g), oc, a, ws) for oc in (0, 1)]
+                    out += [lib.pg_conv_v_bytes(ctypes.byref(op.g), a, ws), lib.pg_conv_mul_ok(ctypes.byref(op.g), a, ws)]
+                    return out
+                base = answers(op.ws_arg)
+                for bigger in (op.ws_arg + 4096, 4 * op.ws_arg, 1 << 33):
+                    assert answers(bigger) == base, (key, algo, io, bigger)
+
+
+def test_weight_prep_pools_are_bounded_and_cleared():
+    """engine._WeightPrep: ONE device-buffer pool per network keyed by entry (not per input extent), at most MAX_PLANS remembered
+    fill plans, both dropped by set_precision / set_tuning."""
+    import patchgan_amd as pg
+    from patchgan_amd import engine as E
+    g = pg.UNet(3, 1, 4, activation='relu', final_act='sigmoid')
+    eng = g.engine
+    for i in range(E._WeightPrep.MAX_PLANS + 5):
+        uc = E.UCache(eng.__dict__.setdefault('_upool', {}))
+        uc.plan_key = (2 + i, 256, 256, None, eng.algo, False)
+        buf = uc[('e', 1, 4096)] = uc.buffer(('e', 1, 4096), 4096, torch.device('cpu'))       # the same entry at every extent
+        uc.log.append((('e', 1, 4096), None, 0, 0, 0, 4096))
+        if i == 3:                                                                         # an entry only one (evicted) plan used
+            uc[('x', 0, 64)] = uc.buffer(('x', 0, 64), 64, torch.device('cpu'))
+            uc.log.append((('x', 0, 64), None, 0, 0, 0, 64))
+        eng.ucache_end(uc)
+        assert eng._upool[('e', 1, 4096)] is buf                                             # one buffer, reused by every extent
+    assert len(eng._uplan) == E._WeightPrep.MAX_PLANS
+    assert list(eng._upool) == [('e', 1, 4096)]                                              # the evicted plan's private entry is gone
+    g.set_tuning(0)
+    assert '_upool' not in eng.__dict__ and '_uplan' not in eng.__dict__
+    eng.__dict__['_upool'] = {1: 2}
+    g.set_precision('fp32')
+    assert '_upool' not in eng.__dict__

@@ -168,3 +168,44 @@ def test_train_reseeds_distributed_sampler_each_epoch(tmp_path):
     assert len(second) == per_epoch and first != second
     assert sorted(sum(first, [])) != list(range(32))          # this rank sees only its half
     assert len(set(sum(first, []))) == 16
+
+
+# ---- the multi-rank launcher of bench.py (`python bench.py --gpus N`): a dead rank must end the job, not hang it ---------------
+
+
+def _spawn(mode, *extra, timeout=60.0):
+    """bench.spawn_ranks over tests/dp_kill_worker.py (world 2, gloo, CPU).  Returns (SystemExit message or None, seconds)."""
+    import time
+    import bench
+    here = os.path.dirname(os.path.abspath(__file__))
+    t0 = time.monotonic()
+    try:
+        bench.spawn_ranks(2, [mode, *map(str, extra)], script=os.path.join(here, 'dp_kill_worker.py'), timeout=timeout, grace=2.0)
+        msg = None
+    except SystemExit as e:
+        msg = str(e.code)
+    return msg, time.monotonic() - t0
+
+
+def test_spawn_ranks_forwards_rank0_line(capfd):
+    msg, _ = _spawn('ok')
+    assert msg is None
+    import json
+    lines = [l for l in capfd.readouterr().out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0]) == {'ok': True, 'value': 1.0}
+
+
+@pytest.mark.parametrize('mode,die_rank,status', [('midstep', 1, 7), ('midstep', 0, 7), ('noshow', 1, 9)])
+def test_spawn_ranks_ends_the_job_when_a_rank_dies(mode, die_rank, status):
+    """A rank that dies mid-step leaves its peer inside a collective, one that never reaches the rendezvous leaves its peer in
+    init_process_group (group timeout: 600 s).  The launcher must notice the first non-zero exit, terminate the survivor, name the
+    failed rank and return non-zero -- within seconds, not after the collective timeout."""
+    msg, dt = _spawn(mode, die_rank, timeout=120.0)
+    assert msg is not None and f'rank {die_rank} exited with status {status}' in msg, msg
+    assert dt < 60.0, dt
+
+
+def test_spawn_ranks_overall_timeout():
+    msg, dt = _spawn('hang', timeout=8.0)
+    assert msg is not None and 'still running after 8 s' in msg, msg
+    assert dt < 40.0, dt

@@ -13,6 +13,7 @@ d = pg.Discriminator(4, 64, n_layers=3).cuda()
 g.set_precision(precision)
 d.set_precision(precision)
 t = pg.Trainer(g, d, tempfile.mkdtemp())
+t.gc_freeze = True
 t.setup_optimizers(2e-4, 2e-4)
 g.train(); d.train()
 gen = torch.Generator(device='cuda').manual_seed(1)
