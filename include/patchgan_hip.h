@@ -96,6 +96,14 @@ typedef struct pg_conv_geom {
 
 int pg_version(void);
 
+/* Byte extent (pixels * ld * element size of a tensor's view) below which the buffer-load kernels -- every fast fp32 kernel and
+ * ALL kernels that take bf16 tensors (PG_IO_*) -- can address a tensor: their gathers use 32-bit byte offsets with an
+ * out-of-range sentinel.  fp32 tensors beyond it run on the generic kernels (64-bit addressing); a bf16 tensor beyond it has no
+ * kernel (PG_EINVAL), and the size queries below (pg_conv_u_bytes, pg_conv_stats_chunks, pg_conv_v_bytes, pg_conv_mul_ok), which
+ * see the geometry only, do not know the views: a caller that plans hand-overs or bf16 storage checks its views against this
+ * number first (patchgan_amd.engine does: ConvOp.fits / _bf16_tensors_ok; tiled inference streams its tiles in bounded batches). */
+size_t pg_conv_max_tensor_bytes(void);
+
 /* Bytes of workspace that lets op (0 = big2small, 1 = small2big, 2 = wgrad) use its preferred
  * split-K factor / Winograd path for geometry g under ANY algo / PG_TUNE_* combination.  A smaller (or NULL) workspace is
  * legal: the split shrinks, the Winograd paths fall back to the implicit GEMM. */

@@ -63,6 +63,7 @@ class ConvPrepItem(ctypes.Structure):
 # name -> (restype, argtypes); mirrors include/patchgan_hip.h one to one
 SIGNATURES = {
     'pg_version': (_i, []),
+    'pg_conv_max_tensor_bytes': (_sz, []),
     'pg_conv_workspace_bytes': (_sz, [_G, _i]),
     'pg_conv_describe': (_i, [_G, _i, _sz, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_l)]),
     'pg_conv_mul_ok': (_i, [_G, _i, _sz]),

@@ -2923,6 +2923,8 @@ int bf16x_run(int dir, const void* in, int ld_in, const float* P, const float* b
 
 extern "C" {
 
+size_t pg_conv_max_tensor_bytes(void) { return (size_t)FAST_LIMIT; }
+
 size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op) {
     if (!geom_ok(g)) return 0;
     if (op == 3) {      // pg_conv4x4_bwd_big: its two halves back to back, or V shared + the larger of the two remainders

@@ -129,7 +129,7 @@ int blocks_for(long total) {
 
 extern "C" {
 
-int pg_version(void) { return 1; }
+int pg_version(void) { return 2; }
 
 int pg_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                  float bc1, float sqrt_bc2, void* stream) {

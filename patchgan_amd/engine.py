@@ -79,6 +79,11 @@ class View:
         return self.H * self.W
 
     @property
+    def extent_bytes(self):
+        """Bytes from this view's first element to the end of its last pixel row (what a kernel's 32-bit offsets must span)."""
+        return self.npix * self.ld * (2 if self.bf else 4)
+
+    @property
     def npix(self):
         return self.N * self.H * self.W
 
@@ -199,6 +204,7 @@ class LaunchProfiler:
 
 
 PROFILER = None
+_MAX_TENSOR_BYTES = None      # pg_conv_max_tensor_bytes(), read once
 
 
 class ConvOp:
@@ -257,6 +263,16 @@ class ConvOp:
         return all(v.ld % 4 == 0 and v.ptr() % 16 == 0 and not v.bf for v in views)     # (the Winograd hand-overs are fp32 paths)
 
     @staticmethod
+    def fits(*views):
+        """Every view is addressable by the buffer-load kernels (pg_conv_max_tensor_bytes: 32-bit byte offsets).  The C side's size
+        queries see the geometry only; the launches also see the views and leave the fast / bf16 paths for a tensor beyond this
+        limit -- so hand-overs (part, v_keep, u_cache, mul_t) are planned only for views that fit."""
+        global _MAX_TENSOR_BYTES
+        if _MAX_TENSOR_BYTES is None:
+            _MAX_TENSOR_BYTES = int(L.load().pg_conv_max_tensor_bytes())
+        return all(v.extent_bytes < _MAX_TENSOR_BYTES for v in views)
+
+    @staticmethod
     def _io(big, small):
         return (L.IO_BIG_BF16 if big.bf else 0) | (L.IO_SMALL_BF16 if small.bf else 0)
 
@@ -270,6 +286,8 @@ class ConvOp:
         statistics from the conv epilogue); 0 = not on this path (or the views are not 16-byte aligned)."""
         big, small = (view_in, view_out) if opcode == 0 else (view_out, view_in)
         io = self._io(big, small)
+        if not self.fits(view_in, view_out):
+            return 0
         if io:      # bf16 tensors: the LDS-DMA kernels' STATS epilogue (both tensors bf16, 16-byte-aligned views)
             if io != L.IO_MASK or not all(v.ptr() % 16 == 0 and v.ld % 8 == 0 for v in (view_in, view_out)):
                 return 0
@@ -301,7 +319,7 @@ class ConvOp:
     def mul_ok(self, small, big, t):
         """small2big(small -> big) can fold `big *= f'(t)` into its epilogue (pg_conv_extras.mul_t): the kernel of this call supports
         it and the tensors satisfy its alignment; t must have big's shape and storage type."""
-        if t.bf != big.bf or (t.N, t.H, t.W, t.C) != (big.N, big.H, big.W, big.C):
+        if t.bf != big.bf or (t.N, t.H, t.W, t.C) != (big.N, big.H, big.W, big.C) or not self.fits(small, big, t):
             return False
         need = (big, t) if self.Ca == 1 else (small, big, t)       # (the one-channel kernel reads `small` by scalars)
         if not all(v.ptr() % 16 == 0 and v.ld % (8 if v.bf else 4) == 0 for v in need):
@@ -380,10 +398,18 @@ class ConvOp:
         PROFILER.launch2(self, (2, 0), go, self._io(big, small)) if PROFILER is not None else go()
 
 
-def _bf16_tensors_ok(ops):
+def _bf16_tensors_ok(ops, ld_mult=1):
     """Every one of these layers has bf16-tensor kernels for its three ops at this geometry (pg_conv_kernel names them): otherwise
     the caller keeps fp32 activation storage for this extent (e.g. 7 x 7 maps on channel counts the LDS-DMA weight gradient does
-    not take: the register-staged kernel's pixel decode needs power-of-two or >= 16-wide maps)."""
+    not take: the register-staged kernel's pixel decode needs power-of-two or >= 16-wide maps).  And every tensor those kernels
+    would see stays below pg_conv_max_tensor_bytes (bf16 tensors have no kernel beyond it; fp32 ones fall back to the generic
+    kernels): ld_mult = the widest buffer an interior tensor is a channel slice of, in multiples of its own channel count (2 for
+    the generator's skip-connection buffers)."""
+    if _MAX_TENSOR_BYTES is None:
+        ConvOp.fits()
+    for op in ops:
+        if max(op.N * op.Hb * op.Wb * op.Cb, op.N * op.Hs * op.Ws * op.Ca) * ld_mult * 2 >= _MAX_TENSOR_BYTES:
+            return False
     return all('bf16' in op.describe(oc, L.IO_MASK)[0] for op in ops for oc in (0, 1, 2))
 
 
@@ -409,7 +435,7 @@ def _ucache(ucache, li, opcode, op, dev, src, dst, p_off=None):
     """(buffer, valid) of the transformed / packed weights of layer li / direction opcode in the caller's per-step cache (a dict that
     lives exactly as long as the weights stay unchanged).  On bf16 tensors one packed bf16 copy serves both directions of a layer (the
     small -> big kernel stages it transposed), so the two directions share an entry."""
-    if ucache is None or not CACHE_U:
+    if ucache is None or not CACHE_U or not ConvOp.fits(src, dst):
         return None, False
     big, small = (src, dst) if opcode == 0 else (dst, src)
     io = ConvOp._io(big, small)
@@ -728,6 +754,8 @@ class _WeightPrep:
 
 
 class GeneratorEngine(_WeightPrep):
+    _LD_MULT = 2          # interior tensors are channel slices of the skip-connection buffers cat_i (twice their channels)
+
     def __init__(self, input_nc, output_nc, nf, activation, final_act, use_dropout, algo=None):
         self.input_nc, self.output_nc, self.nf = input_nc, output_nc, nf
         self.activation, self.final_act, self.use_dropout = activation, final_act, use_dropout
@@ -746,7 +774,7 @@ class GeneratorEngine(_WeightPrep):
         if not hasattr(self, '_sok'):
             self._sok = {}
         if key not in self._sok:
-            self._sok[key] = _bf16_tensors_ok(interior_ops)
+            self._sok[key] = _bf16_tensors_ok(interior_ops, self._LD_MULT)
         return self._sok[key]
 
     def ops(self, N, H, W):
@@ -821,7 +849,7 @@ class GeneratorEngine(_WeightPrep):
                 out = c.hidden
             stats = torch.empty(N * l.a * 2, dtype=torch.float32, device=dev)
             drop = 0.2 if (train and l.dropout) else 0.0
-            vb = op.v_bytes() if (keep_v and KEEP_V and ConvOp._aligned(src, y)) else 0
+            vb = op.v_bytes() if (keep_v and KEEP_V and ConvOp._aligned(src, y) and ConvOp.fits(src, y)) else 0
             vk = torch.empty(vb, dtype=torch.uint8, device=dev) if vb else None
             u, uv = _ucache(ucache, ('e', i), 0, op, dev, src, y, l.p_off)
             conv_instnorm_act(op, 0, src, flat, l.p_off, y, out, stats, act, drop, _shift_seed(_mix_seed(seed, 1, i), sample0 * y.HW * y.C),
@@ -956,6 +984,8 @@ class DiscContext:
 
 
 class DiscriminatorEngine(_WeightPrep):
+    _LD_MULT = 1
+
     def __init__(self, input_nc, ndf, n_layers, norm, algo=None):
         self.input_nc, self.ndf, self.n_layers, self.norm = input_nc, ndf, n_layers, norm
         self.layers = disc_layers(input_nc, ndf, n_layers, norm)
@@ -971,7 +1001,7 @@ class DiscriminatorEngine(_WeightPrep):
         if not hasattr(self, '_sok'):
             self._sok = {}
         if key not in self._sok:
-            self._sok[key] = _bf16_tensors_ok(interior_ops)
+            self._sok[key] = _bf16_tensors_ok(interior_ops, self._LD_MULT)
         return self._sok[key]
 
     def ops(self, N, H, W):
@@ -1017,7 +1047,7 @@ class DiscriminatorEngine(_WeightPrep):
             t = View.alloc(din.N, op.Hs, op.Ws, l.a, dev, bf=bf and (0 < li < last or (li == 0 and seam8)))
             bias = flat if l.bias_key is not None else None
             u, uv = _ucache(ucache, li, 0, op, dev, src, t, l.p_off)
-            vb = op.v_bytes() if (keep_v and KEEP_V and ConvOp._aligned(src, t)) else 0
+            vb = op.v_bytes() if (keep_v and KEEP_V and ConvOp._aligned(src, t) and ConvOp.fits(src, t)) else 0
             vk = torch.empty(vb, dtype=torch.uint8, device=dev) if vb else None
             c.v.append(vk)
             op.big2small(src, flat, l.p_off, bias, l.b_off, t, L.ACT_CODES[l.act], v_keep=vk, u_cache=u, u_valid=uv)   # conv + bias + act fused

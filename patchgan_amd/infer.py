@@ -63,14 +63,21 @@ def build_mask(masks, crop_size, image_size, threshold, overlap):
     return mask[0]
 
 
-def predict_image(generator, image, size, overlap, threshold):
+def predict_image(generator, image, size, overlap, threshold, max_tiles=None):
     """One image [C, H, W] (device tensor) -> mask as numpy: float64 [H, W] for a single-class generator, class index
-    [H, W] otherwise -- reference infer.py:155-163 (n_crop -> generator -> build_mask) on the HIP path end to end."""
+    [H, W] otherwise -- reference infer.py:155-163 (n_crop -> generator -> build_mask) on the HIP path end to end.
+    The tiles STREAM through the generator at most `max_tiles` per forward pass (default: 64 tiles of 256 x 256, scaled with the
+    tile area; tiles are independent samples, so the result does not depend on it): a 1024 x 1024 image (25 tiles) is one pass, a
+    4096 x 4096 one (324 tiles) six -- activation memory and every tensor's byte extent stay bounded whatever the image size."""
     from . import engine as E
     eng = generator.engine
     tiles = E.tiles_gather(image, size, overlap)
     pred = E.View.alloc(tiles.N, size, size, eng.output_nc, image.device)
-    eng.forward(generator.flat, tiles, pred, False, 0)
+    if max_tiles is None:
+        max_tiles = max(1, (64 * 256 * 256) // (size * size))
+    for t0 in range(0, tiles.N, max_tiles):
+        n = min(max_tiles, tiles.N - t0)
+        eng.forward(generator.flat, tiles.samples(t0, n), pred.samples(t0, n), False, 0)
     mask = E.tiles_blend(pred, tuple(image.shape[1:]), threshold, overlap)
     # device -> host through a pinned block of torch's caching host allocator (the numpy array keeps it alive; it returns to the cache when
     # the caller drops the mask): a pageable .cpu() of the 8-MB float64 mask took 0.3-1.2 ms of the 3-ms image, this one 0.15

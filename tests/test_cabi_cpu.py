@@ -192,3 +192,44 @@ def test_weight_prep_pools_are_bounded_and_cleared():
     eng.__dict__['_upool'] = {1: 2}
     g.set_precision('fp32')
     assert '_upool' not in eng.__dict__
+
+
+def test_tensors_beyond_the_32_bit_offset_limit_are_never_planned_onto_the_bf16_kernels():
+    """A bf16 tensor of pg_conv_max_tensor_bytes (1.5 GiB) or more has no kernel (the buffer-load kernels address with 32-bit byte
+    offsets) and the C ABI's size queries see the geometry only.  The engine therefore (a) keeps fp32 activation storage for an
+    input extent any of whose interior tensors -- as the channel slice of the wider skip buffer it lives in -- would reach the
+    limit, and (b) plans no hand-over (InstanceNorm partials, packed-weight cache, V hand-over, epilogue multiplier) for such a view.
+    No launch: queries and host logic only."""
+    from patchgan_amd import _lib, engine as E
+    limit = _lib.load().pg_conv_max_tensor_bytes()
+    assert limit == 0x60000000
+    g = E.GeneratorEngine(3, 1, 64, 'leakyrelu', 'sigmoid', False, algo=_lib.ALGO_BF16)
+    g.act_bf = True
+    for N, ok in ((16, True), (383, True), (384, False), (400, False)):   # enc0's output in cat6: N * 128*128 * 128 ch * 2 B = N * 4 MiB
+        enc, dec = g.ops(N, 256, 256)
+        assert g._storage_ok((N, 256, 256), enc[1:] + dec[:6]) == ok, N
+    d = E.DiscriminatorEngine(4, 64, 3, False, algo=_lib.ALGO_BF16)
+    for N, ok in ((32, True), (767, True), (768, False)):                 # d0's output: N * 128*128 * 64 ch * 2 B = N * 2 MiB
+        ops = d.ops(N, 256, 256)
+        assert d._storage_ok((N, 256, 256), ops[1:-1]) == ok, N
+
+    class FakeTensor:          # a device address without device memory
+        device = torch.device('cpu')
+
+        def data_ptr(self):
+            return 1 << 21
+
+    def view(N, H, W, C, ld):
+        return E.View(FakeTensor(), 0, ld, N, H, W, C, True)
+    for N, fits in ((16, True), (400, False)):
+        op = E.ConvOp(N, 128, 128, 128, 64, 2, _lib.ALGO_BF16)            # enc1 on bf16 tensors, its input a slice of cat6 (ld 128)
+        src, dst = view(N, 128, 128, 64, 128), view(N, 64, 64, 128, 256)
+        assert E.ConvOp.fits(src, dst) == fits
+        assert op.u_bytes(0, _lib.IO_MASK) > 0                            # the geometry-only query always offers a packed-weight cache
+        uc = E.UCache()
+        buf, valid = E._ucache(uc, ('e', 1), 0, op, torch.device('cpu'), src, dst, 0)
+        assert (buf is not None) == fits and not valid
+        assert bool(op.stats_chunks(0, src, dst)) == (fits and bool(_lib.load().pg_conv_stats_chunks(
+            ctypes.byref(op.g), 0, _lib.ALGO_BF16 | _lib.IO_MASK, op.ws_arg)))
+        t = view(N, 128, 128, 64, 128)
+        assert op.mul_ok(dst, view(N, 128, 128, 64, 128), t) in ((True, False) if fits else (False,))
