@@ -45,11 +45,12 @@ BATCH_PER_GPU = CFG['batch']
 SIZE = CFG['size']
 
 
-def make_inputs(batch, rank):
+def make_inputs(batch, rank, cfg=None):
     import torch
+    cfg = cfg or CFG
     g = torch.Generator().manual_seed(7 + rank)
-    x = torch.rand(batch, 3, SIZE, SIZE, generator=g)
-    y = (torch.rand(batch, CFG['out_nc'], SIZE, SIZE, generator=g) > 0.7).float()
+    x = torch.rand(batch, 3, cfg['size'], cfg['size'], generator=g)
+    y = (torch.rand(batch, cfg['out_nc'], cfg['size'], cfg['size'], generator=g) > 0.7).float()
     return x, y
 
 
@@ -180,6 +181,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true',
+                    help='skip the extra_configs leg (cfg4 bf16 training, cfg5 tiled inference) measured after the headline')
     ap.add_argument('--dropout', action='store_true', help='nn.Dropout(0.2) in the generator (CLI default of the reference)')
     ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg2', help='workload (default: the BASELINE metric config)')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
@@ -231,20 +234,66 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {args.gpus}")
 
+    m = measure_training(CFG, args.dtype, args.steps, args.warmup, dev, rank, world, use_dist, events=args.events,
+                         dropout=args.dropout, fp32_activations=args.fp32_activations)
+    if rank == 0:
+        out = {
+            'metric': f'train images/sec (G+D step) at {SIZE}x{SIZE} bs={BATCH_PER_GPU} per GPU', 'value': round(m['value'], 2),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(m['ms_per_step'], 3), 'host_enqueue_ms_per_step': round(m['host_ms_per_step'], 3),
+            'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'activation_storage': m['activation_storage'],
+            'config': {'workload': CFG['desc'] + ', dropout ' + ('on' if args.dropout else 'off'),
+                       'global_batch': BATCH_PER_GPU * world, 'parallelism': f'dp{world}'},
+            'last_losses': m['last_losses'],
+            'roofline': m['roofline'],
+        }
+        if m['comm'] is not None:
+            out['comm'] = m['comm']
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        elif world == 1:
+            out['cpu_baseline'] = None
+        out['conv_kernels_note'] = 'per-kernel table from one fully instrumented warm-up step; roofline from the timed region'
+        out['conv_kernels'] = m['conv_kernels']
+        # the other single-GPU configurations of BASELINE.json, measured AFTER the headline's timed region and JSON assembly (the
+        # headline metric / config / dtype above stay cfg2 fp32): cfg4 in bf16 (the "next" row f2) and cfg5 tiled inference (f1)
+        if world == 1 and not use_dist and not args.no_extra and args.config == 'cfg2' and args.dtype == 'f32':
+            del m
+            out['extra_configs'] = extra_configs(dev)
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=False, events='dominant', dropout=False,
+                     fp32_activations=False):
+    """W untimed + K timed G+D steps of workload `cfg` on this rank's device (inputs resident in HBM; barrier + synchronize on
+    both sides; MAX over ranks).  Returns the pieces of the JSON line: value (whole-job images/s), ms_per_step, roofline of the
+    dominant conv kernel (HIP events on the launch stream inside the timed region), the per-kernel table of one fully
+    instrumented warm-up step, comm statistics under data parallelism."""
+    import torch
+    import torch.distributed as dist
+    import patchgan_amd as pg
+    from patchgan_amd import engine as E
+    from patchgan_amd import parallel
+    batch, size = cfg['batch'], cfg['size']
     torch.manual_seed(1234)
-    G = pg.UNet(3, CFG['out_nc'], CFG['nf'], use_dropout=args.dropout, activation=CFG['activation'],
-                final_act=CFG['final_act']).to(dev)
-    D = pg.Discriminator(3 + CFG['out_nc'], CFG['ndf'], n_layers=CFG['n_layers'], norm=False).to(dev)
-    if args.dtype == 'bf16':
-        G.set_precision('bf16', bf16_storage=not args.fp32_activations)
-        D.set_precision('bf16', bf16_storage=not args.fp32_activations)
+    G = pg.UNet(3, cfg['out_nc'], cfg['nf'], use_dropout=dropout, activation=cfg['activation'],
+                final_act=cfg['final_act']).to(dev)
+    D = pg.Discriminator(3 + cfg['out_nc'], cfg['ndf'], n_layers=cfg['n_layers'], norm=False).to(dev)
+    if dtype == 'bf16':
+        G.set_precision('bf16', bf16_storage=not fp32_activations)
+        D.set_precision('bf16', bf16_storage=not fp32_activations)
     t = pg.Trainer(G, D, tempfile.mkdtemp(prefix='pgbench_'))
-    t.loss_type, t.seg_alpha = CFG['loss_type'], 200
+    t.loss_type, t.seg_alpha = cfg['loss_type'], 200
     t.gc_freeze = True            # as the patchgan_train entry point does (trainer._settle_gc): opt-in, process-global
     t.setup_optimizers(1e-3, 1e-3)
     G.train()
     D.train()
-    x, y = make_inputs(BATCH_PER_GPU, rank)
+    x, y = make_inputs(batch, rank, cfg)
     x, y = x.to(dev), y.to(dev)
 
     def sync():
@@ -255,30 +304,31 @@ def main():
     # warm-up; the last warm-up step is profiled launch by launch to find the dominant conv kernel symbol, so that the
     # timed region only carries events around THAT kernel's launches (2 event records per launch are not free)
     wprof = E.LaunchProfiler()
-    for i in range(args.warmup):
-        E.PROFILER = wprof if i == args.warmup - 1 else None
+    for i in range(warmup):
+        E.PROFILER = wprof if i == warmup - 1 else None
         t.batch(x, y, train=True)
     E.PROFILER = None
     torch.cuda.synchronize()
     wsum = wprof.summary()
     if not wsum:                       # --warmup 0: nothing to pick the dominant kernel from: instrument every launch
-        args.events = 'all'
+        events = 'all'
     dominant = max(wsum.items(), key=lambda kv: kv[1]['ms'])[0] if wsum else None
-    prof = E.LaunchProfiler(only=None if args.events == 'all' else dominant)
-    if args.events != 'none' and wsum:
-        per_step = sum(v['launches'] for k, v in wsum.items() if args.events == 'all' or k == dominant)
-        if args.events == 'dominant':
+    prof = E.LaunchProfiler(only=None if events == 'all' else dominant)
+    if events != 'none' and wsum:
+        per_step = sum(v['launches'] for k, v in wsum.items() if events == 'all' or k == dominant)
+        if events == 'dominant':
             # a bounded sample: every launch of the dominant kernel in the first steps of the timed region, at most ~96 launches
             # (event records are stream operations: instrumenting 20+ steps costs up to 1 ms per step on a busy box)
-            prof.limit = int(per_step * max(1, min(args.steps, 96 // max(1, int(per_step)))))
-        n_ev = prof.limit if prof.limit is not None else int(per_step * args.steps)
+            prof.limit = int(per_step * max(1, min(steps, 96 // max(1, int(per_step)))))
+        n_ev = prof.limit if prof.limit is not None else int(per_step * steps)
         prof.reserve(2 * n_ev + 8)        # the events exist (and have been recorded once) before the timed region starts
-    E.PROFILER = prof if args.events != 'none' else None
+    E.PROFILER = prof if events != 'none' else None
     pd = parallel.current()
     if pd.on:
         pd.timing = []             # (start, end, bytes) HIP events on the comm stream around every collective
         pd.exposed = []            # (before, after, bytes) HIP events on the consuming stream around each wait for one
-    if os.environ.get('PATCHGAN_BENCH_TRACE'):
+    trace = bool(os.environ.get('PATCHGAN_BENCH_TRACE'))
+    if trace:
         import gc
         _gc_t = [0.0]
 
@@ -292,10 +342,10 @@ def main():
     t0 = time.perf_counter()
     last = None
     host_ms = 0.0
-    for _ in range(args.steps):
+    for _ in range(steps):
         cur = t.batch(x, y, train=True)
         host_ms += t.host_ms
-        if os.environ.get('PATCHGAN_BENCH_TRACE'):
+        if trace:
             sys.stderr.write(f'step host_ms {t.host_ms:.3f} reserved_MiB {torch.cuda.memory_reserved() >> 20} segments {torch.cuda.memory_stats().get("segment.all.allocated", -1)}\n')
         if last is not None:
             last['gen']            # as Trainer.train's epoch loop: step i's losses are read once step i + 1 is enqueued
@@ -308,19 +358,19 @@ def main():
     if pd.on:
         recs, pd.timing = pd.timing, None
         waits, pd.exposed = pd.exposed, None
-        per = max(1, len(recs) // args.steps)          # collectives of one step, in issue order (the same every step)
-        by_slot = [[r for r in recs[i::per]] for i in range(per)] if len(recs) == per * args.steps else []
+        per = max(1, len(recs) // steps)          # collectives of one step, in issue order (the same every step)
+        by_slot = [[r for r in recs[i::per]] for i in range(per)] if len(recs) == per * steps else []
         comm = {'backend': dist.get_backend(), 'ranks_in_group': dist.get_world_size(),
-                'collectives_per_step': len(recs) / args.steps,
-                'allreduce_ms_per_step': round(sum(e0.elapsed_time(e1) for e0, e1, _ in recs) / args.steps, 4),
-                'allreduce_MB_per_step': round(sum(b for _, _, b in recs) / args.steps / 1e6, 2),
+                'collectives_per_step': len(recs) / steps,
+                'allreduce_ms_per_step': round(sum(e0.elapsed_time(e1) for e0, e1, _ in recs) / steps, 4),
+                'allreduce_MB_per_step': round(sum(b for _, _, b in recs) / steps / 1e6, 2),
                 # per collective of a step, in issue order: payload and mean duration on the comm stream
                 'per_collective': [{'MB': round(rs[0][2] / 1e6, 3),
                                     'ms': round(sum(e0.elapsed_time(e1) for e0, e1, _ in rs) / len(rs), 4)} for rs in by_slot],
                 # EXPOSED communication: time the consuming (compute) stream stood still waiting on a collective's `done`
                 # event -- everything else of allreduce_ms_per_step ran under compute kernels
-                'exposed_ms_per_step': round(sum(a.elapsed_time(b) for a, b, _ in waits) / args.steps, 4),
-                'waits_per_step': len(waits) / args.steps,
+                'exposed_ms_per_step': round(sum(a.elapsed_time(b) for a, b, _ in waits) / steps, 4),
+                'waits_per_step': len(waits) / steps,
                 'note': 'HIP events on the second (comm) stream around each gradient / loss-term all-reduce; they run '
                         'under the backward and discriminator kernels of the compute stream; exposed_ms_per_step = event '
                         'pairs on the compute stream around each wait for a collective'}
@@ -328,68 +378,103 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
+    res = {'comm': comm, 'elapsed': elapsed}
+    if rank != 0:
+        return res
+    value = batch * world * steps / elapsed
+    summ = prof.summary() if events != 'none' else wsum
+    # dominant kernel = the conv kernel symbol with the most device time (found in the profiled warm-up step)
+    sym, d = max(summ.items(), key=lambda kv: kv[1]['ms'])
+    if events == 'none':
+        d = dict(d, launches=d['launches'] * steps, ms=d['ms'] * steps, flops=d['flops'] * steps, kflops=d['kflops'] * steps)
+    timed_steps = steps if (events != 'dominant' or prof.limit is None) else max(1, d['launches'] // max(1, int(wsum[sym]['launches'])))
+    per_step_all = wsum                      # every conv kernel, from the profiled warm-up step
+    if not per_step_all:
+        per_step_all = {k: dict(launches=v['launches'] / steps, ms=v['ms'] / steps, flops=v['flops'] / steps,
+                                kflops=v['kflops'] / steps) for k, v in summ.items()}
+    conv_ms = sum(v['ms'] for v in per_step_all.values()) * steps
+    # achieved = FLOPs the kernel EXECUTED / its time (a Winograd kernel executes 2.25-2.56x fewer than the layer's
+    # direct-convolution count; crediting it with those would "exceed" the peak)
+    achieved = d['kflops'] / (d['ms'] * 1e-3) / 1e12
+    peak = FP32_MFMA_PEAK_TFLOPS if dtype == 'f32' else 2500.0     # dense MFMA peak of the multiply dtype
+    traffic, traffic_src = pmc_traffic(sym)
+    res.update({
+        'value': value, 'ms_per_step': elapsed / steps * 1e3, 'host_ms_per_step': host_ms / steps,
+        'activation_storage': 'bf16' if (dtype == 'bf16' and G.engine.act_bf) else 'f32',
+        'last_losses': {k: round(v, 5) for k, v in last.items()},
+        'roofline': {'bound': 'mfma', 'kernel': sym,
+                     'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                     'frac': round(achieved / peak, 4), 'traffic': traffic,
+                     'traffic_source': (f'{traffic_src} (committed rocprofv3 --pmc pass of the same command; not measured '
+                                        'in this run)') if traffic_src else None,
+                     'launches_per_step': d['launches'] / timed_steps, 'launches_timed': d['launches'],
+                     'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+                     'achieved_in_direct_conv_flops': round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2),
+                     'kernel_share_of_step': round(d['ms'] / timed_steps / (elapsed / steps * 1e3), 4),
+                     'all_conv_kernels_TFLOPs': round(sum(v['kflops'] for v in per_step_all.values()) * steps / (conv_ms * 1e-3) / 1e12, 2),
+                     'all_conv_kernels_direct_conv_TFLOPs': round(sum(v['flops'] for v in per_step_all.values()) * steps / (conv_ms * 1e-3) / 1e12, 2),
+                     'all_conv_share_of_step': round(conv_ms / steps / (elapsed / steps * 1e3), 4),
+                     'step_frac_of_mfma_roofline': round(value / world * cfg['gflop_per_image'] / 1e3 / peak, 4)},
+        'conv_kernels': {k: {'launches_per_step': v['launches'], 'ms_per_step': round(v['ms'], 4),
+                             'TFLOPs': round(v['kflops'] / (v['ms'] * 1e-3) / 1e12, 2),
+                             'direct_conv_TFLOPs': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)}
+                         for k, v in sorted(per_step_all.items(), key=lambda kv: -kv[1]['ms'])},
+    })
+    return res
 
-    if rank == 0:
-        images = BATCH_PER_GPU * world * args.steps
-        value = images / elapsed
-        summ = prof.summary() if args.events != 'none' else wsum
-        # dominant kernel = the conv kernel symbol with the most device time (found in the profiled warm-up step)
-        sym, d = max(summ.items(), key=lambda kv: kv[1]['ms'])
-        if args.events == 'none':
-            d = dict(d, launches=d['launches'] * args.steps, ms=d['ms'] * args.steps, flops=d['flops'] * args.steps,
-                     kflops=d['kflops'] * args.steps)
-        timed_steps = args.steps if (args.events != 'dominant' or prof.limit is None) else max(1, d['launches'] // max(1, int(wsum[sym]['launches'])))
-        per_step_all = wsum                      # every conv kernel, from the profiled warm-up step
-        if not per_step_all:
-            per_step_all = {k: dict(launches=v['launches'] / args.steps, ms=v['ms'] / args.steps, flops=v['flops'] / args.steps,
-                                    kflops=v['kflops'] / args.steps) for k, v in summ.items()}
-        conv_ms = sum(v['ms'] for v in per_step_all.values()) * args.steps
-        # achieved = FLOPs the kernel EXECUTED / its time (a Winograd kernel executes 2.25-2.56x fewer than the layer's
-        # direct-convolution count; crediting it with those would "exceed" the peak)
-        achieved = d['kflops'] / (d['ms'] * 1e-3) / 1e12
-        peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == 'f32' else 2500.0     # dense MFMA peak of the multiply dtype
-        traffic, traffic_src = pmc_traffic(sym)
-        roofline = {'bound': 'mfma', 'kernel': sym,
-                    'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / peak, 4), 'traffic': traffic,
-                    'traffic_source': (f'{traffic_src} (committed rocprofv3 --pmc pass of the same command; not measured '
-                                       'in this run)') if traffic_src else None,
-                    'launches_per_step': d['launches'] / timed_steps, 'launches_timed': d['launches'],
-                    'avg_launch_ms': round(d['ms'] / d['launches'], 4),
-                    'achieved_in_direct_conv_flops': round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2),
-                    'kernel_share_of_step': round(d['ms'] / timed_steps / (elapsed / args.steps * 1e3), 4),
-                    'all_conv_kernels_TFLOPs': round(sum(v['kflops'] for v in per_step_all.values()) * args.steps / (conv_ms * 1e-3) / 1e12, 2),
-                    'all_conv_kernels_direct_conv_TFLOPs': round(sum(v['flops'] for v in per_step_all.values()) * args.steps / (conv_ms * 1e-3) / 1e12, 2),
-                    'all_conv_share_of_step': round(conv_ms / args.steps / (elapsed / args.steps * 1e3), 4),
-                    'step_frac_of_mfma_roofline': round(value / world * GFLOP_PER_IMAGE / 1e3 / peak, 4)}
-        out = {
-            'metric': f'train images/sec (G+D step) at {SIZE}x{SIZE} bs={BATCH_PER_GPU} per GPU', 'value': round(value, 2),
-            'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'host_enqueue_ms_per_step': round(host_ms / args.steps, 3),
-            'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'activation_storage': ('bf16' if (args.dtype == 'bf16' and G.engine.act_bf) else 'f32'),
-            'config': {'workload': CFG['desc'] + ', dropout ' + ('on' if args.dropout else 'off'),
-                       'global_batch': BATCH_PER_GPU * world, 'parallelism': f'dp{world}'},
-            'last_losses': {k: round(v, 5) for k, v in last.items()},
-            'roofline': roofline,
-        }
-        if comm is not None:
-            out['comm'] = comm
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
-        elif world == 1:
-            out['cpu_baseline'] = None
-        out['conv_kernels_note'] = 'per-kernel table from one fully instrumented warm-up step; roofline from the timed region'
-        kernels = {k: {'launches_per_step': v['launches'], 'ms_per_step': round(v['ms'], 4),
-                                            'TFLOPs': round(v['kflops'] / (v['ms'] * 1e-3) / 1e12, 2),
-                                            'direct_conv_TFLOPs': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)}
-                   for k, v in sorted(per_step_all.items(), key=lambda kv: -kv[1]['ms'])}
-        out['conv_kernels'] = kernels
-        print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+
+def extra_configs(dev):
+    """BASELINE.json's remaining single-GPU configurations, for the driver's record (never the headline `value`):
+      cfg4_bf16  512x512x3 -> 4-class masks, bs 8, bf16 MFMA path with bf16 activation storage: 5 warm-up + 10 timed G+D steps
+      cfg5       1024x1024 image -> 25 tiles of 256x256 (overlap 0.9) through predict_image, nf = 64 fp32: 10 images after 2
+                 warm-up ones, device -> host copy of the mask included; tiles/s and peak device memory."""
+    import gc
+    import torch
+    out = {}
+    try:
+        gc.collect()
+        torch.cuda.empty_cache()
+        m = measure_training(CONFIGS['cfg4'], 'bf16', 10, 5, dev)
+        r = m['roofline']
+        out['cfg4_bf16'] = {
+            'workload': CONFIGS['cfg4']['desc'].replace('cfg4 (fp32 here; its bf16 path is a "next" row)', 'cfg4') + ', bf16 MFMA kernels, '
+                        + m['activation_storage'] + ' activation storage, dropout off',
+            'metric': 'train images/sec (G+D step) at 512x512 bs=8 per GPU', 'value': round(m['value'], 2), 'unit': 'images/sec',
+            'steps': 10, 'warmup': 5, 'ms_per_step': round(m['ms_per_step'], 3), 'dtype': 'bf16',
+            'roofline': {k: r[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source',
+                                           'launches_per_step', 'avg_launch_ms', 'kernel_share_of_step', 'all_conv_kernels_TFLOPs',
+                                           'step_frac_of_mfma_roofline')},
+            'conv_kernels': {k: v for k, v in list(m['conv_kernels'].items())[:8]}, 'last_losses': m['last_losses']}
+        del m
+    except Exception as e:          # the headline line must not be lost to an extra
+        out['cfg4_bf16'] = {'error': f'{type(e).__name__}: {e}'}
+    try:
+        import patchgan_amd as pg
+        from patchgan_amd.infer import predict_image
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.manual_seed(1234)
+        G = pg.UNet(3, 1, 64, use_dropout=False, activation='leakyrelu', final_act='sigmoid').to(dev).eval()
+        img = torch.rand(3, 1024, 1024, generator=torch.Generator().manual_seed(5)).to(dev)
+        for _ in range(2):
+            mask = predict_image(G, img, 256, 0.9, 0.5)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            mask = predict_image(G, img, 256, 0.9, 0.5)       # returns the host mask: each call ends with its D2H copy
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out['cfg5'] = {'workload': 'cfg5: 1024x1024x3 image -> 25 tiles of 256x256 (overlap 0.9) -> UNet nf=64 forward (fp32) -> '
+                                   'overlap-averaged, thresholded mask on the host (patchgan_infer predict_image)',
+                       'metric': 'tiles/sec', 'value': round(25 / dt, 1), 'unit': 'tiles/sec', 'images': n,
+                       'ms_per_image': round(dt * 1e3, 3), 'dtype': 'f32',
+                       'peak_vram_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 3),
+                       'mask_positive_fraction': round(float(mask.mean()), 4)}
+    except Exception as e:
+        out['cfg5'] = {'error': f'{type(e).__name__}: {e}'}
+    return out
 
 
 if __name__ == '__main__':

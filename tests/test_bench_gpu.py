@@ -13,11 +13,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(extra_args, extra_env, timeout=900):
+def _bench(extra_args, extra_env, timeout=900, extras=False):
     env = dict(os.environ, **extra_env)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline'] + extra_args,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline']
+                       + ([] if extras else ['--no-extra']) + extra_args,
                        env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
@@ -31,6 +32,23 @@ def test_bench_single_gpu_line():
     r = out['roofline']
     assert r['bound'] == 'mfma' and 0.05 < r['frac'] < 1.0 and r['kernel'].startswith('k_')
     assert 'comm' not in out
+    # every conv kernel the bench times is pinned per layer at this geometry and batch size (tests/test_bench_layers_gpu.py)
+    from tests import bench_layers as BL
+    planned = {s for k, v in BL.committed_plan().items() if k.startswith('cfg2-fp32-') for s in v}
+    assert set(out['conv_kernels']) <= planned, set(out['conv_kernels']) - planned
+
+
+def test_bench_extra_configs_ride_on_the_headline_line():
+    """The default N = 1 run also measures BASELINE.json's other single-GPU configurations after the headline's timed region -- cfg4
+    in bf16 (images/s, dominant-kernel fraction of the bf16 MFMA peak) and cfg5 tiled inference (tiles/s, peak VRAM) -- under
+    `extra_configs` of the same single line; the headline metric / config / dtype stay cfg2 fp32."""
+    out = _bench([], {}, extras=True)
+    assert out['dtype'] == 'f32' and out['config']['workload'].startswith('cfg2') and '256x256 bs=16' in out['metric']
+    x4, x5 = out['extra_configs']['cfg4_bf16'], out['extra_configs']['cfg5']
+    assert 'error' not in x4 and 'error' not in x5, out['extra_configs']
+    assert x4['dtype'] == 'bf16' and x4['value'] > 100 and x4['roofline']['peak'] == 2500.0 and 0.02 < x4['roofline']['frac'] < 1.0
+    assert 'bf16' in x4['roofline']['kernel'] and 'bf16 activation storage' in x4['workload']
+    assert x5['unit'] == 'tiles/sec' and x5['value'] > 500 and 0.5 < x5['peak_vram_GiB'] < 40
 
 
 def test_bench_rccl_path_one_rank():

@@ -233,3 +233,15 @@ def test_tensors_beyond_the_32_bit_offset_limit_are_never_planned_onto_the_bf16_
             ctypes.byref(op.g), 0, _lib.ALGO_BF16 | _lib.IO_MASK, op.ws_arg)))
         t = view(N, 128, 128, 64, 128)
         assert op.mul_ok(dst, view(N, 128, 128, 64, 128), t) in ((True, False) if fits else (False,))
+
+
+def test_bench_kernel_plan_is_the_committed_one():
+    """tests/golden/bench_kernel_plan.json (written by tools/dump_kernel_plan.py) names, for every conv call of the benchmark
+    configurations at their exact batch sizes, the kernel the planner picks; the per-layer GPU parity test carries those symbols in
+    its ids.  A planner or kernel change that moves a call to another kernel fails HERE, on the CPU, until the plan is re-dumped
+    (and the new kernel thereby enters the per-layer test)."""
+    from tests import bench_layers as BL
+    live, committed = BL.live_plan(), BL.committed_plan()
+    assert sorted(live) == sorted(committed)
+    diff = {k: (committed[k], live[k]) for k in live if live[k] != committed[k]}
+    assert not diff, diff

@@ -5,6 +5,7 @@
     the oracle's n_crop / unet_forward / build_mask; tiles/s and peak VRAM are printed;
   * cfg2 at full width: step-1 weight gradients of the big layers against the oracle's autograd gradients.
 Needs an MI355X."""
+import os
 import time
 
 import numpy as np
@@ -197,3 +198,220 @@ def test_cfg2_full_width_gradients_vs_oracle(tmp_path):
     keys = [k for _, k, _, _ in rows]
     for key in ('encoder.3.model.DownConv3.weight', 'decoder.3.model.UpConv3.weight', 'model.6.weight'):
         assert key in keys       # the big layers named in the review are among those compared
+
+
+def test_cfg2_layer_local_generator_gradients_at_bench_batch():
+    """SURVEY 8(d)'s gradient gate (1e-4) where it can be checked: LAYER-LOCALLY, at the benchmark's width AND batch size (cfg2:
+    nf = ndf = 64, 256 x 256, B = 16, so the kernels are the ones bench.py times).  The end-to-end generator gradients are
+    ill-conditioned at this width (test_cfg2_full_width_gradients_vs_oracle bounds them at 2e-2 in relative L2: InstanceNorm over
+    2 x 2 ... 8 x 8 planes amplifies 1e-6 forward differences), which says nothing about a single kernel.  Here the whole G + D
+    forward / backward of step 1 runs ONCE in float64 (torch double ops on the GPU, the oracle's functions) and hands every
+    generator conv layer its REAL operands -- the layer's input x_l and the gradient dy_l arriving at its conv output, with their
+    real dynamic range -- rounded to fp32; the HIP kernels then compute dW_l = wgrad(x_l, dy_l) and dx_l = dgrad(dy_l, W_l) from
+    exactly those, and are compared with float64 on the same rounded operands: identical inputs, so the difference is kernel
+    error alone.  Stated tolerance: relative max-norm 1e-4 for every dW and dx of the 14 layers (measured: <= 3e-5)."""
+    import torch.nn.functional as F
+    from patchgan_amd import engine as E, _lib as L
+    from tests.bench_layers import Operand
+    from tests.test_bench_layers_gpu import _store, _empty, _read, _unpack
+    B = 16
+    _, _, gw, dw = _models(1, 'sigmoid')
+    x, y = _inputs(B, 1, 256)
+    w64 = {k: v.cuda().double().requires_grad_(True) for k, v in gw.items()}
+    d64 = {k: v.cuda().double() for k, v in dw.items()}
+    x64, y64 = x.cuda().double(), y.cuda().double()
+    # the oracle's generator forward (oracle/patchgan_oracle.py unet_forward), keeping every conv's input and output
+    convs, skips, h = [], [], x64
+    for i in range(7):
+        inp = h
+        yv = F.conv2d(inp, w64[f'encoder.{i}.model.DownConv{i}.weight'], None, stride=2, padding=1)
+        convs.append((f'enc{i}', False, inp, yv))
+        h = O.apply_act(O.instance_norm(yv), 'leakyrelu')
+        skips.append(h)
+    hidden, skips = skips[-1], skips[::-1]
+    for i in range(7):
+        inp = hidden if i == 0 else torch.cat([h, skips[i]], dim=1)
+        yv = F.conv_transpose2d(inp, w64[f'decoder.{i}.model.UpConv{i}.weight'], None, stride=2, padding=1)
+        convs.append((f'dec{i}', True, inp, yv))
+        h = O.instance_norm(yv) if 1 <= i <= 5 else yv
+        h = O.apply_act(h, 'sigmoid' if i == 6 else 'leakyrelu')
+    for _, _, inp, yv in convs:
+        yv.retain_grad()
+        if inp.requires_grad:
+            inp.retain_grad()
+    dfake = O.disc_forward(d64, torch.cat((x64, h), 1), 3, False)
+    loss = O.seg_loss('tversky', h, y64, 200) + F.binary_cross_entropy(dfake, torch.ones_like(dfake))   # trainer.py:71-85
+    loss.backward()
+    enc_ops, dec_ops = E.GeneratorEngine(3, 1, 64, 'leakyrelu', 'sigmoid', False).ops(B, 256, 256)
+    rows = []
+    for (name, transposed, inp, yv), op in zip(convs, enc_ops + dec_ops):
+        key = f"{'decoder' if transposed else 'encoder'}.{name[3:]}.model.{'UpConv' if transposed else 'DownConv'}{name[3:]}.weight"
+        W = w64[key].detach().float()                       # [a, b, 4, 4]
+        P = W.permute(2, 3, 0, 1).contiguous().reshape(-1)
+        xl, dyl = inp.detach().float(), yv.grad.float()     # the layer's real operands, rounded to fp32 once
+        Ca, Cb = op.Ca, op.Cb
+        dP = torch.full((16 * Ca * Cb,), float('nan'), device='cuda')
+        if transposed:     # small = x_l, big = dy_l: dW = wgrad(x, dy), dx = conv(dy, W)      (aten::convolution_backward of a ConvTranspose2d)
+            vs, vb = _store(xl.double(), Operand()), _store(dyl.double(), Operand())
+            dx = _empty(op.N, op.Hs, op.Ws, Ca, Operand())
+            op.bwd_big(vs, vb, P, dP, 0, dx)
+            want_dw = torch.nn.grad.conv2d_weight(dyl.double(), W.shape, xl.double(), stride=2, padding=1)
+            want_dx = F.conv2d(dyl.double(), W.double(), None, stride=2, padding=1)
+        else:              # big = x_l, small = dy_l: dW = wgrad(dy, x), dx = convT(dy, W)
+            vb = _store(xl.double(), Operand(ldm=1 if name == 'enc0' else 2))
+            vs = _store(dyl.double(), Operand())
+            op.wgrad(vs, vb, dP, 0)
+            want_dw = torch.nn.grad.conv2d_weight(xl.double(), W.shape, dyl.double(), stride=2, padding=1)
+            dx = want_dx = None
+            if name != 'enc0':
+                dx = _empty(op.N, op.Hb, op.Wb, Cb, Operand())
+                op.small2big(vs, P, 0, None, 0, dx)
+                want_dx = F.conv_transpose2d(dyl.double(), W.double(), None, stride=2, padding=1)
+        torch.cuda.synchronize()
+        e_w = _rel(_unpack(dP, Ca, Cb), want_dw)
+        e_x = _rel(_read(dx), want_dx) if dx is not None else 0.0
+        # ... and the float64 gradient of the whole network agrees with the local float64 one (the hand-over is the right one)
+        assert _rel(want_dw, w64[key].grad) < 1e-5, name
+        rows.append((name, op.describe(2)[0], e_w, op.describe(0 if transposed else 1)[0], e_x))
+        assert e_w < 1e-4 and e_x < 1e-4, rows[-1]
+    print('cfg2 B=16 layer-local generator gradients vs float64 on identical operands (relative max-norm):')
+    for name, kw, e_w, kx, e_x in rows:
+        print(f'   {name:5s} dW {e_w:.1e} [{kw}]   dx {e_x:.1e} [{kx}]')
+
+
+# ---- cfg1: the COCO-stuff example's hyper-parameters (examples/train_coco.yaml:13-28) ----------------------------------------------
+# nf = 32, ndf = 16, n_layers = 5, relu, sigmoid head, 7 classes, weighted BCE x 200, lr 1e-3 / decay 0.95, batch 4; at 256 x 256 (the
+# reference UNet cannot run its nominal 64 x 64 crops: seven stride-2 stages + InstanceNorm, SURVEY section 5)
+_CFG1 = dict(nf=32, ndf=16, n_layers=5, out_nc=7, activation='relu', final_act='sigmoid', loss_type='weighted_bce', batch=4)
+
+
+def test_cfg1_coco_hyperparameters_two_steps_vs_oracle(tmp_path):
+    """BASELINE config 1 on the HIP path: two training steps at the COCO yaml's exact hyper-parameters (dropout off: the CPU's
+    dropout stream cannot be reproduced) against the CPU oracle (fp32) and its float64 run.
+
+    Stated tolerances: generator output at the initial weights within 2e-4 (max-norm) of the CPU oracle; each of the six loss
+    scalars of both steps within max(1e-4, 4 x E) of the float64 trajectory, E = the fp32 CPU oracle's own distance from float64
+    at that step (ReLU + weighted BCE + a 5-layer discriminator amplify fp32 rounding quickly: SURVEY / DESIGN section 4); step-1
+    parameter gradients of the discriminator within 2e-4 (relative max-norm) of float64, of the generator within 2e-2 in
+    relative L2 and 8 x the fp32 oracle's own distance + 1e-3 (conditioning, as at cfg2)."""
+    import patchgan_amd as pg
+    c = _CFG1
+    torch.manual_seed(1234)
+    g = pg.UNet(3, c['out_nc'], c['nf'], use_dropout=False, activation=c['activation'], final_act=c['final_act'])
+    d = pg.Discriminator(3 + c['out_nc'], c['ndf'], n_layers=c['n_layers'])
+    gw = {k: v.clone() for k, v in g.state_dict().items()}
+    dw = {k: v.clone() for k, v in d.state_dict().items()}
+    x, y = _inputs(c['batch'], c['out_nc'], 256)
+    kw = dict(activation=c['activation'], final_act=c['final_act'], n_layers=c['n_layers'], norm=False, loss_type=c['loss_type'])
+    o64 = O.OracleTrainer({k: v.cuda() for k, v in gw.items()}, {k: v.cuda() for k, v in dw.items()}, dtype=torch.float64, **kw)
+    o32 = O.OracleTrainer(gw, dw, **kw)
+    c64, c32, grads64, grads32 = [], [], None, None
+    for step in range(2):
+        l64, l32 = o64.batch(x.cuda(), y.cuda(), train=True), o32.batch(x, y, train=True)
+        c64.append([float(l64[k]) for k in LOSS_KEYS])
+        c32.append([float(l32[k]) for k in LOSS_KEYS])
+        if step == 0:
+            grads64 = {n: {k: v.clone() for k, v in o64.last[n].items()} for n in ('g_grads', 'd_grads')}
+            grads32 = {n: {k: v.clone() for k, v in o32.last[n].items()} for n in ('g_grads', 'd_grads')}
+    c64, c32 = np.array(c64), np.array(c32)
+    with torch.no_grad():
+        out0 = O.unet_forward(gw, x, c['activation'], c['final_act'])
+    g.cuda()
+    d.cuda()
+    # the planner's choices at these widths (nf 32 / ndf 16: below the Winograd thresholds on most layers) are part of the record
+    enc_ops, dec_ops = g.engine.ops(c['batch'], 256, 256)
+    print('cfg1 kernels: G', [op.describe(0)[0] for op in enc_ops], [op.describe(1)[0] for op in dec_ops])
+    print('cfg1 kernels: D', [op.describe(0)[0] for op in d.engine.ops(2 * c['batch'], 256, 256)])
+    with torch.no_grad():
+        g.train()
+        e_out = _rel(g(x.cuda()).cpu(), out0)
+    t = pg.Trainer(g, d, str(tmp_path / 'c'))
+    t.loss_type = c['loss_type']
+    t.setup_optimizers(1e-3, 1e-3)
+    d.train()
+    got = []
+    for step in range(2):
+        l = t.batch(x, y, train=True)
+        got.append([float(l[k]) for k in LOSS_KEYS])
+        if step == 0:
+            gg = {k: p.grad.clone() for k, p in g.named_parameters()}
+            dg = {k: p.grad.clone() for k, p in d.named_parameters()}
+    got = np.array(got)
+    e64, e32, env = _relrows(got, c64), _relrows(got, c32), _relrows(c32, c64)
+    print(f'cfg1: output vs CPU oracle {e_out:.2e}; losses vs float64 {e64}, vs fp32 CPU {e32}; fp32 CPU oracle vs float64 {env}')
+    assert e_out < 2e-4
+    assert (e64 <= np.maximum(1e-4, 4 * env)).all(), (e64, env)
+
+    def l2(a, b):
+        a, b = a.double().cpu(), b.double().cpu()
+        return ((a - b).norm() / b.norm()).item()
+    for k, v in dg.items():
+        e, noise = _rel(v, grads64['d_grads'][k]), _rel(grads32['d_grads'][k], grads64['d_grads'][k])
+        assert e <= max(2e-4, 4 * noise), ('D', k, e, noise)
+    for k, v in gg.items():
+        e, noise = l2(v, grads64['g_grads'][k]), l2(grads32['g_grads'][k], grads64['g_grads'][k])
+        assert e < 2e-2 and e <= 8 * noise + 1e-3, ('G', k, e, noise)
+
+
+def test_cfg1_patchgan_train_epoch_on_coco_files(tmp_path, monkeypatch, capsys):
+    """BASELINE config 1 end to end: one `patchgan_train` epoch (+ validation, checkpoint) driven by the reference's example YAML
+    (examples/train_coco.yaml: the FLAT legacy schema, COCOStuff dataset type, randomcrop+flip, 7 labels, relu / dropout /
+    sigmoid, n_disc_layers 5, weighted_bce, decay 0.95, load_last_checkpoint with no checkpoint yet) on synthetic COCO-stuff
+    files -- JPEG images + PNG label maps of mixed sizes, resized to 256 x 256 by the dataset -- at batch size 4."""
+    from PIL import Image
+    from patchgan_amd.train import patchgan_train
+    rng = np.random.default_rng(3)
+    for split, n in (('train2017', 12), ('val2017', 4)):
+        os.makedirs(tmp_path / split)
+        for i in range(n):
+            h, w = (300, 340) if i % 2 else (256, 256)
+            img = rng.integers(0, 255, (h, w, 3), dtype=np.uint8)
+            lab = np.full((h, w), 255, dtype=np.uint8)                 # COCO-stuff "unlabeled" = 255 -> wraps to 0 after the + 1
+            for cls in range(8):                                       # stored label = class - 1 (the dataset adds 1)
+                a = 20 + 25 * cls
+                lab[a:a + 40, a:a + 60] = cls
+                img[a:a + 40, a:a + 60] = 30 * cls
+            Image.fromarray(img).save(tmp_path / split / f'{i + 1:012d}.jpg', quality=92)
+            Image.fromarray(lab).save(tmp_path / split / f'{i + 1:012d}.png')
+    cfg = f"""
+dataset:
+  type: COCOStuff
+  augmentation: randomcrop+flip
+  size: 256
+train_data:
+  images: {tmp_path}/train2017
+  masks: {tmp_path}/train2017
+  labels: [1, 2, 3, 4, 5, 6, 7]
+validation_data:
+  images: {tmp_path}/val2017
+  masks: {tmp_path}/val2017
+  labels: [1, 2, 3, 4, 5, 6, 7]
+model_params:
+  gen_filts: 32
+  disc_filts: 16
+  activation: relu
+  use_dropout: True
+  final_activation: sigmoid
+  n_disc_layers: 5
+checkpoint_path: {tmp_path}/checkpoints/checkpoint-COCO/
+load_last_checkpoint: True
+train_params:
+  loss_type: weighted_bce
+  seg_alpha: 200
+  gen_learning_rate: 1.e-3
+  disc_learning_rate: 1.e-3
+  decay_rate: 0.95
+  save_freq: 1
+"""
+    (tmp_path / 'train_coco.yaml').write_text(cfg)
+    monkeypatch.chdir(tmp_path)
+    G_ep, D_ep = patchgan_train(['-c', 'train_coco.yaml', '-n', '1', '-b', '4', '--dataloader_workers', '0'])
+    out = capsys.readouterr().out
+    assert 'Loaded 12 images' in out and 'Loaded 4 images' in out and 'No checkpoints found!' in out
+    assert len(G_ep) == 1 and np.isfinite(G_ep[0]) and np.isfinite(D_ep[0]) and 0 < D_ep[0] < 5
+    ck = tmp_path / 'checkpoints' / 'checkpoint-COCO'
+    assert sorted(os.listdir(ck)) == ['discriminator_ep_001.pth', 'generator_ep_001.pth']
+    sd = torch.load(ck / 'generator_ep_001.pth')
+    assert sd['encoder.0.model.DownConv0.weight'].shape == (32, 3, 4, 4) and sd['decoder.6.model.UpConv6.weight'].shape == (64, 7, 4, 4)
+    dd = torch.load(ck / 'discriminator_ep_001.pth')
+    assert dd['model.0.weight'].shape == (16, 10, 4, 4) and len([k for k in dd if k.endswith('.weight')]) == 7

@@ -110,11 +110,12 @@ def test_loss_curve_vs_golden(name, tmp_path):
 def test_gradients_vs_oracle(name, tmp_path):
     """Step-1 parameter gradients (G after the generator backward, D after the discriminator backward).
 
-    Stated tolerance: relative max-norm error against the fp32 CPU oracle OR against its fp64 run (whichever is
-    closer) within max(2e-4, 4 x the fp32 oracle's own distance from fp64).  Both references are needed: oneDNN's
-    fp32 result for cancellation-heavy gradients (D layer 0 under norm=True) moves by 1e-2 with the host thread
-    count (<= 16 threads vs >= 64, measured), so neither alone is a stable yardstick; the committed golden probes
-    (reference, 8 threads) are checked as well."""
+    Stated tolerance: relative max-norm error against the oracle run in float64 within max(2e-4, 4 x noise), where noise is the
+    fp32 CPU oracle's own distance from that float64 run -- the yardstick is float64 alone (no best-of-several references); the
+    fp32 oracle only measures how much fp32 rounding the configuration amplifies.  (oneDNN's fp32 result for cancellation-heavy
+    gradients -- D layer 0 under norm=True -- moves by 1e-2 with the host thread count, <= 16 threads vs >= 64, measured: that is
+    noise in this sense, and tests/conftest.py pins the thread count to <= 16.)  The distances from the fp32 oracle and from the
+    committed golden probes (reference, 8 threads) are printed for the record."""
     gold = Golden(name)
     g, d, t = build(gold, tmp_path)
     x, y = gold.inputs()
@@ -125,7 +126,7 @@ def test_gradients_vs_oracle(name, tmp_path):
     t.batch(x, y, train=True)
     got = ({k: v.grad for k, v in g.named_parameters()}, {k: v.grad for k, v in d.named_parameters()})
     gp = (gold.probes('ggrad1'), gold.probes('dgrad1'))
-    worst = (0, None)
+    worst = (-1.0, '')
     for i in (0, 1):
         for k, want in g64[i].items():
             e64 = _rel(got[i][k].cpu(), want)
@@ -133,9 +134,8 @@ def test_gradients_vs_oracle(name, tmp_path):
             noise = _rel(g32[i][k], want)
             pr_got, pr_want = probe(got[i][k]), gp[i][k]
             e_probe = np.abs(pr_got[2:] - pr_want[2:]).max() / max(np.abs(pr_want[2:]).max(), 1e-30)
-            e = min(e64, e32, e_probe)
-            worst = max(worst, (e / max(noise, 5e-5), k))
-            assert e <= max(2e-4, 4 * noise), (k, e64, e32, e_probe, noise)
+            worst = max(worst, (e64 / max(noise, 5e-5), k, e64, e32, e_probe, noise))
+            assert e64 <= max(2e-4, 4 * noise), (k, e64, e32, e_probe, noise)
     print(name, 'worst grad error ratio vs fp32 oracle noise', worst)
 
 
