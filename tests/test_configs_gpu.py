@@ -272,7 +272,7 @@ def test_cfg2_layer_local_generator_gradients_at_bench_batch():
         e_x = _rel(_read(dx), want_dx) if dx is not None else 0.0
         # ... and the float64 gradient of the whole network agrees with the local float64 one (the hand-over is the right one)
         assert _rel(want_dw, w64[key].grad) < 1e-5, name
-        rows.append((name, op.describe(2)[0], e_w, op.describe(0 if transposed else 1)[0], e_x))
+        rows.append((name, op.describe(2)[0], e_w, op.describe(0 if transposed else 1)[0] if dx is not None else 'no dx: the image', e_x))
         assert e_w < 1e-4 and e_x < 1e-4, rows[-1]
     print('cfg2 B=16 layer-local generator gradients vs float64 on identical operands (relative max-norm):')
     for name, kw, e_w, kx, e_x in rows:
