@@ -328,6 +328,22 @@ int pg_loss_prepare(const double* S, int N, int C, float beta, double* local2, v
 #define PG_LOSS_BCE 3
 int pg_loss_finalize(const double* S, const double* gsum2, int mode, int N, int C, int HW, int Bglobal,
                      float alpha, float beta, float gamma, float* coef, float* loss_out, void* stream);
+/* gsum2 == NULL (one process: nothing to all-reduce): pg_loss_finalize computes the two terms of pg_loss_prepare itself.
+ *
+ * The same loss evaluation in TWO launches instead of five (losses.py:18-39 + trainer.py:71-85,101-103 are a handful of
+ * elementwise / reduction ATen ops per term; here: one reduction pass, one value + gradient pass):
+ *   pg_loss_reduce_parts   stage 1 without its combine launch: S receives the partial slabs [nsplit][N*C][5]; returns nsplit >= 1
+ *                          (the buffer size is pg_loss_reduce_doubles(N, HW, C) as before) or a negative PG_E* code
+ *   pg_loss_value_grad     adds the slabs in slab order, forms gsum2 (or takes the all-reduced one), writes the loss value to
+ *                          loss_out and -- g != NULL -- the gradient wrt p into g, with exactly the arithmetic of
+ *                          pg_loss_reduce's combine + pg_loss_prepare + pg_loss_finalize + pg_loss_grad (bit-identical results).
+ *                          S_out (may be NULL) receives the summed S[N*C][5].  Needs N*C <= 256 (PG_EINVAL beyond: use the
+ *                          staged entry points). */
+int pg_loss_reduce_parts(const float* p, int ld_p, const float* y, int ld_y, float tconst, int N, int HW, int C, double* S,
+                         void* stream);
+int pg_loss_value_grad(const double* Spart, int nsplit, double* S_out, const double* gsum2, int mode, int N, int C, int HW,
+                       int Bglobal, float alpha, float beta, float gamma, const float* p, int ld_p, const float* y, int ld_y,
+                       float tconst, float* g, int ld_g, float* loss_out, void* stream);
 
 /* ---- optimizer (torch.optim.Adam defaults, trainer.py:169-172) -----------------------------------
  * m += (g-m)*(1-b1); v = v*b2 + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt_bc2 + eps)

@@ -127,11 +127,30 @@ __global__ void k_loss_prepare(const double* __restrict__ S, int N, int C, float
     local2[1] = sy;
 }
 
-__global__ void k_loss_finalize(const double* __restrict__ S, const double* __restrict__ gsum2, int mode, int N, int C,
+// the two batch-global terms of pg_loss_prepare, in its summation order
+__device__ inline void loss_sums(const double* S, int N, int C, double beta, double& acc, double& sy) {
+    acc = 0;
+    sy = 0;
+    for (int n = 0; n < N; ++n) {
+        double tp, denom;
+        tversky_terms(S, n, C, beta, tp, denom);
+        acc += 1.0 - (tp + 1.0) / denom;
+        for (int c = 0; c < C; ++c) sy += S[((long)n * C + c) * 5 + 1];
+    }
+}
+
+__global__ void k_loss_finalize(const double* __restrict__ S, const double* __restrict__ gsum2_in, int mode, int N, int C,
                                 int HW, int Bglobal, float alpha, float beta, float gamma, float* __restrict__ coef,
                                 float* __restrict__ loss_out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const double cnt = (double)Bglobal * C * HW;
+    double gsum2[2] = {0, 0};
+    if (gsum2_in) {
+        gsum2[0] = gsum2_in[0];
+        gsum2[1] = gsum2_in[1];
+    } else if (mode == PG_LOSS_TVERSKY || mode == PG_LOSS_WBCE) {
+        loss_sums(S, N, C, (double)beta, gsum2[0], gsum2[1]);
+    }
     if (mode == PG_LOSS_TVERSKY) {
         const double m = gsum2[0] / (double)Bglobal;
         *loss_out = (float)((double)alpha * pow(m, (double)gamma));
@@ -197,6 +216,97 @@ __global__ void k_loss_grad(const float* __restrict__ p, int ld_p, const float* 
     }
 }
 
+// Stages 1 (tail) + 1b + 2 + 3 in ONE launch (no data parallelism between them): every workgroup first rebuilds the small per-(n, c)
+// table -- the five sums (adding pg_loss_reduce's nsplit partial slabs in z order, as k_loss_combine does), the two batch-global terms
+// (gsum2, or computed here in pg_loss_prepare's order when gsum2 == NULL) and the gradient coefficients, all with the arithmetic of
+// k_loss_combine / k_loss_prepare / k_loss_finalize -- in LDS, workgroup 0 also writes the loss value and the summed S, then the grid
+// strides over the gradient elements like k_loss_grad.  N * C <= FUSED_MAX_NC; the grid is small (<= 512 workgroups) so that the
+// redundant table builds stay a few MB of L2 reads.
+constexpr int FUSED_MAX_NC = 256;
+__global__ __launch_bounds__(256) void k_loss_fused(const double* __restrict__ Spart, int nsplit, double* __restrict__ S_out,
+                                                    const double* __restrict__ gsum2_in, int lmode, int N, int C, int HW, int Bglobal,
+                                                    float alpha, float beta, float gamma, const float* __restrict__ p, int ld_p,
+                                                    const float* __restrict__ y, int ld_y, float tconst, float* __restrict__ g, int ld_g,
+                                                    float* __restrict__ loss_out) {
+    __shared__ double S[FUSED_MAX_NC * 5];
+    __shared__ float coef[FUSED_MAX_NC * 2];
+    __shared__ double gs[2];
+    const int tid = threadIdx.x, NC = N * C, n5 = NC * 5;
+    for (int i = tid; i < n5; i += 256) {
+        double v = 0.0;
+        for (int z = 0; z < nsplit; ++z) v += Spart[(long)z * n5 + i];
+        S[i] = v;
+        if (blockIdx.x == 0 && S_out) S_out[i] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (gsum2_in) {
+            gs[0] = gsum2_in[0];
+            gs[1] = gsum2_in[1];
+        } else if (lmode == PG_LOSS_TVERSKY || lmode == PG_LOSS_WBCE) {
+            loss_sums(S, N, C, (double)beta, gs[0], gs[1]);
+        } else {
+            gs[0] = gs[1] = 0.0;
+        }
+    }
+    __syncthreads();
+    const double cnt = (double)Bglobal * C * HW;
+    if (lmode == PG_LOSS_TVERSKY) {
+        const double m = gs[0] / (double)Bglobal;
+        const double Kf = (double)alpha * (double)gamma * pow(m, (double)gamma - 1.0) / (double)Bglobal;
+        for (int n = tid; n < N; n += 256) {
+            double tp, denom;
+            tversky_terms(S, n, C, (double)beta, tp, denom);
+            const float c1 = (float)(-Kf / denom);
+            const float c0 = (float)(Kf * (tp + 1.0) * (1.0 - (double)beta) / (denom * denom));
+            for (int c = 0; c < C; ++c) {
+                coef[(n * C + c) * 2 + 0] = c1;
+                coef[(n * C + c) * 2 + 1] = c0;
+            }
+        }
+        if (blockIdx.x == 0 && tid == 0) *loss_out = (float)((double)alpha * pow(m, (double)gamma));
+    } else {
+        for (int i = tid; i < NC; i += 256) {
+            float w = 1.f;
+            if (lmode == PG_LOSS_WBCE && C > 1) w = 1.f - (float)S[i * 5 + 1] / (float)gs[1];
+            coef[i * 2 + 0] = (lmode == PG_LOSS_WBCE) ? (float)((double)alpha * (double)w / cnt) : (float)((double)alpha / cnt);
+            coef[i * 2 + 1] = 0.f;
+        }
+        if (blockIdx.x == 0 && tid == 0) {          // the value: k_loss_finalize's sums, in its (n, c) order
+            const int k = (lmode == PG_LOSS_MAE) ? 4 : 3;
+            double acc = 0;
+            for (int i = 0; i < NC; ++i) {
+                float w = 1.f;
+                if (lmode == PG_LOSS_WBCE && C > 1) w = 1.f - (float)S[i * 5 + 1] / (float)gs[1];
+                acc += (lmode == PG_LOSS_WBCE) ? (double)w * S[i * 5 + 3] : S[i * 5 + k];
+            }
+            *loss_out = (float)((double)alpha * acc / cnt);
+        }
+    }
+    __syncthreads();
+    if (!g) return;
+    const int gmode = lmode == PG_LOSS_TVERSKY ? 0 : lmode == PG_LOSS_MAE ? 2 : 1;
+    const long total = (long)N * HW * C;
+    for (long i = blockIdx.x * (long)blockDim.x + tid; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        const int n = (int)(pix / HW);
+        const float pv = p[pix * ld_p + c];
+        const float yv = y ? y[pix * ld_y + c] : tconst;
+        const float k0 = coef[(n * C + c) * 2 + 0], k1 = coef[(n * C + c) * 2 + 1];
+        float r;
+        if (gmode == 0) {
+            r = k0 * yv + k1;
+        } else if (gmode == 1) {
+            r = k0 * (pv - yv) / fmaxf((1.f - pv) * pv, 1e-12f);
+        } else {
+            const float d = pv - yv;
+            r = k0 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+        g[pix * ld_g + c] = r;
+    }
+}
+
 // pixel splits per (n, c) -- per n for the four-channel kernel -- so that a loss over a large map runs on >= ~256 workgroups
 inline bool loss_c4(int HW, int C) { return C == 4 && HW >= 4096; }
 int loss_nsplit(int N, int HW, int C) {
@@ -243,6 +353,33 @@ int pg_loss_reduce(const float* p, int ld_p, const float* y, int ld_y, float tco
     return pg_launch_status();
 }
 
+/* pg_loss_reduce without its combine launch: S receives the nsplit partial slabs [z][N*C][5] (nsplit = the return value >= 1; with
+ * nsplit == 1 that IS the result) -- for pg_loss_value_grad, which adds them itself. */
+int pg_loss_reduce_parts(const float* p, int ld_p, const float* y, int ld_y, float tconst, int N, int HW, int C, double* S,
+                         void* stream) {
+    if (!p || !S || N <= 0 || HW <= 0 || C <= 0 || ld_p < C || (y && ld_y < C)) return PG_EINVAL;
+    const int nsplit = loss_nsplit(N, HW, C);
+    if (loss_c4(HW, C) && nsplit > 1)
+        hipLaunchKernelGGL(k_loss_reduce_c4, dim3(N, nsplit), dim3(256), 0, (hipStream_t)stream, p, ld_p, y, ld_y, tconst, HW, N, S);
+    else
+        hipLaunchKernelGGL(k_loss_reduce, dim3(N * C, nsplit), dim3(256), 0, (hipStream_t)stream, p, ld_p, y, ld_y, tconst, HW, C, S);
+    return hipGetLastError() == hipSuccess ? nsplit : PG_ELAUNCH;
+}
+
+int pg_loss_value_grad(const double* Spart, int nsplit, double* S_out, const double* gsum2, int mode, int N, int C, int HW,
+                       int Bglobal, float alpha, float beta, float gamma, const float* p, int ld_p, const float* y, int ld_y,
+                       float tconst, float* g, int ld_g, float* loss_out, void* stream) {
+    if (!Spart || !loss_out || nsplit < 1 || N <= 0 || C <= 0 || HW <= 0 || Bglobal < N || N * C > FUSED_MAX_NC) return PG_EINVAL;
+    if (mode < PG_LOSS_TVERSKY || mode > PG_LOSS_BCE) return PG_EINVAL;
+    if (g && (!p || ld_p < C || ld_g < C || (y && ld_y < C))) return PG_EINVAL;
+    long b = g ? ((long)N * HW * C + 2047) / 2048 : 1;      // >= 8 elements per thread: the per-workgroup table build stays cheap
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(k_loss_fused, dim3((int)b), dim3(256), 0, (hipStream_t)stream, Spart, nsplit, S_out, gsum2, mode, N, C, HW,
+                       Bglobal, alpha, beta, gamma, p, ld_p, y, ld_y, tconst, g, ld_g, loss_out);
+    return pg_launch_status();
+}
+
 int pg_loss_prepare(const double* S, int N, int C, float beta, double* local2, void* stream) {
     if (!S || !local2 || N <= 0 || C <= 0) return PG_EINVAL;
     hipLaunchKernelGGL(k_loss_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, S, N, C, beta, local2);
@@ -251,7 +388,7 @@ int pg_loss_prepare(const double* S, int N, int C, float beta, double* local2, v
 
 int pg_loss_finalize(const double* S, const double* gsum2, int mode, int N, int C, int HW, int Bglobal, float alpha,
                      float beta, float gamma, float* coef, float* loss_out, void* stream) {
-    if (!S || !gsum2 || !coef || !loss_out || N <= 0 || C <= 0 || HW <= 0 || Bglobal < N) return PG_EINVAL;
+    if (!S || !coef || !loss_out || N <= 0 || C <= 0 || HW <= 0 || Bglobal < N) return PG_EINVAL;      // gsum2 == NULL: computed here
     if (mode < PG_LOSS_TVERSKY || mode > PG_LOSS_BCE) return PG_EINVAL;
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, S, gsum2, mode, N, C, HW, Bglobal,
                        alpha, beta, gamma, coef, loss_out);

@@ -1130,23 +1130,37 @@ class LossBuffers:
 
 class PendingLoss:
     """A loss evaluation whose batch-global reduction terms are still being summed across ranks."""
-    __slots__ = ('buf', 'wait', 'args')
+    __slots__ = ('buf', 'wait', 'args', 'nsplit', 'sums')
+
+
+_FUSED_LOSS_MAX_NC = 256        # pg_loss_value_grad's table (N * C entries) lives in LDS
 
 
 def loss_begin(p, y, tconst, beta=0.75, allreduce=None, need_sums=True):
     """Phase 1 of a loss term over prediction View p against target View y (or the constant tconst): the per-sample
     reductions and the two batch-global terms.  `allreduce(tensor)` starts their SUM across ranks under data parallelism
-    and returns a wait() callable; anything enqueued between loss_begin and loss_finish overlaps that exchange."""
+    and returns a wait() callable; anything enqueued between loss_begin and loss_finish overlaps that exchange.
+    In one process there is nothing to exchange between the phases: phase 1 is then ONE launch (pg_loss_reduce_parts) and phase 2
+    one more (pg_loss_value_grad adds the partial slabs, forms the batch-global terms, the value and the gradient)."""
     lib = L.load()
     buf = LossBuffers(p.N, p.C, p.t.device, p.HW)
     st = _stream()
-    L.check(lib.pg_loss_reduce(p.ptr(), p.ld, y.ptr() if y is not None else None, y.ld if y is not None else 0,
-                               float(tconst), p.N, p.HW, p.C, buf.S.data_ptr(), st), 'pg_loss_reduce')
-    if need_sums:      # the two batch-global terms: only focal-Tversky and weighted BCE read them (pg_loss_finalize)
-        L.check(lib.pg_loss_prepare(buf.S.data_ptr(), p.N, p.C, beta, buf.sums.data_ptr(), st), 'pg_loss_prepare')
     h = PendingLoss()
-    h.buf, h.args = buf, (p, y, tconst, beta)
-    h.wait = allreduce(buf.sums) if (allreduce is not None and need_sums) else None
+    h.buf, h.args, h.wait, h.sums = buf, (p, y, tconst, beta), None, None
+    yp, yl = (y.ptr(), y.ld) if y is not None else (None, 0)
+    exchange = allreduce is not None and need_sums
+    if not exchange and p.N * p.C <= _FUSED_LOSS_MAX_NC:
+        h.nsplit = int(lib.pg_loss_reduce_parts(p.ptr(), p.ld, yp, yl, float(tconst), p.N, p.HW, p.C, buf.S.data_ptr(), st))
+        if h.nsplit < 1:
+            L.check(h.nsplit, 'pg_loss_reduce_parts')
+        return h
+    h.nsplit = 0          # staged: S is the combined result
+    L.check(lib.pg_loss_reduce(p.ptr(), p.ld, yp, yl, float(tconst), p.N, p.HW, p.C, buf.S.data_ptr(), st), 'pg_loss_reduce')
+    if need_sums:      # the two batch-global terms: only focal-Tversky and weighted BCE read them
+        L.check(lib.pg_loss_prepare(buf.S.data_ptr(), p.N, p.C, beta, buf.sums.data_ptr(), st), 'pg_loss_prepare')
+        h.sums = buf.sums
+    if exchange:
+        h.wait = allreduce(buf.sums)
     return h
 
 
@@ -1159,13 +1173,19 @@ def loss_finish(h, mode, alpha, grad_out, loss_out, loss_slot, bglobal, gamma=0.
     if h.wait is not None:
         h.wait()
     st = _stream()
-    L.check(lib.pg_loss_finalize(buf.S.data_ptr(), buf.sums.data_ptr(), mode, p.N, p.C, p.HW, bglobal, alpha, beta, gamma,
+    yp, yl = (y.ptr(), y.ld) if y is not None else (None, 0)
+    sums = h.sums.data_ptr() if h.sums is not None else None
+    if p.N * p.C <= _FUSED_LOSS_MAX_NC:
+        gp, gl = (grad_out.ptr(), grad_out.ld) if grad_out is not None else (None, 0)
+        L.check(lib.pg_loss_value_grad(buf.S.data_ptr(), max(h.nsplit, 1), None, sums, mode, p.N, p.C, p.HW, bglobal, alpha, beta, gamma,
+                                       p.ptr(), p.ld, yp, yl, float(tconst), gp, gl, L.ptr(loss_out, loss_slot), st), 'pg_loss_value_grad')
+        return buf
+    L.check(lib.pg_loss_finalize(buf.S.data_ptr(), sums, mode, p.N, p.C, p.HW, bglobal, alpha, beta, gamma,
                                  buf.coef.data_ptr(), L.ptr(loss_out, loss_slot), st), 'pg_loss_finalize')
     if grad_out is not None:
         gmode = {L.LOSS_TVERSKY: 0, L.LOSS_WBCE: 1, L.LOSS_BCE: 1, L.LOSS_MAE: 2}[mode]
-        L.check(lib.pg_loss_grad(p.ptr(), p.ld, y.ptr() if y is not None else None, y.ld if y is not None else 0,
-                                 float(tconst), buf.coef.data_ptr(), grad_out.ptr(), grad_out.ld, p.N, p.HW, p.C, gmode,
-                                 st), 'pg_loss_grad')
+        L.check(lib.pg_loss_grad(p.ptr(), p.ld, yp, yl, float(tconst), buf.coef.data_ptr(), grad_out.ptr(), grad_out.ld, p.N, p.HW, p.C,
+                                 gmode, st), 'pg_loss_grad')
     return buf
 
 

@@ -228,7 +228,7 @@ class Trainer:
             real.channels(Cin, Cout).from_nchw(y)
         xin, yv, gen = fake.channels(0, Cin), real.channels(Cin, Cout), fake.channels(Cin, Cout)
 
-        losses = torch.zeros(8, dtype=torch.float32, device=dev)   # seg, gdisc, real*0.5, fake*0.5
+        losses = torch.empty(4, dtype=torch.float32, device=dev)   # seg, gdisc, real*0.5, fake*0.5 (each written by its loss kernel)
         allred = dist.all_reduce_side if dist.on else None
 
         # ---- generator step
@@ -303,7 +303,7 @@ class Trainer:
         # the step's one device-to-host copy, asynchronous into a pinned slot: the returned dict waits for it on first access
         ring = getattr(self, '_loss_ring', None)
         if ring is None or ring[0][0].device != torch.device('cpu'):
-            ring = self._loss_ring = [[torch.empty(8, dtype=torch.float32).pin_memory(), None] for _ in range(4)]
+            ring = self._loss_ring = [[torch.empty(4, dtype=torch.float32).pin_memory(), None] for _ in range(4)]
             self._loss_slot = 0
         slot = ring[self._loss_slot]
         self._loss_slot = (self._loss_slot + 1) % len(ring)

@@ -389,6 +389,57 @@ def test_bce_const_target(target):
     assert rel_err(vg.to_nchw(), p.grad) < 2e-5
 
 
+@pytest.mark.parametrize('mode_name,N,C,H,W', [('tversky', 16, 1, 256, 256), ('tversky', 3, 4, 64, 80), ('weighted_bce', 8, 4, 128, 128),
+                                               ('weighted_bce', 4, 7, 64, 64), ('MAE', 2, 2, 40, 24), ('bce', 16, 1, 30, 30),
+                                               ('bce', 40, 7, 8, 8)])
+def test_two_launch_loss_equals_the_staged_one(mode_name, N, C, H, W):
+    """pg_loss_reduce_parts + pg_loss_value_grad (one reduction launch, one value + gradient launch: what Trainer.batch runs in one
+    process) are bit-identical to the staged pg_loss_reduce (+ combine) / pg_loss_prepare / pg_loss_finalize / pg_loss_grad chain
+    that data parallelism keeps (the batch-global terms are all-reduced between its stages) -- with and without a caller-supplied
+    gsum2, with and without a gradient, on split and unsplit reductions (four-channel kernel included); beyond N*C = 256 the
+    two-launch form refuses and the engine stages."""
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view, empty_view, DEV
+    lib = L.load()
+    mode = {'tversky': L.LOSS_TVERSKY, 'weighted_bce': L.LOSS_WBCE, 'MAE': L.LOSS_MAE, 'bce': L.LOSS_BCE}[mode_name]
+    gmode = {L.LOSS_TVERSKY: 0, L.LOSS_WBCE: 1, L.LOSS_BCE: 1, L.LOSS_MAE: 2}[mode]
+    g = torch.Generator().manual_seed(9)
+    p = to_view(torch.rand(N, C, H, W, generator=g).clamp(1e-4, 1 - 1e-4), ld=C + 3, off=1)
+    y = to_view((torch.rand(N, C, H, W, generator=g) > 0.7).float()) if mode != L.LOSS_BCE else None
+    yp, yl = (y.ptr(), y.ld) if y is not None else (None, 0)
+    nd = int(lib.pg_loss_reduce_doubles(N, H * W, C))
+    # staged
+    S = torch.full((nd,), float('nan'), dtype=torch.float64, device=DEV)
+    sums = torch.zeros(2, dtype=torch.float64, device=DEV)
+    coef = torch.empty(N * C * 2, device=DEV)
+    out1, g1 = torch.full((2,), float('nan'), device=DEV), empty_view(N, H, W, C)
+    L.check(lib.pg_loss_reduce(p.ptr(), p.ld, yp, yl, 1.0, N, H * W, C, S.data_ptr(), None), 'reduce')
+    L.check(lib.pg_loss_prepare(S.data_ptr(), N, C, 0.75, sums.data_ptr(), None), 'prepare')
+    L.check(lib.pg_loss_finalize(S.data_ptr(), sums.data_ptr(), mode, N, C, H * W, N, 200.0, 0.75, 0.75, coef.data_ptr(), out1.data_ptr(), None), 'fin')
+    L.check(lib.pg_loss_grad(p.ptr(), p.ld, yp, yl, 1.0, coef.data_ptr(), g1.ptr(), g1.ld, N, H * W, C, gmode, None), 'grad')
+    # two launches; gsum2 computed inside / supplied; value only
+    for supplied in (False, True):
+        S2 = torch.full((nd,), float('nan'), dtype=torch.float64, device=DEV)
+        Sout = torch.full((N * C * 5,), float('nan'), dtype=torch.float64, device=DEV)
+        out2, g2, out3 = torch.full((2,), float('nan'), device=DEV), empty_view(N, H, W, C), torch.full((2,), float('nan'), device=DEV)
+        ns = lib.pg_loss_reduce_parts(p.ptr(), p.ld, yp, yl, 1.0, N, H * W, C, S2.data_ptr(), None)
+        assert ns >= 1
+        gs = sums.data_ptr() if supplied else None
+        L.check(lib.pg_loss_value_grad(S2.data_ptr(), ns, Sout.data_ptr(), gs, mode, N, C, H * W, N, 200.0, 0.75, 0.75, p.ptr(), p.ld, yp, yl,
+                                       1.0, g2.ptr(), g2.ld, out2.data_ptr(), None), 'value_grad')
+        L.check(lib.pg_loss_value_grad(S2.data_ptr(), ns, None, gs, mode, N, C, H * W, N, 200.0, 0.75, 0.75, None, 0, None, 0,
+                                       1.0, None, 0, out3.data_ptr(), None), 'value')
+        torch.cuda.synchronize()
+        assert torch.equal(out2[0], out1[0]) and torch.equal(out3[0], out1[0]), (out1, out2, out3)
+        assert torch.equal(g2.to_nchw(), g1.to_nchw())
+        assert torch.equal(Sout, S[:N * C * 5])
+    if mode_name == 'tversky' and N == 16:
+        assert ns > 1                      # the benchmark's segmentation loss runs the split reduction
+    big = torch.zeros(300 * 5, dtype=torch.float64, device=DEV)
+    assert lib.pg_loss_value_grad(big.data_ptr(), 1, None, None, L.LOSS_BCE, 300, 1, 4, 300, 1.0, 0.75, 0.75, None, 0, None, 0, 1.0, None, 0,
+                                  out1.data_ptr(), None) == -1
+
+
 def test_adam_matches_torch():
     from patchgan_amd import engine as E
     from tests.gpu_util import DEV
