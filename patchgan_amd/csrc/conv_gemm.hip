@@ -1472,6 +1472,132 @@ __global__ __launch_bounds__(256) void k_b2s_tapk(const float* __restrict__ big,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same layers (1..4 big-side channels) as a PERSISTENT, software-pipelined kernel.  The one-shot form above serialises, per
+// workgroup, gather -> LDS -> 64 MFMAs per wave -> stores, reloads the 16-KB weight tile from L2 with scalar loads for every 128
+// pixels, and ran at 2.1 TB/s / 33 % MFMA busy on layers whose MFMA time (2.15 GFLOP at batch 16) and HBM time (84 MB) are both
+// ~15 us.  Here a workgroup keeps its weight FRAGMENTS in registers for its whole life (K / 2 floats per lane), walks pixel tiles
+// t = blockIdx.x, + gridDim.x, ... (neighbouring workgroups work on neighbouring tiles: the 4-row input windows overlap in L2), and
+// issues the gather loads of tile t + 1 into registers before the MFMAs of tile t, so that within ONE workgroup the loads of the
+// next tile, the MFMAs of this one and the stores of the previous one overlap; four workgroups per CU interleave on top of that.
+// ------------------------------------------------------------------------------------------------
+template <int CB>
+__global__ __launch_bounds__(256) void k_b2s_tapkp(const float* __restrict__ big, int ld_big, const float* __restrict__ P,
+                                                   float* __restrict__ out, int ld_out, Geom g, const float* __restrict__ bias,
+                                                   int act, int wide, int vec_out, int ntiles) {
+    constexpr int K = 16 * CB, LDT = K + 4, TM = 128, MI = 2, TPT = 8;
+    __shared__ __attribute__((aligned(16))) float As[TM * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int M = g.N * g.Hs * g.Ws, HWs = g.Hs * g.Ws;
+    const int n0 = blockIdx.y * 64;
+    // weight fragments of this wave's 32 output channels, for the whole kernel: bfr[kk][e] = W[a][k = 8 kk + 4 lh + e], k = tap * CB + c
+    f32x4 bfr[K / 8];
+    {
+        const int a = n0 + wn * 32 + lrow;
+#pragma unroll
+        for (int kk = 0; kk < K / 8; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = kk * 8 + lh * 4 + e, tap = k / CB, c = k - tap * CB;
+                bfr[kk][e] = a < g.Ca ? P[((long)tap * g.Ca + a) * CB + c] : 0.f;
+            }
+    }
+    f32x4 bv[4];           // bias of this lane's four channel quads
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ch = n0 + wn * 32 + 8 * q + 4 * lh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[q][e] = (bias != nullptr && ch + e < g.Ca) ? bias[ch + e] : 0.f;
+    }
+    // gather role of this thread: pixel r of the tile, taps t0 .. t0 + 7 (16 * 128 items / 256 threads)
+    const int r = tid & (TM - 1), t0 = (tid / TM) * TPT;
+    float pre[TPT][CB == 3 ? 4 : CB];
+    auto gather = [&](int tile) {
+        const int m = tile * TM + r;
+        const int mm = min(m, M - 1);
+        const int n = mm / HWs;
+        const int rem = mm - n * HWs;
+        const int p = rem / g.Ws, q = rem - p * g.Ws;
+        const int h0 = g.s * p - 1, w0 = g.s * q - 1;
+        const float* base = big + ((long)(n * g.Hb + h0) * g.Wb + w0) * ld_big;
+#pragma unroll
+        for (int tt = 0; tt < TPT; ++tt) {
+            const int tap = t0 + tt, kh = tap >> 2, kw = tap & 3;
+            const bool ok = m < M && (unsigned)(h0 + kh) < (unsigned)g.Hb && (unsigned)(w0 + kw) < (unsigned)g.Wb;
+            const float* src = base + ((long)kh * g.Wb + kw) * ld_big;
+            if ((CB == 4 || CB == 3) && wide) {        // one 16-byte load per tap (CB == 3: the 4th float, inside the pixel's ld, is dropped)
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(src) : z;
+#pragma unroll
+                for (int c = 0; c < (CB == 3 ? 4 : CB); ++c) pre[tt][c] = v[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) pre[tt][c] = ok ? src[c] : 0.f;
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int tt = 0; tt < TPT; ++tt) {
+            float* dst = &As[r * LDT + (t0 + tt) * CB];
+            if (CB == 4) {
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = pre[tt][c];
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) dst[c] = pre[tt][c];
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) gather(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        stage();
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) gather(tile + gridDim.x);      // in flight under the MFMAs below
+        f32x16 acc[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) acc[i][rr] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < K / 8; ++kk) {
+            f32x4 af[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MI + i) * 32 + lrow) * LDT + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[kk][e], af[i][e], acc[i], 0, 0, 0);   // D[channel][pixel]
+        }
+        __syncthreads();           // every wave has read its fragments: As may be overwritten by the next stage()
+        const int m0 = tile * TM;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + (wm * MI + i) * 32 + lrow;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = n0 + wn * 32 + 8 * q + 4 * lh;
+                if (m >= M || ch >= g.Ca) continue;
+                if (vec_out) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = pg_act_epi(acc[i][4 * q + e] + bv[q][e], act);
+                    *reinterpret_cast<f32x4*>(out + (long)m * ld_out + ch) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (ch + e < g.Ca) out[(long)m * ld_out + ch + e] = pg_act_epi(acc[i][4 * q + e] + bv[q][e], act);
+                }
+            }
+        }
+    }
+}
+
 // ================================================================================================
 // bf16 variants (PG_ALGO_BF16; the "next" row f2, BASELINE config 4): tensors stay fp32 in HBM and in the C ABI -- fp32
 // master weights, fp32 InstanceNorm statistics, fp32 accumulation -- but operand tiles are rounded to bf16 (RNE,
@@ -2735,6 +2861,13 @@ inline size_t b2s_tapn_ws(const Geom& g) { return (size_t)g.N * g.Hb * g.Wb * 16
         default: hipLaunchKernelGGL((k_wgrad_fast<1, 1, 2, 2, POW2>), grid, dim3(256), 0, st, __VA_ARGS__); break; \
     }
 
+inline bool tapkp_enabled() {          // PATCHGAN_TAPK_ONESHOT=1 (experiment): the one-shot k_b2s_tapk instead of the persistent k_b2s_tapkp
+    static const bool off = [] {
+        const char* e = pg_exp_env("PATCHGAN_TAPK_ONESHOT");
+        return e && e[0] == '1';
+    }();
+    return !off;
+}
 inline bool tapk_enabled() {
     static const bool off = [] {
         const char* e = pg_exp_env("PATCHGAN_NO_TAPK");
@@ -3133,7 +3266,7 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
         fl = (g->stride == 1) ? pg_wino_wgrad_flops(g->N, g->Hs, g->Ws, g->Ca, g->Cb)
                               : 2.0 * 16 * g->N * cd(g->Hs, 3) * cd(g->Ws, 3) * g->Ca * 4.0 * g->Cb;
     } else if (mode == 8) {
-        snprintf(buf, sizeof buf, "k_b2s_tapk<%d>", tid);
+        snprintf(buf, sizeof buf, (tid <= 4 && tapkp_enabled()) ? "k_b2s_tapkp<%d>" : "k_b2s_tapk<%d>", tid);
         sp = 1;
     } else if (mode == 7) {          // polyphase Winograd of a stride-2 layer
         snprintf(buf, sizeof buf, "k_wino_bgemm%s<%s>", tid >= 2 ? "_mz" : "", (tid & 1) ? "1,2,2,2" : "2,2,2,2");
@@ -3277,6 +3410,19 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
         const int tmk = g.Cb <= 4 ? 128 : 64;
         dim3 grid((unsigned)(((long)g.N * g.Hs * g.Ws + tmk - 1) / tmk), (g.Ca + 63) / 64, 1);
         TimedLaunch timed(st);
+        if (g.Cb <= 4 && tapkp_enabled()) {
+            // persistent form: 4 workgroups per CU (LDS 17 .. 35 KB, <= 128 VGPRs), each walking tiles blockIdx.x, + gridDim.x, ...
+            const int ntiles = (int)grid.x;
+            const int wide = (g.Cb >= 3) && (ld_big % 4 == 0) && (ld_big >= 4) && aligned16(big);
+            dim3 pgrid((unsigned)std::min<long>(ntiles, std::max<long>(1, 1024 / (long)grid.y)), grid.y, 1);
+            switch (g.Cb) {
+                case 1: hipLaunchKernelGGL(k_b2s_tapkp<1>, pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, wide, vec_out, ntiles); break;
+                case 2: hipLaunchKernelGGL(k_b2s_tapkp<2>, pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, wide, vec_out, ntiles); break;
+                case 3: hipLaunchKernelGGL(k_b2s_tapkp<3>, pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, wide, vec_out, ntiles); break;
+                default: hipLaunchKernelGGL(k_b2s_tapkp<4>, pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, wide, vec_out, ntiles); break;
+            }
+            return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+        }
         switch (g.Cb) {
             case 1: hipLaunchKernelGGL(k_b2s_tapk<1>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4, vec_out); break;
             case 2: hipLaunchKernelGGL(k_b2s_tapk<2>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4, vec_out); break;
