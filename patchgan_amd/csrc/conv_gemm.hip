@@ -1474,46 +1474,62 @@ __global__ __launch_bounds__(256) void k_b2s_tapk(const float* __restrict__ big,
 
 // ------------------------------------------------------------------------------------------------
 // The same layers (1..4 big-side channels) as a PERSISTENT, software-pipelined kernel.  The one-shot form above serialises, per
-// workgroup, gather -> LDS -> 64 MFMAs per wave -> stores, reloads the 16-KB weight tile from L2 with scalar loads for every 128
-// pixels, and ran at 2.1 TB/s / 33 % MFMA busy on layers whose MFMA time (2.15 GFLOP at batch 16) and HBM time (84 MB) are both
-// ~15 us.  Here a workgroup keeps its weight FRAGMENTS in registers for its whole life (K / 2 floats per lane), walks pixel tiles
-// t = blockIdx.x, + gridDim.x, ... (neighbouring workgroups work on neighbouring tiles: the 4-row input windows overlap in L2), and
-// issues the gather loads of tile t + 1 into registers before the MFMAs of tile t, so that within ONE workgroup the loads of the
-// next tile, the MFMAs of this one and the stores of the previous one overlap; four workgroups per CU interleave on top of that.
+// workgroup, gather -> LDS -> 64 MFMAs per wave -> stores, and the co-resident workgroups of a CU run those phases in lockstep:
+// measured on d0 at batch 32 (ablation builds, tools/ab_tapkp.sh) the phase times simply ADD -- 19 us of loads / staging, 28 us of
+// MFMAs (= the fp32 MFMA peak for the layer's 4.3 GFLOP) and 17 us of stores give the 67-77 us of the launch: nothing overlaps.
+// Here ONE wave keeps all three in flight: a workgroup holds its weight FRAGMENTS in registers for its whole life, walks pixel
+// tiles t = blockIdx.x, + gridDim.x, ... (neighbouring workgroups work on neighbouring tiles: the 4-row input windows overlap in
+// L2) with two accumulator sets and two LDS buffers, and inside the MFMA sequence of tile t it issues, one group per k-step,
+// the bias / activation / 16-byte stores of tile t - 1 (the other accumulator set), while the gather loads of tile t + 1 are in
+// flight; their LDS stores go to the other buffer after the last MFMA has been issued.  One barrier per tile.
 // ------------------------------------------------------------------------------------------------
-template <int CB>
-__global__ __launch_bounds__(256) void k_b2s_tapkp(const float* __restrict__ big, int ld_big, const float* __restrict__ P,
-                                                   float* __restrict__ out, int ld_out, Geom g, const float* __restrict__ bias,
-                                                   int act, int wide, int vec_out, int ntiles) {
-    constexpr int K = 16 * CB, LDT = K + 4, TM = 128, MI = 2, TPT = 8;
-    __shared__ __attribute__((aligned(16))) float As[TM * LDT];
+// Branch-free: gathers are raw buffer loads whose offset is forced out of range for padding / ragged rows (the hardware returns 0),
+// stores are raw buffer stores dropped the same way, the activation is a template parameter -- the whole tile step is ONE basic block,
+// so hipcc keeps the interleave below (an earlier form with `ok ? *src : 0` loads compiled to a branch and an `s_waitcnt vmcnt(0)` per
+// load: the phases ran strictly one after the other again).
+// ACT: 0 none, 1 LeakyReLU(0.2) (other activations: the one-shot kernel).  WIDE: one 16-byte load per tap (CB == 4, or CB == 3 inside
+// pixels of stride % 4 == 0: the 4th float is dropped), else CB scalar loads.
+template <int CB, int ACT, bool WIDE>
+__global__ __launch_bounds__(256, 2) void k_b2s_tapkp(const float* __restrict__ big, int ld_big, const float* __restrict__ P,
+                                                      float* __restrict__ out, int ld_out, Geom g, const float* __restrict__ bias,
+                                                      int big_bytes, int out_bytes, int ntiles) {
+    constexpr int K = 16 * CB, LDT = K + 4, TM = 128, MI = 2, TPT = 8, NKK = K / 8, PC = WIDE ? 4 : CB;
+    __shared__ __attribute__((aligned(16))) float smem[2 * TM * LDT];
+    const __amdgpu_buffer_rsrc_t rbig = __builtin_amdgcn_make_buffer_rsrc((void*)big, 0, big_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane & 31, lh = lane >> 5;
     const int M = g.N * g.Hs * g.Ws, HWs = g.Hs * g.Ws;
     const int n0 = blockIdx.y * 64;
     // weight fragments of this wave's 32 output channels, for the whole kernel: bfr[kk][e] = W[a][k = 8 kk + 4 lh + e], k = tap * CB + c
-    f32x4 bfr[K / 8];
+    f32x4 bfr[NKK];
     {
-        const int a = n0 + wn * 32 + lrow;
+        const int a = min(n0 + wn * 32 + lrow, g.Ca - 1);        // (rows beyond Ca are computed and never stored)
 #pragma unroll
-        for (int kk = 0; kk < K / 8; ++kk)
+        for (int kk = 0; kk < NKK; ++kk) {
+            if (CB == 4) {                 // k = 4 tap + c with tap = 2 kk + lh: the tap's four channels are 16 contiguous, aligned bytes
+                bfr[kk] = *reinterpret_cast<const f32x4*>(P + ((long)(2 * kk + lh) * g.Ca + a) * 4);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = kk * 8 + lh * 4 + e, tap = k / CB, c = k - tap * CB;
-                bfr[kk][e] = a < g.Ca ? P[((long)tap * g.Ca + a) * CB + c] : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const int k = kk * 8 + lh * 4 + e, tap = k / CB, c = k - tap * CB;
+                    bfr[kk][e] = P[((long)tap * g.Ca + a) * CB + c];
+                }
             }
+        }
     }
-    f32x4 bv[4];           // bias of this lane's four channel quads
+    // bias of this lane's four channel quads (channels n0 + 32 wn + 8 q + 4 lh .. + 3; Ca % 4 == 0)
+    f32x4 bv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int ch = n0 + wn * 32 + 8 * q + 4 * lh;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[q][e] = (bias != nullptr && ch + e < g.Ca) ? bias[ch + e] : 0.f;
+        const int ch = min(n0 + wn * 32 + 8 * q + 4 * lh, g.Ca - 4);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        bv[q] = bias != nullptr ? *reinterpret_cast<const f32x4*>(bias + ch) : z;
     }
     // gather role of this thread: pixel r of the tile, taps t0 .. t0 + 7 (16 * 128 items / 256 threads)
     const int r = tid & (TM - 1), t0 = (tid / TM) * TPT;
-    float pre[TPT][CB == 3 ? 4 : CB];
+    float pre[TPT][PC];
     auto gather = [&](int tile) {
         const int m = tile * TM + r;
         const int mm = min(m, M - 1);
@@ -1521,24 +1537,23 @@ __global__ __launch_bounds__(256) void k_b2s_tapkp(const float* __restrict__ big
         const int rem = mm - n * HWs;
         const int p = rem / g.Ws, q = rem - p * g.Ws;
         const int h0 = g.s * p - 1, w0 = g.s * q - 1;
-        const float* base = big + ((long)(n * g.Hb + h0) * g.Wb + w0) * ld_big;
+        const int base = ((n * g.Hb + h0) * g.Wb + w0) * ld_big;       // element offset of the window's first pixel (may be negative: masked)
 #pragma unroll
         for (int tt = 0; tt < TPT; ++tt) {
             const int tap = t0 + tt, kh = tap >> 2, kw = tap & 3;
-            const bool ok = m < M && (unsigned)(h0 + kh) < (unsigned)g.Hb && (unsigned)(w0 + kw) < (unsigned)g.Wb;
-            const float* src = base + ((long)kh * g.Wb + kw) * ld_big;
-            if ((CB == 4 || CB == 3) && wide) {        // one 16-byte load per tap (CB == 3: the 4th float, inside the pixel's ld, is dropped)
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(src) : z;
+            const bool ok = (m < M) & ((unsigned)(h0 + kh) < (unsigned)g.Hb) & ((unsigned)(w0 + kw) < (unsigned)g.Wb);
+            const int eo = base + (kh * g.Wb + kw) * ld_big;
+            if (WIDE) {
+                const f32x4 v = bload4(rbig, voff(eo, ok));
 #pragma unroll
-                for (int c = 0; c < (CB == 3 ? 4 : CB); ++c) pre[tt][c] = v[c];
+                for (int c = 0; c < 4; ++c) pre[tt][c] = v[c];
             } else {
 #pragma unroll
-                for (int c = 0; c < CB; ++c) pre[tt][c] = ok ? src[c] : 0.f;
+                for (int c = 0; c < CB; ++c) pre[tt][c] = bload1(rbig, voff(eo + c, ok));
             }
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](float* As) {
 #pragma unroll
         for (int tt = 0; tt < TPT; ++tt) {
             float* dst = &As[r * LDT + (t0 + tt) * CB];
@@ -1553,47 +1568,74 @@ __global__ __launch_bounds__(256) void k_b2s_tapkp(const float* __restrict__ big
             }
         }
     };
-    int tile = blockIdx.x;
-    if (tile < ntiles) gather(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
-        stage();
-        __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) gather(tile + gridDim.x);      // in flight under the MFMAs below
-        f32x16 acc[MI];
+    // store group gi = (i, q) of a finished tile: pixel lrow of row tile i, channels 8 q + 4 lh .. + 3 of this wave's 32
+    auto store_group = [&](const f32x16 (&ac)[MI], int tile_done, int gi) {
+        const int i = gi >> 2, q = gi & 3;
+        const int m = tile_done * TM + (wm * MI + i) * 32 + lrow;
+        const int ch = n0 + wn * 32 + 8 * q + 4 * lh;
+        const bool ok = (m < M) & (ch < g.Ca);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = ac[i][4 * q + e] + bv[q][e];
+            v[e] = ACT == 1 ? (x > 0.f ? x : 0.2f * x) : x;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, voff(m * ld_out + ch, ok), 0, 0);
+    };
+    // one tile: MFMAs of `tile` from As into `cur`, the stores of `prev_tile` (accumulators `prev`) woven between the k-steps, then
+    // the next tile's staged registers into the other LDS buffer
+    auto step = [&](f32x16 (&cur)[MI], const f32x16 (&prev)[MI], int prev_tile, const float* As, float* As_next, int next2) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) acc[i][rr] = 0.f;
+            for (int rr = 0; rr < 16; ++rr) cur[i][rr] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < K / 8; ++kk) {
+        for (int kk = 0; kk < NKK; ++kk) {
             f32x4 af[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MI + i) * 32 + lrow) * LDT + kk * 8 + lh * 4]);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[kk][e], af[i][e], acc[i], 0, 0, 0);   // D[channel][pixel]
+                for (int i = 0; i < MI; ++i) cur[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[kk][e], af[i][e], cur[i], 0, 0, 0);   // D[channel][pixel]
+#pragma unroll
+            for (int gi = (kk * 8) / NKK; gi < ((kk + 1) * 8) / NKK; ++gi) store_group(prev, prev_tile, gi);
+            __builtin_amdgcn_sched_barrier(0);         // keep the stores of the previous tile BETWEEN the MFMA groups
         }
-        __syncthreads();           // every wave has read its fragments: As may be overwritten by the next stage()
-        const int m0 = tile * TM;
+        stage(As_next);            // (registers of the tile after this one; zeros beyond the last tile)
+        __syncthreads();           // As_next is complete; every wave is done reading As (it is overwritten one step later)
+        gather(next2);             // the tile two steps ahead (>= ntiles: every load out of range, no traffic)
+    };
+    float* A0 = smem;
+    float* A1 = smem + TM * LDT;
+    f32x16 accA[MI], accB[MI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + (wm * MI + i) * 32 + lrow;
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ch = n0 + wn * 32 + 8 * q + 4 * lh;
-                if (m >= M || ch >= g.Ca) continue;
-                if (vec_out) {
-                    f32x4 v;
+        for (int rr = 0; rr < 16; ++rr) accB[i][rr] = 0.f;
+    const int G = gridDim.x, big_tile = 0x3fffff;      // big_tile * TM >= M: every row masked
+    int tile = blockIdx.x;
+    gather(tile);
+    stage(A0);
+    __syncthreads();
+    gather(tile + G < ntiles ? tile + G : big_tile);
+    int prev_tile = big_tile;      // nothing to store in the first step
+    for (;;) {
+        step(accA, accB, prev_tile, A0, A1, tile + 2 * G < ntiles ? tile + 2 * G : big_tile);
+        prev_tile = tile;
+        tile += G;
+        if (tile >= ntiles) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = pg_act_epi(acc[i][4 * q + e] + bv[q][e], act);
-                    *reinterpret_cast<f32x4*>(out + (long)m * ld_out + ch) = v;
-                } else {
+            for (int gi = 0; gi < 8; ++gi) store_group(accA, prev_tile, gi);
+            break;
+        }
+        step(accB, accA, prev_tile, A1, A0, tile + 2 * G < ntiles ? tile + 2 * G : big_tile);
+        prev_tile = tile;
+        tile += G;
+        if (tile >= ntiles) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (ch + e < g.Ca) out[(long)m * ld_out + ch + e] = pg_act_epi(acc[i][4 * q + e] + bv[q][e], act);
-                }
-            }
+            for (int gi = 0; gi < 8; ++gi) store_group(accB, prev_tile, gi);
+            break;
         }
     }
 }
@@ -3410,17 +3452,30 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
         const int tmk = g.Cb <= 4 ? 128 : 64;
         dim3 grid((unsigned)(((long)g.N * g.Hs * g.Ws + tmk - 1) / tmk), (g.Ca + 63) / 64, 1);
         TimedLaunch timed(st);
-        if (g.Cb <= 4 && tapkp_enabled()) {
-            // persistent form: 4 workgroups per CU (LDS 17 .. 35 KB, <= 128 VGPRs), each walking tiles blockIdx.x, + gridDim.x, ...
+        const long big_b = tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb), out_b = tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca);
+        if (g.Cb <= 4 && tapkp_enabled() && vec_out && (act == PG_ACT_NONE || act == PG_ACT_LEAKY) && big_b < FAST_LIMIT && out_b < FAST_LIMIT &&
+            (g.Cb != 4 || vec4) && (long)g.N * g.Hs * g.Ws < 0x3fffffL * 64) {
+            // persistent form: 2 workgroups per CU (two LDS buffers of 9 .. 35 KB, two accumulator sets), each walking tiles blockIdx.x, + gridDim.x, ...
             const int ntiles = (int)grid.x;
-            const int wide = (g.Cb >= 3) && (ld_big % 4 == 0) && (ld_big >= 4) && aligned16(big);
-            dim3 pgrid((unsigned)std::min<long>(ntiles, std::max<long>(1, 1024 / (long)grid.y)), grid.y, 1);
+            static const int pwg = pg_exp_env("PATCHGAN_TAPKP_WG") ? atoi(pg_exp_env("PATCHGAN_TAPKP_WG")) : 512;
+            const bool wide3 = (g.Cb == 3) && (ld_big % 4 == 0) && (ld_big >= 4) && aligned16(big);
+            dim3 pgrid((unsigned)std::min<long>(ntiles, std::max<long>(1, pwg / (long)grid.y)), grid.y, 1);
+#define PG_TAPKP(CB_, WIDE_)                                                                                                            \
+    do {                                                                                                                                \
+        if (act == PG_ACT_LEAKY)                                                                                                        \
+            hipLaunchKernelGGL((k_b2s_tapkp<CB_, 1, WIDE_>), pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, (int)big_b, \
+                               (int)out_b, ntiles);                                                                                \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((k_b2s_tapkp<CB_, 0, WIDE_>), pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, (int)big_b, \
+                               (int)out_b, ntiles);                                                                                \
+    } while (0)
             switch (g.Cb) {
-                case 1: hipLaunchKernelGGL(k_b2s_tapkp<1>, pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, wide, vec_out, ntiles); break;
-                case 2: hipLaunchKernelGGL(k_b2s_tapkp<2>, pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, wide, vec_out, ntiles); break;
-                case 3: hipLaunchKernelGGL(k_b2s_tapkp<3>, pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, wide, vec_out, ntiles); break;
-                default: hipLaunchKernelGGL(k_b2s_tapkp<4>, pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, wide, vec_out, ntiles); break;
+                case 1: PG_TAPKP(1, false); break;
+                case 2: PG_TAPKP(2, false); break;
+                case 3: if (wide3) PG_TAPKP(3, true); else PG_TAPKP(3, false); break;
+                default: PG_TAPKP(4, true); break;
             }
+#undef PG_TAPKP
             return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
         }
         switch (g.Cb) {

@@ -391,7 +391,7 @@ def test_bce_const_target(target):
 
 @pytest.mark.parametrize('mode_name,N,C,H,W', [('tversky', 16, 1, 256, 256), ('tversky', 3, 4, 64, 80), ('weighted_bce', 8, 4, 128, 128),
                                                ('weighted_bce', 4, 7, 64, 64), ('MAE', 2, 2, 40, 24), ('bce', 16, 1, 30, 30),
-                                               ('bce', 40, 7, 8, 8)])
+                                               ('bce', 36, 7, 8, 8)])
 def test_two_launch_loss_equals_the_staged_one(mode_name, N, C, H, W):
     """pg_loss_reduce_parts + pg_loss_value_grad (one reduction launch, one value + gradient launch: what Trainer.batch runs in one
     process) are bit-identical to the staged pg_loss_reduce (+ combine) / pg_loss_prepare / pg_loss_finalize / pg_loss_grad chain
