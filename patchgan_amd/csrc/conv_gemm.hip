@@ -1489,12 +1489,18 @@ __global__ __launch_bounds__(256) void k_b2s_tapk(const float* __restrict__ big,
 // load: the phases ran strictly one after the other again).
 // ACT: 0 none, 1 LeakyReLU(0.2) (other activations: the one-shot kernel).  WIDE: one 16-byte load per tap (CB == 4, or CB == 3 inside
 // pixels of stride % 4 == 0: the 4th float is dropped), else CB scalar loads.
-template <int CB, int ACT, bool WIDE>
-__global__ __launch_bounds__(256, 2) void k_b2s_tapkp(const float* __restrict__ big, int ld_big, const float* __restrict__ P,
+// STATS (K5: InstanceNorm statistics from the conv epilogue, unet.py:19-20; ACT == 0, no bias): next to the stores of a finished tile each
+// wave also emits the sums / sums of squares of ITS 64 pixels x 32 channels -- a lane adds its two row tiles (fp32: one rounding per
+// pair), the 64 lanes exchange them through a wave-private LDS patch, lane (slot, half) sums 32 pixels in fp64 and writes
+// part[((n * chunks + chunk) * Ca + c) * 2 + {0, 1}], chunk = 2 * (tile within the sample) + wm.  Tiles never straddle samples
+// (Hs * Ws % 128 == 0, checked by the host); fixed order, deterministic.
+template <int CB, int ACT, bool WIDE, bool STATS = false>
+__global__ __launch_bounds__(256, STATS ? 1 : 2) void k_b2s_tapkp(const float* __restrict__ big, int ld_big, const float* __restrict__ P,
                                                       float* __restrict__ out, int ld_out, Geom g, const float* __restrict__ bias,
-                                                      int big_bytes, int out_bytes, int ntiles) {
+                                                      int big_bytes, int out_bytes, int ntiles, double* __restrict__ part = nullptr) {
     constexpr int K = 16 * CB, LDT = K + 4, TM = 128, MI = 2, TPT = 8, NKK = K / 8, PC = WIDE ? 4 : CB;
-    __shared__ __attribute__((aligned(16))) float smem[2 * TM * LDT];
+    constexpr int SROW = 68;       // stats patch: 32 value slots x (64 lanes + 4 pad) floats per wave
+    __shared__ __attribute__((aligned(16))) float smem[2 * TM * LDT + (STATS ? 4 * 32 * SROW : 0)];
     const __amdgpu_buffer_rsrc_t rbig = __builtin_amdgcn_make_buffer_rsrc((void*)big, 0, big_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1582,9 +1588,35 @@ __global__ __launch_bounds__(256, 2) void k_b2s_tapkp(const float* __restrict__ 
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, voff(m * ld_out + ch, ok), 0, 0);
     };
+    // STATS: the two halves of the exchange (wave-private LDS patch: program order + lgkmcnt order them, no barrier)
+    float* spatch = smem + 2 * TM * LDT + wave * 32 * SROW;
+    auto stats_put = [&](const f32x16 (&ac)[MI]) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            spatch[j * SROW + lane] = ac[0][j] + ac[1][j];
+            spatch[(16 + j) * SROW + lane] = __builtin_fmaf(ac[0][j], ac[0][j], ac[1][j] * ac[1][j]);
+        }
+    };
+    auto stats_get = [&](int tile_done) {
+        // this lane: slot v = lane & 31 (0..15: sum of accumulator register v, 16..31: its squares), half h = lane >> 5 of the writers
+        const int v = lane & 31, h = lane >> 5;
+        double sum = 0.0;
+#pragma unroll
+        for (int p4 = 0; p4 < 8; ++p4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&spatch[v * SROW + h * 32 + p4 * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += (double)t[e];
+        }
+        const int rr = v & 15;
+        const int ch = n0 + wn * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+        const int tps = HWs / TM;                              // tiles per sample
+        const int n = tile_done / tps, chunk = 2 * (tile_done - n * tps) + wm;
+        if (tile_done < ntiles && ch < g.Ca) part[(((long)n * (2 * tps) + chunk) * g.Ca + ch) * 2 + (v >> 4)] = sum;
+    };
     // one tile: MFMAs of `tile` from As into `cur`, the stores of `prev_tile` (accumulators `prev`) woven between the k-steps, then
     // the next tile's staged registers into the other LDS buffer
     auto step = [&](f32x16 (&cur)[MI], const f32x16 (&prev)[MI], int prev_tile, const float* As, float* As_next, int next2) {
+        if (STATS) stats_put(prev);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1600,6 +1632,7 @@ __global__ __launch_bounds__(256, 2) void k_b2s_tapkp(const float* __restrict__ 
                 for (int i = 0; i < MI; ++i) cur[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[kk][e], af[i][e], cur[i], 0, 0, 0);   // D[channel][pixel]
 #pragma unroll
             for (int gi = (kk * 8) / NKK; gi < ((kk + 1) * 8) / NKK; ++gi) store_group(prev, prev_tile, gi);
+            if (STATS && kk == NKK / 2) stats_get(prev_tile);
             __builtin_amdgcn_sched_barrier(0);         // keep the stores of the previous tile BETWEEN the MFMA groups
         }
         stage(As_next);            // (registers of the tile after this one; zeros beyond the last tile)
@@ -1627,6 +1660,10 @@ __global__ __launch_bounds__(256, 2) void k_b2s_tapkp(const float* __restrict__ 
         if (tile >= ntiles) {
 #pragma unroll
             for (int gi = 0; gi < 8; ++gi) store_group(accA, prev_tile, gi);
+            if (STATS) {
+                stats_put(accA);
+                stats_get(prev_tile);
+            }
             break;
         }
         step(accB, accA, prev_tile, A1, A0, tile + 2 * G < ntiles ? tile + 2 * G : big_tile);
@@ -1635,6 +1672,10 @@ __global__ __launch_bounds__(256, 2) void k_b2s_tapkp(const float* __restrict__ 
         if (tile >= ntiles) {
 #pragma unroll
             for (int gi = 0; gi < 8; ++gi) store_group(accB, prev_tile, gi);
+            if (STATS) {
+                stats_put(accB);
+                stats_get(prev_tile);
+            }
             break;
         }
     }
@@ -2910,6 +2951,12 @@ inline bool tapkp_enabled() {          // PATCHGAN_TAPK_ONESHOT=1 (experiment): 
     }();
     return !off;
 }
+// chunks per sample of the persistent image-facing kernel's InstanceNorm partial sums (2 per 128-pixel tile: one per wave row); 0: n/a
+inline int tapkp_stats_chunks(const Geom& g) {
+    const long hw = (long)g.Hs * g.Ws;
+    if (g.Cb > 4 || g.Ca % 4 != 0 || hw % 128 != 0 || (g.Ca <= 8 && g.Cb % KC == 0) || force_generic()) return 0;
+    return (int)(2 * (hw / 128));
+}
 inline bool tapk_enabled() {
     static const bool off = [] {
         const char* e = pg_exp_env("PATCHGAN_NO_TAPK");
@@ -3423,8 +3470,11 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
         const int rc = bf16x_run(0, big, ld_big, P, bias, small, ld_small, g, act, io & PG_IO_SMALL_BF16, ws, ws_bytes, st, x, tune.bf16ring);
         if (rc != BF16X_SKIP) return rc;
     }
-    // only the Winograd paths have partial sums / transformed operands to hand over (the pg_conv_*_bytes / _chunks queries said 0)
-    if (part || x.v_keep || x.u_cache) return PG_EINVAL;
+    // only the Winograd paths (and, for the partial sums, the persistent image-facing kernel below) have operands to hand over
+    // (the pg_conv_*_bytes / _chunks queries said 0)
+    if (x.v_keep || x.u_cache) return PG_EINVAL;
+    if (part && !(algo == PG_ALGO_AUTO && !io && tapk_enabled() && tapkp_enabled() && tapkp_stats_chunks(g) > 0 && !bias && act == PG_ACT_NONE))
+        return PG_EINVAL;
     if (!io && b2s_tapn_ok(g) && (ld_big % 4 == 0) && aligned16(big) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= b2s_tapn_ws(g) && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT) {
         // D[big pixel][(tap, a)] = big . P^T (row GEMM over the pixels), then gather the 16 taps per output pixel
@@ -3460,6 +3510,19 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
             static const int pwg = pg_exp_env("PATCHGAN_TAPKP_WG") ? atoi(pg_exp_env("PATCHGAN_TAPKP_WG")) : 512;
             const bool wide3 = (g.Cb == 3) && (ld_big % 4 == 0) && (ld_big >= 4) && aligned16(big);
             dim3 pgrid((unsigned)std::min<long>(ntiles, std::max<long>(1, pwg / (long)grid.y)), grid.y, 1);
+            if (part) {             // (act == none, no bias, whole tiles per sample: checked above); one workgroup per CU (88 .. 104 KB of LDS)
+                pgrid.x = (unsigned)std::min<long>(ntiles, std::max<long>(1, 256 / (long)grid.y));
+                switch (g.Cb) {
+                    case 1: hipLaunchKernelGGL((k_b2s_tapkp<1, 0, false, true>), pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, (int)big_b, (int)out_b, ntiles, part); break;
+                    case 2: hipLaunchKernelGGL((k_b2s_tapkp<2, 0, false, true>), pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, (int)big_b, (int)out_b, ntiles, part); break;
+                    case 3:
+                        if (wide3) hipLaunchKernelGGL((k_b2s_tapkp<3, 0, true, true>), pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, (int)big_b, (int)out_b, ntiles, part);
+                        else hipLaunchKernelGGL((k_b2s_tapkp<3, 0, false, true>), pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, (int)big_b, (int)out_b, ntiles, part);
+                        break;
+                    default: hipLaunchKernelGGL((k_b2s_tapkp<4, 0, true, true>), pgrid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, (int)big_b, (int)out_b, ntiles, part); break;
+                }
+                return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+            }
 #define PG_TAPKP(CB_, WIDE_)                                                                                                            \
     do {                                                                                                                                \
         if (act == PG_ACT_LEAKY)                                                                                                        \
@@ -3478,6 +3541,7 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
 #undef PG_TAPKP
             return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
         }
+        if (part) return PG_EINVAL;        // (a view the persistent kernel does not take: unaligned output, tensor beyond 32-bit offsets)
         switch (g.Cb) {
             case 1: hipLaunchKernelGGL(k_b2s_tapk<1>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4, vec_out); break;
             case 2: hipLaunchKernelGGL(k_b2s_tapk<2>, grid, dim3(256), 0, st, big, ld_big, P, small, ld_small, g, bias, act, vec4, vec_out); break;
@@ -3826,6 +3890,7 @@ int pg_conv_stats_chunks(const pg_conv_geom* gg, int op, int algo, size_t ws_byt
         if (wino_b2s_ok(g, tune) && ws_bytes >= pg_wino_ws_bytes(g.N, g.Hs, g.Ws, g.Cb, g.Ca, tune.mo1)) return 0;
         if (wino2_b2s_ok(g, tune) && ws_bytes >= pg_wino2_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb))
             return pg_wino2_b2s_stats_chunks(g.N, g.Hs, g.Ws, g.Ca);
+        if (tapk_enabled() && tapkp_enabled()) return tapkp_stats_chunks(g);      // image-facing layer (enc0): k_b2s_tapkp<.., STATS>
         return 0;
     }
     if (wino_s2b_ok(g, tune) && ws_bytes >= pg_wino_ws_bytes(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1)) return 0;

@@ -291,8 +291,8 @@ class ConvOp:
         if io:      # bf16 tensors: the LDS-DMA kernels' STATS epilogue (both tensors bf16, 16-byte-aligned views)
             if io != L.IO_MASK or not all(v.ptr() % 16 == 0 and v.ld % 8 == 0 for v in (view_in, view_out)):
                 return 0
-        elif not self._aligned(view_in, view_out):
-            return 0
+        elif not self._aligned(view_out) or (not self._aligned(view_in) and not (opcode == 0 and self.Cb <= 3)):
+            return 0          # (the image-facing kernel k_b2s_tapkp gathers <= 3-channel pixels by scalars: any input view)
         return self._query(('chunks', opcode, io), lambda: L.load().pg_conv_stats_chunks(ctypes.byref(self.g), opcode, self.algo | io,
                                                                                         self.ws_arg))
 

@@ -185,7 +185,8 @@ def test_bench_layer_call_vs_float64(cs):
                 got2 = _read(o2)
                 assert torch.equal(got2, plain), cs.key
                 sums = part.view(N, chunks, Ca, 2).sum(1)
-                tol_s = 1e-5 if bfm else 1e-12       # (the bf16 epilogue sums in fp32 inside a tile)
+                # (the bf16 epilogue sums in fp32 inside a tile; the image-facing fp32 kernel adds PAIRS in fp32, then fp64)
+                tol_s = 1e-5 if bfm else 2e-6 if Cb <= 4 else 1e-12
                 assert torch.allclose(sums[..., 0], got2.sum((2, 3)), rtol=tol_s, atol=tol_s * got2.abs().sum((2, 3)).max().item())
                 assert torch.allclose(sums[..., 1], (got2 * got2).sum((2, 3)), rtol=max(tol_s, 1e-9), atol=1e-9)
         io = cs.io

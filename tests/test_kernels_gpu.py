@@ -550,6 +550,56 @@ def test_conv_emits_instancenorm_partials(geom):
         plain.big2small(vin, P, 0, None, 0, y, part=torch.empty(16, dtype=torch.float64, device=DEV))
 
 
+@pytest.mark.parametrize('geom,ld_in', [((4, 64, 64, 64, 3, 2), 4), ((2, 256, 256, 64, 3, 2), 7), ((3, 32, 32, 8, 4, 2), 4), ((2, 64, 64, 4, 3, 2), 3),
+                                        ((5, 32, 64, 72, 1, 2), 1), ((2, 256, 256, 128, 2, 2), 2)], ids=lambda v: 'x'.join(map(str, v)) if isinstance(v, tuple) else f'ld{v}')
+def test_image_facing_conv_emits_instancenorm_partials(geom, ld_in):
+    """K5 on the first encoder layer (unet.py:89-92: Conv2d over the 3-channel image -> InstanceNorm): the persistent image-facing
+    kernel k_b2s_tapkp<.., STATS> writes, next to its output, per-sample partial sums / sums of squares (two chunks per 128-pixel
+    tile; a lane adds pairs in fp32, everything above that in fp64).  The conv output is bit-identical to the plain call, the merged
+    sums equal the sums of the output to 2e-6 (relative to sum |y| resp. sum y^2), and pg_instnorm_act_fwd_parts normalises to the
+    same result as the separate statistics pass.  Input views with any pixel stride (x is a slice of the discriminator-input buffer)."""
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view, empty_view, pack, rel_err, DEV
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    op = E.ConvOp(*geom, L.ALGO_AUTO)
+    assert op.describe(0)[0] == f'k_b2s_tapkp<{Cb}>'
+    P = pack(Wt)
+    vin = to_view(big, ld=ld_in, off=0)
+    y1, y2 = empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=4), empty_view(N, Hs, Ws, Ca, ld=Ca + 4, off=4)
+    chunks = op.stats_chunks(0, vin, y1)
+    assert chunks == 2 * (Hs * Ws // 128)
+    part = torch.full((N * chunks * Ca * 2,), float('nan'), dtype=torch.float64, device=DEV)
+    op.big2small(vin, P, 0, None, 0, y1, part=part)
+    op.big2small(vin, P, 0, None, 0, y2)
+    torch.cuda.synchronize()
+    o1 = y1.to_nchw()
+    assert torch.equal(o1, y2.to_nchw())
+    assert rel_err(o1, F.conv2d(big, Wt, None, stride=2, padding=1)) < 2e-5
+    sums = part.view(N, chunks, Ca, 2).sum(1).cpu()
+    od = o1.double().cpu()
+    assert torch.allclose(sums[..., 0], od.sum((2, 3)), rtol=0, atol=2e-6 * od.abs().sum((2, 3)).max().item())
+    assert torch.allclose(sums[..., 1], (od * od).sum((2, 3)), rtol=2e-6, atol=0)
+    outs, stats = [], []
+    for fused in (True, False):
+        out = empty_view(N, Hs, Ws, Ca, ld=Ca + 8, off=4)
+        st = torch.empty(N * Ca * 2, device=DEV)
+        if fused:
+            L.check(L.load().pg_instnorm_act_fwd_parts(y1.ptr(), y1.ld, out.ptr(), out.ld, st.data_ptr(), part.data_ptr(), chunks, N,
+                                                       Hs * Ws, Ca, ACTS['leakyrelu'], 1e-5, 0.0, 0, None), 'parts')
+        else:
+            E.instnorm_act_fwd(y1, out, st, ACTS['leakyrelu'])
+        outs.append(out.to_nchw())
+        stats.append(st.clone())
+    torch.cuda.synchronize()
+    assert rel_err(outs[0], outs[1]) < 2e-6 and rel_err(stats[0], stats[1]) < 2e-6
+    # with a bias / activation in the epilogue, or on planes that 128-pixel tiles do not divide, there are no partials
+    with pytest.raises(RuntimeError):
+        op.big2small(vin, P, 0, None, 0, y2, ACTS['leakyrelu'], part=part)
+    odd = E.ConvOp(N, 36, 44, Ca, Cb, 2, L.ALGO_AUTO)
+    assert odd.stats_chunks(0, to_view(torch.zeros(N, Cb, 36, 44), ld=max(ld_in, Cb)), empty_view(N, 18, 22, Ca)) == 0
+
+
 @pytest.mark.parametrize('geom,bits', [((6, 62, 58, 256, 128, 2), 0), ((16, 32, 32, 288, 160, 2), 0), ((9, 32, 32, 128, 64, 1), 0),
                                        ((4, 70, 74, 96, 40, 2), 'all'), ((9, 32, 32, 128, 64, 1), 'f3'), ((10, 31, 31, 64, 128, 1), 'f3')],
                          ids=lambda v: 'x'.join(map(str, v)) if isinstance(v, tuple) else str(v))
