@@ -158,7 +158,8 @@ def test_cfg2_full_width_gradients_vs_oracle(tmp_path):
     next to the fp32 CPU oracle's own distance from float64.
 
     Stated tolerances.  Discriminator (well conditioned; its d3 / d2 / d1 layers run the Winograd kernels): relative max-norm
-    1e-4 (measured <= 1.2e-5; the fp32 CPU oracle: 1e-5 .. 7e-5).  Generator: relative L2 2e-2 and no worse than 8 x the fp32
+    1e-4 (measured <= 1.2e-5; the fp32 CPU oracle: 1e-5 .. 7e-5), 1e-3 for the first layer's weight and bias (a single LeakyReLU
+    sign flip at an output within an ulp of zero is worth 2e-4 there: see the comment at the assertion).  Generator: relative L2 2e-2 and no worse than 8 x the fp32
     CPU oracle's own relative-L2 distance + 1e-3 -- at this width the generator's backward chain amplifies fp32 rounding so
     much that EXACT fp32 evaluations (the one-thread-per-output kernels, the implicit GEMM, oneDNN on the CPU) sit 3e-4 .. 7e-3
     in relative L2 and up to 1e-1 in max-norm from float64 (tools/debug_grads_full.py prints the table), so a max-norm bound
@@ -187,7 +188,11 @@ def test_cfg2_full_width_gradients_vs_oracle(tmp_path):
     for k, p in d.named_parameters():
         e = _rel(p.grad, o64.last['d_grads'][k])
         rows.append(('D', k, e, _rel(ot.last['d_grads'][k], o64.last['d_grads'][k])))
-        assert e < 1e-4, (k, e)
+        # model.0.* sit behind the LeakyReLU kink of 8.4 M first-layer outputs: ONE output within an ulp of zero whose fp32 sign
+        # differs from float64's changes its dy by a factor 5 and moves model.0.bias by 1.8e-4 / model.0.weight by 5.9e-5 of their
+        # max-norm (measured with the persistent first-layer kernel, whose output is 4.9e-7 from float64 with exactly one such
+        # flip; the one-shot kernel had none on these inputs and sits at 3e-6: tools/debug_flips.py, tools/debug_dgrads.py)
+        assert e < (1e-3 if k.startswith('model.0.') else 1e-4), (k, e)
     for k, p in g.named_parameters():
         e, noise = l2(p.grad, o64.last['g_grads'][k]), l2(ot.last['g_grads'][k], o64.last['g_grads'][k])
         rows.append(('G', k, e, noise))
