@@ -1681,6 +1681,121 @@ __global__ __launch_bounds__(256, STATS ? 1 : 2) void k_b2s_tapkp(const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the same image-facing layers (enc0, d0: Cb = 3 / 4; dec6: Cb = output_nc) with the 16 taps folded into N, as a
+// PERSISTENT kernel: dP[(tap, b)][a] = sum_pix small[pix][a] * big[window(pix), tap][b].  The taps-in-N kernel k_wgrad_tapn<.., 1> cuts
+// the pixel dimension into ~1000 slices of 8 chunks (one 16-KB slab each, a 16-MB reduce) and every workgroup pays a prologue and an
+// epilogue for 256 pixels; it ran at 45-74 us on layers whose MFMA and HBM times are ~15 us each.  Here <= 512 workgroups walk
+// 128-pixel tiles t = blockIdx.x, + gridDim.x, ..., accumulate their BM x BN block of dP over all of them in ONE accumulator set,
+// and write one slab at the end (fixed-order reduce over the workgroups as before: deterministic).  Per tile: the small-side tile
+// [128 pixels][BM channels] (contiguous rows) and the gathered window tile [128 pixels][16 CB] come through registers (branch-free
+// buffer loads, issued for tile t + 1 before the MFMAs of tile t) into LDS; both MFMA operands are read with ds_read_b32 (pixel =
+// the MFMA's k index).  WM x WN waves: 2 x 2 (64 channels x 64 columns) for CB >= 3, 4 x 1 (128 channels x 32 columns) for CB <= 2.
+// ------------------------------------------------------------------------------------------------
+template <int CB, bool WIDE, int WM>
+__global__ __launch_bounds__(256, 2) void k_wgrad_tapnp(const float* __restrict__ small, int ld_small, const float* __restrict__ big,
+                                                        int ld_big, float* __restrict__ slabs, long slab_stride, Geom g,
+                                                        int small_bytes, int big_bytes, int ntiles) {
+    constexpr int WN = 4 / WM, BM = 32 * WM, K = 16 * CB, TM = 128, TPT = 8, PC = WIDE ? 4 : CB;
+    constexpr int LDA = BM + 4, LDB = 32 * WN + 4;          // (columns >= K of the window tile are zero)
+    constexpr int AQ = BM / 4, ALD = TM * AQ / 256;         // float4 loads of the small-side tile per thread
+    __shared__ __attribute__((aligned(16))) float smem[TM * LDA + TM * LDB];
+    float* As = smem;
+    float* Bs = smem + TM * LDA;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)small, 0, small_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)big, 0, big_bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int M = g.N * g.Hs * g.Ws, HWs = g.Hs * g.Ws;
+    const int a0 = blockIdx.y * BM;
+    // the window tile's pad columns are written once
+    for (int i = tid; i < TM * LDB; i += 256) Bs[i] = 0.f;
+    __syncthreads();
+    const int r = tid & (TM - 1), t0 = (tid / TM) * TPT;    // gather role: pixel r of the tile, taps t0 .. t0 + 7
+    f32x4 pa[ALD];
+    float pb[TPT][PC];
+    auto fetch = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < ALD; ++i) {
+            const int idx = tid + 256 * i, pix = idx / AQ, q4 = idx - pix * AQ;
+            const int m = tile * TM + pix, a = a0 + q4 * 4;
+            pa[i] = bload4(rs, voff(m * ld_small + a, (m < M) & (a < g.Ca)));
+        }
+        const int m = tile * TM + r;
+        const int mm = min(m, M - 1);
+        const int n = mm / HWs;
+        const int rem = mm - n * HWs;
+        const int p = rem / g.Ws, q = rem - p * g.Ws;
+        const int h0 = g.s * p - 1, w0 = g.s * q - 1;
+        const int base = ((n * g.Hb + h0) * g.Wb + w0) * ld_big;
+#pragma unroll
+        for (int tt = 0; tt < TPT; ++tt) {
+            const int tap = t0 + tt, kh = tap >> 2, kw = tap & 3;
+            const bool ok = (m < M) & ((unsigned)(h0 + kh) < (unsigned)g.Hb) & ((unsigned)(w0 + kw) < (unsigned)g.Wb);
+            const int eo = base + (kh * g.Wb + kw) * ld_big;
+            if (WIDE) {
+                const f32x4 v = bload4(rb, voff(eo, ok));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pb[tt][c] = v[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) pb[tt][c] = bload1(rb, voff(eo + c, ok));
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < ALD; ++i) {
+            const int idx = tid + 256 * i, pix = idx / AQ, q4 = idx - pix * AQ;
+            *reinterpret_cast<f32x4*>(&As[pix * LDA + q4 * 4]) = pa[i];
+        }
+#pragma unroll
+        for (int tt = 0; tt < TPT; ++tt) {
+            float* dst = &Bs[r * LDB + (t0 + tt) * CB];
+            if (CB == 4) {
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = pb[tt][c];
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) dst[c] = pb[tt][c];
+            }
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) acc[rr] = 0.f;
+    const int G = gridDim.x, big_tile = 0x3fffff;
+    int tile = blockIdx.x;
+    fetch(tile);
+    for (; tile < ntiles; tile += G) {
+        stage();
+        __syncthreads();
+        fetch(tile + G < ntiles ? tile + G : big_tile);     // in flight under the MFMAs below (beyond the last tile: every load masked)
+        __builtin_amdgcn_sched_barrier(0x386);
+#pragma unroll 16
+        for (int s2 = 0; s2 < TM / 2; ++s2) {
+            const float af = As[(2 * s2 + lh) * LDA + wm * 32 + lrow];
+            const float bf = Bs[(2 * s2 + lh) * LDB + wn * 32 + lrow];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);          // D[channel a][column (tap, b)]
+        }
+        __syncthreads();
+    }
+    // one slab per workgroup column: slab[(tap * Ca + a) * Cb + b]
+    float* o = slabs + (long)blockIdx.x * slab_stride;
+    const int col = wn * 32 + lrow;
+    if (col < K) {
+        const int tap = col / CB, b = col - tap * CB;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int a = a0 + wm * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            if (a < g.Ca) o[((long)tap * g.Ca + a) * CB + b] = acc[rr];
+        }
+    }
+}
+
 // ================================================================================================
 // bf16 variants (PG_ALGO_BF16; the "next" row f2, BASELINE config 4): tensors stay fp32 in HBM and in the C ABI -- fp32
 // master weights, fp32 InstanceNorm statistics, fp32 accumulation -- but operand tiles are rounded to bf16 (RNE,
@@ -2951,6 +3066,16 @@ inline bool tapkp_enabled() {          // PATCHGAN_TAPK_ONESHOT=1 (experiment): 
     }();
     return !off;
 }
+// persistent taps-in-N weight gradient (k_wgrad_tapnp): <= 4 big-side channels, enough 128-pixel tiles to give every workgroup a few
+inline int wgrad_tapnp_slabs(const Geom& g) {
+    const long tiles = ((long)g.N * g.Hs * g.Ws + 127) / 128;
+    const long rows = (g.Ca + (g.Cb <= 2 ? 127 : 63)) / (g.Cb <= 2 ? 128 : 64);
+    return (int)std::max<long>(1, std::min<long>(tiles, 512 / rows));
+}
+inline bool wgrad_tapnp_ok(const Geom& g) {
+    return g.Cb <= 4 && g.Ca % 4 == 0 && (long)g.N * g.Hs * g.Ws >= 4096 && (long)g.N * g.Hs * g.Ws < 0x3fffffL * 64 && !force_generic() &&
+           tapkp_enabled();
+}
 // chunks per sample of the persistent image-facing kernel's InstanceNorm partial sums (2 per 128-pixel tile: one per wave row); 0: n/a
 inline int tapkp_stats_chunks(const Geom& g) {
     const long hw = (long)g.Hs * g.Ws;
@@ -3375,6 +3500,9 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
         sp = 1;
     } else if (mode == 3) {
         snprintf(buf, sizeof buf, "k_b2s_fast<%s,true>+%s", TILE[tid], oc == 0 ? "k_gather_big2small" : "k_col2im_small2big");
+    } else if (mode == 1 && oc == 2 && wgrad_tapnp_ok(to_geom(g)) && algo != PG_ALGO_BF16) {
+        snprintf(buf, sizeof buf, "k_wgrad_tapnp<%d>", g->Cb);          // persistent taps-in-N weight gradient of the image-facing layers
+        sp = wgrad_tapnp_slabs(to_geom(g));
     } else if (mode) {
         snprintf(buf, sizeof buf, "k_wgrad_tapn<%s,%d>", TILE[tid], mode);
     } else {
@@ -4025,6 +4153,28 @@ static int wgrad_impl(const float* small, int ld_small, const float* big, int ld
             PG_DISPATCH_TILE(k_wgrad, p.t.id, grid, st, small, ld_small, big, ld_big, dst, p.out_elems, g, p.cps,
                              p.tiles_n, vecm, vecn);
         }
+    } else if (mode == 1 && wgrad_tapnp_ok(g) && vecm && aligned16(ws) &&
+               (g.Cb != 4 || ((ld_big % 4 == 0) && aligned16(big))) && tensor_bytes(Kp, ld_small, g.Ca) < FAST_LIMIT &&
+               tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT &&
+               ws_bytes >= reserved + (size_t)wgrad_tapnp_slabs(g) * p.out_elems * sizeof(float)) {
+        // persistent form: one slab per workgroup column, reduced in workgroup order
+        const int ntiles = (int)((Kp + 127) / 128), G = wgrad_tapnp_slabs(g);
+        const int small_b = (int)tensor_bytes(Kp, ld_small, g.Ca), big_b = (int)tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb);
+        const bool wide3 = (g.Cb == 3) && (ld_big % 4 == 0) && (ld_big >= 4) && aligned16(big);
+        float* slabs = (float*)((char*)ws + reserved);
+        if (g.Cb <= 2) {
+            dim3 grid(G, (g.Ca + 127) / 128, 1);
+            if (g.Cb == 1) hipLaunchKernelGGL((k_wgrad_tapnp<1, false, 4>), grid, dim3(256), 0, st, small, ld_small, big, ld_big, slabs, p.out_elems, g, small_b, big_b, ntiles);
+            else hipLaunchKernelGGL((k_wgrad_tapnp<2, false, 4>), grid, dim3(256), 0, st, small, ld_small, big, ld_big, slabs, p.out_elems, g, small_b, big_b, ntiles);
+        } else {
+            dim3 grid(G, (g.Ca + 63) / 64, 1);
+            if (g.Cb == 4) hipLaunchKernelGGL((k_wgrad_tapnp<4, true, 2>), grid, dim3(256), 0, st, small, ld_small, big, ld_big, slabs, p.out_elems, g, small_b, big_b, ntiles);
+            else if (wide3) hipLaunchKernelGGL((k_wgrad_tapnp<3, true, 2>), grid, dim3(256), 0, st, small, ld_small, big, ld_big, slabs, p.out_elems, g, small_b, big_b, ntiles);
+            else hipLaunchKernelGGL((k_wgrad_tapnp<3, false, 2>), grid, dim3(256), 0, st, small, ld_small, big, ld_big, slabs, p.out_elems, g, small_b, big_b, ntiles);
+        }
+        timed->~TimedLaunch();
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+        return launch_reduce(slabs, p.out_elems, G, dP, g.Cb, 16L * g.Ca, g.Cb, nullptr, 0, st);
     } else if (mode == 1) {
         dim3 grid(p.tiles_m * p.tiles_n, 1, p.split);
         const int vecy = (g.Cb == 4) && (ld_big % 4 == 0) && aligned16(big);

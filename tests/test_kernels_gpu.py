@@ -33,6 +33,10 @@ GEOMS = [
     (2, 16, 16, 32, 1, 2),      # dec6-like: small2big via row GEMM + col2im, Cb = 1 (no weight re-layout)
     (2, 12, 20, 64, 3, 2),      # same path with the (tap, b) weight re-layout, Cb = 3
     (2, 9, 9, 32, 8, 1),        # same path, stride 1
+    (4, 64, 64, 64, 4, 2),      # >= 4096 small pixels on <= 4 big-side channels: the persistent image-facing kernels (k_b2s_tapkp, k_wgrad_tapnp)
+    (5, 64, 64, 72, 3, 2),      # same, ragged channel blocks, 3-channel pixels
+    (4, 66, 62, 132, 1, 2),     # same, one big-side channel (dec6's backward), ragged pixel tiles
+    (4, 64, 64, 40, 2, 2),      # same, two channels
 ]
 ACTS = {'none': 0, 'leakyrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 

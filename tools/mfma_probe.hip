@@ -4,6 +4,11 @@
 //   mode 1: no global loads (the staged registers are loop constants)
 //   mode 2: no LDS stores and no barriers (ds_read + MFMA only, stale tile)
 //   mode 3: MFMA only (fragments are loop constants)
+//   mode 6: the full loop with the Winograd INPUT TRANSFORM done while staging the A operand -- what fusing k_wino2_v into the
+//           batched polyphase GEMM would do: a staged 16-byte piece V[xi][tile][4 channels] of F(3x3,2x2) on the points 0, 1, -1, inf
+//           is +-(d[a0][b0] +- d[a0][b1] +- d[a1][b0] +- d[a1][b1]) of four pixels of the 4x4 window (B^T has two non-zeros per row),
+//           i.e. FOUR 16-byte gathers and three vector adds per staged piece instead of one load (the B operand, the weights, is as in
+//           mode 0).  "6 x" = the same with the A rows shared by all workgroups of a column (operand served by L2).
 // build: hipcc -O3 --offload-arch=gfx950 tools/mfma_probe.hip -o tools/mfma_probe ; run: tools/mfma_probe [wgs] [chunks]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -62,9 +67,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             }
             __builtin_amdgcn_sched_barrier(0x386);
         }
+        if (MODE == 6) {          // A piece = d00 - d01 - d10 + d11 of four window pixels (rows +0, +1, +W, +W+1 of the activation)
+            const int ko = ((c + 1) % (K / KC)) * KC * 4, px = K * 4, rowp = 8 * K * 4;
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 d00 = bload4(rA, aoff[i] + ko), d01 = bload4(rA, aoff[i] + ko + px);
+                const f32x4 d10 = bload4(rA, aoff[i] + ko + rowp), d11 = bload4(rA, aoff[i] + ko + rowp + px);
+                ra[i] = (d00 - d01) - (d10 - d11);
+                rb[i] = bload4(rB, boff[i] + ko);
+            }
+            __builtin_amdgcn_sched_barrier(0x386);
+        }
 #pragma unroll
         for (int kk = 0; kk < KC / 8; ++kk) {
-            if (MODE <= 2) {
+            if (MODE <= 2 || MODE == 6) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * 2 + i) * 32 + lrow) * LDK + kk * 8 + lh * 4]);
@@ -79,7 +94,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
-        if (MODE <= 1) {
+        if (MODE <= 1 || MODE == 6) {
             __syncthreads();
             for (int i = 0; i < 4; ++i) {
                 *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
@@ -249,6 +264,104 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     out[blockIdx.x * 256 + tid] = s;
 }
 
+
+// ---- probe 7: the 64x64-tile weight-gradient-like loop (one 32x32 accumulator tile per wave, the dominant kernel's shape) -------------
+// DB = 0: one LDS buffer, register prefetch of chunk c+1 under the MFMAs of chunk c, then barrier / LDS store / barrier (what
+//         k_wino_wgrad_gemm<1,1,2,2> does)
+// DB = 1: two LDS buffers, ONE barrier per chunk: the staged registers of chunk c+1 are stored into the other buffer after the last MFMA
+//         of chunk c has been issued, the loads of chunk c+2 are issued right behind the barrier
+template <int DB, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_probe7(const float* A, const float* B,
+                                                                                               float* out, int K, int nch, int bytes) {
+    __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * 128 * LDK];
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lh = lane >> 5, kq = tid & 7, r0 = tid >> 3;
+    const int m0 = (blockIdx.x % (bytes / (K * 256))) * 64;
+    int aoff[2], boff[2];
+    for (int i = 0; i < 2; ++i) {
+        aoff[i] = ((m0 + r0 + 32 * i) * K + kq * 4) * 4;
+        boff[i] = ((r0 + 32 * i) * K + kq * 4) * 4;
+    }
+    const int nk = K / KC;
+    f32x4 ra[2], rb[2];
+    auto loads = [&](int c) {
+        const int ko = (c % nk) * KC * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ra[i] = bload4(rA, aoff[i] + ko);
+            rb[i] = bload4(rB, boff[i] + ko);
+        }
+    };
+    auto stores = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(&buf[(r0 + 32 * i) * LDK + kq * 4]) = ra[i];
+            *reinterpret_cast<f32x4*>(&buf[(64 + r0 + 32 * i) * LDK + kq * 4]) = rb[i];
+        }
+    };
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto mfmas = [&](const float* buf) {
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(&buf[(wm * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(&buf[(64 + wn * 32 + lrow) * LDK + kk * 8 + lh * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+        }
+    };
+    loads(0);
+    stores(smem);
+    __syncthreads();
+    if (DB == 0) {
+        for (int c = 0; c < nch; ++c) {
+            loads(c + 1);
+            __builtin_amdgcn_sched_barrier(0x386);
+            mfmas(smem);
+            __syncthreads();
+            stores(smem);
+            __syncthreads();
+        }
+    } else {
+        loads(1);
+        for (int c = 0; c < nch; c += 2) {
+            mfmas(smem);
+            stores(smem + 128 * LDK);
+            __syncthreads();
+            loads(c + 2);
+            __builtin_amdgcn_sched_barrier(0x386);
+            mfmas(smem + 128 * LDK);
+            stores(smem);
+            __syncthreads();
+            loads(c + 3);
+            __builtin_amdgcn_sched_barrier(0x386);
+        }
+    }
+    float sum = 0.f;
+    for (int r = 0; r < 16; ++r) sum += acc[r];
+    out[blockIdx.x * 256 + tid] = sum;
+}
+
+template <int DB, int WPE>
+void run7(const char* name, const float* A, const float* B, float* out, int K, int nch, int wgs, int bytes) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_probe7<DB, WPE>), dim3(wgs), dim3(256), 0, 0, A, B, out, K, nch, bytes);
+    (void)hipEventRecord(e0, 0);
+    const int reps = 5;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((k_probe7<DB, WPE>), dim3(wgs), dim3(256), 0, 0, A, B, out, K, nch, bytes);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    const double flop = 2.0 * 64 * 64 * 32 * (double)nch * wgs;
+    printf("%-34s waves/SIMD %d  wgs %5d  %8.1f us  %7.1f TFLOP/s\n", name, WPE, wgs, ms * 1e3, flop / ms / 1e9);
+}
+
 template <int MODE, int WPE>
 void run(const char* name, const float* A, const float* B, float* out, int K, int nch, int wgs, int bytes) {
     hipEvent_t e0, e1;
@@ -334,5 +447,12 @@ int main(int argc, char** argv) {
     run<0, 1>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
     run<0, 3>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
     run<0, 4>("0 full loop", A, B, out, K, nch, wgs, (int)bytes);
+    run<6, 2>("6 input transform while staging A", A, B, out, K, nch, wgs, (int)bytes);
+    run<6, 3>("6 input transform while staging A", A, B, out, K, nch, wgs, (int)bytes);
+    run<6, 4>("6 input transform while staging A", A, B, out, K, nch, wgs, (int)bytes);
+    run7<0, 4>("7 64x64 tile, one LDS buffer", A, B, out, K, nch, wgs, (int)bytes);
+    run7<1, 4>("7 64x64 tile, two LDS buffers", A, B, out, K, nch, wgs, (int)bytes);
+    run7<0, 2>("7 64x64 tile, one LDS buffer", A, B, out, K, nch, wgs, (int)bytes);
+    run7<1, 2>("7 64x64 tile, two LDS buffers", A, B, out, K, nch, wgs, (int)bytes);
     return 0;
 }
