@@ -2679,41 +2679,45 @@ __global__ void k_big2small_direct(const float* __restrict__ big, int ld_big, co
 // (out_bf); mul: times f'(t) of the layer below (pg_epi_mul; t in the output's storage type).  Many short workgroups: the per-pixel
 // chain (16 loads, FMAs, store) is latency-bound, ~8 workgroups per CU hide it (64-pixel workgroups: 70 us, 7-pixel ones: 40 us;
 // a 4-pixel software pipeline per thread: slower, 64 more registers).
-__global__ __launch_bounds__(256) void k_s2b_ca1(const float* __restrict__ small, int ld_small, const float* __restrict__ P,
-                                                 const float* __restrict__ bias, float* __restrict__ big, int ld_big, Geom g, int act,
-                                                 int out_bf, pg_epi_mul mul, int pix_per_block) {
-    const int cq = g.Cb >> 2;                                      // channel quads
-    const int qd = threadIdx.x % cq, lane_p = threadIdx.x / cq, np = 256 / cq;     // host: 256 % cq == 0, cq <= 256
+// Stride-1 form (the discriminator head's data gradient, disc.py:45: Cout = 1, 4x4, stride 1): a workgroup first stages its SAMPLE's
+// whole one-channel map (Hs x Ws floats, a few KB) into LDS inside a zero border of two, so that the 16 taps of a pixel are 16
+// unmasked, conflict-free broadcast reads -- the generic kernel below fetched them with 16 global loads per pixel AND PER WAVE (64
+// identical addresses each: ~1 M broadcast loads per launch through the address path, 1.4 TB/s of output where stores alone run 6).
+// grid (workgroups per sample, N); a thread keeps its channel quad's 16 weight vectors in registers and walks pixels.
+__global__ __launch_bounds__(256) void k_s2b_ca1_s1(const float* __restrict__ small, int ld_small, const float* __restrict__ P,
+                                                    const float* __restrict__ bias, float* __restrict__ big, int ld_big, Geom g, int act,
+                                                    int out_bf, pg_epi_mul mul, int pix_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];     // [(Hs + 4)][(Ws + 4)], the map at (2, 2)
+    const int n = blockIdx.y, PW = g.Ws + 4, HWs = g.Hs * g.Ws, HWb = g.Hb * g.Wb;
+    for (int i = threadIdx.x; i < (g.Hs + 4) * PW; i += 256) xs[i] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < HWs; i += 256) {
+        const int ih = i / g.Ws, iw = i - ih * g.Ws;
+        xs[(ih + 2) * PW + iw + 2] = small[(long)(n * HWs + i) * ld_small];
+    }
+    const int cq = g.Cb >> 2;
+    const int qd = threadIdx.x % cq, np = 256 / cq;
+    const int lane_p = (cq % 64 == 0) ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / cq) : (int)threadIdx.x / cq;
     const int b = qd * 4;
     f32x4 w[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const f32x4*>(P + (long)t * g.Cb + b);      // Ca == 1: P[tap][0][b]
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4*>(bias + b);
-    const long total = (long)g.N * g.Hb * g.Wb;
-    const long p0 = (long)blockIdx.x * pix_per_block;
-    const long p1 = min(total, p0 + pix_per_block);
-    for (long m = p0 + lane_p; m < p1; m += np) {
-        const int n = (int)(m / (g.Hb * g.Wb));
-        const int rem = (int)(m - (long)n * g.Hb * g.Wb);
-        const int h = rem / g.Wb, wq = rem - h * g.Wb;
+    __syncthreads();
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(HWb, p0 + pix_per_block);
+    for (int pix = p0 + lane_p; pix < p1; pix += np) {
+        const int h = pix / g.Wb, wq = pix - h * g.Wb;
+        // tap (kh, kw) reads small[h + 1 - kh][wq + 1 - kw] = xs[h + 3 - kh][wq + 3 - kw]
+        const float* xr = xs + (h + 3) * PW + wq + 3;
         f32x4 acc = bv;
 #pragma unroll
-        for (int kh = 0; kh < 4; ++kh) {
-            const int hh = h + 1 - kh;
-            const int ih = (g.s == 2) ? hh >> 1 : hh;
-            const bool okh = hh >= 0 && !(g.s == 2 && (hh & 1)) && ih < g.Hs;
+        for (int kh = 0; kh < 4; ++kh)
 #pragma unroll
-            for (int kw = 0; kw < 4; ++kw) {
-                const int ww = wq + 1 - kw;
-                const int iw = (g.s == 2) ? ww >> 1 : ww;
-                const bool ok = okh && ww >= 0 && !(g.s == 2 && (ww & 1)) && iw < g.Ws;
-                const float x = ok ? small[(long)((n * g.Hs + ih) * g.Ws + iw) * ld_small] : 0.f;
-                acc += x * w[kh * 4 + kw];
-            }
-        }
+            for (int kw = 0; kw < 4; ++kw) acc += xr[-kh * PW - kw] * w[kh * 4 + kw];
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = pg_act_epi(acc[e], act);
+        const long m = (long)n * HWb + pix;
         if (mul.t) {
             f32x4 tv;
             if (out_bf) {
@@ -2729,6 +2733,87 @@ __global__ __launch_bounds__(256) void k_s2b_ca1(const float* __restrict__ small
             *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(big) + m * ld_big + b) = to_bf16(acc);
         else
             *reinterpret_cast<f32x4*>(big + m * ld_big + b) = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_s2b_ca1(const float* __restrict__ small, int ld_small, const float* __restrict__ P,
+                                                 const float* __restrict__ bias, float* __restrict__ big, int ld_big, Geom g, int act,
+                                                 int out_bf, pg_epi_mul mul, int pix_per_block) {
+    constexpr int PP = 2;                                          // pixels per thread and trip
+    const int cq = g.Cb >> 2;                                      // channel quads
+    // host: 256 % cq == 0, cq <= 256.  With >= 64 quads (Cb >= 256: the discriminator head at ndf >= 32) a wave works on ONE pixel:
+    // its pixel index is made provably wave-uniform (readfirstlane), so the pixel decode, the 16 tap addresses and the tap loads
+    // themselves run on the scalar unit (s_load) instead of once per lane -- the kernel was bound by that per-lane integer work
+    const int qd = threadIdx.x % cq, np = 256 / cq;
+    const int lane_p = (cq % 64 == 0) ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / cq) : (int)threadIdx.x / cq;
+    const int b = qd * 4;
+    f32x4 w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const f32x4*>(P + (long)t * g.Cb + b);      // Ca == 1: P[tap][0][b]
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + b);
+    const int total = g.N * g.Hb * g.Wb;                           // (host: < 2^31; 32-bit pixel decode: a 64-bit division per pixel
+    const int p0 = blockIdx.x * pix_per_block;                     //  was the single most expensive thing in this kernel)
+    const int p1 = min(total, p0 + pix_per_block);
+    const int HWb = g.Hb * g.Wb;
+    for (int m0 = p0 + lane_p; m0 < p1; m0 += np * PP) {
+        // the taps' inputs: UNCONDITIONAL loads from clamped addresses, masked afterwards -- all of them (and the multiplier's loads)
+        // are in flight together; `ok ? small[..] : 0` compiled to a branch and a wait per tap
+        float xv[PP][16];
+        f32x4 tv[PP];
+        int mm[PP];
+        bool live[PP];
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const int m = m0 + u * np;
+            live[u] = m < p1;
+            mm[u] = live[u] ? m : p1 - 1;
+            const int n = mm[u] / HWb;
+            const int rem = mm[u] - n * HWb;
+            const int h = rem / g.Wb, wq = rem - h * g.Wb;
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh) {
+                const int hh = h + 1 - kh;
+                const int ih = (g.s == 2) ? hh >> 1 : hh;
+                const bool okh = (hh >= 0) & !((g.s == 2) & (hh & 1)) & (ih < g.Hs);
+                const int ihc = min(max(ih, 0), g.Hs - 1);
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int ww = wq + 1 - kw;
+                    const int iw = (g.s == 2) ? ww >> 1 : ww;
+                    const bool ok = okh & (ww >= 0) & !((g.s == 2) & (ww & 1)) & (iw < g.Ws);
+                    const int iwc = min(max(iw, 0), g.Ws - 1);
+                    const float x = small[(long)((n * g.Hs + ihc) * g.Ws + iwc) * ld_small];
+                    xv[u][kh * 4 + kw] = ok ? x : 0.f;
+                }
+            }
+            if (mul.t) {
+                if (out_bf) {
+                    const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(mul.t) + (long)mm[u] * mul.ld + b);
+                    tv[u] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                } else {
+                    tv[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(mul.t) + (long)mm[u] * mul.ld + b);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            f32x4 acc = bv;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc += xv[u][t] * w[t];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = pg_act_epi(acc[e], act);
+            if (mul.t) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] *= pg_act_grad_from_out(tv[u][e], mul.act);
+            }
+            if (live[u]) {
+                if (out_bf)
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(big) + (long)mm[u] * ld_big + b) = to_bf16(acc);
+                else
+                    *reinterpret_cast<f32x4*>(big + (long)mm[u] * ld_big + b) = acc;
+            }
+        }
     }
 }
 
@@ -3464,7 +3549,7 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     double fl = direct;
     char buf[128];
     if (code == 1050) {
-        snprintf(buf, sizeof buf, "k_s2b_ca1");
+        snprintf(buf, sizeof buf, (g->stride == 1 && (size_t)(g->Hs + 4) * (g->Ws + 4) * sizeof(float) <= 48 * 1024) ? "k_s2b_ca1_s1" : "k_s2b_ca1");
     } else if (code >= 1020 && code < 1030) {
         snprintf(buf, sizeof buf, "%s", pg_bf16x_wgrad_kernel_name(code - 1020));
     } else if (code >= 1030 && code < 1040) {
@@ -3770,8 +3855,21 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
                         (!mul.t || aligned_bf_view(mul.t, mul.ld, out_bf));
         if (al && !part && !x.u_cache) {
             const long total = (long)g.N * g.Hb * g.Wb;
-            const int ppb = (int)std::min<long>(64, std::max<long>(4, total / 2048));
+            // pixels per workgroup: ~1500 workgroups, whole trips of 2 pixels per thread row (256 / (Cb / 4) pixel rows per workgroup)
+            const int trip = 2 * (256 / (g.Cb / 4));
+            static const int ca1_wgs = pg_exp_env("PATCHGAN_CA1_WGS") ? atoi(pg_exp_env("PATCHGAN_CA1_WGS")) : 1536;
+            const int ppb = (int)std::max<long>(trip, ((total / ca1_wgs + trip - 1) / trip) * trip);
             TimedLaunch timed(st);
+            const size_t xs_bytes = (size_t)(g.Hs + 4) * (g.Ws + 4) * sizeof(float);
+            if (g.s == 1 && xs_bytes <= 48 * 1024 && g.Hb == g.Hs + 1 && g.Wb == g.Ws + 1) {
+                // per-sample form: ~1536 workgroups in all, whole pixel rows of the workgroup (256 / (Cb / 4) pixels per trip)
+                const int npr = 256 / (g.Cb / 4), hwb = g.Hb * g.Wb;
+                const long per = std::max<long>(1, 1536 / g.N);
+                const int ppb1 = (int)(((hwb + per - 1) / per + npr - 1) / npr * npr);
+                hipLaunchKernelGGL(k_s2b_ca1_s1, dim3((unsigned)((hwb + ppb1 - 1) / ppb1), g.N), dim3(256), xs_bytes, st, small, ld_small, P, bias,
+                                   big, ld_big, g, act, out_bf ? 1 : 0, mul, ppb1);
+                return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+            }
             hipLaunchKernelGGL(k_s2b_ca1, dim3((unsigned)((total + ppb - 1) / ppb)), dim3(256), 0, st, small, ld_small, P, bias, big, ld_big, g,
                                act, out_bf ? 1 : 0, mul, ppb);
             return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
