@@ -2979,8 +2979,7 @@ Plan plan_b2s(const pg_conv_geom* g) {
     p.tiles_n = (g->Ca + p.t.bn - 1) / p.t.bn;
     p.ncls = 1;
     p.nchunks = (16 * g->Cb + KC - 1) / KC;
-    // (one 64-row tile column -- the 2x2 / 4x4 bottleneck maps at batch 16 -- runs shorter slices: 21 -> 16 us per call, measured)
-    p.split = pick_split((long)p.tiles_m * p.tiles_n, p.nchunks, M <= 64 ? 4 : 8);
+    p.split = pick_split((long)p.tiles_m * p.tiles_n, p.nchunks, 8);
     p.out_elems = M * g->Ca;
     return p;
 }
@@ -2995,7 +2994,7 @@ Plan plan_s2b(const pg_conv_geom* g) {
     p.tiles_n = (g->Cb + p.t.bn - 1) / p.t.bn;
     const int taps = (g->stride == 2) ? 4 : 16;
     p.nchunks = (taps * g->Ca + KC - 1) / KC;
-    p.split = pick_split((long)p.tiles_m * p.tiles_n * p.ncls, p.nchunks, Mc <= 64 ? 4 : 8);      // (26 -> 22 us on those maps)
+    p.split = pick_split((long)p.tiles_m * p.tiles_n * p.ncls, p.nchunks, 8);
     p.out_elems = (long)g->N * g->Hb * g->Wb * g->Cb;
     return p;
 }
