@@ -324,9 +324,6 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         prof.reserve(2 * n_ev + 8)        # the events exist (and have been recorded once) before the timed region starts
     E.PROFILER = prof if events != 'none' else None
     pd = parallel.current()
-    if pd.on:
-        pd.timing = []             # (start, end, bytes) HIP events on the comm stream around every collective
-        pd.exposed = []            # (before, after, bytes) HIP events on the consuming stream around each wait for one
     trace = bool(os.environ.get('PATCHGAN_BENCH_TRACE'))
     if trace:
         import gc
@@ -356,11 +353,24 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
     E.PROFILER = None
     comm = None
     if pd.on:
+        # communication statistics from `csteps` EXTRA steps after the timed region (every rank runs them: they hold collectives):
+        # HIP events around each collective (comm stream) and around each wait for one (compute stream).  Not inside the timed
+        # region: an event record or a stream wait is a barrier packet on MI355X (5-10 us of an otherwise back-to-back kernel
+        # queue, tools/dp_sync_probe.py), three of them per collective on the compute stream, and with them every bucket is
+        # waited for one by one instead of once for all (parallel.GradReducer.finish)
+        csteps = max(1, min(steps, 8))
+        pd.timing, pd.exposed = [], []
+        for _ in range(csteps):
+            t.batch(x, y, train=True)
+        t.flush()
+        sync()
         recs, pd.timing = pd.timing, None
         waits, pd.exposed = pd.exposed, None
+        tsteps, steps = steps, csteps             # (the statistics below are per sampled step)
         per = max(1, len(recs) // steps)          # collectives of one step, in issue order (the same every step)
         by_slot = [[r for r in recs[i::per]] for i in range(per)] if len(recs) == per * steps else []
         comm = {'backend': dist.get_backend(), 'ranks_in_group': dist.get_world_size(),
+                'sampled_steps': csteps,
                 'collectives_per_step': len(recs) / steps,
                 'allreduce_ms_per_step': round(sum(e0.elapsed_time(e1) for e0, e1, _ in recs) / steps, 4),
                 'allreduce_MB_per_step': round(sum(b for _, _, b in recs) / steps / 1e6, 2),
@@ -371,9 +381,11 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
                 # event -- everything else of allreduce_ms_per_step ran under compute kernels
                 'exposed_ms_per_step': round(sum(a.elapsed_time(b) for a, b, _ in waits) / steps, 4),
                 'waits_per_step': len(waits) / steps,
-                'note': 'HIP events on the second (comm) stream around each gradient / loss-term all-reduce; they run '
+                'note': 'sampled on extra steps AFTER the timed region (the timed steps carry no communication events): HIP '
+                        'events on the second (comm) stream around each gradient / loss-term all-reduce; they run '
                         'under the backward and discriminator kernels of the compute stream; exposed_ms_per_step = event '
                         'pairs on the compute stream around each wait for a collective'}
+        steps = tsteps
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -265,6 +265,8 @@ class Trainer:
             ge.ucache_end(gcache)
             if g_reducer is None:
                 self._adam_step('g')                                                          # trainer.py:90
+            else:
+                g_reducer.finish(launch_only=True)     # the last (first layers') bucket leaves as soon as backward has produced it
         del dc
 
         # ---- discriminator step: real and (pre-update, detached) fake in one 2N batch        trainer.py:96-99
@@ -286,11 +288,12 @@ class Trainer:
             dflat = D.ensure_grad_flat()
             de.backward(D.flat, dflat, dc2, god, need_wgrad=True, need_dx=False, ucache=ucache)   # trainer.py:106
             if g_reducer is not None:
-                g_reducer.finish()                 # G's buckets have been in flight since the generator backward
-                self._adam_step('g')
                 # D's gradient (11 MB at ndf=64) is all-reduced asynchronously and applied by flush() at the first use of
-                # D's weights -- after the NEXT step's generator forward, which does not read them (trainer.py:63-66)
+                # D's weights -- after the NEXT step's generator forward, which does not read them (trainer.py:63-66); handed to
+                # the comm stream BEFORE the compute stream waits for G's buckets, so it is queued behind them without a gap
                 self._pending_d = dist.all_reduce_side(dflat)
+                g_reducer.finish()                     # G's buckets have been in flight since the generator backward
+                self._adam_step('g')
             else:
                 self._adam_step('d')                                                          # trainer.py:107
         de.ucache_end(ucache)

@@ -49,6 +49,38 @@ def _reducer_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_grad_reducer_waits_once_for_in_order_collectives():
+    """Device collectives share one in-order comm stream: finish() waits for the last bucket only (one barrier packet on the
+    compute stream instead of one per bucket); host work handles and timed waits are waited for one by one; finish(launch_only)
+    hands the remainder over without waiting."""
+    from patchgan_amd.parallel import GradReducer
+
+    class FakeDist:
+        def __init__(self, in_order):
+            self.calls, self.waited, self.in_order = [], [], in_order
+
+        def all_reduce_side(self, t):
+            i = len(self.calls)
+            self.calls.append(t.numel())
+
+            def wait():
+                self.waited.append(i)
+            wait.in_order = self.in_order
+            return wait
+
+    for in_order, want in ((True, [3]), (False, [0, 1, 2, 3])):
+        d = FakeDist(in_order)
+        r = GradReducer(d, torch.zeros(1000), bucket_bytes=4 * 300)
+        for hi, lo in ((1000, 700), (700, 400), (400, 100)):
+            r.ready(lo, hi)
+        assert d.calls == [300, 300, 300] and d.waited == []
+        r.finish(launch_only=True)
+        assert d.calls == [300, 300, 300, 100] and d.waited == []
+        r.finish()
+        assert d.calls == [300, 300, 300, 100] and d.waited == want
+        assert sorted(r.launched) == [(0, 100), (100, 400), (400, 700), (700, 1000)]
+
+
 def test_grad_reducer_world2():
     port = _free_port()
     ctx = mp.get_context('spawn')
