@@ -1796,6 +1796,135 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_tapnp(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ConvTranspose2d(4, 2, 1) onto <= 4 channels (the generator's head dec6, the discriminator's first-layer data gradient) in ONE pass,
+// taps folded into N:
+//     D[p][(b, tap)] = small[p][:] . P[tap][:][b]                      (MFMA 16x16x4: rows = small pixels, one 16-column tile = the 16
+//                                                                       taps of output channel b)
+//     big[n, h, w, b] = act(bias[b] + the four D entries that reach (h, w))
+// The two-launch form (row GEMM k_b2s_fast<.., true> + k_col2im_s2_lds) writes D to HBM and reads it back: 16.8 / 67 MB each way at
+// batch 16, 57 / 70 us for layers whose own traffic is 138 / 84 MB (22 / 13 us).  Here a workgroup owns a TF_H x TF_W block of small
+// pixels of one sample, keeps its D block in LDS, and writes the (2 TF_H - 2) x (2 TF_W - 2) output pixels all of whose four taps lie
+// inside the block; blocks step by TF_H - 1 / TF_W - 1 small pixels (one row / column of every block is recomputed by its
+// neighbour: 18 % more MFMA work on a memory-bound kernel, re-read from L2), and start at small pixel -1 (zeros) so the image border
+// needs no special case.  PERSISTENT: <= 512 workgroups walk blocks blockIdx.x, + gridDim.x, ...; the lanes' operand rows come
+// straight from global memory in MFMA fragment order (lane (pixel r, k group q) loads 16 bytes = 4 consecutive channels, which feed
+// four MFMAs; the matching weight fragments are read from an LDS image of P with the same k order), no LDS staging of `small`, and
+// block t + 1's loads are issued before block t's MFMAs (two register sets).
+// ------------------------------------------------------------------------------------------------
+constexpr int TF_H = 8, TF_W = 16;
+template <int CB, int KK>     // CB output channels, Ca == 16 * KK input channels
+__global__ __launch_bounds__(256, 2) void k_s2b_tapnf(const float* __restrict__ small, int ld_small, const float* __restrict__ P,
+                                                      const float* __restrict__ bias, float* __restrict__ big, int ld_big, Geom g, int act,
+                                                      int small_bytes, int big_bytes, int nbh, int nbw, int nblocks, int vec4) {
+    constexpr int Ca = 16 * KK;
+    constexpr int SK = 16 * CB + 4;      // k-row pitch of the weight image: the four k groups of a fragment read land in four bank quarters
+    // D block in LDS: [pixel][tap][channel], so a lane's CB channels of one (pixel, tap) are one ds_write / one ds_read (CB = 4: 16 bytes)
+    constexpr int SD = (CB == 4) ? 16 * CB + 4 : (CB == 2) ? 16 * CB + 2 : 16 * CB + 1;
+    constexpr int OH = 2 * TF_H - 2, OW = 2 * TF_W - 2;
+    __shared__ float Bs[Ca * SK];
+    __shared__ float Ds[TF_H * TF_W * SD];
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)small, 0, small_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)big, 0, big_bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    for (int i = tid; i < Ca * CB * 16; i += 256) {          // Bs[k][b][tap] = P[tap][k][b]
+        const int tap = i & 15, b = (i >> 4) % CB, k = i / (16 * CB);
+        Bs[k * SK + b * 16 + tap] = P[((long)tap * Ca + k) * CB + b];
+    }
+    float bv[CB];
+#pragma unroll
+    for (int b = 0; b < CB; ++b) bv[b] = bias ? bias[b] : 0.f;
+    __syncthreads();
+
+    const int G = gridDim.x;
+    int blk = xcd_remap(blockIdx.x, G);
+    // this lane's two pixel rows of block `b`: rows 2 * wave + {0, 1} of the block, column c
+    auto issue = [&](f32x4 (&a)[2][KK], int b) {
+        const bool on = b < nblocks;
+        const int bb = on ? b : 0;
+        const int bj = bb % nbw, t = bb / nbw;
+        const int bi = t % nbh, n = t / nbh;
+        const int j = bj * (TF_W - 1) - 1 + c;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int i = bi * (TF_H - 1) - 1 + 2 * wave + rt;
+            const bool ok = on && (unsigned)i < (unsigned)g.Hs && (unsigned)j < (unsigned)g.Ws;
+            const int off = ((n * g.Hs + i) * g.Ws + j) * ld_small + q * 4;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) a[rt][kk] = bload4(rS, voff(off + kk * 16, ok));
+        }
+    };
+    auto body = [&](f32x4 (&cur)[2][KK], f32x4 (&nxt)[2][KK], int b) {
+        issue(nxt, b + G);
+        PIN_VMEM();
+        f32x4 acc[2][CB];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[rt][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float bf[CB];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) bf[cb] = Bs[(kk * 16 + q * 4 + e) * SK + cb * 16 + c];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        acc[rt][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[rt][kk][e], bf[cb], acc[rt][cb], 0, 0, 0);
+            }
+        // D block -> LDS: lane (tap c, group q) holds pixels 4 q + {0..3} of its two block rows
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Ds[((2 * wave + rt) * TF_W + q * 4 + e) * SD + c * CB + cb] = acc[rt][cb][e];
+        __syncthreads();
+        const int bj = b % nbw, t = b / nbw;
+        const int bi = t % nbh, n = t / nbh;
+        const int h0 = 2 * (bi * (TF_H - 1) - 1) + 1, w0 = 2 * (bj * (TF_W - 1) - 1) + 1;
+        for (int o = tid; o < OH * OW; o += 256) {
+            const int oh = o / OW, ow = o - oh * OW;
+            const int h = h0 + oh, w = w0 + ow;
+            // output row h0 + oh (h0 odd): oh even -> rows oh/2 (kh 2) and oh/2 + 1 (kh 0); oh odd -> rows (oh+1)/2 (kh 1) and (oh-1)/2 (kh 3)
+            const int la = (oh + 1) >> 1, ka = (oh & 1) ? 1 : 2, lb = (oh & 1) ? la - 1 : la + 1, kb = (oh & 1) ? 3 : 0;
+            const int ma = (ow + 1) >> 1, ua = (ow & 1) ? 1 : 2, mb = (ow & 1) ? ma - 1 : ma + 1, ub = (ow & 1) ? 3 : 0;
+            const float* d00 = Ds + (la * TF_W + ma) * SD + (ka * 4 + ua) * CB;
+            const float* d01 = Ds + (la * TF_W + mb) * SD + (ka * 4 + ub) * CB;
+            const float* d10 = Ds + (lb * TF_W + ma) * SD + (kb * 4 + ua) * CB;
+            const float* d11 = Ds + (lb * TF_W + mb) * SD + (kb * 4 + ub) * CB;
+            const bool ok = (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
+            const int eo = ((n * g.Hb + h) * g.Wb + w) * ld_big;
+            float v[CB];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) v[cb] = pg_act_epi(bv[cb] + ((d00[cb] + d01[cb]) + (d10[cb] + d11[cb])), act);
+            if (CB == 4 && vec4) {
+                const f32x4 o4 = {v[0], v[1 % CB], v[2 % CB], v[3 % CB]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rO, voff(eo, ok), 0, 0);
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[cb]), rO, voff(eo + cb, ok), 0, 0);
+            }
+        }
+        __syncthreads();
+    };
+    f32x4 A0[2][KK], A1[2][KK];
+    issue(A0, blk);
+    while (blk < nblocks) {
+        body(A0, A1, blk);
+        blk += G;
+        if (blk >= nblocks) break;
+        body(A1, A0, blk);
+        blk += G;
+    }
+}
+
 // ================================================================================================
 // bf16 variants (PG_ALGO_BF16; the "next" row f2, BASELINE config 4): tensors stay fp32 in HBM and in the C ABI -- fp32
 // master weights, fp32 InstanceNorm statistics, fp32 accumulation -- but operand tiles are rounded to bf16 (RNE,
@@ -3097,6 +3226,14 @@ int launch_reduce(const float* slabs, long slab_stride, int S, float* out, int l
 
 // taps-folded-into-N forward paths: eligibility and workspace (floats)
 inline bool s2b_tapn_ok(const Geom& g) { return g.Cb <= 8 && g.Ca % KC == 0 && !force_generic(); }
+// the one-pass form of it (k_s2b_tapnf): stride 2 onto <= 4 channels from 32 / 64 / 128 (fp32 tensors)
+inline bool tapnf_enabled() {
+    static const bool off = pg_exp_env("PATCHGAN_NO_TAPNF") != nullptr;
+    return !off;
+}
+inline bool s2b_tapnf_ok(const Geom& g) {
+    return g.s == 2 && g.Cb <= 4 && (g.Ca == 32 || g.Ca == 64 || g.Ca == 128) && !force_generic() && tapnf_enabled();
+}
 inline bool b2s_tapn_ok(const Geom& g) { return g.Ca <= 8 && g.Cb % KC == 0 && !force_generic(); }
 inline size_t s2b_tapn_ws(const Geom& g) {
     return ((size_t)16 * g.Cb * g.Ca + (size_t)g.N * g.Hs * g.Ws * 16 * g.Cb) * sizeof(float) + 256;
@@ -3471,6 +3608,13 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         if (workgroups) *workgroups = (long)bp.tiles_m * bp.tiles_n * bp.ncls * bp.split;
         return PG_OK;
     }
+    if (op == 1 && !(algo_full & PG_IO_MASK) && s2b_tapnf_ok(gq)) {      // 1060 + Cb: k_s2b_tapnf<Cb>
+        if (tile_id) *tile_id = 1060 + gq.Cb;
+        if (split) *split = 1;
+        const long nb = (long)gq.N * ((gq.Hb + 2 * TF_H - 2) / (2 * TF_H - 2)) * ((gq.Wb + 2 * TF_W - 2) / (2 * TF_W - 2));
+        if (workgroups) *workgroups = std::min<long>(nb, (gq.Ca == 128) ? 512 : 768);
+        return PG_OK;
+    }
     if ((op == 0 && b2s_tapn_ok(gq) && ws_bytes >= b2s_tapn_ws(gq)) || (op == 1 && s2b_tapn_ok(gq) && ws_bytes >= s2b_tapn_ws(gq))) {
         const long M1 = (op == 0) ? (long)g->N * g->Hb * g->Wb : (long)g->N * g->Hs * g->Ws;
         const int Nc = 16 * ((op == 0) ? g->Ca : g->Cb);
@@ -3550,7 +3694,9 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     const double direct = 2.0 * g->N * g->Hs * g->Ws * 16.0 * g->Ca * g->Cb;
     double fl = direct;
     char buf[128];
-    if (code == 1050) {
+    if (code > 1060 && code <= 1064) {
+        snprintf(buf, sizeof buf, "k_s2b_tapnf<%d>", code - 1060);          // one-pass taps-in-N ConvTranspose2d onto <= 4 channels
+    } else if (code == 1050) {
         snprintf(buf, sizeof buf, (g->stride == 1 && (size_t)(g->Hs + 4) * (g->Ws + 4) * sizeof(float) <= 48 * 1024) ? "k_s2b_ca1_s1" : "k_s2b_ca1");
     } else if (code >= 1020 && code < 1030) {
         snprintf(buf, sizeof buf, "%s", pg_bf16x_wgrad_kernel_name(code - 1020));
@@ -3929,6 +4075,37 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         if (rc != BF16X_SKIP) return rc;
     }
     if (part || x.u_cache || mul.t) return PG_EINVAL;
+    if (!io && s2b_tapnf_ok(g) && (ld_small % 4 == 0) && aligned16(small) &&
+        tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT) {
+        const int nbh = (g.Hb + 2 * TF_H - 2) / (2 * TF_H - 2), nbw = (g.Wb + 2 * TF_W - 2) / (2 * TF_W - 2);
+        const long nb = (long)g.N * nbh * nbw;
+        if (nb < 0x7fffffffL) {
+            const int sb = (int)tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca), bb = (int)tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb);
+            // workgroups per CU by LDS and registers: 2 for Ca = 128, else 3
+            static const int wgs_env = pg_exp_env("PATCHGAN_TAPNF_WG") ? atoi(pg_exp_env("PATCHGAN_TAPNF_WG")) : 0;
+            const int wgs = wgs_env > 0 ? wgs_env : (g.Ca == 128) ? 512 : 768;
+            const dim3 grid((unsigned)std::min<long>(nb, wgs));
+            const int v4 = (g.Cb == 4 && ld_big % 4 == 0 && aligned16(big)) ? 1 : 0;
+            TimedLaunch timed(st);
+#define PG_TAPNF(CBv, KKv)                                                                                                          \
+    hipLaunchKernelGGL((k_s2b_tapnf<CBv, KKv>), grid, dim3(256), 0, st, small, ld_small, P, bias, big, ld_big, g, act, sb, bb, nbh, nbw, (int)nb, v4)
+#define PG_TAPNF_K(CBv)                                                                                                             \
+    switch (g.Ca) {                                                                                                                 \
+        case 32: PG_TAPNF(CBv, 2); break;                                                                                           \
+        case 64: PG_TAPNF(CBv, 4); break;                                                                                           \
+        default: PG_TAPNF(CBv, 8); break;                                                                                           \
+    }
+            switch (g.Cb) {
+                case 1: PG_TAPNF_K(1) break;
+                case 2: PG_TAPNF_K(2) break;
+                case 3: PG_TAPNF_K(3) break;
+                default: PG_TAPNF_K(4) break;
+            }
+#undef PG_TAPNF_K
+#undef PG_TAPNF
+            return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
+        }
+    }
     if (!io && s2b_tapn_ok(g) && (ld_small % 4 == 0) && aligned16(small) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= s2b_tapn_ws(g) && tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT) {
         // D[small pixel][(tap, b)] = small . W' (row GEMM), then col2im: each big pixel sums the taps that reach it

@@ -52,7 +52,7 @@ def test_kernel_plan_of_the_benchmark_layers():
     if os.environ.get('PATCHGAN_WINO2') or os.environ.get('PATCHGAN_NO_WINOGRAD'):
         pytest.skip('kernel-selection switches set in the environment')
     want = {   # (N, Hb, Wb, Ca, Cb, stride): (big2small, small2big, wgrad) kernel families under PG_ALGO_AUTO
-        (16, 256, 256, 64, 3, 2): ('k_b2s_tapk', 'k_b2s_fast<2,1,2,2,true>+k_col2im', 'k_wgrad_tapn'),     # enc0
+        (16, 256, 256, 64, 3, 2): ('k_b2s_tapk', 'k_s2b_tapnf<3>', 'k_wgrad_tapn'),     # enc0
         (16, 128, 128, 128, 64, 2): ('k_wino_bgemm', 'k_wino_bgemm', 'k_wino_wgrad_gemm<1,1,2,2>'),           # enc1
         (16, 64, 64, 256, 128, 2): ('k_wino_bgemm', 'k_wino_bgemm', 'k_wino_wgrad_gemm<1,1,2,2>'),            # enc2
         (16, 16, 16, 512, 512, 2): ('k_b2s_fast', 'k_s2b_fast', 'k_wgrad_fast'),                              # enc4: too few tiles
@@ -245,3 +245,15 @@ def test_bench_kernel_plan_is_the_committed_one():
     assert sorted(live) == sorted(committed)
     diff = {k: (committed[k], live[k]) for k in live if live[k] != committed[k]}
     assert not diff, diff
+
+
+def test_one_pass_transposed_conv_onto_few_channels_is_planned_where_it_exists():
+    """Stride-2 small -> big onto <= 4 channels from 32 / 64 / 128 fp32 channels runs the one-pass kernel k_s2b_tapnf (D block in
+    LDS); other channel counts, 5-8 channels and stride 1 keep the two-launch row GEMM + col2im; bf16 tensors keep theirs."""
+    from patchgan_amd import engine as E, _lib as L
+    for Ca in (32, 64, 128):
+        for Cb in (1, 2, 3, 4):
+            assert E.ConvOp(2, 32, 32, Ca, Cb, 2, L.ALGO_AUTO).describe(1)[0] == f'k_s2b_tapnf<{Cb}>'
+    for geom in ((2, 32, 32, 96, 2, 2), (2, 32, 32, 64, 6, 2), (2, 9, 9, 32, 4, 1)):
+        assert E.ConvOp(*geom, L.ALGO_AUTO).describe(1)[0].endswith('k_col2im_small2big'), geom
+    assert 'tapnf' not in E.ConvOp(2, 32, 32, 64, 4, 2, L.ALGO_BF16).describe(1, L.IO_SMALL_BF16)[0]

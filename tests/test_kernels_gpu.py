@@ -30,8 +30,11 @@ GEOMS = [
     (2, 64, 64, 128, 64, 2),    # enc-like: all fast kernels, power-of-two decode
     (2, 16, 16, 1, 64, 1),      # D-head-like: big2small via row GEMM + tap gather
     (1, 15, 13, 4, 32, 2),      # same path, stride 2, odd extents, 4 output channels
-    (2, 16, 16, 32, 1, 2),      # dec6-like: small2big via row GEMM + col2im, Cb = 1 (no weight re-layout)
-    (2, 12, 20, 64, 3, 2),      # same path with the (tap, b) weight re-layout, Cb = 3
+    (2, 16, 16, 32, 1, 2),      # dec6-like: stride-2 small2big onto <= 4 channels from 32 / 64 / 128 in one pass (k_s2b_tapnf<1>)
+    (2, 12, 20, 64, 3, 2),      # same kernel, 3 channels, blocks that overhang the image
+    (3, 34, 30, 128, 4, 2),     # same, 4 channels (16-byte stores), 128 input channels, several blocks per sample
+    (2, 16, 16, 96, 1, 2),      # other channel counts: small2big via row GEMM + col2im, Cb = 1 (no weight re-layout)
+    (2, 12, 20, 96, 3, 2),      # same path with the (tap, b) weight re-layout, Cb = 3
     (2, 9, 9, 32, 8, 1),        # same path, stride 1
     (4, 64, 64, 64, 4, 2),      # >= 4096 small pixels on <= 4 big-side channels: the persistent image-facing kernels (k_b2s_tapkp, k_wgrad_tapnp)
     (5, 64, 64, 72, 3, 2),      # same, ragged channel blocks, 3-channel pixels
