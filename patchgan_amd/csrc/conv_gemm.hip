@@ -1813,29 +1813,44 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_tapnp(const float* __restrict_
 // block t + 1's loads are issued before block t's MFMAs (two register sets).
 // ------------------------------------------------------------------------------------------------
 constexpr int TF_H = 8, TF_W = 16;
-template <int CB, int KK>     // CB output channels, Ca == 16 * KK input channels
-__global__ __launch_bounds__(256, 2) void k_s2b_tapnf(const float* __restrict__ small, int ld_small, const float* __restrict__ P,
+typedef __bf16 tf_bf16x8 __attribute__((ext_vector_type(8)));
+// BF: `small` is a bf16 tensor (PG_ALGO_BF16 with bf16 activation storage): a lane's 16 bytes are 8 consecutive channels = its operand of
+// one v_mfma_f32_16x16x32_bf16, the weights are rounded to bf16 as they are laid into LDS ([(b, tap)][k], k contiguous), fp32 accumulation
+// and an fp32 result as everywhere in that mode.  KK = operand loads per pixel: Ca / 16 (fp32) or Ca / 32 (bf16).
+template <int CB, int KK, bool BF>
+__global__ __launch_bounds__(256, 2) void k_s2b_tapnf(const void* __restrict__ small_v, int ld_small, const float* __restrict__ P,
                                                       const float* __restrict__ bias, float* __restrict__ big, int ld_big, Geom g, int act,
-                                                      int small_bytes, int big_bytes, int nbh, int nbw, int nblocks, int vec4) {
-    constexpr int Ca = 16 * KK;
-    constexpr int SK = 16 * CB + 4;      // k-row pitch of the weight image: the four k groups of a fragment read land in four bank quarters
+                                                      int small_bytes, int big_bytes, int nbh, int nbw, int nblocks, int vec4, int cb_total,
+                                                      int b0) {
+    // (5 .. 8 output channels run as two launches: channels b0 .. b0 + CB - 1 of cb_total each)
+    constexpr int Ca = (BF ? 32 : 16) * KK;
+    constexpr int SK = 16 * CB + 4;      // fp32: k-row pitch of the weight image: the four k groups of a fragment read land in four bank quarters
+    constexpr int SKB = Ca + 8;          // bf16: (b, tap)-row pitch in elements (16 bytes of padding: conflict-free ds_read_b128 per 16 lanes)
     // D block in LDS: [pixel][tap][channel], so a lane's CB channels of one (pixel, tap) are one ds_write / one ds_read (CB = 4: 16 bytes)
-    constexpr int SD = (CB == 4) ? 16 * CB + 4 : (CB == 2) ? 16 * CB + 2 : 16 * CB + 1;
+    constexpr int SD = (CB % 4 == 0) ? 16 * CB + 4 : (CB % 2 == 0) ? 16 * CB + 2 : 16 * CB + 1;
     constexpr int OH = 2 * TF_H - 2, OW = 2 * TF_W - 2;
-    __shared__ float Bs[Ca * SK];
-    __shared__ float Ds[TF_H * TF_W * SD];
-    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)small, 0, small_bytes, 0x00020000);
+    constexpr int BS_BYTES = BF ? 16 * CB * SKB * 2 : Ca * SK * 4;
+    __shared__ __attribute__((aligned(16))) char Bs_raw[BS_BYTES];
+    __shared__ __attribute__((aligned(16))) float Ds[TF_H * TF_W * SD];
+    float* const Bs = reinterpret_cast<float*>(Bs_raw);
+    __bf16* const Bh = reinterpret_cast<__bf16*>(Bs_raw);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)small_v, 0, small_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)big, 0, big_bytes, 0x00020000);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, q = lane >> 4;
-    for (int i = tid; i < Ca * CB * 16; i += 256) {          // Bs[k][b][tap] = P[tap][k][b]
-        const int tap = i & 15, b = (i >> 4) % CB, k = i / (16 * CB);
-        Bs[k * SK + b * 16 + tap] = P[((long)tap * Ca + k) * CB + b];
+    for (int i = tid; i < Ca * CB * 16; i += 256) {
+        if constexpr (BF) {                                  // Bh[(b, tap)][k] = bf16(P[tap][k][b])
+            const int k = i % Ca, bt = i / Ca, tap = bt & 15, b = bt >> 4;
+            Bh[bt * SKB + k] = (__bf16)P[((long)tap * Ca + k) * cb_total + b0 + b];
+        } else {                                             // Bs[k][b][tap] = P[tap][k][b]
+            const int tap = i & 15, b = (i >> 4) % CB, k = i / (16 * CB);
+            Bs[k * SK + b * 16 + tap] = P[((long)tap * Ca + k) * cb_total + b0 + b];
+        }
     }
     float bv[CB];
 #pragma unroll
-    for (int b = 0; b < CB; ++b) bv[b] = bias ? bias[b] : 0.f;
+    for (int b = 0; b < CB; ++b) bv[b] = bias ? bias[b0 + b] : 0.f;
     __syncthreads();
 
     const int G = gridDim.x;
@@ -1851,9 +1866,14 @@ __global__ __launch_bounds__(256, 2) void k_s2b_tapnf(const float* __restrict__ 
         for (int rt = 0; rt < 2; ++rt) {
             const int i = bi * (TF_H - 1) - 1 + 2 * wave + rt;
             const bool ok = on && (unsigned)i < (unsigned)g.Hs && (unsigned)j < (unsigned)g.Ws;
-            const int off = ((n * g.Hs + i) * g.Ws + j) * ld_small + q * 4;
+            const int off = ((n * g.Hs + i) * g.Ws + j) * ld_small + q * (BF ? 8 : 4);
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) a[rt][kk] = bload4(rS, voff(off + kk * 16, ok));
+            for (int kk = 0; kk < KK; ++kk) {
+                if constexpr (BF)
+                    a[rt][kk] = bload4(rS, (int)(((unsigned)(off + kk * 32) << 1) | (ok ? 0u : 0x80000000u)));
+                else
+                    a[rt][kk] = bload4(rS, voff(off + kk * 16, ok));
+            }
         }
     };
     auto body = [&](f32x4 (&cur)[2][KK], f32x4 (&nxt)[2][KK], int b) {
@@ -1864,19 +1884,33 @@ __global__ __launch_bounds__(256, 2) void k_s2b_tapnf(const float* __restrict__ 
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) acc[rt][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF) {
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
+            for (int kk = 0; kk < KK; ++kk) {
+                tf_bf16x8 bf[CB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float bf[CB];
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) bf[cb] = Bs[(kk * 16 + q * 4 + e) * SK + cb * 16 + c];
+                for (int cb = 0; cb < CB; ++cb) bf[cb] = *reinterpret_cast<const tf_bf16x8*>(Bh + (cb * 16 + c) * SKB + kk * 32 + q * 8);
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb)
-                        acc[rt][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[rt][kk][e], bf[cb], acc[rt][cb], 0, 0, 0);
+                        acc[rt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tf_bf16x8, cur[rt][kk]), bf[cb], acc[rt][cb], 0, 0, 0);
             }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float bf[CB];
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) bf[cb] = Bs[(kk * 16 + q * 4 + e) * SK + cb * 16 + c];
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb)
+                            acc[rt][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[rt][kk][e], bf[cb], acc[rt][cb], 0, 0, 0);
+                }
+        }
         // D block -> LDS: lane (tap c, group q) holds pixels 4 q + {0..3} of its two block rows
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -1899,13 +1933,16 @@ __global__ __launch_bounds__(256, 2) void k_s2b_tapnf(const float* __restrict__ 
             const float* d10 = Ds + (lb * TF_W + ma) * SD + (kb * 4 + ua) * CB;
             const float* d11 = Ds + (lb * TF_W + mb) * SD + (kb * 4 + ub) * CB;
             const bool ok = (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
-            const int eo = ((n * g.Hb + h) * g.Wb + w) * ld_big;
+            const int eo = ((n * g.Hb + h) * g.Wb + w) * ld_big + b0;
             float v[CB];
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) v[cb] = pg_act_epi(bv[cb] + ((d00[cb] + d01[cb]) + (d10[cb] + d11[cb])), act);
-            if (CB == 4 && vec4) {
-                const f32x4 o4 = {v[0], v[1 % CB], v[2 % CB], v[3 % CB]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rO, voff(eo, ok), 0, 0);
+            if (CB % 4 == 0 && vec4) {
+#pragma unroll
+                for (int c4 = 0; c4 < CB / 4; ++c4) {
+                    const f32x4 o4 = {v[(4 * c4) % CB], v[(4 * c4 + 1) % CB], v[(4 * c4 + 2) % CB], v[(4 * c4 + 3) % CB]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rO, voff(eo + 4 * c4, ok), 0, 0);
+                }
             } else {
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
@@ -3226,14 +3263,19 @@ int launch_reduce(const float* slabs, long slab_stride, int S, float* out, int l
 
 // taps-folded-into-N forward paths: eligibility and workspace (floats)
 inline bool s2b_tapn_ok(const Geom& g) { return g.Cb <= 8 && g.Ca % KC == 0 && !force_generic(); }
-// the one-pass form of it (k_s2b_tapnf): stride 2 onto <= 4 channels from 32 / 64 / 128 (fp32 tensors)
+// the one-pass form of it (k_s2b_tapnf): stride 2 onto <= 8 channels (5 .. 8: two launches of <= 4) from 32 / 64 / 128
 inline bool tapnf_enabled() {
     static const bool off = pg_exp_env("PATCHGAN_NO_TAPNF") != nullptr;
     return !off;
 }
 inline bool s2b_tapnf_ok(const Geom& g) {
-    return g.s == 2 && g.Cb <= 4 && (g.Ca == 32 || g.Ca == 64 || g.Ca == 128) && !force_generic() && tapnf_enabled();
+    return g.s == 2 && g.Cb <= 8 && (g.Ca == 32 || g.Ca == 64 || g.Ca == 128) && !force_generic() && tapnf_enabled();
 }
+struct Tune;
+inline bool s2b_tapnf_bf_ok(const Geom& g, int algo_full, const Tune& t);      // the same kernel on a bf16 `small` (PG_ALGO_BF16), below Tune
+// one launch of k_s2b_tapnf (the caller has checked eligibility, alignment and the 32-bit offset limits)
+static int launch_tapnf(bool bf, const void* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, const Geom& g,
+                        int act, long small_bytes, long big_bytes, hipStream_t st);
 inline bool b2s_tapn_ok(const Geom& g) { return g.Ca <= 8 && g.Cb % KC == 0 && !force_generic(); }
 inline size_t s2b_tapn_ws(const Geom& g) {
     return ((size_t)16 * g.Cb * g.Ca + (size_t)g.N * g.Hs * g.Ws * 16 * g.Cb) * sizeof(float) + 256;
@@ -3419,6 +3461,52 @@ inline bool bf16x_s2b_tapn_ok(const Geom& g, int algo_full, const Tune& t) {
     if ((algo_full & PG_IO_MASK) != PG_IO_SMALL_BF16 || g.Cb > 8) return false;
     return pg_bf16x_geom_ok(3, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, 16 * g.Cb, g.s);
 }
+inline bool s2b_tapnf_bf_ok(const Geom& g, int algo_full, const Tune& t) {
+    if ((algo_full & PG_ALGO_MASK) != PG_ALGO_BF16 || !t.bf16x || (algo_full & PG_IO_MASK) != PG_IO_SMALL_BF16) return false;
+    return s2b_tapnf_ok(g);
+}
+static int launch_tapnf(bool bf, const void* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, const Geom& g,
+                        int act, long small_bytes, long big_bytes, hipStream_t st) {
+    const int nbh = (g.Hb + 2 * TF_H - 2) / (2 * TF_H - 2), nbw = (g.Wb + 2 * TF_W - 2) / (2 * TF_W - 2);
+    const long nb = (long)g.N * nbh * nbw;
+    if (nb >= 0x7fffffffL) return PG_EINVAL;
+    // workgroups per CU by LDS and registers: 2 for 128 fp32 input channels, else 3
+    static const int wgs_env = pg_exp_env("PATCHGAN_TAPNF_WG") ? atoi(pg_exp_env("PATCHGAN_TAPNF_WG")) : 0;
+    const int wgs = wgs_env > 0 ? wgs_env : (g.Ca == 128 && !bf) ? 512 : 768;
+    const dim3 grid((unsigned)std::min<long>(nb, wgs));
+    const int v4 = (g.Cb % 4 == 0 && ld_big % 4 == 0 && aligned16(big)) ? 1 : 0;
+    const int sb = (int)small_bytes, bb = (int)big_bytes;
+    TimedLaunch timed(st);
+#define PG_TAPNF(CBv, KKv, BFv)                                                                                                     \
+    hipLaunchKernelGGL((k_s2b_tapnf<CBv, KKv, BFv>), grid, dim3(256), 0, st, small, ld_small, P, bias, big, ld_big, g, act, sb, bb, nbh, nbw, \
+                       (int)nb, v4, g.Cb, b0)
+#define PG_TAPNF_K(CBv)                                                                                                             \
+    if (bf) {                                                                                                                       \
+        switch (g.Ca) {                                                                                                             \
+            case 32: PG_TAPNF(CBv, 1, true); break;                                                                                 \
+            case 64: PG_TAPNF(CBv, 2, true); break;                                                                                 \
+            default: PG_TAPNF(CBv, 4, true); break;                                                                                 \
+        }                                                                                                                           \
+    } else {                                                                                                                        \
+        switch (g.Ca) {                                                                                                             \
+            case 32: PG_TAPNF(CBv, 2, false); break;                                                                                \
+            case 64: PG_TAPNF(CBv, 4, false); break;                                                                                \
+            default: PG_TAPNF(CBv, 8, false); break;                                                                                \
+        }                                                                                                                           \
+    }
+    for (int b0 = 0; b0 < g.Cb; b0 += 4) {
+        switch (std::min(4, g.Cb - b0)) {
+            case 1: PG_TAPNF_K(1) break;
+            case 2: PG_TAPNF_K(2) break;
+            case 3: PG_TAPNF_K(3) break;
+            default: PG_TAPNF_K(4) break;
+        }
+        if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
+    }
+#undef PG_TAPNF_K
+#undef PG_TAPNF
+    return PG_OK;
+}
 inline size_t bf16x_s2b_tapn_ws(const Geom& g) {
     return pg_bf16x_w_bytes(g.Ca, g.Cb) + (size_t)g.N * g.Hs * g.Ws * 16 * g.Cb * sizeof(float);
 }
@@ -3592,6 +3680,13 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         if (workgroups) *workgroups = 2048;
         return PG_OK;
     }
+    if (op == 1 && s2b_tapnf_bf_ok(gq, algo_full, tune)) {      // 1070 + Cb: k_s2b_tapnf<Cb, bf16>
+        if (tile_id) *tile_id = 1070 + gq.Cb;
+        if (split) *split = 1;
+        const long nb = (long)gq.N * ((gq.Hb + 2 * TF_H - 2) / (2 * TF_H - 2)) * ((gq.Wb + 2 * TF_W - 2) / (2 * TF_W - 2));
+        if (workgroups) *workgroups = std::min<long>(nb, 768);
+        return PG_OK;
+    }
     if (op == 1 && bf16x_s2b_tapn_ok(gq, algo_full, tune) && ws_bytes >= bf16x_s2b_tapn_ws(gq)) {
         const pg_bf16x_plan bp = pg_bf16x_plan_of(3, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, 16 * gq.Cb, gq.s, 0);
         if (tile_id) *tile_id = 1030 + bp.tile;
@@ -3696,6 +3791,12 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     char buf[128];
     if (code > 1060 && code <= 1064) {
         snprintf(buf, sizeof buf, "k_s2b_tapnf<%d>", code - 1060);          // one-pass taps-in-N ConvTranspose2d onto <= 4 channels
+    } else if (code > 1064 && code <= 1068) {
+        snprintf(buf, sizeof buf, "k_s2b_tapnf<4>+k_s2b_tapnf<%d>", code - 1064);      // 5 .. 8 channels: two launches
+    } else if (code > 1070 && code <= 1074) {
+        snprintf(buf, sizeof buf, "k_s2b_tapnf<%d,bf16>", code - 1070);     // ... from a bf16 tensor
+    } else if (code > 1074 && code <= 1078) {
+        snprintf(buf, sizeof buf, "k_s2b_tapnf<4,bf16>+k_s2b_tapnf<%d,bf16>", code - 1074);
     } else if (code == 1050) {
         snprintf(buf, sizeof buf, (g->stride == 1 && (size_t)(g->Hs + 4) * (g->Ws + 4) * sizeof(float) <= 48 * 1024) ? "k_s2b_ca1_s1" : "k_s2b_ca1");
     } else if (code >= 1020 && code < 1030) {
@@ -4052,6 +4153,10 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         return pg_wino2_s2b(small, ld_small, P, bias, big, ld_big, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, part,
                             x.u_cache, x.u_valid, mul);
     }
+    if (s2b_tapnf_bf_ok(g, algo | io, tune) && !part && !x.u_cache && !mul.t && (ld_small % 8 == 0) && aligned16(small) &&
+        tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca, true) < FAST_LIMIT && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT)
+        return launch_tapnf(true, small, ld_small, P, bias, big, ld_big, g, act, tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca, true),
+                            tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb), st);
     if (bf16x_s2b_tapn_ok(g, algo | io, tune) && !part && !x.u_cache && !mul.t && ws && aligned16(ws) && ws_bytes >= bf16x_s2b_tapn_ws(g) &&
         aligned_bf_view(small, ld_small, true) && aligned16(P) &&
         tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca, true) < FAST_LIMIT) {
@@ -4076,36 +4181,9 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
     }
     if (part || x.u_cache || mul.t) return PG_EINVAL;
     if (!io && s2b_tapnf_ok(g) && (ld_small % 4 == 0) && aligned16(small) &&
-        tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT) {
-        const int nbh = (g.Hb + 2 * TF_H - 2) / (2 * TF_H - 2), nbw = (g.Wb + 2 * TF_W - 2) / (2 * TF_W - 2);
-        const long nb = (long)g.N * nbh * nbw;
-        if (nb < 0x7fffffffL) {
-            const int sb = (int)tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca), bb = (int)tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb);
-            // workgroups per CU by LDS and registers: 2 for Ca = 128, else 3
-            static const int wgs_env = pg_exp_env("PATCHGAN_TAPNF_WG") ? atoi(pg_exp_env("PATCHGAN_TAPNF_WG")) : 0;
-            const int wgs = wgs_env > 0 ? wgs_env : (g.Ca == 128) ? 512 : 768;
-            const dim3 grid((unsigned)std::min<long>(nb, wgs));
-            const int v4 = (g.Cb == 4 && ld_big % 4 == 0 && aligned16(big)) ? 1 : 0;
-            TimedLaunch timed(st);
-#define PG_TAPNF(CBv, KKv)                                                                                                          \
-    hipLaunchKernelGGL((k_s2b_tapnf<CBv, KKv>), grid, dim3(256), 0, st, small, ld_small, P, bias, big, ld_big, g, act, sb, bb, nbh, nbw, (int)nb, v4)
-#define PG_TAPNF_K(CBv)                                                                                                             \
-    switch (g.Ca) {                                                                                                                 \
-        case 32: PG_TAPNF(CBv, 2); break;                                                                                           \
-        case 64: PG_TAPNF(CBv, 4); break;                                                                                           \
-        default: PG_TAPNF(CBv, 8); break;                                                                                           \
-    }
-            switch (g.Cb) {
-                case 1: PG_TAPNF_K(1) break;
-                case 2: PG_TAPNF_K(2) break;
-                case 3: PG_TAPNF_K(3) break;
-                default: PG_TAPNF_K(4) break;
-            }
-#undef PG_TAPNF_K
-#undef PG_TAPNF
-            return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
-        }
-    }
+        tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT)
+        return launch_tapnf(false, small, ld_small, P, bias, big, ld_big, g, act, tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca),
+                            tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb), st);
     if (!io && s2b_tapn_ok(g) && (ld_small % 4 == 0) && aligned16(small) && aligned16(P) && aligned16(ws) &&
         ws_bytes >= s2b_tapn_ws(g) && tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca) < FAST_LIMIT) {
         // D[small pixel][(tap, b)] = small . W' (row GEMM), then col2im: each big pixel sums the taps that reach it

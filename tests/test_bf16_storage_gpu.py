@@ -215,8 +215,8 @@ SEAMS = [(2, 64, 64, 64, 3, 2), (2, 32, 48, 64, 7, 2), (1, 33, 31, 128, 4, 2), (
 def test_bf16_kernels_on_image_facing_layers(geom):
     """The few-channel layers next to the images (enc0, d0, the generator head) on the bf16 kernels: the few-channel tensor is a
     bf16 tensor in 8-channel pixels (ld 8, zero pads -- one 16-byte DMA piece per pixel).  big2small = k_conv_bf16x<..,2,64> (the 16
-    taps of a pixel are its K = 128 row), weight gradient = k_wgrad_bf16x<..,true> (taps folded into N), small2big = bf16 row GEMM
-    k_conv_bf16x<..,3,64> + col2im with an fp32 result.  Against torch in float64 on bf16-representable operands: 2e-5 for fp32
+    taps of a pixel are its K = 128 row), weight gradient = k_wgrad_bf16x<..,true> (taps folded into N), small2big = the one-pass
+    k_s2b_tapnf<Cb,bf16> (stride 2 onto <= 4 channels) or the bf16 row GEMM k_conv_bf16x<..,3,64> + col2im, with an fp32 result.  Against torch in float64 on bf16-representable operands: 2e-5 for fp32
     results, one bf16 ulp for bf16 results."""
     from patchgan_amd import engine as E, _lib as L
     from tests.gpu_util import to_view_bf, to_view_bf8, empty_view, empty_view_bf, pack, unpack, rel_err, DEV
@@ -252,7 +252,11 @@ def test_bf16_kernels_on_image_facing_layers(geom):
     assert rel_err(unpack(dP, Ca, Cb), Wr.grad) < 2e-5, rel_err(unpack(dP, Ca, Cb), Wr.grad)
     assert rel_err(db.cpu(), small.double().sum((0, 2, 3))) < 2e-5
     # data gradient / ConvTranspose2d forward onto the few-channel tensor (fp32 result)
-    assert 'k_conv_bf16x' in op.describe(1, L.IO_SMALL_BF16)[0] and ',3,64>' in op.describe(1, L.IO_SMALL_BF16)[0]
+    sym = op.describe(1, L.IO_SMALL_BF16)[0]
+    if s == 2 and Ca in (32, 64, 128):          # one pass: taps in N on bf16 MFMAs, the D block in LDS (5-8 channels: two launches)
+        assert sym == (f'k_s2b_tapnf<{Cb},bf16>' if Cb <= 4 else f'k_s2b_tapnf<4,bf16>+k_s2b_tapnf<{Cb - 4},bf16>'), sym
+    else:
+        assert 'k_conv_bf16x' in sym and ',3,64>' in sym, sym
     bias_b = torch.randn(Cb)
     lin = torch.nn.grad.conv2d_input((N, Cb, Hb, Wb), Wt.double(), small.double(), stride=s, padding=1) + bias_b.double().view(1, -1, 1, 1)
     out = empty_view(N, Hb, Wb, Cb, ld=Cb + 4, off=4)

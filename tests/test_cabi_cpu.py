@@ -248,12 +248,16 @@ def test_bench_kernel_plan_is_the_committed_one():
 
 
 def test_one_pass_transposed_conv_onto_few_channels_is_planned_where_it_exists():
-    """Stride-2 small -> big onto <= 4 channels from 32 / 64 / 128 fp32 channels runs the one-pass kernel k_s2b_tapnf (D block in
-    LDS); other channel counts, 5-8 channels and stride 1 keep the two-launch row GEMM + col2im; bf16 tensors keep theirs."""
+    """Stride-2 small -> big onto <= 8 channels from 32 / 64 / 128 channels runs the one-pass kernel k_s2b_tapnf (D block in LDS; 5-8
+    channels as two launches of <= 4); other channel counts and stride 1 keep the two-launch row GEMM + col2im."""
     from patchgan_amd import engine as E, _lib as L
     for Ca in (32, 64, 128):
         for Cb in (1, 2, 3, 4):
             assert E.ConvOp(2, 32, 32, Ca, Cb, 2, L.ALGO_AUTO).describe(1)[0] == f'k_s2b_tapnf<{Cb}>'
-    for geom in ((2, 32, 32, 96, 2, 2), (2, 32, 32, 64, 6, 2), (2, 9, 9, 32, 4, 1)):
+    assert E.ConvOp(2, 32, 32, 64, 7, 2, L.ALGO_AUTO).describe(1)[0] == 'k_s2b_tapnf<4>+k_s2b_tapnf<3>'
+    for geom in ((2, 32, 32, 96, 2, 2), (2, 32, 32, 256, 6, 2), (2, 9, 9, 32, 4, 1)):
         assert E.ConvOp(*geom, L.ALGO_AUTO).describe(1)[0].endswith('k_col2im_small2big'), geom
-    assert 'tapnf' not in E.ConvOp(2, 32, 32, 64, 4, 2, L.ALGO_BF16).describe(1, L.IO_SMALL_BF16)[0]
+    # a bf16 `small` (fp32 result): the same kernel on bf16 MFMAs; both tensors bf16: the bf16 kernels of the wide layers' family
+    assert E.ConvOp(2, 32, 32, 64, 4, 2, L.ALGO_BF16).describe(1, L.IO_SMALL_BF16)[0] == 'k_s2b_tapnf<4,bf16>'
+    assert E.ConvOp(2, 32, 32, 64, 7, 2, L.ALGO_BF16).describe(1, L.IO_SMALL_BF16)[0] == 'k_s2b_tapnf<4,bf16>+k_s2b_tapnf<3,bf16>'
+    assert 'tapnf' not in E.ConvOp(2, 32, 32, 64, 4, 2, L.ALGO_BF16).describe(1, L.IO_SMALL_BF16 | L.IO_BIG_BF16)[0]

@@ -31,7 +31,7 @@ for it in range(cases):
     if kind == 's2':
         stride = 2
         Hb, Wb = random.choice([16, 30, 33, 64, 100, 128, 129, 256]), random.choice([16, 18, 31, 64, 96, 128, 200, 256])
-        Cb = random.choice([1, 2, 3, 4, 4])
+        Cb = random.choice([1, 2, 3, 4, 4, 5, 7, 8])
         Ca = random.choice([4, 8, 12, 16, 32, 64, 64, 128, 6, 10])
     else:                                                # the discriminator's one-channel head: stride 1 onto Ca = 1
         stride = 1
