@@ -191,29 +191,65 @@ __global__ void k_loss_finalize(const double* __restrict__ S, const double* __re
     }
 }
 
-__global__ void k_loss_grad(const float* __restrict__ p, int ld_p, const float* __restrict__ y, int ld_y, float tconst,
-                            const float* __restrict__ coef, float* __restrict__ g, int ld_g, int N, int HW, int C,
-                            int mode) {
-    const long total = (long)N * HW * C;
+// The gradient pass of a loss term, shared by k_loss_grad (coef in global memory) and k_loss_fused (coef in LDS): one thread per PIXEL
+// and trip, 32-bit pixel decode (the per-ELEMENT 64-bit i % C, i / C, pix / HW of the first version cost more than the memory
+// traffic: 35 us for 1 M elements), the four channels of a C == 4 pixel as one 16-byte load / store where the views allow it.
+// Element arithmetic unchanged (bit-identical results).
+__device__ __forceinline__ float loss_grad_elem(float pv, float yv, float k0, float k1, int gmode) {
+    if (gmode == 0) return k0 * yv + k1;
+    if (gmode == 1) return k0 * (pv - yv) / fmaxf((1.f - pv) * pv, 1e-12f);      // torch binary_cross_entropy_backward
+    const float d = pv - yv;
+    return k0 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+}
+template <typename CoefPtr>
+__device__ __forceinline__ void loss_grad_pass(const float* __restrict__ p, int ld_p, const float* __restrict__ y, int ld_y, float tconst,
+                                               CoefPtr coef, float* __restrict__ g, int ld_g, int N, int HW, int C, int gmode) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const long npix = (long)N * HW;
+    auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0; };
+    if (npix < 0x7fffffffL) {
+        const unsigned np = (unsigned)npix, stride = gridDim.x * blockDim.x, hw = (unsigned)HW;
+        const bool vp = al(p, ld_p), vy = y && al(y, ld_y), vg = al(g, ld_g);
+        for (unsigned pix = blockIdx.x * blockDim.x + threadIdx.x; pix < np; pix += stride) {
+            const unsigned n = pix / hw;
+            const float* pp = p + (size_t)pix * ld_p;
+            const float* yp = y ? y + (size_t)pix * ld_y : nullptr;
+            float* gp = g + (size_t)pix * ld_g;
+            if (C == 4) {       // (a slice of a wider pixel -- the mask channels of the discriminator-input buffer -- is accessed by element)
+                const f4 pv = vp ? *reinterpret_cast<const f4*>(pp) : f4{pp[0], pp[1], pp[2], pp[3]};
+                const f4 yv = !yp ? f4{tconst, tconst, tconst, tconst} : vy ? *reinterpret_cast<const f4*>(yp) : f4{yp[0], yp[1], yp[2], yp[3]};
+                f4 r;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) r[c] = loss_grad_elem(pv[c], yv[c], coef[(n * 4 + c) * 2 + 0], coef[(n * 4 + c) * 2 + 1], gmode);
+                if (vg) {
+                    *reinterpret_cast<f4*>(gp) = r;
+                } else {
+                    gp[0] = r[0];
+                    gp[1] = r[1];
+                    gp[2] = r[2];
+                    gp[3] = r[3];
+                }
+            } else {
+                for (int c = 0; c < C; ++c)
+                    gp[c] = loss_grad_elem(pp[c], yp ? yp[c] : tconst, coef[(n * C + c) * 2 + 0], coef[(n * C + c) * 2 + 1], gmode);
+            }
+        }
+        return;
+    }
+    const long total = npix * C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const long pix = i / C;
-        const int n = (int)(pix / HW);
-        const float pv = p[pix * ld_p + c];
-        const float yv = y ? y[pix * ld_y + c] : tconst;
-        const float k0 = coef[((long)n * C + c) * 2 + 0], k1 = coef[((long)n * C + c) * 2 + 1];
-        float r;
-        if (mode == 0) {
-            r = k0 * yv + k1;
-        } else if (mode == 1) {
-            // torch binary_cross_entropy_backward: (p - y) / max((1-p)*p, 1e-12) * grad * weight
-            r = k0 * (pv - yv) / fmaxf((1.f - pv) * pv, 1e-12f);
-        } else {
-            const float d = pv - yv;
-            r = k0 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-        }
-        g[pix * ld_g + c] = r;
+        const long n = pix / HW;
+        g[pix * ld_g + c] = loss_grad_elem(p[pix * ld_p + c], y ? y[pix * ld_y + c] : tconst, coef[(n * C + c) * 2 + 0],
+                                           coef[(n * C + c) * 2 + 1], gmode);
     }
+}
+
+__global__ void k_loss_grad(const float* __restrict__ p, int ld_p, const float* __restrict__ y, int ld_y, float tconst,
+                            const float* __restrict__ coef, float* __restrict__ g, int ld_g, int N, int HW, int C,
+                            int mode) {
+    loss_grad_pass(p, ld_p, y, ld_y, tconst, coef, g, ld_g, N, HW, C, mode);
 }
 
 // Stages 1 (tail) + 1b + 2 + 3 in ONE launch (no data parallelism between them): every workgroup first rebuilds the small per-(n, c)
@@ -233,8 +269,18 @@ __global__ __launch_bounds__(256) void k_loss_fused(const double* __restrict__ S
     __shared__ double gs[2];
     const int tid = threadIdx.x, NC = N * C, n5 = NC * 5;
     for (int i = tid; i < n5; i += 256) {
+        // the slabs in z order (k_loss_combine's order), 16 loads in flight at a time: one dependent load per slab made this loop the
+        // longest part of the kernel (128 slabs = 128 L2 latencies per workgroup)
         double v = 0.0;
-        for (int z = 0; z < nsplit; ++z) v += Spart[(long)z * n5 + i];
+        int z = 0;
+        for (; z + 16 <= nsplit; z += 16) {
+            double t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t[k] = Spart[(long)(z + k) * n5 + i];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v += t[k];
+        }
+        for (; z < nsplit; ++z) v += Spart[(long)z * n5 + i];
         S[i] = v;
         if (blockIdx.x == 0 && S_out) S_out[i] = v;
     }
@@ -286,25 +332,7 @@ __global__ __launch_bounds__(256) void k_loss_fused(const double* __restrict__ S
     __syncthreads();
     if (!g) return;
     const int gmode = lmode == PG_LOSS_TVERSKY ? 0 : lmode == PG_LOSS_MAE ? 2 : 1;
-    const long total = (long)N * HW * C;
-    for (long i = blockIdx.x * (long)blockDim.x + tid; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long pix = i / C;
-        const int n = (int)(pix / HW);
-        const float pv = p[pix * ld_p + c];
-        const float yv = y ? y[pix * ld_y + c] : tconst;
-        const float k0 = coef[(n * C + c) * 2 + 0], k1 = coef[(n * C + c) * 2 + 1];
-        float r;
-        if (gmode == 0) {
-            r = k0 * yv + k1;
-        } else if (gmode == 1) {
-            r = k0 * (pv - yv) / fmaxf((1.f - pv) * pv, 1e-12f);
-        } else {
-            const float d = pv - yv;
-            r = k0 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-        }
-        g[pix * ld_g + c] = r;
-    }
+    loss_grad_pass(p, ld_p, y, ld_y, tconst, (const float*)coef, g, ld_g, N, HW, C, gmode);
 }
 
 // pixel splits per (n, c) -- per n for the four-channel kernel -- so that a loss over a large map runs on >= ~256 workgroups

@@ -507,8 +507,48 @@ __global__ void k_act_bwd(TPtr g1, int ld_g1, TPtr g2, int ld_g2,
     }
 }
 
+// Softmax over the C channels of a pixel (unet.py:60, nn.Softmax(dim=1)) and its backward (two gradient sources summed on the fly).
+// One thread per pixel; C == 4 on 16-byte-aligned views (the multi-class head of BASELINE config 3/4): the pixel is one 16-byte load /
+// store and every exponential is evaluated once (the scalar form below: C scalar accesses, each exponential twice).  Same expression
+// per element in both forms (bit-identical).
+typedef float sm_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool sm_al(const void* p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; }
+__device__ __forceinline__ sm_f4 sm_ld(const float* p, bool vec) {
+    if (vec) return *reinterpret_cast<const sm_f4*>(p);
+    return sm_f4{p[0], p[1], p[2], p[3]};
+}
+__device__ __forceinline__ void sm_st(float* p, sm_f4 v, bool vec) {
+    if (vec) {
+        *reinterpret_cast<sm_f4*>(p) = v;
+    } else {
+        p[0] = v[0];
+        p[1] = v[1];
+        p[2] = v[2];
+        p[3] = v[3];
+    }
+}
 __global__ void k_softmax_fwd(const float* __restrict__ y, int ld_y, float* __restrict__ out, int ld_out, long npix,
                               int C) {
+    if (C == 4) {       // (a slice of a wider pixel -- the mask channels of the discriminator-input buffer -- is accessed by element)
+        const bool vy = sm_al(y, ld_y), vo = sm_al(out, ld_out);
+        for (long pix = blockIdx.x * (long)blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+            const sm_f4 v = sm_ld(y + pix * ld_y, vy);
+            float m = v[0];
+#pragma unroll
+            for (int c = 1; c < 4; ++c) m = fmaxf(m, v[c]);
+            sm_f4 e;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                e[c] = expf(v[c] - m);
+                s += e[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) e[c] = e[c] / s;
+            sm_st(out + pix * ld_out, e, vo);
+        }
+        return;
+    }
     for (long pix = blockIdx.x * (long)blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
         const float* p = y + pix * ld_y;
         float m = p[0];
@@ -523,6 +563,24 @@ __global__ void k_softmax_fwd(const float* __restrict__ y, int ld_y, float* __re
 __global__ void k_softmax_bwd(const float* __restrict__ g1, int ld_g1, const float* __restrict__ g2, int ld_g2,
                               const float* __restrict__ out, int ld_out, float* __restrict__ dy, int ld_dy, long npix,
                               int C) {
+    if (C == 4) {
+        const bool v1 = sm_al(g1, ld_g1), v2 = g2 && sm_al(g2, ld_g2), vo = sm_al(out, ld_out), vd = sm_al(dy, ld_dy);
+        for (long pix = blockIdx.x * (long)blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+            const sm_f4 o = sm_ld(out + pix * ld_out, vo);
+            sm_f4 a = sm_ld(g1 + pix * ld_g1, v1);
+            const sm_f4 b = g2 ? sm_ld(g2 + pix * ld_g2, v2) : sm_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] = a[c] + b[c];
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dot += a[c] * o[c];
+            sm_f4 d;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[c] = o[c] * (a[c] - dot);
+            sm_st(dy + pix * ld_dy, d, vd);
+        }
+        return;
+    }
     for (long pix = blockIdx.x * (long)blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
         const float* o = out + pix * ld_out;
         const float* a = g1 + pix * ld_g1;
