@@ -35,10 +35,28 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
         adam_one(p[i], g[i], m[i], v[i], lr_over_bc1, beta1, beta2, eps, sqrt_bc2);
 }
 
-// dst NHWC (pixel stride ld_dst) <- src NCHW; one thread per (pixel, channel), channel fastest
+// dst NHWC (pixel stride ld_dst) <- src NCHW; one thread per PIXEL: the C plane reads of a wave are C coalesced rows (one thread per
+// (pixel, channel) read a different cache line per lane and paid three 64-bit divisions per element), the C floats of a pixel are
+// written together
 __global__ void k_nchw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int ld_dst, int N, int C,
                                long HW) {
-    const long total = (long)N * HW * C;
+    const long npix = (long)N * HW;
+    if (npix < 0x7fffffffL && C <= 8) {
+        const unsigned np = (unsigned)npix, hwu = (unsigned)HW, stride = gridDim.x * blockDim.x;
+        for (unsigned pix = blockIdx.x * blockDim.x + threadIdx.x; pix < np; pix += stride) {
+            const unsigned n = pix / hwu, hw = pix - n * hwu;
+            const float* sp = src + (size_t)n * C * HW + hw;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = (c < C) ? sp[(size_t)c * HW] : 0.f;
+            float* dp = dst + (size_t)pix * ld_dst;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < C) dp[c] = v[c];
+        }
+        return;
+    }
+    const long total = npix * C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const long pix = i / C;
@@ -144,7 +162,7 @@ int pg_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
 int pg_nchw_to_nhwc(const float* src, float* dst, int ld_dst, int N, int C, int H, int W, void* stream) {
     if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld_dst < C) return PG_EINVAL;
     const long HW = (long)H * W;
-    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(blocks_for((long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, src, dst,
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(blocks_for(C <= 8 ? (long)N * HW : (long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, src, dst,
                        ld_dst, N, C, HW);
     return pg_launch_status();
 }
