@@ -119,7 +119,11 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);   /* op 3 = pg_co
  * op + 16 * PG_ALGO_*; for PG_ALGO_AUTO (op < 16) wide stride-1 layers report the Winograd kernels instead: + 40 / + 50 =
  * k_wino_gemm<2,1,2,2,2,2> / <1,1,2,2,4,2>, + 90 = its F(3x3,4x4) instance <1,1,2,2,2,3> (ops 0/1; tile / split of the implicit-GEMM plan otherwise unchanged), 60 =
  * k_wino_wgrad_gemm<2,2,2,2> with split = its K slices (op 2; 63: 64x64 tiles <1,1,2,2>; 61 / 62: its polyphase stride-2 form with 128x128 / 64x64 tiles), 70 / 71 = k_wino_bgemm<2,2,2,2> / <1,2,2,2>, 72 / 73 = k_wino_bgemm_mz<...> (polyphase
- * Winograd of a stride-2 layer, ops 0/1).  For profiling only. */
+ * Winograd of a stride-2 layer, ops 0/1).  80 + Cb: the image-facing forward kernels k_b2s_tapk / k_b2s_tapkp<Cb> (op 0, <= 5 big-side
+ * channels).  Codes >= 1000: 1000 + 100 * ring + 10 * dir + tile = the LDS-DMA bf16 kernels k_conv_bf16x on bf16 tensors, 1020 + tile =
+ * k_wgrad_bf16x, 1030 + tile = bf16 row GEMM + col2im, 1040 + tile = k_conv_bf16x on 8-channel pixels, 1050 = the one-channel head's data
+ * gradient k_s2b_ca1 / k_s2b_ca1_s1, 1060 + Cb (1070 + Cb: from a bf16 tensor) = the one-pass transposed convolution onto <= 8 channels
+ * k_s2b_tapnf<Cb> (Cb > 4: two launches, <4> + <Cb - 4>).  For profiling only. */
 int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_id, int* split, long* workgroups);
 
 /* The kernel symbol (as rocprofv3 prints it, without the namespace / argument list) of the main GEMM kernel that op would
