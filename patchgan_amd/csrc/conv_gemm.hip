@@ -2877,10 +2877,27 @@ __global__ __launch_bounds__(256) void k_s2b_ca1_s1(const float* __restrict__ sm
         // tap (kh, kw) reads small[h + 1 - kh][wq + 1 - kw] = xs[h + 3 - kh][wq + 3 - kw]
         const float* xr = xs + (h + 3) * PW + wq + 3;
         f32x4 acc = bv;
+        // The tap values never reach a packed multiply straight from the LDS return: `acc += x * w` compiles to v_pk_mul_f32 with the
+        // scalar x broadcast through op_sel, and where that takes its LOW half from the ODD register of a pair that a ds_read2_b32
+        // has just returned, lanes 48-63 of the low half were seen to use the register's OLD content although s_waitcnt lgkmcnt had
+        // been satisfied (one tap of e0 / e2 dropped, ~1 call in 40, only next to another process on the GPU: EXPERIMENTS.md,
+        // "k_s2b_ca1_s1: cause").  A plain VALU read of the returned register is safe (v_readfirstlane where the wave's pixel is
+        // uniform -- the values then live in scalar registers --, a v_mov_b32 otherwise); tests/test_codeobj_cpu.py scans the
+        // library for the failing operand form.
+        float xv[16];
 #pragma unroll
         for (int kh = 0; kh < 4; ++kh)
 #pragma unroll
-            for (int kw = 0; kw < 4; ++kw) acc += xr[-kh * PW - kw] * w[kh * 4 + kw];
+            for (int kw = 0; kw < 4; ++kw) xv[kh * 4 + kw] = xr[-kh * PW - kw];
+        if (cq % 64 == 0) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) xv[t] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xv[t])));
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) asm volatile("v_mov_b32 %0, %1" : "=v"(xv[t]) : "v"(xv[t]));
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc += xv[t] * w[t];
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = pg_act_epi(acc[e], act);
         const long m = (long)n * HWb + pix;
@@ -3798,8 +3815,8 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     } else if (code > 1074 && code <= 1078) {
         snprintf(buf, sizeof buf, "k_s2b_tapnf<4,bf16>+k_s2b_tapnf<%d,bf16>", code - 1074);
     } else if (code == 1050) {
-        snprintf(buf, sizeof buf, (g->stride == 1 && !(algo_full & PG_IO_BIG_BF16) && (size_t)(g->Hs + 4) * (g->Ws + 4) * sizeof(float) <= 48 * 1024)
-                                      ? "k_s2b_ca1_s1" : "k_s2b_ca1");      // (the LDS-staged form: fp32 output only, see s2b_impl)
+        snprintf(buf, sizeof buf, (g->stride == 1 && (size_t)(g->Hs + 4) * (g->Ws + 4) * sizeof(float) <= 48 * 1024)
+                                      ? "k_s2b_ca1_s1" : "k_s2b_ca1");      // (the LDS-staged form: stride 1, see s2b_impl)
     } else if (code >= 1020 && code < 1030) {
         snprintf(buf, sizeof buf, "%s", pg_bf16x_wgrad_kernel_name(code - 1020));
     } else if (code >= 1030 && code < 1040) {
@@ -4111,11 +4128,8 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
             const int ppb = (int)std::max<long>(trip, ((total / ca1_wgs + trip - 1) / trip) * trip);
             TimedLaunch timed(st);
             const size_t xs_bytes = (size_t)(g.Hs + 4) * (g.Ws + 4) * sizeof(float);
-            // fp32 output only: with a bf16 output this form showed rare run-to-run differences (1e-8 .. 1e-5 on the losses) when two
-            // processes shared the GPU -- ~1 event per 40 steps against none in 360 steps with the generic kernel below, none in 288
-            // fp32 steps; cause not found (EXPERIMENTS.md, "OPEN").  PATCHGAN_CA1S1_BF16=1 (under PATCHGAN_EXPERIMENT) re-enables it.
-            static const bool no_s1 = pg_exp_env("PATCHGAN_NO_CA1S1") != nullptr, s1_bf = pg_exp_env("PATCHGAN_CA1S1_BF16") != nullptr;
-            if (!no_s1 && (!out_bf || s1_bf) && g.s == 1 && xs_bytes <= 48 * 1024 && g.Hb == g.Hs + 1 && g.Wb == g.Ws + 1) {
+            static const bool no_s1 = pg_exp_env("PATCHGAN_NO_CA1S1") != nullptr;
+            if (!no_s1 && g.s == 1 && xs_bytes <= 48 * 1024 && g.Hb == g.Hs + 1 && g.Wb == g.Ws + 1) {
                 // per-sample form: ~1536 workgroups in all, whole pixel rows of the workgroup (256 / (Cb / 4) pixels per trip)
                 const int npr = 256 / (g.Cb / 4), hwb = g.Hb * g.Wb;
                 const long per = std::max<long>(1, 1536 / g.N);

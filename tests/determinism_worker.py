@@ -1,6 +1,7 @@
 """Back-to-back repetitions of K training steps (bf16 network of tools/debug_repro.py, N = 1), device clones of the step's end-of-step
 tensors after every step (no host synchronisation inside a repetition beyond the step's own loss read-back), compared with repetition 0
-at the end.  Run two of these at once on one GPU.  usage: python tools/debug_cc2.py [precision] [reps] [steps] [clone: 0|1]"""
+at the end.  Run two of these at once on one GPU (tests/test_determinism_gpu.py does).
+usage: python tests/determinism_worker.py [precision] [reps] [steps] [clone: 0|1]"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

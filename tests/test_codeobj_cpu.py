@@ -30,3 +30,44 @@ def test_mfma_kernels_keep_accumulators_in_registers():
     for n, k in hot.items():
         if 'k_conv_bf16x' in n or 'k_wgrad_bf16x' in n:
             assert k['.vgpr_count'] + k.get('.agpr_count', 0) <= 256, (n, k['.vgpr_count'])
+
+
+OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+
+
+@pytest.mark.skipif(not os.path.exists(SO) or not os.path.exists(OBJDUMP), reason='library or llvm-objdump missing')
+def test_no_packed_f32_low_half_from_the_odd_register_of_a_fresh_lds_pair(tmp_path):
+    """Cause of round 3's open issue (k_s2b_ca1_s1 returning different values next to a second process on the GPU): `acc += x * w`
+    with x read from LDS compiled to v_pk_mul_f32 ... op_sel:[0,1] straight off a ds_read2_b32 pair; lanes 48-63 of the low half
+    then used the register's old content although s_waitcnt lgkmcnt was satisfied (one tap of the sum dropped; tools/debug_cc5.py,
+    two processes: an event in 50 of 92 repetitions of 18 steps; with the values passed through v_readfirstlane / v_mov_b32 first:
+    0 of 92).  No kernel of the library may contain that operand form."""
+    import subprocess
+    from tests.codeobj_util import code_objects, packed_f32_reads_of_fresh_lds_pairs
+    objs = code_objects(SO)
+    assert len(objs) >= 7
+    bad = {}
+    ninstr = 0
+    for i, co in enumerate(objs):
+        elf = tmp_path / f'co{i}.elf'
+        elf.write_bytes(co)
+        dis = subprocess.run([OBJDUMP, '-d', '--mcpu=gfx950', str(elf)], check=True, capture_output=True, text=True).stdout.splitlines()
+        ninstr += len(dis)
+        for fn, ins in packed_f32_reads_of_fresh_lds_pairs(dis):
+            bad.setdefault(fn, []).append(ins)
+        del dis
+    assert ninstr > 500000, ninstr
+    assert not bad, {k: v[:2] for k, v in bad.items()}
+
+
+def test_the_scan_recognises_the_failing_form():
+    from tests.codeobj_util import packed_f32_reads_of_fresh_lds_pairs
+    bad = ['0000000000001000 <k>:',
+           '\tds_read2_b32 v[92:93], v0 offset0:6 offset1:7          // 000000001000: D86E0706',
+           '\ts_waitcnt lgkmcnt(0)                                  // 000000001008: BF8CC07F',
+           '\tv_pk_mul_f32 v[0:1], v[12:13], v[92:93] op_sel:[0,1]   // 00000000100C: D3B14000']
+    assert [i for _, i in packed_f32_reads_of_fresh_lds_pairs(bad)] == ['v_pk_mul_f32 v[0:1], v[12:13], v[92:93] op_sel:[0,1]']
+    ok = bad[:3] + ['\tv_mov_b32_e32 v93, v93', bad[3]]
+    assert not list(packed_f32_reads_of_fresh_lds_pairs(ok))
+    natural = bad[:3] + ['\tv_pk_mul_f32 v[0:1], v[12:13], v[92:93] op_sel_hi:[1,0]']       # high half from the even register: never seen to fail
+    assert not list(packed_f32_reads_of_fresh_lds_pairs(natural))
