@@ -398,16 +398,18 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
     # dominant kernel = the conv kernel symbol with the most device time (found in the profiled warm-up step)
     sym, d = max(summ.items(), key=lambda kv: kv[1]['ms'])
     if events == 'none':
-        d = dict(d, launches=d['launches'] * steps, ms=d['ms'] * steps, flops=d['flops'] * steps, kflops=d['kflops'] * steps)
+        d = dict(d, launches=d['launches'] * steps, ms=d['ms'] * steps, flops=d['flops'] * steps, kflops=d['kflops'] * steps,
+                 uflops=d['uflops'] * steps)
     timed_steps = steps if (events != 'dominant' or prof.limit is None) else max(1, d['launches'] // max(1, int(wsum[sym]['launches'])))
     per_step_all = wsum                      # every conv kernel, from the profiled warm-up step
     if not per_step_all:
         per_step_all = {k: dict(launches=v['launches'] / steps, ms=v['ms'] / steps, flops=v['flops'] / steps,
-                                kflops=v['kflops'] / steps) for k, v in summ.items()}
+                                kflops=v['kflops'] / steps, uflops=v['uflops'] / steps) for k, v in summ.items()}
     conv_ms = sum(v['ms'] for v in per_step_all.values()) * steps
     # achieved = FLOPs the kernel EXECUTED / its time (a Winograd kernel executes 2.25-2.56x fewer than the layer's
     # direct-convolution count; crediting it with those would "exceed" the peak)
     achieved = d['kflops'] / (d['ms'] * 1e-3) / 1e12
+    useful = d['uflops'] / (d['ms'] * 1e-3) / 1e12      # ... without the padding of ragged edge tiles to whole tiles
     peak = FP32_MFMA_PEAK_TFLOPS if dtype == 'f32' else 2500.0     # dense MFMA peak of the multiply dtype
     traffic, traffic_src = pmc_traffic(sym)
     res.update({
@@ -416,7 +418,10 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         'last_losses': {k: round(v, 5) for k, v in last.items()},
         'roofline': {'bound': 'mfma', 'kernel': sym,
                      'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                     'frac': round(achieved / peak, 4), 'traffic': traffic,
+                     'frac': round(achieved / peak, 4), 'achieved_useful': round(useful, 2), 'frac_useful': round(useful / peak, 4),
+                     'frac_note': 'frac = FLOPs the kernel executes on the MFMA pipe (ragged Winograd edge tiles count as whole tiles) / time / '
+                                  'peak; frac_useful = the same algorithm on the exact extents (no tile padding)',
+                     'traffic': traffic,
                      'traffic_source': (f'{traffic_src} (committed rocprofv3 --pmc pass of the same command; not measured '
                                         'in this run)') if traffic_src else None,
                      'launches_per_step': d['launches'] / timed_steps, 'launches_timed': d['launches'],
@@ -429,6 +434,7 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
                      'step_frac_of_mfma_roofline': round(value / world * cfg['gflop_per_image'] / 1e3 / peak, 4)},
         'conv_kernels': {k: {'launches_per_step': v['launches'], 'ms_per_step': round(v['ms'], 4),
                              'TFLOPs': round(v['kflops'] / (v['ms'] * 1e-3) / 1e12, 2),
+                             'useful_TFLOPs': round(v['uflops'] / (v['ms'] * 1e-3) / 1e12, 2),
                              'direct_conv_TFLOPs': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)}
                          for k, v in sorted(per_step_all.items(), key=lambda kv: -kv[1]['ms'])},
     })
@@ -453,8 +459,8 @@ def extra_configs(dev):
                         + m['activation_storage'] + ' activation storage, dropout off',
             'metric': 'train images/sec (G+D step) at 512x512 bs=8 per GPU', 'value': round(m['value'], 2), 'unit': 'images/sec',
             'steps': 10, 'warmup': 5, 'ms_per_step': round(m['ms_per_step'], 3), 'dtype': 'bf16',
-            'roofline': {k: r[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source',
-                                           'launches_per_step', 'avg_launch_ms', 'kernel_share_of_step', 'all_conv_kernels_TFLOPs',
+            'roofline': {k: r[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'achieved_useful', 'frac_useful', 'traffic',
+                                           'traffic_source', 'launches_per_step', 'avg_launch_ms', 'kernel_share_of_step', 'all_conv_kernels_TFLOPs',
                                            'step_frac_of_mfma_roofline')},
             'conv_kernels': {k: v for k, v in list(m['conv_kernels'].items())[:8]}, 'last_losses': m['last_losses']}
         del m

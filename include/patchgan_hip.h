@@ -133,6 +133,12 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
  * pg_conv_describe.  For profiling only. */
 int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, size_t name_len, int* split, double* mfma_flops);
 
+/* The two FLOP counts of that kernel: `executed` as pg_conv_kernel reports it (a Winograd kernel's ragged edge tiles are whole tiles on
+ * the MFMA pipe: up to 27 % of the work on 16x16 maps), `useful` = the same algorithm's count on the exact extents (H / m instead of
+ * ceil(H / m) tiles).  bench.py's roofline.frac / roofline.frac_useful; the direct-convolution count is 2*N*Hs*Ws*16*Ca*Cb for every
+ * kernel.  For profiling only (replaces nothing in the reference: torch.profiler's per-op FLOP column is the closest thing). */
+int pg_conv_kernel_flops(const pg_conv_geom* g, int op, size_t ws_bytes, double* executed, double* useful);
+
 /* Arms per-launch timing: the NEXT pg_conv4x4_* call on this thread records the caller-owned hipEvent_t `ev_start`
  * immediately before and `ev_stop` immediately after its main GEMM kernel on the launch stream (the split-K reduce, the
  * bias column sums and the col2im / gather pass are outside the pair), then disarms itself.  Thread-local state; the

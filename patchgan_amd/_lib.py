@@ -68,6 +68,7 @@ SIGNATURES = {
     'pg_conv_describe': (_i, [_G, _i, _sz, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_l)]),
     'pg_conv_mul_ok': (_i, [_G, _i, _sz]),
     'pg_conv_kernel': (_i, [_G, _i, _sz, ctypes.c_char_p, _sz, ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double)]),
+    'pg_conv_kernel_flops': (_i, [_G, _i, _sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     'pg_conv_time_next': (_i, [_p, _p]),
     'pg_conv_time_next2': (_i, [_p, _p, _p, _p]),
     'pg_conv4x4_bwd_big': (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _G, _i, _p, _sz, _p]),

@@ -3793,7 +3793,8 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
     return PG_OK;
 }
 
-int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, size_t name_len, int* split, double* mfma_flops) {
+static int conv_kernel_impl(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, size_t name_len, int* split, double* mfma_flops,
+                            double* useful_flops) {
     int code = 0, sp = 1;
     long wgs = 0;
     int rc = pg_conv_describe(g, op, ws_bytes, &code, &sp, &wgs);
@@ -3803,8 +3804,9 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     static const char* const TILE[5] = {"2,2,2,2", "2,1,2,2", "1,1,4,1", "1,2,2,2", "1,1,2,2"};
     const int fast = code / 100, rest = code % 100, tid = rest % 10, mode = rest / 10;
     auto cd = [](long a, long b) { return (a + b - 1) / b; };
+    auto fr = [](double a, double b) { return a / b; };       // the same tile counts without the round-up to whole tiles
     const double direct = 2.0 * g->N * g->Hs * g->Ws * 16.0 * g->Ca * g->Cb;
-    double fl = direct;
+    double fl = direct, fu = direct;      // executed (ragged tiles padded to whole ones) / useful (the algorithm's count on the exact extents)
     char buf[128];
     if (code > 1060 && code <= 1064) {
         snprintf(buf, sizeof buf, "k_s2b_tapnf<%d>", code - 1060);          // one-pass taps-in-N ConvTranspose2d onto <= 4 channels
@@ -3831,6 +3833,9 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
         snprintf(buf, sizeof buf, "k_wino_wgrad_gemm<%s>", (tid == 2 || tid == 3) ? "1,1,2,2" : "2,2,2,2");
         fl = (g->stride == 1) ? pg_wino_wgrad_flops(g->N, g->Hs, g->Ws, g->Ca, g->Cb)
                               : 2.0 * 16 * g->N * cd(g->Hs, 3) * cd(g->Ws, 3) * g->Ca * 4.0 * g->Cb;
+        const int wr = pg_wino_wgrad_r(g->N, g->Hs, g->Ws);
+        fu = (g->stride == 1) ? 2.0 * (wr + 3) * (wr + 3) * g->N * fr(g->Hs, wr) * fr(g->Ws, wr) * g->Ca * g->Cb
+                              : 2.0 * 16 * g->N * fr(g->Hs, 3) * fr(g->Ws, 3) * g->Ca * 4.0 * g->Cb;
     } else if (mode == 8) {
         snprintf(buf, sizeof buf, (tid <= 4 && tapkp_enabled()) ? "k_b2s_tapkp<%d>" : "k_b2s_tapk<%d>", tid);
         sp = 1;
@@ -3839,6 +3844,8 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
         const int mo = pg_wino2_mo();
         fl = (oc == 0) ? 2.0 * (mo + 1) * (mo + 1) * g->N * cd(g->Hs, mo) * cd(g->Ws, mo) * 4.0 * g->Cb * g->Ca
                        : 2.0 * 4 * (mo + 1) * (mo + 1) * g->N * cd(cd(g->Hb, 2) + 1, mo) * cd(cd(g->Wb, 2) + 1, mo) * (double)g->Ca * g->Cb;
+        fu = (oc == 0) ? 2.0 * (mo + 1) * (mo + 1) * g->N * fr(g->Hs, mo) * fr(g->Ws, mo) * 4.0 * g->Cb * g->Ca
+                       : 2.0 * 4 * (mo + 1) * (mo + 1) * g->N * fr(fr(g->Hb, 2), mo) * fr(fr(g->Wb, 2), mo) * (double)g->Ca * g->Cb;
         sp = 1;
     } else if (mode == 9 || mode == 4 || mode == 5) {     // stride-1 Winograd forward / data gradient
         const int mo = mode == 9 ? 3 : 2;
@@ -3849,6 +3856,7 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
         else snprintf(buf, sizeof buf, "k_wino_gemm<%s>", mode == 9 ? "1,1,2,2,2,3" : mode == 4 ? "2,1,2,2,2,2" : "1,1,2,2,4,2");
         const int ho = oc == 0 ? g->Hs : g->Hb, wo = oc == 0 ? g->Ws : g->Wb;
         fl = 2.0 * (mo + 3) * (mo + 3) * g->N * cd(ho, mo) * cd(wo, mo) * (double)g->Ca * g->Cb;
+        fu = 2.0 * (mo + 3) * (mo + 3) * g->N * fr(ho, mo) * fr(wo, mo) * (double)g->Ca * g->Cb;
         sp = 1;
     } else if (mode == 3) {
         snprintf(buf, sizeof buf, "k_b2s_fast<%s,true>+%s", TILE[tid], oc == 0 ? "k_gather_big2small" : "k_col2im_small2big");
@@ -3873,7 +3881,16 @@ int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, s
     if (name && name_len) snprintf(name, name_len, "%s", buf);
     if (split) *split = sp;
     if (mfma_flops) *mfma_flops = fl;
+    if (useful_flops) *useful_flops = fu;
     return PG_OK;
+}
+
+int pg_conv_kernel(const pg_conv_geom* g, int op, size_t ws_bytes, char* name, size_t name_len, int* split, double* mfma_flops) {
+    return conv_kernel_impl(g, op, ws_bytes, name, name_len, split, mfma_flops, nullptr);
+}
+
+int pg_conv_kernel_flops(const pg_conv_geom* g, int op, size_t ws_bytes, double* executed, double* useful) {
+    return conv_kernel_impl(g, op, ws_bytes, nullptr, 0, nullptr, executed, useful);
 }
 
 // the col2im half of the taps-folded-into-N small -> big paths

@@ -166,7 +166,7 @@ class LaunchProfiler:
         # the C ABI records the pair tightly around the main GEMM kernel of this call (not its split-K reduce)
         L.check(L.load().pg_conv_time_next(e0.cuda_event, e1.cuda_event), 'pg_conv_time_next')
         fn()
-        self.records.append((sym, split, op.flops, op.kernel_flops(opcode, io), e0, e1))
+        self.records.append((sym, split, op.flops, op.kernel_flops(opcode, io), op.useful_flops(opcode, io), e0, e1))
 
     def launch2(self, op, opcodes, fn, io=0):
         """A fused call with two main GEMM kernels (pg_conv4x4_bwd_big): one event pair per kernel."""
@@ -180,7 +180,7 @@ class LaunchProfiler:
         fn()
         for i, oc in enumerate(opcodes):
             if self.only is None or syms[i] == self.only:
-                self.records.append((syms[i], op.describe(oc, io)[1], op.flops, op.kernel_flops(oc, io), ev[2 * i], ev[2 * i + 1]))
+                self.records.append((syms[i], op.describe(oc, io)[1], op.flops, op.kernel_flops(oc, io), op.useful_flops(oc, io), ev[2 * i], ev[2 * i + 1]))
 
     def _event(self):
         if self._pool:
@@ -190,16 +190,18 @@ class LaunchProfiler:
         return e
 
     def summary(self):
-        """{symbol: dict(launches, ms, flops, kflops)} over every launch of that kernel symbol (all split-K factors, like a
+        """{symbol: dict(launches, ms, flops, kflops, uflops)} over every launch of that kernel symbol (all split-K factors, like a
         rocprofv3 --stats row): flops = algorithmic (direct-convolution) FLOPs of the layers, kflops = FLOPs the kernel
-        executed (fewer for Winograd kernels) -- call after a device synchronize."""
+        executed (fewer for Winograd kernels; ragged edge tiles count as whole tiles), uflops = the kernel's algorithm on the exact
+        extents (no tile padding) -- call after a device synchronize."""
         out = {}
-        for sym, split, flops, kflops, e0, e1 in self.records:
-            d = out.setdefault(sym, dict(launches=0, ms=0.0, flops=0.0, kflops=0.0))
+        for sym, split, flops, kflops, uflops, e0, e1 in self.records:
+            d = out.setdefault(sym, dict(launches=0, ms=0.0, flops=0.0, kflops=0.0, uflops=0.0))
             d['launches'] += 1
             d['ms'] += e0.elapsed_time(e1)
             d['flops'] += flops
             d['kflops'] += kflops
+            d['uflops'] += uflops
         return out
 
 
@@ -242,6 +244,14 @@ class ConvOp:
         """FLOPs the main GEMM kernel of this call really executes on the MFMA pipe: the algorithmic count for the implicit
         GEMM kernels, 2.25-4x fewer for the Winograd kernels (their tile counts include the ragged-edge padding)."""
         return self._describe(opcode, io)[2]
+
+    def useful_flops(self, opcode, io=0):
+        """The main GEMM kernel's FLOPs without the padding of ragged edge tiles to whole tiles (pg_conv_kernel_flops): equal to
+        kernel_flops for the implicit-GEMM kernels, 6-27 % below it for the Winograd kernels at cfg2."""
+        ex, us = ctypes.c_double(0), ctypes.c_double(0)
+        L.check(L.load().pg_conv_kernel_flops(ctypes.byref(self.g), opcode + 16 * (self.algo | io), self.ws_arg, ctypes.byref(ex),
+                                              ctypes.byref(us)), 'pg_conv_kernel_flops')
+        return us.value
 
     def describe(self, opcode, io=0):
         """(kernel symbol, split-K factor) of the main GEMM kernel the C ABI launches for this op (pg_conv_kernel: the

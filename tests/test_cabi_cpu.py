@@ -261,3 +261,20 @@ def test_one_pass_transposed_conv_onto_few_channels_is_planned_where_it_exists()
     assert E.ConvOp(2, 32, 32, 64, 4, 2, L.ALGO_BF16).describe(1, L.IO_SMALL_BF16)[0] == 'k_s2b_tapnf<4,bf16>'
     assert E.ConvOp(2, 32, 32, 64, 7, 2, L.ALGO_BF16).describe(1, L.IO_SMALL_BF16)[0] == 'k_s2b_tapnf<4,bf16>+k_s2b_tapnf<3,bf16>'
     assert 'tapnf' not in E.ConvOp(2, 32, 32, 64, 4, 2, L.ALGO_BF16).describe(1, L.IO_SMALL_BF16 | L.IO_BIG_BF16)[0]
+
+
+def test_useful_flops_are_the_executed_ones_without_tile_padding():
+    """pg_conv_kernel_flops: executed >= useful, equal where no ragged tiles exist; the polyphase F(2x2,3x3) weight gradient of a
+    16 x 16 map (cfg2 enc3: 6 x 6 tiles of 3 for 16 rows) executes (18 / 16)^2 = 1.27x its useful count (VERDICT r03, weak #6)."""
+    from patchgan_amd import engine as E
+    op = E.ConvOp(16, 32, 32, 512, 256, 2, E.DEFAULT_ALGO)          # enc3 at cfg2
+    name, _ = op.describe(2)
+    ex, us = op.kernel_flops(2), op.useful_flops(2)
+    if name.startswith('k_wino_wgrad_gemm'):
+        assert abs(ex / us - (18 / 16) ** 2) < 1e-9, (ex, us)
+        assert us < op.flops                                        # Winograd: fewer multiplies than the direct count
+    for oc in (0, 1, 2):
+        assert op.useful_flops(oc) <= op.kernel_flops(oc) * (1 + 1e-12)
+    small = E.ConvOp(16, 8, 8, 512, 512, 2, E.DEFAULT_ALGO)         # enc5: implicit GEMM, no padding to report
+    for oc in (0, 1, 2):
+        assert small.useful_flops(oc) == small.kernel_flops(oc) == small.flops
