@@ -34,7 +34,7 @@ CONFIGS = {
                       'focal-Tversky*200 + BCE, Adam 1e-3'),
     'cfg4': dict(size=512, batch=8, out_nc=4, nf=64, ndf=64, n_layers=3, activation='leakyrelu', final_act='softmax',
                  loss_type='weighted_bce', gflop_per_image=352.99,
-                 desc='cfg4 (fp32 here; its bf16 path is a "next" row): 512x512x3->4-class masks, bs 8/GPU, nf=ndf=64'),
+                 desc='cfg4: 512x512x3->4-class masks, bs 8/GPU, nf=ndf=64'),
     'cfg1': dict(size=256, batch=4, out_nc=7, nf=32, ndf=16, n_layers=5, activation='relu', final_act='sigmoid',
                  loss_type='weighted_bce', gflop_per_image=12.2,
                  desc='cfg1: COCO-yaml hyper-parameters (nf=32, ndf=16, n_layers=5, relu, 7 classes, weighted BCE), 256x256 bs 4'),
@@ -89,29 +89,127 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(max_seconds=25.0):
-    """The CPU oracle's G+D step on the same cfg2 workload, all host cores available to this process."""
+def cpu_baseline(max_seconds=25.0, cfg=None, max_steps=5):
+    """The CPU oracle's G+D step on the same workload (cfg2 unless `cfg`), all host cores available to this process."""
     import torch
     from oracle import patchgan_oracle as O
+    cfg = cfg or CFG
     cores = usable_cpus()
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
-    gw = O.default_init(O.unet_weight_shapes(3, CFG['out_nc'], CFG['nf']))
-    dw = O.default_init(O.disc_weight_shapes(3 + CFG['out_nc'], CFG['ndf'], CFG['n_layers'], False))
-    ot = O.OracleTrainer(gw, dw, activation=CFG['activation'], final_act=CFG['final_act'], n_layers=CFG['n_layers'],
-                         norm=False, loss_type=CFG['loss_type'], seg_alpha=200)
-    x, y = make_inputs(BATCH_PER_GPU, 0)
+    gw = O.default_init(O.unet_weight_shapes(3, cfg['out_nc'], cfg['nf']))
+    dw = O.default_init(O.disc_weight_shapes(3 + cfg['out_nc'], cfg['ndf'], cfg['n_layers'], False))
+    ot = O.OracleTrainer(gw, dw, activation=cfg['activation'], final_act=cfg['final_act'], n_layers=cfg['n_layers'],
+                         norm=False, loss_type=cfg['loss_type'], seg_alpha=200)
+    x, y = make_inputs(cfg['batch'], 0, cfg)
     ot.batch(x, y, train=True)                       # warm-up (oneDNN primitive creation)
     t0 = time.perf_counter()
     n = 0
     while True:
         ot.batch(x, y, train=True)
         n += 1
-        if time.perf_counter() - t0 > max_seconds * 0.6 or n >= 5:
+        if time.perf_counter() - t0 > max_seconds * 0.6 or n >= max_steps:
             break
     dt = time.perf_counter() - t0
-    return {'value': round(BATCH_PER_GPU * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} G+D steps of the same workload (bs {BATCH_PER_GPU}, {SIZE}x{SIZE}) after 1 warm-up step; {dt / n:.2f} s/step'}
+    return {'value': round(cfg['batch'] * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} G+D steps of the same workload (bs {cfg["batch"]}, {cfg["size"]}x{cfg["size"]}) after 1 warm-up step; {dt / n:.2f} s/step'}
+
+
+def cpu_baseline_tiles(tiles=25, reps=3):
+    """The CPU oracle's generator forward over the 25 tiles of one 1024x1024 image (cfg5's dominant work; n_crop / build_mask are
+    not in it), all host cores."""
+    import torch
+    from oracle import patchgan_oracle as O
+    cores = usable_cpus()
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    gw = O.default_init(O.unet_weight_shapes(3, 1, 64))
+    x = torch.rand(tiles, 3, 256, 256, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        O.unet_forward(gw, x[:5], 'leakyrelu', 'sigmoid')            # warm-up
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            O.unet_forward(gw, x, 'leakyrelu', 'sigmoid')
+        dt = (time.perf_counter() - t0) / reps
+    return {'value': round(tiles / dt, 2), 'unit': 'tiles/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{reps} generator forwards over {tiles} tiles of 256x256 (one 1024x1024 image) after a 5-tile warm-up; {dt:.2f} s per image'}
+
+
+def _write_coco_like(folder, n, size, seed=0):
+    """n synthetic COCO-stuff-like files: JPEG photographs (smooth content, quality 90) + PNG label maps."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(folder, 'img'))
+    os.makedirs(os.path.join(folder, 'mask'))
+    base = rng.integers(0, 256, (n, size // 8, size // 8, 3), dtype=np.uint8)
+    lab = rng.integers(0, 3, (n, size // 16, size // 16), dtype=np.uint8)
+    for i in range(n):
+        Image.fromarray(base[i]).resize((size, size), Image.BICUBIC).save(os.path.join(folder, 'img', f'{i:012d}.jpg'), quality=90)
+        Image.fromarray(lab[i]).resize((size, size), Image.NEAREST).save(os.path.join(folder, 'mask', f'{i:012d}.png'))
+
+
+class _Stamped:
+    """A DataLoader handed to Trainer.train that notes when each batch left it (and restarts like the loader itself)."""
+
+    def __init__(self, loader):
+        self.loader, self.stamps = loader, []
+        self.sampler = getattr(loader, 'sampler', None)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        self.stamps.append([])
+        for item in self.loader:
+            self.stamps[-1].append(time.perf_counter())
+            yield item
+
+
+def e2e_training(dev, batches=48, files=192):
+    """End-to-end rate of the reference's training loop (train.py:77-83 -> trainer.py:215-218) at cfg2: JPEG / PNG files ->
+    COCOStuffDataset -> DataLoader(shuffle, pin_memory, workers, persistent) -> host-to-device copy -> Trainer.train's step, for the
+    reference's float items and for decoded bytes (device_pipeline=True: `/ 255.` and the one-hot mask on the GPU).  Two epochs of
+    `batches` steps each through Trainer.train; the rate is the second epoch's, from its 6th batch to the drained GPU."""
+    import shutil
+    import torch
+    import patchgan_amd as pg
+    from torch.utils.data import ConcatDataset, DataLoader
+    from patchgan_amd.io import COCOStuffDataset
+    cfg = CONFIGS['cfg2']
+    cores = usable_cpus()
+    workers = max(2, min(12, cores - 3))
+    torch.set_num_threads(max(1, cores - workers))
+    folder = tempfile.mkdtemp(prefix='pg_e2e_')
+    out = {'workload': f'cfg2 fed by DataLoader: {files} synthetic 256x256 JPEG + PNG files (repeated to {batches} batches of 16 per epoch), '
+                       f'{workers} workers, pin_memory, shuffle; Trainer.train, 2 epochs, the second one timed from its 6th batch',
+           'unit': 'images/sec', 'host_cpus': cores, 'workers': workers}
+    try:
+        _write_coco_like(folder, files, cfg['size'])
+        for fmt in ('float', 'u8_device_pipeline'):
+            torch.manual_seed(1234)
+            G = pg.UNet(3, 1, cfg['nf'], use_dropout=False, activation=cfg['activation'], final_act=cfg['final_act']).to(dev)
+            D = pg.Discriminator(4, cfg['ndf'], n_layers=cfg['n_layers']).to(dev)
+            tr = pg.Trainer(G, D, os.path.join(folder, 'ckpt_' + fmt))
+            tr.loss_type, tr.seg_alpha = cfg['loss_type'], 200
+            if fmt != 'float':
+                tr.label_values = [1]
+            ds = COCOStuffDataset(os.path.join(folder, 'img'), os.path.join(folder, 'mask'), labels=[1], size=cfg['size'],
+                                  augmentation='resize', device_pipeline=(fmt != 'float'))
+            ds = ConcatDataset([ds] * ((batches * cfg['batch'] + files - 1) // files))
+            dl = _Stamped(DataLoader(ds, batch_size=cfg['batch'], shuffle=True, pin_memory=True, drop_last=True, num_workers=workers,
+                                     persistent_workers=True, prefetch_factor=4))
+            tr.train(dl, [], 2, dsc_learning_rate=1e-3, gen_learning_rate=1e-3, save_freq=1000)
+            torch.cuda.synchronize()
+            t_end = time.perf_counter()
+            st = dl.stamps[1]              # second epoch of the training loader (stamps[0] = first)
+            n = len(st) - 5
+            out[fmt] = {'value': round(n * cfg['batch'] / (t_end - st[5]), 1), 'steps_timed': n,
+                        'h2d_bytes_per_image': (3 * 4 + 1 * 4) * cfg['size'] ** 2 if fmt == 'float' else (3 + 1) * cfg['size'] ** 2}
+            del dl, tr, G, D
+    finally:
+        shutil.rmtree(folder, ignore_errors=True)
+    return out
 
 
 def spawn_ranks(n, argv, script=None, timeout=None, grace=5.0):
@@ -261,7 +359,7 @@ def main():
         # headline metric / config / dtype above stay cfg2 fp32): cfg4 in bf16 (the "next" row f2) and cfg5 tiled inference (f1)
         if world == 1 and not use_dist and not args.no_extra and args.config == 'cfg2' and args.dtype == 'f32':
             del m
-            out['extra_configs'] = extra_configs(dev)
+            out['extra_configs'] = extra_configs(dev, cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
@@ -441,11 +539,13 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
     return res
 
 
-def extra_configs(dev):
+def extra_configs(dev, cpu=True):
     """BASELINE.json's remaining single-GPU configurations, for the driver's record (never the headline `value`):
       cfg4_bf16  512x512x3 -> 4-class masks, bs 8, bf16 MFMA path with bf16 activation storage: 5 warm-up + 10 timed G+D steps
       cfg5       1024x1024 image -> 25 tiles of 256x256 (overlap 0.9) through predict_image, nf = 64 fp32: 10 images after 2
-                 warm-up ones, device -> host copy of the mask included; tiles/s and peak device memory."""
+                 warm-up ones, device -> host copy of the mask included; tiles/s, peak device memory, fraction of the fp32 MFMA
+                 roofline, the CPU oracle's forward over the same 25 tiles.
+      e2e_cfg2   the reference's training LOOP at cfg2: files -> DataLoader -> H2D -> Trainer.train's step (e2e_training)."""
     import gc
     import torch
     out = {}
@@ -455,7 +555,7 @@ def extra_configs(dev):
         m = measure_training(CONFIGS['cfg4'], 'bf16', 10, 5, dev)
         r = m['roofline']
         out['cfg4_bf16'] = {
-            'workload': CONFIGS['cfg4']['desc'].replace('cfg4 (fp32 here; its bf16 path is a "next" row)', 'cfg4') + ', bf16 MFMA kernels, '
+            'workload': CONFIGS['cfg4']['desc'] + ', bf16 MFMA kernels, '
                         + m['activation_storage'] + ' activation storage, dropout off',
             'metric': 'train images/sec (G+D step) at 512x512 bs=8 per GPU', 'value': round(m['value'], 2), 'unit': 'images/sec',
             'steps': 10, 'warmup': 5, 'ms_per_step': round(m['ms_per_step'], 3), 'dtype': 'bf16',
@@ -464,6 +564,7 @@ def extra_configs(dev):
                                            'step_frac_of_mfma_roofline')},
             'conv_kernels': {k: v for k, v in list(m['conv_kernels'].items())[:8]}, 'last_losses': m['last_losses']}
         del m
+        out['cfg4_bf16']['cpu_baseline'] = cpu_baseline(max_seconds=20.0, cfg=CONFIGS['cfg4'], max_steps=2) if cpu else None
     except Exception as e:          # the headline line must not be lost to an extra
         out['cfg4_bf16'] = {'error': f'{type(e).__name__}: {e}'}
     try:
@@ -490,8 +591,23 @@ def extra_configs(dev):
                        'ms_per_image': round(dt * 1e3, 3), 'dtype': 'f32',
                        'peak_vram_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 3),
                        'mask_positive_fraction': round(float(mask.mean()), 4)}
+        # the generator forward's direct-convolution work (190.589 GFLOP per 16 images of 256x256 at nf = 64) over the
+        # whole predict_image call (gather, 25 forwards, blend, device -> host copy of the mask), against the fp32 MFMA peak
+        gflop = 190.589 / 16 * 25
+        out['cfg5']['roofline'] = {'bound': 'mfma', 'achieved': round(gflop / dt / 1e3, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': round(gflop / dt / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                                   'note': 'direct-convolution FLOPs of the 25 generator forwards / the whole predict_image time '
+                                           '(Winograd kernels execute 2.25-4x fewer; includes tile gather, blend and the mask copy)'}
+        del G, img
+        out['cfg5']['cpu_baseline'] = cpu_baseline_tiles() if cpu else None
     except Exception as e:
-        out['cfg5'] = {'error': f'{type(e).__name__}: {e}'}
+        out['cfg5'] = dict(out.get('cfg5', {}), error=f'{type(e).__name__}: {e}')
+    try:
+        gc.collect()
+        torch.cuda.empty_cache()
+        out['e2e_cfg2'] = e2e_training(dev)
+    except Exception as e:
+        out['e2e_cfg2'] = {'error': f'{type(e).__name__}: {e}'}
     return out
 
 

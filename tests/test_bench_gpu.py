@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(extra_args, extra_env, timeout=900, extras=False):
+def _bench(extra_args, extra_env, timeout=900, extras=False, cpu=False):
     env = dict(os.environ, **extra_env)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline']
-                       + ([] if extras else ['--no-extra']) + extra_args,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2']
+                       + ([] if cpu else ['--no-cpu-baseline']) + ([] if extras else ['--no-extra']) + extra_args,
                        env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
@@ -41,14 +41,26 @@ def test_bench_single_gpu_line():
 def test_bench_extra_configs_ride_on_the_headline_line():
     """The default N = 1 run also measures BASELINE.json's other single-GPU configurations after the headline's timed region -- cfg4
     in bf16 (images/s, dominant-kernel fraction of the bf16 MFMA peak) and cfg5 tiled inference (tiles/s, peak VRAM) -- under
-    `extra_configs` of the same single line; the headline metric / config / dtype stay cfg2 fp32."""
-    out = _bench([], {}, extras=True)
+    `extra_configs` of the same single line; the headline metric / config / dtype stay cfg2 fp32.  Each carries its CPU-oracle leg
+    (bounded), cfg5 its fraction of the fp32 MFMA roofline, and `e2e_cfg2` the loader-fed rate of Trainer.train for both item formats."""
+    out = _bench([], {}, extras=True, cpu=True)
     assert out['dtype'] == 'f32' and out['config']['workload'].startswith('cfg2') and '256x256 bs=16' in out['metric']
     x4, x5 = out['extra_configs']['cfg4_bf16'], out['extra_configs']['cfg5']
     assert 'error' not in x4 and 'error' not in x5, out['extra_configs']
     assert x4['dtype'] == 'bf16' and x4['value'] > 100 and x4['roofline']['peak'] == 2500.0 and 0.02 < x4['roofline']['frac'] < 1.0
     assert 'bf16' in x4['roofline']['kernel'] and 'bf16 activation storage' in x4['workload']
     assert x5['unit'] == 'tiles/sec' and x5['value'] > 500 and 0.5 < x5['peak_vram_GiB'] < 40
+    assert out['cpu_baseline']['kind'] == 'port' and 0 < out['cpu_baseline']['value'] < out['value']
+    assert x4['cpu_baseline']['unit'] == 'images/sec' and 0 < x4['cpu_baseline']['value'] < x4['value']
+    assert x5['cpu_baseline']['unit'] == 'tiles/sec' and 0 < x5['cpu_baseline']['value'] < x5['value']
+    assert x5['roofline']['peak'] == 157.3 and 0.05 < x5['roofline']['frac'] < 1.0
+    r = out['roofline']
+    assert 0 < r['frac_useful'] <= r['frac'] < 1.0
+    e = out['extra_configs']['e2e_cfg2']
+    assert 'error' not in e, e
+    for fmt in ('float', 'u8_device_pipeline'):
+        assert e[fmt]['steps_timed'] >= 30 and 50 < e[fmt]['value'] <= out['value'] * 1.05, e
+    assert e['u8_device_pipeline']['h2d_bytes_per_image'] * 4 == e['float']['h2d_bytes_per_image']
 
 
 def test_bench_rccl_path_one_rank():
