@@ -282,6 +282,8 @@ def main():
     ap.add_argument('--no-extra', action='store_true',
                     help='skip the extra_configs leg (cfg4 bf16 training, cfg5 tiled inference) measured after the headline')
     ap.add_argument('--dropout', action='store_true', help='nn.Dropout(0.2) in the generator (CLI default of the reference)')
+    ap.add_argument('--no-graph', action='store_true',
+                    help='enqueue every step launch by launch (default on one GPU with dropout off: the steady-state step is replayed from a captured hipGraph)')
     ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg2', help='workload (default: the BASELINE metric config)')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
                     help="f32 = the parity path the metric is quoted on; bf16 = bf16-multiply / fp32-accumulate conv kernels ('next' row f2)")
@@ -333,12 +335,13 @@ def main():
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {args.gpus}")
 
     m = measure_training(CFG, args.dtype, args.steps, args.warmup, dev, rank, world, use_dist, events=args.events,
-                         dropout=args.dropout, fp32_activations=args.fp32_activations)
+                         dropout=args.dropout, fp32_activations=args.fp32_activations, graph=not args.no_graph)
     if rank == 0:
         out = {
             'metric': f'train images/sec (G+D step) at {SIZE}x{SIZE} bs={BATCH_PER_GPU} per GPU', 'value': round(m['value'], 2),
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(m['ms_per_step'], 3), 'host_enqueue_ms_per_step': round(m['host_ms_per_step'], 3),
+            'step_launch': 'hipGraph replay of the captured step' if m['graph'] else 'launch by launch',
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'activation_storage': m['activation_storage'],
@@ -367,7 +370,7 @@ def main():
 
 
 def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=False, events='dominant', dropout=False,
-                     fp32_activations=False):
+                     fp32_activations=False, graph=True):
     """W untimed + K timed G+D steps of workload `cfg` on this rank's device (inputs resident in HBM; barrier + synchronize on
     both sides; MAX over ranks).  Returns the pieces of the JSON line: value (whole-job images/s), ms_per_step, roofline of the
     dominant conv kernel (HIP events on the launch stream inside the timed region), the per-kernel table of one fully
@@ -388,6 +391,7 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
     t = pg.Trainer(G, D, tempfile.mkdtemp(prefix='pgbench_'))
     t.loss_type, t.seg_alpha = cfg['loss_type'], 200
     t.gc_freeze = True            # as the patchgan_train entry point does (trainer._settle_gc): opt-in, process-global
+    t.graph = bool(graph) and not use_dist and not dropout     # the steady-state step replayed from a hipGraph (Trainer._batch_graph)
     t.setup_optimizers(1e-3, 1e-3)
     G.train()
     D.train()
@@ -421,6 +425,18 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         n_ev = prof.limit if prof.limit is not None else int(per_step * steps)
         prof.reserve(2 * n_ev + 8)        # the events exist (and have been recorded once) before the timed region starts
     E.PROFILER = prof if events != 'none' else None
+    graphed = False
+    if t.graph:
+        # untimed: more steps until the step runs from its captured graph (a kind of step is captured after Trainer.GRAPH_WARM_STEPS eager
+        # ones).  The timed steps are then replays of that graph and carry no per-launch events; the dominant kernel's launches are timed
+        # on eager steps of the same trainer right after the timed region (below)
+        E.PROFILER = None
+        for _ in range(t.GRAPH_WARM_STEPS + 3):
+            if t.graph_captured():
+                break
+            t.batch(x, y, train=True)
+        graphed = t.graph_captured()
+        E.PROFILER = None if graphed else (prof if events != 'none' else None)
     pd = parallel.current()
     trace = bool(os.environ.get('PATCHGAN_BENCH_TRACE'))
     if trace:
@@ -437,7 +453,7 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
     t0 = time.perf_counter()
     last = None
     host_ms = 0.0
-    for _ in range(steps):
+    for i in range(steps):
         cur = t.batch(x, y, train=True)
         host_ms += t.host_ms
         if trace:
@@ -448,6 +464,18 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
     t.flush()                      # the last step's (deferred, data-parallel) discriminator update belongs to the timed work
     sync()
     elapsed = time.perf_counter() - t0
+    sample_note = 'every launch of the kernel in the first steps of the timed region (<= 96 launches), HIP events on the launch stream'
+    if graphed and events != 'none' and wsum:
+        # the timed steps were hipGraph replays (no per-launch events: the HIP runtime torch brings along refuses external event-record
+        # nodes inside a capture, tools/graph_event_probe.py): the sample is taken on launch-by-launch steps of the same trainer, same
+        # buffers, right after the timed region -- the same kernels with the same arguments, HIP events on the launch stream
+        E.PROFILER = prof
+        nsample = max(1, prof.limit // max(1, int(per_step))) if prof.limit else min(steps, 4)
+        for _ in range(nsample):
+            t.batch(x, y, train=True)
+        torch.cuda.synchronize()
+        sample_note = (f'{nsample} launch-by-launch steps right after the timed region (the timed steps are hipGraph replays, which cannot '
+                       f'carry per-launch events on this runtime): every launch of the kernel, HIP events on the launch stream')
     E.PROFILER = None
     comm = None
     if pd.on:
@@ -488,7 +516,7 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
-    res = {'comm': comm, 'elapsed': elapsed}
+    res = {'comm': comm, 'elapsed': elapsed, 'graph': graphed}
     if rank != 0:
         return res
     value = batch * world * steps / elapsed
@@ -499,6 +527,8 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         d = dict(d, launches=d['launches'] * steps, ms=d['ms'] * steps, flops=d['flops'] * steps, kflops=d['kflops'] * steps,
                  uflops=d['uflops'] * steps)
     timed_steps = steps if (events != 'dominant' or prof.limit is None) else max(1, d['launches'] // max(1, int(wsum[sym]['launches'])))
+    if graphed and events != 'none' and wsum:
+        timed_steps = nsample
     per_step_all = wsum                      # every conv kernel, from the profiled warm-up step
     if not per_step_all:
         per_step_all = {k: dict(launches=v['launches'] / steps, ms=v['ms'] / steps, flops=v['flops'] / steps,
@@ -522,7 +552,7 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
                      'traffic': traffic,
                      'traffic_source': (f'{traffic_src} (committed rocprofv3 --pmc pass of the same command; not measured '
                                         'in this run)') if traffic_src else None,
-                     'launches_per_step': d['launches'] / timed_steps, 'launches_timed': d['launches'],
+                     'launches_per_step': d['launches'] / timed_steps, 'launches_timed': d['launches'], 'sample': sample_note,
                      'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                      'achieved_in_direct_conv_flops': round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2),
                      'kernel_share_of_step': round(d['ms'] / timed_steps / (elapsed / steps * 1e3), 4),

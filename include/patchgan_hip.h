@@ -360,6 +360,12 @@ int pg_loss_value_grad(const double* Spart, int nsplit, double* S_out, const dou
  * over n contiguous floats; bc1 = 1-b1^t and sqrt_bc2 = sqrt(1-b2^t) are computed by the caller. */
 int pg_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                  float eps, float bc1, float sqrt_bc2, void* stream);
+/* The same update with the two step-dependent scalars read from DEVICE memory: scalars[0] = lr / bc1, scalars[1] = sqrt(bc2) (floats the
+ * caller wrote there, stream-ordered before this launch).  The launch then carries nothing that changes from step to step, so a
+ * captured hipGraph of the whole G+D step (Trainer.graph) can be replayed with a new Adam step count and learning rate
+ * (optimizer.step() of trainer.py:90,107 inside the replayed step). */
+int pg_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps, const float* scalars,
+                     void* stream);
 
 /* ---- layout (the reference is NCHW end to end; trainer.py:55-66) ---------------------------------- */
 int pg_nchw_to_nhwc(const float* src, float* dst, int ld_dst, int N, int C, int H, int W, void* stream);

@@ -105,6 +105,7 @@ SIGNATURES = {
     'pg_loss_reduce_parts': (_i, [_p, _i, _p, _i, _f, _i, _i, _i, _p, _p]),
     'pg_loss_value_grad': (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _i, _p, _i, _f, _p, _i, _p, _p]),
     'pg_adam_step': (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p]),
+    'pg_adam_step_dev': (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _p, _p]),
     'pg_nchw_to_nhwc': (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     'pg_nhwc_to_nchw': (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     'pg_copy_channels': (_i, [_p, _i, _p, _i, _l, _i, _p]),

@@ -16,8 +16,15 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p - lr_over_bc1 * (m / denom);
 }
 
+// DEV: the two step-dependent scalars (lr / bc1, sqrt(bc2)) come from device memory -- the form a captured hipGraph replays with a
+// new Adam step count (pg_adam_step_dev); otherwise they are kernel arguments.  Same arithmetic either way.
+template <bool DEV>
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                       long n, float lr_over_bc1, float beta1, float beta2, float eps, float sqrt_bc2) {
+                       long n, float lr_over_bc1, float beta1, float beta2, float eps, float sqrt_bc2, const float* __restrict__ scal) {
+    if constexpr (DEV) {
+        lr_over_bc1 = scal[0];
+        sqrt_bc2 = scal[1];
+    }
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -154,8 +161,18 @@ int pg_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
     if (!p || !g || !m || !v || n <= 0 || bc1 <= 0.f || sqrt_bc2 <= 0.f) return PG_EINVAL;
     const uintptr_t al = (uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v;
     if (al & 15) return PG_EINVAL;
-    hipLaunchKernelGGL(k_adam, dim3(blocks_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr / bc1,
-                       beta1, beta2, eps, sqrt_bc2);
+    hipLaunchKernelGGL(k_adam<false>, dim3(blocks_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr / bc1,
+                       beta1, beta2, eps, sqrt_bc2, (const float*)nullptr);
+    return pg_launch_status();
+}
+
+int pg_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps, const float* scalars,
+                     void* stream) {
+    if (!p || !g || !m || !v || !scalars || n <= 0) return PG_EINVAL;
+    const uintptr_t al = (uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v;
+    if (al & 15) return PG_EINVAL;
+    hipLaunchKernelGGL(k_adam<true>, dim3(blocks_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1, beta2, eps,
+                       0.f, scalars);
     return pg_launch_status();
 }
 

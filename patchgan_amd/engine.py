@@ -19,6 +19,8 @@ import ctypes
 import os
 import math
 
+import numpy as np
+
 import torch
 
 from . import _lib as L
@@ -152,9 +154,12 @@ class LaunchProfiler:
         """Create n events ahead of the timed region: creating (and first-recording, which is what makes torch allocate the
         hipEvent_t) an event per launch inside it costs host time and a stream operation each."""
         for _ in range(n):
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            self._pool.append(e)
+            self._pool.append(self._new_event())
+
+    def _new_event(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()          # torch creates the hipEvent_t lazily, at the first record: force it (the C side re-records the event)
+        return e
 
     def launch(self, op, opcode, fn, io=0):
         if op.algo & L.ALGO_MASK == L.ALGO_DIRECT:
@@ -185,9 +190,7 @@ class LaunchProfiler:
     def _event(self):
         if self._pool:
             return self._pool.pop()
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()          # torch creates the hipEvent_t lazily: force it, the C side re-records it
-        return e
+        return self._new_event()
 
     def summary(self):
         """{symbol: dict(launches, ms, flops, kflops, uflops)} over every launch of that kernel symbol (all split-K factors, like a
@@ -196,9 +199,10 @@ class LaunchProfiler:
         extents (no tile padding) -- call after a device synchronize."""
         out = {}
         for sym, split, flops, kflops, uflops, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
             d = out.setdefault(sym, dict(launches=0, ms=0.0, flops=0.0, kflops=0.0, uflops=0.0))
             d['launches'] += 1
-            d['ms'] += e0.elapsed_time(e1)
+            d['ms'] += ms
             d['flops'] += flops
             d['kflops'] += kflops
             d['uflops'] += uflops
@@ -573,6 +577,18 @@ def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     bc2 = 1.0 - beta2 ** step
     L.check(L.load().pg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2,
                                   eps, bc1, math.sqrt(bc2), _stream()), 'pg_adam_step')
+
+
+def adam_scalars(step, lr, beta1=0.9, beta2=0.999):
+    """(lr / bc1, sqrt(bc2)) as the float32 values pg_adam_step forms from its arguments: what pg_adam_step_dev reads from device memory."""
+    bc1 = np.float32(1.0 - beta1 ** step)
+    return np.float32(lr) / bc1, np.float32(math.sqrt(1.0 - beta2 ** step))
+
+
+def adam_step_dev(p, g, m, v, scalars, beta1=0.9, beta2=0.999, eps=1e-8):
+    """adam_step with lr / bc1 and sqrt(bc2) taken from the device tensor `scalars` (2 floats): a launch without step-dependent arguments."""
+    L.check(L.load().pg_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), beta1, beta2, eps,
+                                      scalars.data_ptr(), _stream()), 'pg_adam_step_dev')
 
 
 def tiles_gather(image, size, overlap):

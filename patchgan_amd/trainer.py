@@ -150,6 +150,9 @@ class Trainer:
     neptune_config = None
     label_values = None      # label list of the dataset, only for the uint8 (device-side) input path of batch()
     gc_freeze = False        # opt-in: gc.collect() + gc.freeze() after training steps 1 and 3 (_settle_gc; process-global)
+    graph = False            # opt-in: replay the steady-state training step from a captured hipGraph (_batch_graph)
+    GRAPH_WARM_STEPS = 3     # eager steps of a given kind before it is captured (kernel plans, weight-cache plans, workspaces settle)
+    MAX_GRAPHS = 2           # captured kinds of step kept (each holds its activations: ~4 GB at cfg2)
 
     def __init__(self, generator, discriminator, savefolder, device='cuda'):
         generator.apply(weights_init)
@@ -169,6 +172,7 @@ class Trainer:
         self._step = 0
         self._pending_d = None
         self.bucket_bytes = 32 << 20   # all-reduce bucket size under data parallelism (parallel.GradReducer)
+        self._graphs, self._graph_seen, self._adam_dev = {}, {}, None
 
     # -------------------------------------------------------------------------------------- optimizers
     def setup_optimizers(self, gen_lr=1e-3, dsc_lr=1e-3):
@@ -177,6 +181,7 @@ class Trainer:
         g, d = self.generator.flat, self.discriminator.flat
         self._adam = (torch.zeros_like(g), torch.zeros_like(g), torch.zeros_like(d), torch.zeros_like(d))
         self._t_g = self._t_d = 0
+        self._graphs, self._graph_seen = {}, {}        # captured steps update the OLD moment buffers
 
     # -------------------------------------------------------------------------------------- one G+D step
     def batch(self, x, y, train=False):
@@ -210,10 +215,28 @@ class Trainer:
                                f"discriminator input {de.input_nc}")
         if train and self._adam is None:
             self.setup_optimizers(self.gen_lr, self.dsc_lr)
+        self._step += 1
+        losses = None
+        if train and self._graph_eligible():
+            losses = self._batch_graph(x, y, u8, (N, H, W, Cin, Cout))
+        if losses is None:
+            losses = self._enqueue_step(x, y, u8, N, H, W, Cin, Cout, train)
+        if train and self.gc_freeze:
+            _settle_gc(self._step)
+        self.host_ms = (time.perf_counter() - t_host0) * 1e3       # host time to enqueue the whole step (bench.py reports it)
+        return self._publish(losses)
+
+    def _enqueue_step(self, x, y, u8, N, H, W, Cin, Cout, train):
+        """Every launch of one step on the current stream, from the device-resident inputs to the four loss scalars (returned as a
+        device tensor).  Nothing in here reads the device; the only step-dependent HOST values are the dropout seed (self._step) and
+        Adam's step count / learning rate (_adam_step) -- with dropout off and self._adam_dev set the sequence is the same from step
+        to step, which is what _batch_graph captures."""
+        G, D = self.generator, self.discriminator
+        ge, de = G.engine, D.engine
+        dev = G.flat.device
         dist = _dist()
         Bglobal = N * dist.world
         Cd = Cin + Cout
-        self._step += 1
 
         # discriminator input buffer: samples [0,N) real = x|y, [N,2N) fake = x|G(x)   (trainer.py:65,96,98)
         din = E.View.alloc(2 * N, H, W, Cd, dev)
@@ -300,9 +323,9 @@ class Trainer:
         if wait_losses is not None:
             wait_losses()
         self._last_gen = gen
-        if train and self.gc_freeze:
-            _settle_gc(self._step)
-        self.host_ms = (time.perf_counter() - t_host0) * 1e3       # host time to enqueue the whole step (bench.py reports it)
+        return losses
+
+    def _publish(self, losses):
         # the step's one device-to-host copy, asynchronous into a pinned slot: the returned dict waits for it on first access
         ring = getattr(self, '_loss_ring', None)
         if ring is None or ring[0][0].device != torch.device('cpu'):
@@ -328,13 +351,93 @@ class Trainer:
             self._adam_step('d')
 
     def _adam_step(self, which):
-        if which == 'g':
+        net, (m, v) = (self.generator, self._adam[0:2]) if which == 'g' else (self.discriminator, self._adam[2:4])
+        if self._adam_dev is not None:
+            # a step being captured: lr / bc1 and sqrt(bc2) come from device memory (written before every replay, _batch_graph)
+            E.adam_step_dev(net.flat, net.grad_flat, m, v, self._adam_dev[0:2] if which == 'g' else self._adam_dev[2:4])
+        elif which == 'g':
             self._t_g += 1
-            E.adam_step(self.generator.flat, self.generator.grad_flat, self._adam[0], self._adam[1], self._t_g, self.gen_lr)
+            E.adam_step(net.flat, net.grad_flat, m, v, self._t_g, self.gen_lr)
         else:
             self._t_d += 1
-            E.adam_step(self.discriminator.flat, self.discriminator.grad_flat, self._adam[2], self._adam[3], self._t_d,
-                        self.dsc_lr)
+            E.adam_step(net.flat, net.grad_flat, m, v, self._t_d, self.dsc_lr)
+
+    # -------------------------------------------------------------------------------------- the step as a hipGraph
+    def _graph_eligible(self):
+        """Single GPU, dropout off (its per-layer seeds are launch arguments derived from the step number on the host), and no launch
+        profiler armed (its HIP events are per launch: the HIP runtime torch brings along refuses external event-record nodes inside a
+        capture, tools/graph_event_probe.py)."""
+        G = self.generator
+        if not self.graph or os.environ.get('PATCHGAN_GRAPH', '1') == '0' or _dist().on or E.PROFILER is not None:
+            return False
+        return not (G.training and G.engine.use_dropout)
+
+    def _batch_graph(self, x, y, u8, dims):
+        """The training step replayed from a captured hipGraph: ~220 launches become one hipGraphLaunch (host enqueue 1.9 ms -> well
+        under 0.1 ms per step at cfg2; the step itself is unchanged -- same kernels, same arguments, bit-identical results).
+        A kind of step (shapes, loss settings, precision / tuning of both networks) is captured after GRAPH_WARM_STEPS eager steps of
+        that kind; until then, and for any step that is not eligible, None is returned and the caller
+        enqueues the step launch by launch.  Per replay the host copies the inputs into the graph's input buffers, writes Adam's two
+        step-dependent scalars per network (lr / bc1, sqrt(bc2): pg_adam_step_dev reads them from device memory) and launches."""
+        G, D = self.generator, self.discriminator
+        key = (u8, dims, self.loss_type, float(self.seg_alpha), float(self.tversky_beta), float(self.tversky_gamma),
+                tuple(self.label_values) if self.label_values is not None else None, G.training, D.training,
+                G.engine.algo, bool(G.engine.act_bf), D.engine.algo, bool(D.engine.act_bf), G.flat.data_ptr(), D.flat.data_ptr(),
+                tuple(x.shape), tuple(y.shape), x.dtype, y.dtype)
+        st = self._graphs.get(key)
+        if st is None:
+            seen = self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            if seen <= self.GRAPH_WARM_STEPS:
+                return None
+            try:
+                st = self._capture(key, x, y, u8, dims)
+            except Exception as e:          # a runtime that cannot capture this step: launch by launch from here on, loudly
+                import warnings
+                warnings.warn(f'patchgan_amd: hipGraph capture of the training step failed ({type(e).__name__}: {e}); continuing launch by launch')
+                self.graph = False
+                return None
+        else:
+            self._graphs[key] = self._graphs.pop(key)          # most recently used last
+        st.x.copy_(x, non_blocking=True)
+        st.y.copy_(y, non_blocking=True)
+        self._t_g += 1
+        self._t_d += 1
+        host = st.host[st.slot]
+        st.slot = (st.slot + 1) % len(st.host)
+        h = host.numpy()
+        h[0:2] = E.adam_scalars(self._t_g, self.gen_lr)
+        h[2:4] = E.adam_scalars(self._t_d, self.dsc_lr)
+        st.scal.copy_(host, non_blocking=True)
+        st.graph.replay()
+        self._last_gen = st.gen
+        return st.losses
+
+    def _capture(self, key, x, y, u8, dims):
+        class _StepGraph:
+            pass
+        st = _StepGraph()
+        dev = x.device
+        st.x, st.y = torch.empty_like(x), torch.empty_like(y)
+        st.scal = torch.zeros(4, dtype=torch.float32, device=dev)
+        # (a ring: the copy of slot i to the device may still be queued when the host prepares the next steps; _publish's ring of
+        #  four loss slots keeps the host at most four steps ahead of the device)
+        st.host, st.slot = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(8)], 0
+        while len(self._graphs) >= self.MAX_GRAPHS:
+            self._graphs.pop(next(iter(self._graphs)))
+        st.graph = torch.cuda.CUDAGraph()
+        self._adam_dev = st.scal
+        try:
+            with torch.cuda.graph(st.graph, capture_error_mode='thread_local'):
+                st.losses = self._enqueue_step(st.x, st.y, u8, *dims, True)
+                st.gen = self._last_gen
+        finally:
+            self._adam_dev = None
+        self._graphs[key] = st
+        return st
+
+    def graph_captured(self):
+        """True once some kind of training step runs from a captured graph (bench.py warms up until then)."""
+        return bool(self._graphs)
 
     # -------------------------------------------------------------------------------------- epoch driver
     def train(self, train_data, val_data, epochs, dsc_learning_rate=1.e-3, gen_learning_rate=1.e-3, save_freq=10,
