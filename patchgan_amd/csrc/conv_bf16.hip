@@ -83,8 +83,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // pixel tiles, a transpose through LDS (lane <-> value, fixed order), the waves that share the channels combined in wave order.
 // BT (dir 1): the weights come in the SAME packed layout as dir 0 ([tap][a][b], b contiguous): the B tile is staged [k = a][n = b] and its
 // fragments come out of transposing reads, so one bf16 copy of a layer's weights serves both directions.
-template <int MR, int NR, int WM, int WN, int DRC, int KB, bool MUL = false, bool STATS = false, bool BT = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv_bf16x(
+// OCC: waves per SIMD = workgroups per CU.  The 64-accumulator tiles (128 x 128, 256 x 64) fit four (<= 128 registers, 32 - 40 KB of
+// LDS each): three other workgroups' DMA phases then cover a workgroup's multiply phase instead of one (cfg4 layers, same box:
+// enc1 forward 61 -> 51 us, dec5 data gradient 104 -> 80 us, d1 forward at 2N 156 -> 117 us; EXPERIMENTS.md round 4)
+template <int MR, int NR, int WM, int WN, int DRC, int KB, bool MUL = false, bool STATS = false, bool BT = false,
+          int OCC = (MR * NR <= 4 && KB == 64) ? 4 : 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_conv_bf16x(
     const __bf16* __restrict__ in, int ld_in, const __bf16* __restrict__ W, void* __restrict__ out, int ld_out, long slab_stride, XGeom g,
     int cps, const float* __restrict__ bias, int act, int in_bytes, int w_bytes, int out_bf, int tiles_n, pg_epi_mul mul, double* __restrict__ part,
     int chunks) {
@@ -431,8 +435,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // read shifted windows of the same `big` pixels from that XCD's L2.
 // TAPN: `big` has 8 channels per pixel (ld_big == 8, g.Cb <= 8 real ones): the 16 taps x 8 channels are the 128 b-columns of ONE GEMM
 // (no tap dimension in the grid); one DMA lane fetches one tap's pixel (16 bytes), its own (kh, kw) offset instead of the block's.
-template <int MR, int NR, int WM, int WN, bool TAPN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wgrad_bf16x(
+template <int MR, int NR, int WM, int WN, bool TAPN = false, int OCC = (MR * NR <= 4) ? 4 : 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_wgrad_bf16x(
     const __bf16* __restrict__ small, int ld_small, const __bf16* __restrict__ big, int ld_big, float* __restrict__ out, long slab_stride,
     XGeom g, int cps, int small_bytes, int big_bytes, int tiles_b, int ntiles, float inv_hw, float inv_w) {
     static_assert(WM * WN == 4, "four waves");
@@ -688,9 +692,12 @@ pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, i
     // Measured on the cfg4 layers (tools/layer_bench_bf16.py, one device): the 256 x 128 tile wins only where it alone fills the chip
     // twice over (>= ~480 workgroups = two per CU) on a long K; one workgroup per CU loses to 128 x 128 tiles at two to four per CU,
     // and a split-K pass (slab write + reduce) costs more than it returns once ~400 workgroups exist without it.
+    // Round 4: at four workgroups per CU (OCC above) the 128 x 128 tile is as fast or faster everywhere the 256 x 128 one used to
+    // win (dec4 88 -> 79 us, d2 at 2N 87 -> 79, d3 at 2N 275 -> 265 forward / 265 -> 272 data gradient): the wide tile stays reachable
+    // through PATCHGAN_BF16X_TILE=0 only.
+    (void)blocks;
     if (forced >= 0 && forced <= 2) p.tile = forced;
     else if (Cout <= 64) p.tile = 2;
-    else if (blocks(256, 128) >= 480 && p.nchunks >= 32) p.tile = 0;
     else p.tile = 1;
     p.bm = (p.tile == 1) ? 128 : 256;
     p.bn = (p.tile == 2) ? 64 : 128;
@@ -777,8 +784,12 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
     const __bf16* I = (const __bf16*)in;
     const __bf16* Wp = (const __bf16*)W;
 #define PG_BF16X_ARGS I, ld_in, Wp, out, ld_out, slab_stride, g, p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul, part, chunks
-#define PG_BF16X_K(MR, NR, WM, WN, D, KB, MUL, ST, BT) \
-    hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB, MUL, ST, BT>), grid, dim3(256), 0, st, PG_BF16X_ARGS)
+    static const bool occ2 = pg_exp_env("PATCHGAN_BF16X_OCC2") != nullptr;      // A/B: the 64-accumulator tiles at two workgroups per CU
+#define PG_BF16X_K(MR, NR, WM, WN, D, KB, MUL, ST, BT)                                                                          \
+    do {                                                                                                                       \
+        if (occ2) hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB, MUL, ST, BT, 2>), grid, dim3(256), 0, st, PG_BF16X_ARGS); \
+        else hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB, MUL, ST, BT>), grid, dim3(256), 0, st, PG_BF16X_ARGS);     \
+    } while (0)
 #define PG_BF16X_LAUNCH(MR, NR, WM, WN)                                                                                      \
     do {                                                                                                                     \
         if (dir == 1 && !p->ring && bt) {                                                                                    \
@@ -879,9 +890,14 @@ int pg_bf16x_wgrad(const void* small, int ld_small, long small_bytes, const void
     const float inv_hw = 1.0f / (float)(Hs * Ws), inv_w = 1.0f / (float)Ws;
     const __bf16* S = (const __bf16*)small;
     const __bf16* B = (const __bf16*)big;
+    static const bool wocc2 = pg_exp_env("PATCHGAN_BF16X_OCC2") != nullptr;
 #define PG_BF16X_WG(MR, NR, WM, WN, TN)                                                                                      \
-    hipLaunchKernelGGL((k_wgrad_bf16x<MR, NR, WM, WN, TN>), grid, dim3(256), 0, st, S, ld_small, B, ld_big, out, slab_stride, g, p->cps, \
-                       (int)small_bytes, (int)big_bytes, p->tiles_n, ntiles, inv_hw, inv_w)
+    do {                                                                                                                     \
+        if (wocc2) hipLaunchKernelGGL((k_wgrad_bf16x<MR, NR, WM, WN, TN, 2>), grid, dim3(256), 0, st, S, ld_small, B, ld_big, out, slab_stride, g, p->cps, \
+                                      (int)small_bytes, (int)big_bytes, p->tiles_n, ntiles, inv_hw, inv_w);                  \
+        else hipLaunchKernelGGL((k_wgrad_bf16x<MR, NR, WM, WN, TN>), grid, dim3(256), 0, st, S, ld_small, B, ld_big, out, slab_stride, g, p->cps, \
+                                (int)small_bytes, (int)big_bytes, p->tiles_n, ntiles, inv_hw, inv_w);                        \
+    } while (0)
     switch (p->tile) {
         case 0: PG_BF16X_WG(4, 2, 2, 2, false); break;
         case 1: PG_BF16X_WG(2, 2, 2, 2, false); break;
