@@ -311,6 +311,9 @@ int pg_loss_reduce(const float* p, int ld_p, const float* y, int ld_y, float tco
 /* Number of doubles S must hold for pg_loss_reduce(N, HW, C): N*C*5 results, followed by scratch for the per-split
  * partial sums large maps are reduced through. */
 long pg_loss_reduce_doubles(int N, int HW, int C);
+/* Largest N * C for which pg_loss_value_grad (value + gradient of a loss term in one launch, its per-(sample, channel) table in LDS)
+ * applies; beyond it the caller uses pg_loss_finalize + pg_loss_grad (same results).  Replaces nothing in the reference. */
+int pg_loss_fused_max_nc(void);
 
 /* Stage 2: gradient of a scalar loss wrt p from per-(n,c) coefficients:
  *   mode 0 (affine in y; focal-Tversky):   g = coef[n][c][0] * y + coef[n][c][1]

@@ -98,6 +98,7 @@ SIGNATURES = {
     'pg_softmax_bwd': (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _l, _i, _p]),
     'pg_dropout_mask': (_i, [_p, _l, _f, _u64, _p]),
     'pg_loss_reduce_doubles': (_l, [_i, _i, _i]),
+    'pg_loss_fused_max_nc': (_i, []),
     'pg_loss_reduce': (_i, [_p, _i, _p, _i, _f, _i, _i, _i, _p, _p]),
     'pg_loss_prepare': (_i, [_p, _i, _i, _f, _p, _p]),
     'pg_loss_finalize': (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p]),

@@ -350,6 +350,8 @@ int loss_nsplit(int N, int HW, int C) {
 
 extern "C" {
 
+int pg_loss_fused_max_nc(void) { return FUSED_MAX_NC; }
+
 long pg_loss_reduce_doubles(int N, int HW, int C) {
     if (N <= 0 || HW <= 0 || C <= 0) return 0;
     const int ns = loss_nsplit(N, HW, C);

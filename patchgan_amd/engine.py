@@ -1146,7 +1146,9 @@ class DiscriminatorEngine(_WeightPrep):
 
 
 class LossBuffers:
-    """Scratch for one loss evaluation: S [N*C*5] f64, sums [2] f64, coef [N*C*2] f32."""
+    """Scratch for one loss evaluation: S f64 (the per-(sample, channel) reduction terms: COMBINED [N*C*5] sums on the staged path,
+    the nsplit partial slabs on the one-launch path, which combines them inside pg_loss_value_grad), sums [2] f64, coef [N*C*2] f32.
+    Kept alive by the caller until the launches that use it are enqueued; nothing reads it afterwards."""
 
     def __init__(self, N, C, device, HW=1):
         self.S = torch.empty(int(L.load().pg_loss_reduce_doubles(N, HW, C)), dtype=torch.float64, device=device)
@@ -1159,7 +1161,15 @@ class PendingLoss:
     __slots__ = ('buf', 'wait', 'args', 'nsplit', 'sums')
 
 
-_FUSED_LOSS_MAX_NC = 256        # pg_loss_value_grad's table (N * C entries) lives in LDS
+def _fused_loss_max_nc():
+    """pg_loss_value_grad's table (N * C entries) lives in LDS: the library says how many fit (pg_loss_fused_max_nc)."""
+    global _FUSED_LOSS_MAX_NC
+    if _FUSED_LOSS_MAX_NC is None:
+        _FUSED_LOSS_MAX_NC = int(L.load().pg_loss_fused_max_nc())
+    return _FUSED_LOSS_MAX_NC
+
+
+_FUSED_LOSS_MAX_NC = None
 
 
 def loss_begin(p, y, tconst, beta=0.75, allreduce=None, need_sums=True):
@@ -1175,7 +1185,7 @@ def loss_begin(p, y, tconst, beta=0.75, allreduce=None, need_sums=True):
     h.buf, h.args, h.wait, h.sums = buf, (p, y, tconst, beta), None, None
     yp, yl = (y.ptr(), y.ld) if y is not None else (None, 0)
     exchange = allreduce is not None and need_sums
-    if not exchange and p.N * p.C <= _FUSED_LOSS_MAX_NC:
+    if not exchange and p.N * p.C <= _fused_loss_max_nc():
         h.nsplit = int(lib.pg_loss_reduce_parts(p.ptr(), p.ld, yp, yl, float(tconst), p.N, p.HW, p.C, buf.S.data_ptr(), st))
         if h.nsplit < 1:
             L.check(h.nsplit, 'pg_loss_reduce_parts')
@@ -1192,7 +1202,7 @@ def loss_begin(p, y, tconst, beta=0.75, allreduce=None, need_sums=True):
 
 def loss_finish(h, mode, alpha, grad_out, loss_out, loss_slot, bglobal, gamma=0.75):
     """Phase 2: the loss value into loss_out[loss_slot] and, if grad_out is not None, its gradient wrt p into View
-    grad_out (seeded with the GLOBAL batch terms)."""
+    grad_out (seeded with the GLOBAL batch terms).  Returns the scratch buffers (see LossBuffers: not a result)."""
     lib = L.load()
     p, y, tconst, beta = h.args
     buf = h.buf
@@ -1201,7 +1211,7 @@ def loss_finish(h, mode, alpha, grad_out, loss_out, loss_slot, bglobal, gamma=0.
     st = _stream()
     yp, yl = (y.ptr(), y.ld) if y is not None else (None, 0)
     sums = h.sums.data_ptr() if h.sums is not None else None
-    if p.N * p.C <= _FUSED_LOSS_MAX_NC:
+    if p.N * p.C <= _fused_loss_max_nc():
         gp, gl = (grad_out.ptr(), grad_out.ld) if grad_out is not None else (None, 0)
         L.check(lib.pg_loss_value_grad(buf.S.data_ptr(), max(h.nsplit, 1), None, sums, mode, p.N, p.C, p.HW, bglobal, alpha, beta, gamma,
                                        p.ptr(), p.ld, yp, yl, float(tconst), gp, gl, L.ptr(loss_out, loss_slot), st), 'pg_loss_value_grad')

@@ -76,7 +76,7 @@ class Dist:
         done = torch.cuda.Event()
         done.record(comm)
         if self.timing is None:
-            return _StreamWait(done)
+            return _StreamWait(done, comm)
         nbytes = t.numel() * t.element_size()
 
         def wait_timed():
@@ -112,8 +112,8 @@ class _StreamWait:
     record is a barrier packet, 5-10 us of an otherwise back-to-back kernel queue on MI355X, tools/dp_sync_probe.py)."""
     in_order = True
 
-    def __init__(self, done):
-        self.done = done
+    def __init__(self, done, comm=None):
+        self.done, self.comm = done, comm
 
     def __call__(self):
         torch.cuda.current_stream().wait_event(self.done)
@@ -165,9 +165,13 @@ class GradReducer:
         self._launch()
         if launch_only:
             return
+        last = self.waits[-1] if self.waits else None
         for i, w in enumerate(self.waits):
-            if i + 1 < len(self.waits) and getattr(w, 'in_order', False) and getattr(self.waits[-1], 'in_order', False):
-                continue                     # covered by the wait for the last bucket (one in-order comm stream)
+            # covered by the wait for the last bucket ONLY if both are event waits behind the same in-order comm stream (a process group
+            # that hands back anything else -- a host-side work handle, another stream -- gets every wait)
+            if (i + 1 < len(self.waits) and isinstance(w, _StreamWait) and isinstance(last, _StreamWait)
+                    and w.comm is not None and w.comm is last.comm):
+                continue
             w()
         self.waits = []
 

@@ -469,6 +469,15 @@ class Trainer:
             self.neptune_config['model/parameters/lr_decay'] = lr_decay
 
         history = {'gen': [], 'disc': []}
+        try:
+            return self._epochs(train_data, val_data, epochs, save_freq, lr_decay, decay_freq, plateau, history)
+        finally:
+            # also on an exception / KeyboardInterrupt inside the loop.  gc.unfreeze() is process-global: it also thaws what the host
+            # application froze itself (which is why gc_freeze is opt-in)
+            if self.gc_freeze:
+                _unsettle_gc()
+
+    def _epochs(self, train_data, val_data, epochs, save_freq, lr_decay, decay_freq, plateau, history):
         for epoch in range(self.start, epochs + 1):
             if _dist().rank == 0:
                 print(f"Epoch {epoch} -- lr: {self.gen_lr:5.3e}, {self.dsc_lr:5.3e}")
@@ -494,8 +503,6 @@ class Trainer:
             if epoch % save_freq == 0:
                 self.save(epoch)
         self.flush()
-        if self.gc_freeze:
-            _unsettle_gc()
         return history['gen'], history['disc']
 
     def _run_epoch(self, data, train, epoch, desc, **bar_kwargs):

@@ -51,25 +51,41 @@ def _reducer_worker(rank, world, port, q):
 
 def test_grad_reducer_waits_once_for_in_order_collectives():
     """Device collectives share one in-order comm stream: finish() waits for the last bucket only (one barrier packet on the
-    compute stream instead of one per bucket); host work handles and timed waits are waited for one by one; finish(launch_only)
-    hands the remainder over without waiting."""
-    from patchgan_amd.parallel import GradReducer
+    compute stream instead of one per bucket) -- but ONLY for event waits that sit behind the SAME comm stream (_StreamWait with that
+    stream); host work handles, timed waits, waits of another stream or of an unknown kind are waited for one by one;
+    finish(launch_only) hands the remainder over without waiting."""
+    from patchgan_amd.parallel import GradReducer, _StreamWait
+
+    class Waited(_StreamWait):
+        def __init__(self, log, i, comm):
+            super().__init__(None, comm)
+            self.log, self.i = log, i
+
+        def __call__(self):
+            self.log.append(self.i)
 
     class FakeDist:
-        def __init__(self, in_order):
-            self.calls, self.waited, self.in_order = [], [], in_order
+        def __init__(self, kind):
+            self.calls, self.waited, self.kind = [], [], kind
+            self.comm = object()
 
         def all_reduce_side(self, t):
             i = len(self.calls)
             self.calls.append(t.numel())
+            if self.kind == 'one_stream':
+                return Waited(self.waited, i, self.comm)
+            if self.kind == 'stream_per_call':
+                return Waited(self.waited, i, object())
+            if self.kind == 'no_stream':
+                return Waited(self.waited, i, None)
 
-            def wait():
+            def wait():                      # a host-side handle that merely CLAIMS to be in order
                 self.waited.append(i)
-            wait.in_order = self.in_order
+            wait.in_order = True
             return wait
 
-    for in_order, want in ((True, [3]), (False, [0, 1, 2, 3])):
-        d = FakeDist(in_order)
+    for kind, want in (('one_stream', [3]), ('stream_per_call', [0, 1, 2, 3]), ('no_stream', [0, 1, 2, 3]), ('callable', [0, 1, 2, 3])):
+        d = FakeDist(kind)
         r = GradReducer(d, torch.zeros(1000), bucket_bytes=4 * 300)
         for hi, lo in ((1000, 700), (700, 400), (400, 100)):
             r.ready(lo, hi)
@@ -77,7 +93,7 @@ def test_grad_reducer_waits_once_for_in_order_collectives():
         r.finish(launch_only=True)
         assert d.calls == [300, 300, 300, 100] and d.waited == []
         r.finish()
-        assert d.calls == [300, 300, 300, 100] and d.waited == want
+        assert d.calls == [300, 300, 300, 100] and d.waited == want, (kind, d.waited)
         assert sorted(r.launched) == [(0, 100), (100, 400), (400, 700), (700, 1000)]
 
 
