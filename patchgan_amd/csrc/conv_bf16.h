@@ -11,7 +11,7 @@
 // 3 = row GEMM  out[m][n] = sum_a small[m][a] * W[n][a]  over the N*Hs*Ws pixels of `small`, n < Cb (callers pass Cb = 16 * real Cb:
 //     the taps-folded-into-N first half of a few-channel ConvTranspose2d; W = pack dir 1 of the real layer)
 struct pg_bf16x_plan {
-    int tile;              // 0: 256x128 rows x channels per workgroup, 1: 128x128, 2: 256x64
+    int tile;              // 0: 256x128 rows x channels per workgroup (four waves), 1: 128x128, 2: 256x64, 3: 256x128 on eight waves
     int bm, bn;
     int tiles_m, tiles_n, ncls;
     int nchunks;           // 64-wide K chunks: taps * Cin / 64

@@ -88,18 +88,19 @@ __device__ __forceinline__ void wait_vmcnt() {
 // enc1 forward 61 -> 51 us, dec5 data gradient 104 -> 80 us, d1 forward at 2N 156 -> 117 us; EXPERIMENTS.md round 4)
 template <int MR, int NR, int WM, int WN, int DRC, int KB, bool MUL = false, bool STATS = false, bool BT = false,
           int OCC = (MR * NR <= 4 && KB == 64) ? 4 : 2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_conv_bf16x(
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_conv_bf16x(
     const __bf16* __restrict__ in, int ld_in, const __bf16* __restrict__ W, void* __restrict__ out, int ld_out, long slab_stride, XGeom g,
     int cps, const float* __restrict__ bias, int act, int in_bytes, int w_bytes, int out_bf, int tiles_n, pg_epi_mul mul, double* __restrict__ part,
     int chunks) {
-    static_assert(WM * WN == 4, "four waves");
+    constexpr int NW = WM * WN;                                    // waves per workgroup: 4, or 8 (the 256 x 128 tile of 64 x 64 per wave:
+    static_assert(NW == 4 || NW == 8, "four or eight waves");      //  0.375 DMA pieces per MFMA at four waves per SIMD from two workgroups)
     static_assert(KB == 32 || KB == 64, "chunk width");
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
     constexpr int ROWB = KB * 2;                                   // bytes per LDS row
     constexpr int RPP = 1024 / ROWB, SPR = ROWB / 16;              // rows per DMA piece, 16-byte slots per row
-    constexpr int AP = BM / (4 * RPP), BP = BN / (4 * RPP);        // pieces per wave and chunk
+    constexpr int AP = BM / (NW * RPP), BP = BN / (NW * RPP);      // pieces per wave and chunk
     constexpr int NST = (KB == 32) ? 3 : 1, STAGE = (BM + BN) * ROWB;
-    constexpr int STATB = STATS ? (4 * 64 * 33 + 4 * 64) * 4 : 0;   // STATS: [wave][lane][33] transpose area + [wave][64] results
+    constexpr int STATB = STATS ? (NW * 64 * 33 + NW * 64) * 4 : 0; // STATS: [wave][lane][33] transpose area + [wave][64] results
     __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE > STATB ? NST * STAGE : STATB];
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, w_bytes, 0x00020000);
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
         if constexpr (BT) {
-            const int r = (wave * BP + j) * RPB + lane / LPRB;     // (BP == 64 / RPB / 4 for both tile widths)
+            const int r = (wave * BP + j) * RPB + lane / LPRB;     // (BP == 64 / RPB / NW for every tile width)
             const int ch = (lane % LPRB) ^ swzT(r);
             const int b = n0 + ch * 8;
             b_off[j] = (b < Cout) ? (r * Cout + b) * 2 : (int)0x80000000u;
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             // lane-major [lane][33] image of the 32 per-lane sums (s1 | s2), then lane L adds column L & 31 over the 32 lanes of its
             // half in lane order: sums over the wave's MR * 32 pixels for channel nb + 8q + 4 * half + e, k = 4q + e = (L & 15)
             float* const tr = reinterpret_cast<float*>(smem) + wave * 64 * 33;
-            float* const res = reinterpret_cast<float*>(smem) + 4 * 64 * 33 + wave * 64;
+            float* const res = reinterpret_cast<float*>(smem) + NW * 64 * 33 + wave * 64;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 tr[lane * 33 + k] = s1[k];
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             if (wm == 0) {                                         // the WM waves that share these channels, in wave order
                 float tot = t;
 #pragma unroll
-                for (int w2 = 1; w2 < WM; ++w2) tot += reinterpret_cast<const float*>(smem)[4 * 64 * 33 + (w2 * WN + wn) * 64 + lane];
+                for (int w2 = 1; w2 < WM; ++w2) tot += reinterpret_cast<const float*>(smem)[NW * 64 * 33 + (w2 * WN + wn) * 64 + lane];
                 const int which = lrow >> 4, k = lrow & 15;
                 const int ch = nb + 8 * (k >> 2) + 4 * lh + (k & 3);
                 // the tile's sample and chunk: every row of the tile lies in one sample (host-checked)
@@ -695,8 +696,12 @@ pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, i
     // Round 4: at four workgroups per CU (OCC above) the 128 x 128 tile is as fast or faster everywhere the 256 x 128 one used to
     // win (dec4 88 -> 79 us, d2 at 2N 87 -> 79, d3 at 2N 275 -> 265 forward / 265 -> 272 data gradient): the wide tile stays reachable
     // through PATCHGAN_BF16X_TILE=0 only.
+    // The 256 x 128 tile on EIGHT waves (tile 3, PATCHGAN_BF16X_TILE=3: 64 x 64 per wave like the 128 x 128 tile, two workgroups per CU,
+    // 0.375 DMA pieces per MFMA instead of 0.5) wins the back-to-back layer benchmark wherever it fills the chip without a K split
+    // (d3 at 2N 258 -> 239 us, dec4 77 -> 71) but LOSES inside the training step, where its operands come from HBM rather than from
+    // a warm L2 (cfg4 bf16 step 6.28 -> 6.50 ms with it on every such layer): not selected.
     (void)blocks;
-    if (forced >= 0 && forced <= 2) p.tile = forced;
+    if (forced >= 0 && forced <= 3 && !(forced == 3 && (Cout <= 64 || ring > 0))) p.tile = forced;
     else if (Cout <= 64) p.tile = 2;
     else p.tile = 1;
     p.bm = (p.tile == 1) ? 128 : 256;
@@ -732,9 +737,9 @@ int pg_bf16x_stats_chunks(int dir, const pg_bf16x_plan* p, int N, int Hb, int Wb
 }
 
 const char* pg_bf16x_kernel_name(int dir, int tile, int ring) {
-    static const char* const tiles[3] = {"4,2,2,2", "2,2,2,2", "2,2,4,1"};
+    static const char* const tiles[4] = {"4,2,2,2", "2,2,2,2", "2,2,4,1", "2,2,4,2"};
     static thread_local char buf[64];
-    snprintf(buf, sizeof buf, "k_conv_bf16x<%s,%d,%d>", tiles[tile < 0 || tile > 2 ? 0 : tile], dir, (ring && dir < 2) ? 32 : 64);
+    snprintf(buf, sizeof buf, "k_conv_bf16x<%s,%d,%d>", tiles[tile < 0 || tile > 3 ? 0 : tile], dir, (ring && dir < 2) ? 32 : 64);
     return buf;
 }
 
@@ -787,8 +792,8 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
     static const bool occ2 = pg_exp_env("PATCHGAN_BF16X_OCC2") != nullptr;      // A/B: the 64-accumulator tiles at two workgroups per CU
 #define PG_BF16X_K(MR, NR, WM, WN, D, KB, MUL, ST, BT)                                                                          \
     do {                                                                                                                       \
-        if (occ2) hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB, MUL, ST, BT, 2>), grid, dim3(256), 0, st, PG_BF16X_ARGS); \
-        else hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB, MUL, ST, BT>), grid, dim3(256), 0, st, PG_BF16X_ARGS);     \
+        if (occ2) hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB, MUL, ST, BT, 2>), grid, dim3(WM * WN * 64), 0, st, PG_BF16X_ARGS); \
+        else hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB, MUL, ST, BT>), grid, dim3(WM * WN * 64), 0, st, PG_BF16X_ARGS);     \
     } while (0)
 #define PG_BF16X_LAUNCH(MR, NR, WM, WN)                                                                                      \
     do {                                                                                                                     \
@@ -809,6 +814,7 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
     switch (p->tile) {
         case 0: PG_BF16X_LAUNCH(4, 2, 2, 2); break;
         case 1: PG_BF16X_LAUNCH(2, 2, 2, 2); break;
+        case 3: PG_BF16X_LAUNCH(2, 2, 4, 2); break;        // 256 x 128 on eight waves
         default: PG_BF16X_LAUNCH(2, 2, 4, 1); break;
     }
 #undef PG_BF16X_LAUNCH

@@ -29,6 +29,7 @@ def _bench(extra_args, extra_env, timeout=900, extras=False, cpu=False):
 def test_bench_single_gpu_line():
     out = _bench([], {})
     assert out['n_gpus'] == 1 and out['unit'] == 'images/sec' and out['value'] > 100
+    assert out['step_launch'].startswith('hipGraph') and out['host_enqueue_ms_per_step'] < 1.0 and out['roofline']['launches_timed'] >= 8
     r = out['roofline']
     assert r['bound'] == 'mfma' and 0.05 < r['frac'] < 1.0 and r['kernel'].startswith('k_')
     assert 'comm' not in out
@@ -67,8 +68,9 @@ def test_bench_rccl_path_one_rank():
     """backend "nccl" (= RCCL) really executes: a one-rank process group with the data-parallel path forced on runs every
     collective of the step (bucketed gradient all-reduces on the comm stream, loss terms, the deferred discriminator update)
     through RCCL and must reproduce the single-process losses."""
-    plain = _bench([], {})
+    plain = _bench(['--no-graph'], {})      # launch by launch like the data-parallel path: the same number of steps before the last timed one
     out = _bench([], {'PATCHGAN_DP_FORCE': '1', 'MASTER_PORT': '29631'})
+    assert plain['step_launch'] == out['step_launch'] == 'launch by launch'
     assert out['comm']['backend'] == 'nccl' and out['comm']['ranks_in_group'] == 1
     assert out['comm']['collectives_per_step'] >= 7            # 6 x 32 MiB G buckets + D gradient + loss terms
     assert out['comm']['allreduce_MB_per_step'] > 170          # 167 MB + 11 MB of gradients
