@@ -1074,8 +1074,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // Multi-batch variant: a workgroup owns one (m, n) tile position and runs `zb` consecutive batches z through ONE flattened (z, chunk) loop: the
 // loads of the next batch's first chunk are in flight during the last MFMAs of the current one and the tile stores are
 // fire-and-forget, so the short K loops of these layers (4..32 chunks) do not pay a prologue and an epilogue each.
-template <int MR, int NR, int WM, int WN>
-__global__ __launch_bounds__(256) void k_wino_bgemm_mz(const float* __restrict__ A, const float* __restrict__ B,
+// Two waves per SIMD: without the attribute hipcc took 196 VGPRs + 64 AGPRs = one wave per SIMD (one workgroup per CU, nothing to overlap
+// its barriers with); at two the same 196 registers fit twice (cfg2 step 9.07 -> 8.93 ms on one box); at three / four the kernel spills
+// (116 / 260 bytes of scratch: 9.29 / 9.21 ms).
+template <int MR, int NR, int WM, int WN, int WPE = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_bgemm_mz(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, int Mrows, int Ncols, int K, int zb, int a_bytes,
                                                        int b_bytes, int tiles_m, int tiles_n) {
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32, AI = BM / 32, BI = BN / 32;
@@ -1831,13 +1834,16 @@ int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ELAUNCH;
 }
 
-// batches per workgroup of k_wino_bgemm_mz (1 -> the single-batch kernel; PATCHGAN_BGEMM_MZ=0 forces that): the largest divisor of X that still leaves >= 768 workgroups (3 per CU)
+// batches per workgroup of k_wino_bgemm_mz (1 -> the single-batch kernel): the largest divisor of X that still leaves >= 768 workgroups.
+// OFF by default since round 4 (PATCHGAN_BGEMM_MZ=1 enables it): measured in the cfg2 step on one box, the multi-batch kernel as hipcc
+// built it until then (196 VGPRs + 64 AGPRs: ONE wave per SIMD) 9.07 ms, the same kernel held to two waves per SIMD 8.95, the single-batch
+// kernel (126 registers, four waves per SIMD, four workgroups per CU covering each other's prologues) 8.90.
 static int bgemm_zb(long tiles_mn, int X) {
-    static const bool off = [] {
+    static const bool on = [] {
         const char* e = pg_exp_env("PATCHGAN_BGEMM_MZ");
-        return e && e[0] == '0';
+        return e && e[0] == '1';
     }();
-    if (off) return 1;
+    if (!on) return 1;
     int zb = 1;
     for (int d = 2; d <= X; ++d)
         if (X % d == 0 && tiles_mn * (X / d) >= 768) zb = d;
