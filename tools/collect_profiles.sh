@@ -12,9 +12,11 @@ EXTRA="$@"          # extra bench.py arguments, e.g. --config cfg4 --dtype bf16
 R=$PWD
 export TMPDIR=/tmp
 cd /tmp
-ARGS="$R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra --events none $EXTRA"
+# the kernel trace is of the DRIVER's command shape (20 timed steps behind 5 warm-up ones, hipGraph replays, the eager sampling steps after them)
+ARGS="$R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra $EXTRA"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/stats -o s --output-format csv -- python3 $ARGS > $R/gpurun_out/$TAG.stats_bench.json 2>/dev/null
-ARGS="$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --events none $EXTRA"
+# counters: launch by launch (a counter pass serialises the kernels anyway), two steps
+ARGS="$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --events none --no-graph $EXTRA"
 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/$TAG/fetch -o f --output-format csv -- python3 $ARGS > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/$TAG/write -o w --output-format csv -- python3 $ARGS > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/$TAG/mfma -o m --output-format csv -- python3 $ARGS > /dev/null 2>&1
