@@ -192,6 +192,7 @@ def e2e_training(dev, batches=48, files=192):
             D = pg.Discriminator(4, cfg['ndf'], n_layers=cfg['n_layers']).to(dev)
             tr = pg.Trainer(G, D, os.path.join(folder, 'ckpt_' + fmt))
             tr.loss_type, tr.seg_alpha = cfg['loss_type'], 200
+            tr.graph = tr.gc_freeze = True          # as the patchgan_train entry point sets them
             if fmt != 'float':
                 tr.label_values = [1]
             ds = COCOStuffDataset(os.path.join(folder, 'img'), os.path.join(folder, 'mask'), labels=[1], size=cfg['size'],

@@ -71,3 +71,41 @@ def test_the_scan_recognises_the_failing_form():
     assert not list(packed_f32_reads_of_fresh_lds_pairs(ok))
     natural = bad[:3] + ['\tv_pk_mul_f32 v[0:1], v[12:13], v[92:93] op_sel_hi:[1,0]']       # high half from the even register: never seen to fail
     assert not list(packed_f32_reads_of_fresh_lds_pairs(natural))
+
+
+@pytest.mark.skipif(not os.path.exists(SO), reason='library not built')
+def test_hot_kernels_keep_the_occupancy_they_were_tuned_at():
+    """Round 4's two speed-ups were occupancy accidents, not algorithms: the bf16 LDS-DMA tiles with 64 accumulators ran two workgroups
+    per CU where four fit (cfg4 bf16 step 6.94 -> 6.35 ms), and hipcc had built the multi-batch fp32 Winograd GEMM at 196 VGPRs + 64
+    AGPRs = ONE wave per SIMD (cfg2 step 9.07 -> 8.90 ms with the four-wave kernel).  Waves per SIMD = min(8, 512 // allocated
+    registers) with an allocation granule of 8 (MI355X_MICROARCH.md, register files); a change that pushes one of these kernels over its
+    budget costs that much again, silently."""
+    ks = kernels(SO)
+
+    def waves(k):
+        regs = k['.vgpr_count'] + k.get('.agpr_count', 0)
+        return min(8, 512 // (((regs + 7) // 8) * 8))
+
+    want = {  # substring of the mangled name -> minimum waves per SIMD by registers
+        'k_wino_bgemmILi2ELi2ELi2ELi2E': 4, 'k_wino_bgemmILi1ELi2ELi2ELi2E': 4, 'k_wino_wgrad_gemmILi1ELi1ELi2ELi2E': 4,
+        'k_wino_wgrad_gemmILi2ELi2ELi2ELi2E': 4, 'k_wino_gemm_rowILi4ELi1E': 4, 'k_wgrad_fastILi2ELi2ELi2ELi2E': 4,
+        'k_b2s_fastILi2ELi2ELi2ELi2E': 3, 'k_s2b_fastILi2ELi2ELi2ELi2E': 3,
+    }
+    seen = {w: 0 for w in want}
+    seen['bf16 OCC4'] = 0
+    bad = {}
+    for n, k in ks.items():
+        for w, need in want.items():
+            if w in n:
+                seen[w] += 1
+                if waves(k) < need or k['.private_segment_fixed_size'] > 64:
+                    bad[n] = (waves(k), need, k['.private_segment_fixed_size'])
+        # the 64-accumulator bf16 tiles at OCC 4 (trailing template argument 4): <= 128 registers, no scratch, LDS for four per CU
+        if ('k_conv_bf16x' in n or 'k_wgrad_bf16x' in n) and 'ELi4EEEv' in n:
+            wgs = 16 // (k['.max_flat_workgroup_size'] // 64)          # workgroups per CU at four waves per SIMD (four- or eight-wave tiles)
+            if waves(k) < 4 or k['.private_segment_fixed_size'] > 0 or wgs * k['.group_segment_fixed_size'] > 160 * 1024:
+                bad[n] = (waves(k), 4, k['.private_segment_fixed_size'], k['.group_segment_fixed_size'])
+            seen['bf16 OCC4'] = seen.get('bf16 OCC4', 0) + 1
+    assert all(v > 0 for v in seen.values()), seen
+    assert seen['bf16 OCC4'] >= 10, seen
+    assert not bad, bad
