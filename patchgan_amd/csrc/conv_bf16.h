@@ -17,6 +17,7 @@ struct pg_bf16x_plan {
     int nchunks;           // 64-wide K chunks: taps * Cin / 64
     int split, cps;        // split-K slices and chunks per slice (after pg_bf16x_clamp)
     int ring;              // 1: the three-stage ring kernel (32-wide chunks), 0: one buffer of 64-wide chunks
+    int win;               // 1: the window-staged stride-2 kernel k_conv_bf16r (dir 0 / 1, tile 1 or 2, maps in whole R x 16 rectangles)
     long out_elems;        // elements of one fp32 slab
 };
 

@@ -424,6 +424,294 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(OC
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Window-staged form of the stride-2 layers (round 4): pixels through an LDS window, weights straight into registers.
+// What bounds the kernel above inside the training step is not its MFMA rate and not its bytes (a first form of this kernel that only
+// staged the A side once per four taps moved 35 % fewer bytes in the same time) but the per-tap cycle itself -- DMA, wait for it to
+// land (~1-2 us from HBM / the Infinity Cache under load), barrier, 16 MFMAs, barrier -- whose waits only the OTHER workgroups of the CU
+// cover.  Here:
+//   * a workgroup owns an R x 16 rectangle of output (class) pixels.  The four taps of a parity class (dir 1), or of one
+//     input-parity group (dir 0: taps (2 dh + ph, 2 dw + pw) read big pixels (2 (i + dh) - 1 + ph, 2 (j + dw) - 1 + pw): the same
+//     2 x 2-tap pattern on the (ph, pw) sub-image), read ONE (R + 1) x 17 window of pixels shifted by a pixel: it is staged once per
+//     64-channel chunk by LDS-DMA (19.6 KB instead of 4 x 16 KB) into one of TWO buffers -- the next chunk's window lands while this
+//     one is multiplied -- and the taps read their fragments from it at tap-shifted row addresses;
+//   * the weight fragments never touch LDS: a lane's MFMA operand is 8 consecutive K values of one output channel = 16 contiguous bytes
+//     of the packed weights W[tap][n][k], loaded with one buffer_load_dwordx4 per fragment a whole tap ahead (two register sets);
+//   * so a macro chunk (4 taps, 64 MFMAs per wave) costs ONE barrier and no exposed wait in steady state, against 8 barriers and 4
+//     exposed waits above.
+// DRC 0: big -> small; DRC 1: small -> big, class = blockIdx.z % 4; both take weights with K contiguous per output channel (dir 1: the
+// per-tap transposed pack, pg_bf16x_pack dir 1).
+template <int MR, int NR, int WM, int WN, int DRC, bool MUL = false, bool STATS = false, int OCC = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_conv_bf16r(
+    const __bf16* __restrict__ in, int ld_in, const __bf16* __restrict__ W, void* __restrict__ out, int ld_out, long slab_stride, XGeom g,
+    int cps, const float* __restrict__ bias, int act, int in_bytes, int w_bytes, int out_bf, int tiles_n, pg_epi_mul mul, double* __restrict__ part,
+    int chunks) {
+    static_assert(WM * WN == 4 && (DRC == 0 || DRC == 1), "four waves; stride-2 conv pair");
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32, R = BM / 16;          // tile = R rows x 16 columns of (class) pixels
+    constexpr int WC = 17, NWR = (R + 1) * WC;                                 // window: (R + 1) x 17 pixels, one 128-byte LDS row each
+    constexpr int WP = (NWR + 31) / 32;                                        // window DMA pieces per wave (8 rows per piece)
+    constexpr int WBYTES = WP * 4 * 1024;
+    constexpr int STATB = STATS ? (4 * 64 * 33 + 4 * 64) * 4 : 0;
+    constexpr int SMEM = 2 * WBYTES;
+    __shared__ __attribute__((aligned(1024))) char smem[SMEM > STATB ? SMEM : STATB];
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, w_bytes, 0x00020000);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    const int ncls = (DRC == 1) ? 4 : 1;
+    const int cls = blockIdx.z % ncls, slice = blockIdx.z / ncls;
+    const int ah = (DRC == 1) ? (cls >> 1) : 0, aw = (DRC == 1) ? (cls & 1) : 0;
+    const int Hc = (DRC == 0) ? g.Hs : g.Hb / 2, Wc = (DRC == 0) ? g.Ws : g.Wb / 2;      // host: Hc % R == 0, Wc % 16 == 0
+    const int Cin = (DRC == 0) ? g.Cb : g.Ca, Cout = (DRC == 0) ? g.Ca : g.Cb;
+    const int Hin = (DRC == 0) ? g.Hb : g.Hs, Win = (DRC == 0) ? g.Wb : g.Ws;
+    const int tiles_c = Wc / 16, tiles_r = Hc / R;
+
+    const int wk = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = wk / tiles_n, tn = wk - tm * tiles_n;
+    const int n0 = tn * BN;
+    const int nsmp = tm / (tiles_r * tiles_c), trc = tm - nsmp * (tiles_r * tiles_c);
+    const int r0 = (trc / tiles_c) * R, c0 = (trc % tiles_c) * 16;
+    // K: macro chunks = (group, 64-channel chunk) with 4 taps each; cps counts 64-wide (tap, chunk) units and is a multiple of 4
+    const int cch = Cin / 64, ngrp = (DRC == 0) ? 4 : 1;
+    const int nmac = ngrp * cch;
+    const int m_begin = slice * (cps >> 2), m_end = min(nmac, m_begin + (cps >> 2));
+
+    // ---- window DMA: piece i of this wave covers window rows (wave * WP + i) * 8 .. + 7; lane -> (row, 16-byte slot)
+    int w_y[WP], w_x[WP], w_cc[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int w = (wave * WP + i) * 8 + (lane >> 3);
+        const int wr = w / WC, wc = w - wr * WC;
+        // slot s of window row (wr, wc) holds the logical 8-channel group s ^ (wc & 7): with the 17-row pitch this keeps the tap-shifted
+        // fragment reads (16 consecutive columns of row r in lanes 0-15, of row r + 1 in lanes 16-31) conflict-free for ds_read_b128's
+        // lane groups (the flat kernel's (row >> 1) & 7 would be 2-way conflicted on EVERY read here: checked by enumeration)
+        w_cc[i] = ((lane & 7) ^ (wc & 7)) * 8;
+        w_y[i] = (w < NWR) ? wr : -0x10000;                        // beyond the window: never valid
+        w_x[i] = wc;
+    }
+    // ---- weight fragments: the FRAGMENT-ORDERED pack (pg_bf16x_pack dir 4 / 5) W[tap][n tile of 32][64-channel chunk][k-step][lane][8]:
+    //      the 64 lanes' operands of one MFMA are 1 KiB contiguous -- one fully coalesced buffer_load_dwordx4 per fragment (rows of a
+    //      [n][k] pack would be a 64-line gather per instruction: tried, 1 ms slower per cfg4 step)
+    const int NT = (Cout + 31) / 32;
+    int b_row[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int nt = n0 / 32 + wn * NR + j;
+        b_row[j] = (nt < NT) ? (nt * cch * 4 * 64 + lane) * 16 : (int)0x80000000u;
+    }
+    char* const w_dst = smem + wave * WP * 1024;
+
+    // ---- fragment rows: MFMA tile i of this wave = tile rows (wm * MR + i) * 32 + lrow -> (rr, cc) -> window row rr * 17 + cc (+ tap shift)
+    int wbase[MR], wcol[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int ml = (wm * MR + i) * 32 + lrow;
+        wbase[i] = (ml >> 4) * WC + (ml & 15);
+        wcol[i] = ml & 15;
+    }
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int ST = (DRC == 0) ? 2 : 1;
+    const int nsteps = 4 * (m_end - m_begin);
+    auto issue_window = [&](int mi) {                              // window of macro chunk m_begin + mi into buffer mi & 1 (beyond the end: zeros)
+        const int mc = m_begin + mi;
+        const int grp = (DRC == 0) ? mc / cch : 0, cin0 = (mc - grp * cch) * 64;
+        const int ph = grp >> 1, pw = grp & 1;
+        const int oy = (DRC == 0) ? 2 * (r0 - 1 + ph) + 1 - ph : r0 + ah - 1;     // window origin in the source tensor's coordinates
+        const int ox = (DRC == 0) ? 2 * (c0 - 1 + pw) + 1 - pw : c0 + aw - 1;
+        const bool live = mc < m_end;
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            const int y = oy + ST * w_y[i], x = ox + ST * w_x[i];
+            const bool ok = live && (unsigned)y < (unsigned)Hin && (unsigned)x < (unsigned)Win;
+            const int off = (((nsmp * Hin + y) * Win + x) * ld_in + cin0 + w_cc[i]) * 2;
+            dma16(rin, w_dst + (mi & 1) * WBYTES + i * 1024, ok ? off : (int)0x80000000u);
+        }
+    };
+    bf16x8 breg[4][NR][4];                                         // one register set per tap position: [tap][column tile][k-step]
+    auto load_b = [&](int s, bf16x8 (&dst)[NR][4]) {               // step s = (macro chunk, tap); beyond the end: zeros (keeps the vmcnt counts)
+        const int mc = m_begin + (s >> 2), t = s & 3;
+        const int grp = (DRC == 0) ? mc / cch : 0, cin0 = (mc - grp * cch) * 64;
+        const int ph = grp >> 1, pw = grp & 1;
+        const int kh = (DRC == 0) ? 2 * (t >> 1) + ph : (1 - ah) + 2 * (t >> 1);
+        const int kw = (DRC == 0) ? 2 * (t & 1) + pw : (1 - aw) + 2 * (t & 1);
+        const unsigned kill = (s < nsteps) ? 0u : 0x80000000u;
+        const int w_uni = (((kh * 4 + kw) * NT * cch + (cin0 >> 6)) * 4 * 64) * 16;     // (tap, ., chunk, k-step 0) of the fragment-ordered pack
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)((unsigned)(b_row[j] + w_uni + ks * 1024) | kill), 0, 0));
+                dst[j][ks] = __builtin_bit_cast(bf16x8, v);
+            }
+    };
+    auto multiply = [&](int s, const bf16x8 (&bsrc)[NR][4]) {
+        const int t = s & 3;
+        const int e_r = (DRC == 0) ? (t >> 1) : 1 - (t >> 1), e_c = (DRC == 0) ? (t & 1) : 1 - (t & 1);
+        const int wsh = e_r * WC + e_c;
+        const char* const win = smem + ((s >> 2) & 1) * WBYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[MR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                const int w = wbase[i] + wsh;
+                af[i] = *reinterpret_cast<const bf16x8*>(win + w * 128 + (((ks * 2 + lh) ^ ((wcol[i] + e_c) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bsrc[j][ks], af[i], acc[i][j], 0, 0, 0);   // D[channel][pixel]
+        }
+    };
+    // Schedule (loads and LDS-DMA pieces complete in issue order; NB = the NR * 4 fragment loads of one tap).  The fragments of step s
+    // live in register set s & 3 and are requested THREE taps ahead (a tap is 16 MFMAs: one tap of distance left the MFMAs waiting on
+    // L2); the next chunk's window is requested at tap 0.  Before the MFMAs of tap t the newest requests still allowed in flight:
+    //   chunk start: fragments(s0 + 1), (s0 + 2)                                       -> <= 2 NB   (window(mi), fragments(s0) are in)
+    //   t = 0: request fragments(s0 + 3), window(mi + 1)
+    //   t >= 1: request fragments(s0 + t + 3); fragments(s0 + t) are in once <= 3 NB + WP remain
+    constexpr int NB = NR * 4;
+    if (nsteps > 0) {
+        issue_window(0);
+        load_b(0, breg[0]);
+        load_b(1, breg[1]);
+        load_b(2, breg[2]);
+    }
+#pragma unroll 1
+    for (int mi = 0; 4 * mi < nsteps; ++mi) {
+        const int s0 = 4 * mi;
+        wait_vmcnt<2 * NB>();
+        __builtin_amdgcn_s_barrier();                              // this chunk's window is complete; everyone is done with the other buffer
+        load_b(s0 + 3, breg[3]);
+        issue_window(mi + 1);
+        multiply(s0, breg[0]);
+        load_b(s0 + 4, breg[0]);
+        wait_vmcnt<3 * NB + WP>();
+        multiply(s0 + 1, breg[1]);
+        load_b(s0 + 5, breg[1]);
+        wait_vmcnt<3 * NB + WP>();
+        multiply(s0 + 2, breg[2]);
+        load_b(s0 + 6, breg[2]);
+        wait_vmcnt<3 * NB + WP>();
+        multiply(s0 + 3, breg[3]);
+    }
+    wait_vmcnt<0>();                                               // the killed tail loads / pieces drain before the kernel ends
+    __syncthreads();
+
+    // ---- epilogue (as k_conv_bf16x): lane = pixel lrow of tile i; register r = channel (r & 3) + 8 * (r >> 2) + 4 * lh of tile j
+    const bool fin = (slab_stride == 0);
+    const int ldo = fin ? ld_out : Cout;
+    char* const obase = (char*)out + (fin ? 0L : (long)slice * slab_stride * 4);
+    const bool obf = fin && out_bf;
+    long opix[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int ml = (wm * MR + i) * 32 + lrow;
+        const int ii = r0 + (ml >> 4), jj = c0 + (ml & 15);
+        opix[i] = (DRC == 0) ? (long)((nsmp * g.Hs + ii) * g.Ws + jj) : (long)((nsmp * g.Hb + 2 * ii + ah) * g.Wb + 2 * jj + aw);
+    }
+    if constexpr (STATS) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int nb = n0 + (wn * NR + j) * 32;
+        float s1[STATS ? 16 : 1], s2[STATS ? 16 : 1];
+        if constexpr (STATS) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s1[k] = s2[k] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+            const long orow = opix[i] * ldo;
+            f32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = nb + 8 * q + 4 * lh;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (fin && bias != nullptr && ch < Cout) bv = *reinterpret_cast<const f32x4*>(bias + ch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = acc[i][j][4 * q + e];
+                    v[q][e] = fin ? act_epi(x + bv[e], act) : x;
+                }
+                if constexpr (MUL) {
+                    const long tidx = opix[i] * mul.ld + min(ch, Cout - 4);
+                    f32x4 tv;
+                    if (obf) {
+                        const u32x2 h = *reinterpret_cast<const u32x2*>((const char*)mul.t + tidx * 2);
+                        tv = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
+                                   __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
+                    } else {
+                        tv = *reinterpret_cast<const f32x4*>((const char*)mul.t + tidx * 4);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[q][e] *= pg_act_grad_sel(tv[e], mul.act);
+                }
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r = (float)(__bf16)v[q][e];
+                        s1[4 * q + e] += r;
+                        s2[4 * q + e] += r * r;
+                    }
+                }
+            }
+            if (obf) {
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    const u32x2 lo = __builtin_amdgcn_permlane32_swap(pack2(v[q][0], v[q][1]), pack2(v[q + 1][0], v[q + 1][1]), false, false);
+                    const u32x2 hi = __builtin_amdgcn_permlane32_swap(pack2(v[q][2], v[q][3]), pack2(v[q + 1][2], v[q + 1][3]), false, false);
+                    const int ch = nb + 8 * (q + lh);
+                    const u32x4 o4 = {lo[0], hi[0], lo[1], hi[1]};
+                    if (ch < Cout) *reinterpret_cast<u32x4*>(obase + (orow + ch) * 2) = o4;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = nb + 8 * q + 4 * lh;
+                    if (ch < Cout) *reinterpret_cast<f32x4*>(obase + (orow + ch) * 4) = v[q];
+                }
+            }
+        }
+        if constexpr (STATS) {
+            float* const tr = reinterpret_cast<float*>(smem) + wave * 64 * 33;
+            float* const res = reinterpret_cast<float*>(smem) + 4 * 64 * 33 + wave * 64;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                tr[lane * 33 + k] = s1[k];
+                tr[lane * 33 + 16 + k] = s2[k];
+            }
+            __syncthreads();
+            float t = 0.f;
+#pragma unroll
+            for (int l = 0; l < 32; ++l) t += tr[(lh * 32 + l) * 33 + lrow];
+            res[lane] = t;
+            __syncthreads();
+            if (wm == 0) {
+                float tot = t;
+#pragma unroll
+                for (int w2 = 1; w2 < WM; ++w2) tot += reinterpret_cast<const float*>(smem)[4 * 64 * 33 + (w2 * WN + wn) * 64 + lane];
+                const int which = lrow >> 4, k = lrow & 15;
+                const int ch = nb + 8 * (k >> 2) + 4 * lh + (k & 3);
+                const int chunk = cls * (tiles_r * tiles_c) + trc;     // this tile's slot among the sample's `chunks` partial sums
+                if (ch < Cout) part[(((long)nsmp * chunks + chunk) * Cout + ch) * 2 + which] = (double)tot;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Weight gradient on bf16 tensors:  dP[tap][a][b] = sum_m small[m][a] * big[pix(m, tap)][b]  -- per tap a GEMM whose K index is
 // the pixel m, the STRIDED index of both operands (channels are the contiguous one).  The tiles therefore sit in LDS as
 // [pixel][channel] rows exactly as they lie in HBM (LDS-DMA, 16 B per lane, zero padding by the descriptor's range check) and the
@@ -637,6 +925,34 @@ __global__ __launch_bounds__(256) void k_pack_w8_bf16(const float* __restrict__ 
     pack_w8_body(P, W, Ca, Cb, blockIdx.x, gridDim.x);
 }
 
+// P[tap][a][b] -> the fragment-ordered pack of k_conv_bf16r: W[tap][n tile][64-k chunk][k-step][lane][8], element (n = 32 nt + (lane & 31),
+// k = 64 kc + 16 ks + 8 (lane >> 5) + e).  swap = 0: n = a, k = b (big -> small); swap = 1: n = b, k = a (small -> big).  One thread per
+// fragment; channels beyond the count are zero.
+__device__ __forceinline__ void pack_frag_body(const float* __restrict__ P, __bf16* __restrict__ W, int Ca, int Cb, int swap, int blk, int nblk) {
+    const int Cn = swap ? Cb : Ca, Ck = swap ? Ca : Cb;
+    const int NT = (Cn + 31) / 32, KC = Ck / 64;
+    const long total = 16L * NT * KC * 4 * 64;
+    for (long i = blk * 256L + threadIdx.x; i < total; i += (long)nblk * 256) {
+        const int lane = (int)(i & 63);
+        long r = i >> 6;
+        const int ks = (int)(r & 3);
+        r >>= 2;
+        const int kc = (int)(r % KC);
+        r /= KC;
+        const int nt = (int)(r % NT), tap = (int)(r / NT);
+        const int n = nt * 32 + (lane & 31), k0 = kc * 64 + ks * 16 + (lane >> 5) * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = (n < Cn) ? (swap ? P[((long)tap * Ca + k0 + e) * Cb + n] : P[((long)tap * Ca + n) * Cb + k0 + e]) : 0.f;
+        const u32x4 o = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        *reinterpret_cast<u32x4*>(W + i * 8) = o;
+    }
+}
+__global__ __launch_bounds__(256) void k_pack_frag_bf16(const float* __restrict__ P, __bf16* __restrict__ W, int Ca, int Cb, int swap) {
+    pack_frag_body(P, W, Ca, Cb, swap, blockIdx.x, gridDim.x);
+}
+
 // The packs of several layers in ONE launch (pg_bf16x_pack_batch): item i owns the blocks [block0_i, block0_{i+1})
 struct PackItem {
     const float* P;
@@ -655,6 +971,8 @@ __global__ __launch_bounds__(256) void k_pack_batch(const PackBatch b) {
     const int blk = blockIdx.x - t.block0;
     if (t.dir == 2)
         pack_w8_body(t.P, t.W, t.Ca, t.Cb, blk, t.nblk);
+    else if (t.dir >= 4)
+        pack_frag_body(t.P, t.W, t.Ca, t.Cb, t.dir == 5, blk, t.nblk);
     else
         pack_w_body(t.P, t.W, t.Ca, t.Cb, t.dir != 0, blk, t.nblk, tile);
 }
@@ -681,6 +999,7 @@ bool pg_bf16x_geom_ok(int dir, int N, int Hb, int Wb, int Hs, int Ws, int Ca, in
 
 pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride, int ring) {
     pg_bf16x_plan p;
+    p.win = 0;
     const int Cin = (dir == 0) ? Cb : Ca, Cout = (dir == 0 || dir == 2) ? Ca : Cb;
     p.ncls = (dir == 1 && stride == 2) ? 4 : 1;
     const long Mc = (dir != 1) ? (long)N * Hs * Ws : (p.ncls == 4 ? (long)N * ((Hb + 1) / 2) * ((Wb + 1) / 2) : (long)N * Hb * Wb);
@@ -716,12 +1035,31 @@ pg_bf16x_plan pg_bf16x_plan_of(int dir, int N, int Hb, int Wb, int Hs, int Ws, i
     p.cps = (p.nchunks + p.split - 1) / p.split;
     p.split = (p.nchunks + p.cps - 1) / p.cps;
     p.ring = (ring >= 0 && dir < 2) ? (ring ? 1 : 0) : 0;
+    // window-staged kernel (k_conv_bf16r): stride-2 layers whose (class) maps tile into whole R x 16 rectangles
+    p.win = 0;
+    static const bool nowin = pg_exp_env("PATCHGAN_BF16X_NOWIN") != nullptr;
+    if (!nowin && dir <= 1 && stride == 2 && p.ring == 0 && ring <= 0 && (p.tile == 1 || p.tile == 2) && Cin % 64 == 0 &&
+        !((Hb | Wb) & 1) && Hb == 2 * Hs && Wb == 2 * Ws) {
+        const int R = p.bm / 16;
+        if (Hs % R == 0 && Ws % 16 == 0) p.win = 1;
+    }
+    if (p.win) {            // its K loop runs in units of four taps: whole macro chunks per slice
+        const int nm = p.nchunks / 4, cpm = (nm + p.split - 1) / p.split;
+        p.cps = 4 * cpm;
+        p.split = (nm + cpm - 1) / cpm;
+    }
     return p;
 }
 
 void pg_bf16x_clamp(pg_bf16x_plan* p, size_t avail) {
     const long smax = (long)(avail / (sizeof(float) * (size_t)p->out_elems));
     if (p->split > 1 && smax < p->split) p->split = smax < 2 ? 1 : (int)smax;
+    if (p->win) {
+        const int nm = p->nchunks / 4, cpm = (nm + p->split - 1) / p->split;
+        p->cps = 4 * cpm;
+        p->split = (nm + cpm - 1) / cpm;
+        return;
+    }
     p->cps = (p->nchunks + p->split - 1) / p->split;
     p->split = (p->nchunks + p->cps - 1) / p->cps;
 }
@@ -739,14 +1077,22 @@ int pg_bf16x_stats_chunks(int dir, const pg_bf16x_plan* p, int N, int Hb, int Wb
 const char* pg_bf16x_kernel_name(int dir, int tile, int ring) {
     static const char* const tiles[4] = {"4,2,2,2", "2,2,2,2", "2,2,4,1", "2,2,4,2"};
     static thread_local char buf[64];
-    snprintf(buf, sizeof buf, "k_conv_bf16x<%s,%d,%d>", tiles[tile < 0 || tile > 3 ? 0 : tile], dir, (ring && dir < 2) ? 32 : 64);
+    if (ring == 2) snprintf(buf, sizeof buf, "k_conv_bf16r<%s,%d>", tile == 1 ? "4,1,1,4" : "4,1,2,2", dir);      // window-staged
+    else snprintf(buf, sizeof buf, "k_conv_bf16x<%s,%d,%d>", tiles[tile < 0 || tile > 3 ? 0 : tile], dir, (ring && dir < 2) ? 32 : 64);
     return buf;
 }
 
-size_t pg_bf16x_w_bytes(int Ca, int Cb) { return ((size_t)16 * Ca * std::max(Cb, 8) * 2 + 255) & ~(size_t)255; }
+size_t pg_bf16x_w_bytes(int Ca, int Cb) {       // (channel counts padded to 32: the fragment-ordered pack holds whole 32-channel tiles)
+    return ((size_t)16 * ((Ca + 31) / 32 * 32) * std::max((Cb + 31) / 32 * 32, 8) * 2 + 255) & ~(size_t)255;
+}
 
 // workgroups of one layer's pack (0: this layout / channel count has no pack)
 static int pack_blocks(int Ca, int Cb, int dir) {
+    if (dir == 4 || dir == 5) {        // fragment-ordered (k_conv_bf16r): K = Cb (4) / Ca (5) in whole 64-chunks
+        const int Cn = dir == 5 ? Cb : Ca, Ck = dir == 5 ? Ca : Cb;
+        if (Ck % 64) return 0;
+        return (int)std::min<long>((16L * ((Cn + 31) / 32) * (Ck / 64) * 4 * 64 + 255) / 256, 4096);
+    }
     if (dir == 2) return (int)std::min<long>((16L * Ca + 255) / 256, 2048);        // W8[a][tap][8]: the Cb <= 8 channels of each tap, zero padded
     if (dir == 0) return (Cb & 3) ? 0 : (int)std::min<long>((4L * Ca * Cb + 255) / 256, 2048);
     return (int)std::min<long>(16L * ((Ca + 31) / 32) * ((Cb + 31) / 32), 4096);    // dir 1 and 3: each tap transposed to [b][a]
@@ -755,7 +1101,9 @@ static int pack_blocks(int Ca, int Cb, int dir) {
 int pg_bf16x_pack(const float* P, void* W, int Ca, int Cb, int dir, hipStream_t st) {
     const int blocks = pack_blocks(Ca, Cb, dir);
     if (blocks == 0) return PG_EINVAL;
-    if (dir == 2)
+    if (dir == 4 || dir == 5)
+        hipLaunchKernelGGL(k_pack_frag_bf16, dim3(blocks), dim3(256), 0, st, P, (__bf16*)W, Ca, Cb, dir == 5 ? 1 : 0);
+    else if (dir == 2)
         hipLaunchKernelGGL(k_pack_w8_bf16, dim3(blocks), dim3(256), 0, st, P, (__bf16*)W, Ca, Cb);
     else
         hipLaunchKernelGGL(k_pack_w_bf16, dim3(blocks), dim3(256), 0, st, P, (__bf16*)W, Ca, Cb, dir == 0 ? 0 : 1);
@@ -770,7 +1118,7 @@ int pg_bf16x_pack_batch(int n, const pg_bf16x_pack_item* items, hipStream_t st) 
     long blocks = 0;
     for (int i = 0; i < n; ++i) {
         const pg_bf16x_pack_item& s = items[i];
-        const int nb = (s.P && s.W && s.Ca > 0 && s.Cb > 0 && s.dir >= 0 && s.dir <= 3) ? pack_blocks(s.Ca, s.Cb, s.dir) : 0;
+        const int nb = (s.P && s.W && s.Ca > 0 && s.Cb > 0 && s.dir >= 0 && s.dir <= 5) ? pack_blocks(s.Ca, s.Cb, s.dir) : 0;
         if (nb == 0) return PG_EINVAL;
         b.it[i] = PackItem{s.P, (__bf16*)s.W, s.Ca, s.Cb, s.dir, (int)blocks, nb};
         blocks += nb;
@@ -789,6 +1137,29 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
     const __bf16* I = (const __bf16*)in;
     const __bf16* Wp = (const __bf16*)W;
 #define PG_BF16X_ARGS I, ld_in, Wp, out, ld_out, slab_stride, g, p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul, part, chunks
+    if (p->win) {
+        if ((dir == 1 && bt) || dir > 1 || (p->tile != 1 && p->tile != 2)) return PG_EINVAL;      // (weights: the fragment-ordered pack, dir 4 / 5)
+        const int w_bytes = 16 * (((dir == 0 ? Ca : Cb) + 31) / 32 * 32) * (dir == 0 ? Cb : Ca) * 2;
+#define PG_BF16W_K(MR, NR, WM, WN, D, MUL, ST) \
+    hipLaunchKernelGGL((k_conv_bf16r<MR, NR, WM, WN, D, MUL, ST>), grid, dim3(256), 0, st, PG_BF16X_ARGS)
+#define PG_BF16W_LAUNCH(MR, NR, WM, WN)                                        \
+    do {                                                                       \
+        if (dir == 0 && part) PG_BF16W_K(MR, NR, WM, WN, 0, false, true);      \
+        else if (dir == 0 && !mul.t) PG_BF16W_K(MR, NR, WM, WN, 0, false, false); \
+        else if (dir == 0) return PG_EINVAL;                                   \
+        else if (part) PG_BF16W_K(MR, NR, WM, WN, 1, false, true);             \
+        else if (mul.t) PG_BF16W_K(MR, NR, WM, WN, 1, true, false);            \
+        else PG_BF16W_K(MR, NR, WM, WN, 1, false, false);                      \
+    } while (0)
+        // wave tiling: every wave owns ALL pixel rows of its 32 output channels (128 x 32 / 128 x 32 of a 256 x 64 tile), so that the weight
+        // fragments, which each wave loads for itself, are not loaded twice per workgroup (64 x 64 per wave: the fragment loads alone
+        // would fill the 64 B / clk path into the registers for as long as the MFMAs run)
+        if (p->tile == 1) PG_BF16W_LAUNCH(4, 1, 1, 4);
+        else PG_BF16W_LAUNCH(4, 1, 2, 2);
+#undef PG_BF16W_LAUNCH
+#undef PG_BF16W_K
+        return pg_launch_status();
+    }
     static const bool occ2 = pg_exp_env("PATCHGAN_BF16X_OCC2") != nullptr;      // A/B: the 64-accumulator tiles at two workgroups per CU
 #define PG_BF16X_K(MR, NR, WM, WN, D, KB, MUL, ST, BT)                                                                          \
     do {                                                                                                                       \
@@ -835,6 +1206,7 @@ bool pg_bf16x_wgrad_geom_ok(int N, int Hb, int Wb, int Hs, int Ws, int Ca, int C
 pg_bf16x_plan pg_bf16x_wgrad_plan(int N, int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int stride) {
     (void)Hb; (void)Wb; (void)stride;
     pg_bf16x_plan p;
+    p.win = 0;
     static const int forced = pg_exp_env("PATCHGAN_BF16X_WTILE") ? atoi(pg_exp_env("PATCHGAN_BF16X_WTILE")) : -1;
     // tiles (a x b): 0: 256 x 128, 1: 128 x 128, 2: 256 x 64, 3: 128 x 64
     if (Cb <= 8) {                     // taps in N: tiles 4 / 5 = 64 / 128 a-channels x (16 taps x 8)

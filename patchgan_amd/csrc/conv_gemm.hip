@@ -3572,12 +3572,14 @@ int bf16x_run(int dir, const void* in, int ld_in, const float* P, const float* b
     // small -> big reads the SAME packed copy as big -> small (transposed staging in the kernel): one pack per layer serves both
     // (not the ring-staged variant, PG_TUNE_BF16X_RING: it keeps the per-tap transposed pack; callers that share one cache entry
     // between the two directions of a layer must not set that bit -- engine._ucache checks it)
-    const int bt = (dir == 1 && !(ring > 0)) ? 1 : 0;
+    pg_bf16x_plan p = pg_bf16x_plan_of(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, ring);
+    // (the window-staged kernel reads weight fragments straight from global memory: K contiguous per output channel = the per-tap
+    //  transposed pack for small -> big; pg_conv_prep_batch and pg_bf16x_own_pack() follow the same rule)
+    const int bt = (dir == 1 && !(ring > 0) && !p.win) ? 1 : 0;
     if (!(x.u_cache && x.u_valid)) {
-        int rc = pg_bf16x_pack(P, W, g.Ca, g.Cb, bt ? 0 : dir, st);
+        int rc = pg_bf16x_pack(P, W, g.Ca, g.Cb, p.win ? 4 + dir : bt ? 0 : dir, st);
         if (rc != PG_OK) return rc;
     }
-    pg_bf16x_plan p = pg_bf16x_plan_of(dir, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, ring);
     pg_bf16x_clamp(&p, avail);
     const int chunks = x.part ? pg_bf16x_stats_chunks(dir, &p, g.N, g.Hb, g.Wb, g.Hs, g.Ws) : 0;
     if (x.part && (!chunks || !out_bf)) return PG_EINVAL;
@@ -3715,7 +3717,7 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         const int xdir = (op == 0 && gq.Cb <= 8) ? 2 : op;
         pg_bf16x_plan bp = pg_bf16x_plan_of(xdir, gq.N, gq.Hb, gq.Wb, gq.Hs, gq.Ws, gq.Ca, gq.Cb, gq.s, tune.bf16ring);
         pg_bf16x_clamp(&bp, ws_bytes - pg_bf16x_w_bytes(g->Ca, g->Cb));
-        if (tile_id) *tile_id = (xdir == 2) ? 1040 + bp.tile : 1000 + 100 * bp.ring + 10 * op + bp.tile;
+        if (tile_id) *tile_id = (xdir == 2) ? 1040 + bp.tile : 1000 + 100 * (bp.win ? 2 : bp.ring) + 10 * op + bp.tile;   // (1200 + ..: k_conv_bf16r)
         if (split) *split = bp.split;
         if (workgroups) *workgroups = (long)bp.tiles_m * bp.tiles_n * bp.ncls * bp.split;
         return PG_OK;
@@ -4347,7 +4349,8 @@ int pg_conv_prep_batch(int n, const pg_conv_prep_item* items, void* stream) {
         } else if (bf16x_ok(g, op, it.algo, tune)) {
             // big -> small: [tap][a][b] (8-channel-pixel form for a few-channel big); small -> big: the same pack (transposed staging in
             // the kernel) unless the ring-staged variant is pinned (bf16x_run)
-            const int dir = (op == 0) ? (g.Cb <= 8 ? 2 : 0) : (tune.bf16ring > 0 ? 1 : 0);
+            const bool own = g.Cb > 8 && pg_bf16x_plan_of(op, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, g.s, tune.bf16ring).win;
+            const int dir = own ? 4 + op : (op == 0) ? (g.Cb <= 8 ? 2 : 0) : (tune.bf16ring > 0 ? 1 : 0);
             bv.push_back(pg_bf16x_pack_item{it.P, it.u, g.Ca, g.Cb, dir});
         } else {
             return PG_EINVAL;

@@ -461,7 +461,10 @@ def _ucache(ucache, li, opcode, op, dev, src, dst, p_off=None):
     nb = op.u_bytes(opcode, io)
     if not nb:
         return None, False
-    shared = io == L.IO_MASK and op.Cb > 8 and not (op.algo & L.TUNE_BF16X_RING)
+    # (the window-staged kernel k_conv_bf16r reads weight fragments straight from global memory and takes a fragment-ordered pack of its
+    #  own per direction: its layers keep one entry per direction)
+    shared = (io == L.IO_MASK and op.Cb > 8 and not (op.algo & L.TUNE_BF16X_RING)
+              and not op.describe(0, io)[0].startswith('k_conv_bf16r') and not op.describe(1, io)[0].startswith('k_conv_bf16r'))
     key = (li, 'w', nb) if shared else (li, opcode, nb)         # nb separates the F(2x2,4x4) / F(3x3,4x4) transforms of the stride-1 layer
     if key in ucache:
         return ucache[key], True
