@@ -91,7 +91,7 @@ template <int MR, int NR, int WM, int WN, int DRC, int KB, bool MUL = false, boo
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_conv_bf16x(
     const __bf16* __restrict__ in, int ld_in, const __bf16* __restrict__ W, void* __restrict__ out, int ld_out, long slab_stride, XGeom g,
     int cps, const float* __restrict__ bias, int act, int in_bytes, int w_bytes, int out_bf, int tiles_n, pg_epi_mul mul, double* __restrict__ part,
-    int chunks) {
+    int chunks, int cls_in_x) {
     constexpr int NW = WM * WN;                                    // waves per workgroup: 4, or 8 (the 256 x 128 tile of 64 x 64 per wave:
     static_assert(NW == 4 || NW == 8, "four or eight waves");      //  0.375 DMA pieces per MFMA at four waves per SIMD from two workgroups)
     static_assert(KB == 32 || KB == 64, "chunk width");
@@ -117,7 +117,10 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(OC
     // the first half of the taps-folded-into-N ConvTranspose2d of the few-channel heads (second half: k_col2im_small2big)
     constexpr bool B2S = (DRC == 0 || DRC == 2 || DRC == 3);
     const int ncls = (DRC == 1 && g.s == 2) ? 4 : 1;
-    const int cls = blockIdx.z % ncls, slice = blockIdx.z / ncls;
+    // cls_in_x: the four parity classes of a tile position are neighbours in the work index (same XCD, in flight together), so the
+    // `small` window they all read comes from that XCD's L2 three times out of four instead of from the fabric once per class
+    const int wk0 = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int cls = cls_in_x ? (wk0 & (ncls - 1)) : blockIdx.z % ncls, slice = cls_in_x ? blockIdx.z : blockIdx.z / ncls;
     const int ah = (ncls == 4) ? (cls >> 1) : 0, aw = (ncls == 4) ? (cls & 1) : 0;
     const int T = (DRC == 3) ? 1 : (DRC == 1 && g.s == 2) ? 2 : 4, Tsh = (T == 2) ? 1 : 2;
     const int Hc = B2S ? g.Hs : (g.s == 2 ? (g.Hb - ah + 1) / 2 : g.Hb);
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(OC
     const int kh0 = (DRC == 1 && g.s == 2) ? (1 - ah) : 0, kw0 = (DRC == 1 && g.s == 2) ? (1 - aw) : 0;
     constexpr int TPC = KB / 8;                                    // DRC 2: taps per chunk
 
-    const int wk = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int wk = (cls_in_x && ncls == 4) ? (wk0 >> 2) : wk0;
     const int tm = wk / tiles_n, tn = wk - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     if (m0 >= Mc) return;                                          // a smaller parity class (odd Hb / Wb): whole workgroup
@@ -444,7 +447,7 @@ template <int MR, int NR, int WM, int WN, int DRC, bool MUL = false, bool STATS 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_conv_bf16r(
     const __bf16* __restrict__ in, int ld_in, const __bf16* __restrict__ W, void* __restrict__ out, int ld_out, long slab_stride, XGeom g,
     int cps, const float* __restrict__ bias, int act, int in_bytes, int w_bytes, int out_bf, int tiles_n, pg_epi_mul mul, double* __restrict__ part,
-    int chunks) {
+    int chunks, int cls_in_x) {
     static_assert(WM * WN == 4 && (DRC == 0 || DRC == 1), "four waves; stride-2 conv pair");
     constexpr int BM = WM * MR * 32, BN = WN * NR * 32, R = BM / 16;          // tile = R rows x 16 columns of (class) pixels
     constexpr int WC = 17, NWR = (R + 1) * WC;                                 // window: (R + 1) x 17 pixels, one 128-byte LDS row each
@@ -462,14 +465,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     const int lrow = lane & 31, lh = lane >> 5;
 
     const int ncls = (DRC == 1) ? 4 : 1;
-    const int cls = blockIdx.z % ncls, slice = blockIdx.z / ncls;
+    const int wk0 = pg_xcd_remap(blockIdx.x, gridDim.x);               // (cls_in_x: as in k_conv_bf16x)
+    const int cls = cls_in_x ? (wk0 & (ncls - 1)) : blockIdx.z % ncls, slice = cls_in_x ? blockIdx.z : blockIdx.z / ncls;
     const int ah = (DRC == 1) ? (cls >> 1) : 0, aw = (DRC == 1) ? (cls & 1) : 0;
     const int Hc = (DRC == 0) ? g.Hs : g.Hb / 2, Wc = (DRC == 0) ? g.Ws : g.Wb / 2;      // host: Hc % R == 0, Wc % 16 == 0
     const int Cin = (DRC == 0) ? g.Cb : g.Ca, Cout = (DRC == 0) ? g.Ca : g.Cb;
     const int Hin = (DRC == 0) ? g.Hb : g.Hs, Win = (DRC == 0) ? g.Wb : g.Ws;
     const int tiles_c = Wc / 16, tiles_r = Hc / R;
 
-    const int wk = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int wk = (cls_in_x && ncls == 4) ? (wk0 >> 2) : wk0;
     const int tm = wk / tiles_n, tn = wk - tm * tiles_n;
     const int n0 = tn * BN;
     const int nsmp = tm / (tiles_r * tiles_c), trc = tm - nsmp * (tiles_r * tiles_c);
@@ -1132,11 +1136,13 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
                   int act, int out_bf, hipStream_t st, pg_epi_mul mul, double* part, int chunks, int bt) {
     if (part && (mul.t || dir > 1 || p->split != 1 || !out_bf || slab_stride != 0)) return PG_EINVAL;
     const XGeom g{N, Hb, Wb, Hs, Ws, Ca, Cb, stride};
-    const dim3 grid((unsigned)(p->tiles_m * p->tiles_n), 1, (unsigned)(p->ncls * p->split));
+    static const bool clsz = pg_exp_env("PATCHGAN_BF16X_CLSZ") != nullptr;      // A/B: the parity classes as grid z (one class after the other)
+    const int cls_in_x = (p->ncls == 4 && !clsz) ? 1 : 0;
+    const dim3 grid((unsigned)(p->tiles_m * p->tiles_n * (cls_in_x ? 4 : 1)), 1, (unsigned)(cls_in_x ? p->split : p->ncls * p->split));
     const int w_bytes = (dir == 2) ? 16 * Ca * 8 * 2 : (dir == 3) ? Ca * Cb * 2 : 16 * Ca * Cb * 2;
     const __bf16* I = (const __bf16*)in;
     const __bf16* Wp = (const __bf16*)W;
-#define PG_BF16X_ARGS I, ld_in, Wp, out, ld_out, slab_stride, g, p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul, part, chunks
+#define PG_BF16X_ARGS I, ld_in, Wp, out, ld_out, slab_stride, g, p->cps, bias, act, (int)in_bytes, w_bytes, out_bf, p->tiles_n, mul, part, chunks, cls_in_x
     if (p->win) {
         if ((dir == 1 && bt) || dir > 1 || (p->tile != 1 && p->tile != 2)) return PG_EINVAL;      // (weights: the fragment-ordered pack, dir 4 / 5)
         const int w_bytes = 16 * (((dir == 0 ? Ca : Cb) + 31) / 32 * 32) * (dir == 0 ? Cb : Ca) * 2;

@@ -79,13 +79,19 @@ def test_conv_kernels_on_bf16_tensors(geom):
 
 
 XGEOMS = [(2, 64, 64, 128, 64, 2), (2, 32, 32, 64, 64, 2), (1, 24, 20, 96, 128, 2), (2, 31, 29, 64, 64, 1), (2, 8, 8, 512, 512, 2),
-          (3, 35, 37, 72, 64, 2), (5, 128, 128, 128, 64, 2), (1, 16, 16, 256, 1024, 2), (2, 2, 2, 128, 128, 2), (2, 31, 31, 128, 256, 1)]
+          (3, 35, 37, 72, 64, 2), (5, 128, 128, 128, 64, 2), (1, 16, 16, 256, 1024, 2), (2, 2, 2, 128, 128, 2), (2, 31, 31, 128, 256, 1),
+          (2, 32, 32, 512, 512, 2), (1, 64, 32, 256, 64, 2), (3, 32, 64, 128, 192, 2)]
+# (geometry, direction) pairs the window-staged kernel k_conv_bf16r must take: stride 2, even maps that tile into whole R x 16
+# rectangles of (class) pixels, input channels % 64 == 0 -- with a K split (512 -> 512 on 16 x 16), non-square maps, 192 = 1.5 tiles
+WIN_EXPECT = {((2, 64, 64, 128, 64, 2), 0), ((2, 64, 64, 128, 64, 2), 1), ((2, 32, 32, 64, 64, 2), 0), ((2, 32, 32, 64, 64, 2), 1),
+              ((5, 128, 128, 128, 64, 2), 0), ((5, 128, 128, 128, 64, 2), 1), ((2, 32, 32, 512, 512, 2), 0), ((2, 32, 32, 512, 512, 2), 1),
+              ((1, 64, 32, 256, 64, 2), 0), ((1, 64, 32, 256, 64, 2), 1), ((3, 32, 64, 128, 192, 2), 0), ((3, 32, 64, 128, 192, 2), 1)}
 
 
 @pytest.mark.parametrize('geom', XGEOMS, ids=lambda g: 'x'.join(map(str, g)))
 def test_lds_dma_bf16_kernels(geom):
     """k_conv_bf16x (conv_bf16.hip: LDS-DMA operand tiles, 256 x 128 / 128 x 128 / 256 x 64 workgroup tiles, transposed product
-    with 16-byte stores) on 16-byte-aligned bf16 tensors, both directions, against torch in float64 on the same bf16-representable
+    with 16-byte stores) and k_conv_bf16r (window-staged stride-2 form: WIN_EXPECT) on 16-byte-aligned bf16 tensors, both directions, against torch in float64 on the same bf16-representable
     inputs AND weights -- every product is then exact in fp32, so only the summation order differs: fp32 outputs within 2e-5
     (max-norm), bf16 outputs within one bf16 ulp of the rounded reference.  Also: the register-staged kernels (PG_TUNE_BF16X_OFF)
     agree to the same bound, split-K slabs / ragged tiles / odd parity classes / stride 1 are in the list, and a caller-owned
@@ -117,7 +123,11 @@ def test_lds_dma_bf16_kernels(geom):
         if cin % 64:
             continue
         io_in = L.IO_BIG_BF16 if opcode == 0 else L.IO_SMALL_BF16
-        assert op.describe(opcode, io_in)[0].startswith('k_conv_bf16x') and op.describe(opcode, io_in)[0].endswith(',64>')
+        name = op.describe(opcode, io_in)[0]
+        if (tuple(geom), opcode) in WIN_EXPECT:
+            assert name.startswith('k_conv_bf16r'), name
+        else:
+            assert name.startswith('k_conv_bf16x') and name.endswith(',64>'), name
         assert ring.describe(opcode, io_in)[0].startswith('k_conv_bf16x') and ring.describe(opcode, io_in)[0].endswith(',32>')
         assert not old.describe(opcode, io_in)[0].startswith('k_conv_bf16x')
         bias = torch.randn(cout)

@@ -141,4 +141,100 @@ def test_bf16_lds_dma_kernels_match_direct_on_random_geometries(seed, staging):
             picked.add(op.describe(2, L.IO_MASK)[0])
             assert rel_err(dPg, dPr) < 3e-5, ('wgrad', geom)
     print('bf16 kernels exercised:', sorted(picked))
-    assert sum(k.startswith('k_conv_bf16x') for k in picked) >= 6 and sum(k.startswith('k_wgrad_bf16x') for k in picked) >= 3, sorted(picked)
+    assert sum(k.startswith('k_conv_bf16x') or k.startswith('k_conv_bf16r') for k in picked) >= 6 and sum(k.startswith('k_wgrad_bf16x') for k in picked) >= 3, sorted(picked)
+
+
+def _geoms_window(n, seed):
+    """Geometries k_conv_bf16r takes in at least one direction: stride 2, even maps, class maps of whole R x 16 rectangles."""
+    rng = random.Random(2000 + seed)
+    out = []
+    while len(out) < n:
+        N = rng.choice([1, 2, 3])
+        Hs = 8 * rng.randint(1, 6)
+        Ws = 16 * rng.randint(1, 3)
+        Ca = rng.choice([64, 64, 128, 192, 256, 512])
+        Cb = rng.choice([64, 64, 128, 192, 320, 512])
+        if N * 4 * Hs * Ws * max(Ca, Cb) > 6_000_000 or Ca * Cb > 140_000:
+            continue
+        out.append((N, 2 * Hs, 2 * Ws, Ca, Cb, 2))
+    return out
+
+
+@pytest.mark.parametrize('seed', [0, 1])
+def test_bf16_window_kernel_matches_direct_on_random_geometries(seed):
+    """k_conv_bf16r (window-staged stride-2 kernel, both directions, both tilings, K splits, ragged channel tiles, fp32 and bf16
+    outputs, the activation-derivative multiplier and the InstanceNorm partial sums in its epilogue) against PG_ALGO_DIRECT on
+    bf16-representable operands: products exact, so fp32 results agree to summation order and bf16 results to one ulp of the rounded
+    direct result; the partial sums are those of the stored tensor."""
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view, to_view_bf, empty_view, empty_view_bf, pack, rel_err, DEV
+    ran = {0: 0, 1: 0}
+    extras = {'mul': 0, 'part': 0, 'split': 0}
+    for geom in _geoms_window(14, seed):
+        N, Hb, Wb, Ca, Cb, s = geom
+        g = torch.Generator().manual_seed(hash(geom) & 0xFFFF)
+        Hs, Ws = Hb // 2, Wb // 2
+        big = torch.randn(N, Cb, Hb, Wb, generator=g).bfloat16().float()
+        small = torch.randn(N, Ca, Hs, Ws, generator=g).bfloat16().float()
+        Wt = (torch.randn(Ca, Cb, 4, 4, generator=g) / math.sqrt(max(Ca, Cb) * 16)).bfloat16().float()
+        bias = torch.randn(max(Ca, Cb), generator=g)
+        P = pack(Wt)
+        ref, op = E.ConvOp(*geom, L.ALGO_DIRECT), E.ConvOp(*geom, L.ALGO_BF16)
+
+        def close_bf(got, want):
+            wr = want.float().bfloat16().double().cpu()
+            return ((got.double().cpu() - wr).abs() <= wr.abs() * 2.0 ** -7 + 1e-5 * wr.abs().max()).all()
+
+        for opcode in (0, 1):
+            sym, split = op.describe(opcode, L.IO_MASK)
+            if not sym.startswith('k_conv_bf16r'):
+                continue
+            ran[opcode] += 1
+            extras['split'] += split > 1
+            cout = Ca if opcode == 0 else Cb
+            oshape = (N, Hs, Ws, Ca) if opcode == 0 else (N, Hb, Wb, Cb)
+            src_f = to_view(big if opcode == 0 else small)
+            src = to_view_bf(big if opcode == 0 else small, ld=(Cb if opcode == 0 else Ca) + 8, off=8)
+            call_r = ref.big2small if opcode == 0 else ref.small2big
+            call = op.big2small if opcode == 0 else op.small2big
+            want = empty_view(*oshape)
+            call_r(src_f, P, 0, bias.cuda(), 0, want, 1)
+            for out_bf in (True, False):
+                got = (empty_view_bf if out_bf else empty_view)(*oshape, ld=cout + 8, off=8)
+                call(src, P, 0, bias.cuda(), 0, got, 1)
+                torch.cuda.synchronize()
+                if out_bf:
+                    assert close_bf(got.to_nchw(), want.to_nchw()), (geom, opcode, sym, split)
+                else:
+                    assert rel_err(got.to_nchw(), want.to_nchw()) < 2e-5, (geom, opcode, sym, split)
+            # InstanceNorm partial sums from the epilogue (bf16 output, no bias / activation)
+            y = empty_view_bf(*oshape, ld=cout + 8, off=8)
+            chunks = op.stats_chunks(opcode, src, y)
+            if chunks:
+                extras['part'] += 1
+                part = torch.full((N * chunks * cout * 2,), float('nan'), dtype=torch.float64, device=DEV)
+                call(src, P, 0, None, 0, y, part=part)
+                y2 = empty_view_bf(*oshape, ld=cout + 8, off=8)
+                call(src, P, 0, None, 0, y2)
+                torch.cuda.synchronize()
+                assert torch.equal(y.to_nchw(), y2.to_nchw()), (geom, opcode)
+                yv = y.to_nchw().double().cpu()
+                sums = part.view(N, chunks, cout, 2).sum(1).cpu()
+                assert ((sums[..., 0] - yv.sum((2, 3))).abs() <= 1e-5 * yv.abs().sum((2, 3)) + 1e-6).all(), (geom, opcode)
+                assert ((sums[..., 1] - (yv * yv).sum((2, 3))).abs() <= 1e-5 * (yv * yv).sum((2, 3)) + 1e-6).all(), (geom, opcode)
+            # the activation backward of the layer below in the data-gradient epilogue
+            if opcode == 1:
+                t = torch.tanh(torch.randn(N, Cb, Hb, Wb, generator=g)).bfloat16().float()       # an activation OUTPUT of the layer below
+                vt = to_view_bf(t, ld=Cb + 8, off=8)
+                fused = empty_view_bf(*oshape, ld=cout + 8, off=8)
+                if op.mul_ok(src, fused, vt):
+                    extras['mul'] += 1
+                    op.small2big(src, P, 0, None, 0, fused, mul=(vt, L.ACT_TANH))
+                    lin = empty_view(*oshape)
+                    ref.small2big(src_f, P, 0, None, 0, lin)
+                    torch.cuda.synchronize()
+                    wantm = lin.to_nchw().double().cpu() * (1 - t.double() ** 2)
+                    assert close_bf(fused.to_nchw(), wantm), (geom, 'mul')
+    print('window kernel launches checked:', ran, extras)
+    assert ran[0] >= 5 and ran[1] >= 5, ran
+    assert extras['mul'] >= 3 and extras['part'] >= 3 and extras['split'] >= 2, extras

@@ -1,7 +1,7 @@
 """Every conv launch of ONE training step in its place in the step (cold operands, neighbours as they are), with the layer geometry:
 kernel symbol, split, microseconds (mean of the sampled steps, HIP events on the launch stream), executed and useful TFLOP/s.  The
 back-to-back layer benchmarks rank kernels differently; this is the table to choose by.
-    python tools/step_launch_table.py [cfg4] [bf16|f32] [steps=6]"""
+    python tools/step_launch_table.py [cfg4] [bf16|f32] [steps=6]        PG_TUNE=<bits> sets PG_TUNE_* bits on both networks"""
 import os
 import sys
 import tempfile
@@ -21,6 +21,9 @@ D = pg.Discriminator(3 + cfg['out_nc'], cfg['ndf'], n_layers=cfg['n_layers'], no
 if dtype == 'bf16':
     G.set_precision('bf16')
     D.set_precision('bf16')
+if os.environ.get('PG_TUNE'):            # e.g. PG_TUNE=0x4000 = TUNE_BF16X_RING on every layer
+    G.set_tuning(int(os.environ['PG_TUNE'], 0))
+    D.set_tuning(int(os.environ['PG_TUNE'], 0))
 t = pg.Trainer(G, D, tempfile.mkdtemp(prefix='pgtab_'))
 t.loss_type, t.seg_alpha = cfg['loss_type'], 200
 t.setup_optimizers(1e-3, 1e-3)
