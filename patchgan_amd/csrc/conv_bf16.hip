@@ -1087,7 +1087,8 @@ const char* pg_bf16x_kernel_name(int dir, int tile, int ring) {
 }
 
 size_t pg_bf16x_w_bytes(int Ca, int Cb) {       // (channel counts padded to 32: the fragment-ordered pack holds whole 32-channel tiles)
-    return ((size_t)16 * ((Ca + 31) / 32 * 32) * std::max((Cb + 31) / 32 * 32, 8) * 2 + 255) & ~(size_t)255;
+    if (Cb <= 8) return ((size_t)16 * Ca * 8 * 2 + 255) & ~(size_t)255;      // 8-channel-pixel form: no fragment pack
+    return ((size_t)16 * ((Ca + 31) / 32 * 32) * ((Cb + 31) / 32 * 32) * 2 + 255) & ~(size_t)255;
 }
 
 // workgroups of one layer's pack (0: this layout / channel count has no pack)
