@@ -1249,7 +1249,11 @@ pg_bf16x_plan pg_bf16x_wgrad_plan(int N, int Hb, int Wb, int Hs, int Ws, int Ca,
     p.nchunks = (int)((M + 63) / 64);
     p.out_elems = 16L * Ca * Cb;
     const long nb = (long)p.tiles_m * p.tiles_n * 16;
-    static const int target = pg_exp_env("PATCHGAN_BF16X_WTARGET") ? atoi(pg_exp_env("PATCHGAN_BF16X_WTARGET")) : 512;
+    // workgroups to aim for: what the chip holds at once -- the 64-channel-wide tiles (2, 3) run four workgroups per CU.  Measured in the
+    // cfg4 step (tools/step_launch_table.py): 128 -> 64 channels at 256 x 256, 2N: 158 -> 116 us with 64 slices instead of 32; the
+    // 128 x 128 tile (also four per CU) gains nothing from it (23 -> 28 us on 1024 x 512 at 16 x 16), the 256 x 128 one (two per CU) loses
+    static const int wtarget = pg_exp_env("PATCHGAN_BF16X_WTARGET") ? atoi(pg_exp_env("PATCHGAN_BF16X_WTARGET")) : 0;
+    const int target = wtarget > 0 ? wtarget : (p.tile >= 2 ? 1024 : 512);
     long s = (nb >= target) ? 1 : (target + nb - 1) / nb;
     const long smax = std::max<long>(1, p.nchunks / 4);
     if (s > smax) s = smax;
