@@ -20,6 +20,7 @@
 // 16 bytes of one pixel row -- 8 bf16 channels -- instead of sixteen 2-byte stores.
 #include "pg_common.h"
 #include "conv_bf16.h"
+#include <type_traits>
 
 namespace {
 
@@ -41,6 +42,48 @@ __device__ __forceinline__ float act_epi(float v, int act) {
     if (act == PG_ACT_LEAKY) return v > 0.f ? v : 0.2f * v;
     if (act == PG_ACT_RELU) return v > 0.f ? v : 0.f;
     return pg_act(v, act);
+}
+
+// The epilogues below run over 64 accumulators per lane, fully unrolled.  With the activation as a RUN-TIME value every element carried
+// its own compare-and-branch ladder and an inlined tanhf / expf: ~7000 instructions (56 KB of code) per kernel, executed in 5-14 us per
+// tile -- MORE than the MFMA loop of a two-chunk layer (measured with the phase stamps of PG_TRACE_R: main loop 4.7 us, epilogue 14 us on
+// the 128 -> 64 channel data gradient).  The activation and the multiplier's activation are therefore dispatched ONCE per tile into a
+// body compiled for that value (tag -1: the run-time ladder, kept for the combination nothing on the training path uses).
+template <int A>
+using pg_ic = std::integral_constant<int, A>;
+template <int ACT>
+__device__ __forceinline__ float act_sel(float v, int act) {
+    if constexpr (ACT < 0) return act_epi(v, act);
+    else return pg_act(v, ACT);
+}
+template <int MACT>
+__device__ __forceinline__ float act_grad_c(float a, int mact) {
+    if constexpr (MACT < 0) return pg_act_grad_sel(a, mact);
+    else return pg_act_grad_sel(a, MACT);
+}
+template <bool MUL, class F>
+__device__ __forceinline__ void epi_dispatch(int act, int mact, F&& f) {
+    if constexpr (MUL) {
+        if (act != PG_ACT_NONE) {
+            f(pg_ic<-1>{}, pg_ic<-1>{});
+            return;
+        }
+        switch (mact) {
+            case PG_ACT_LEAKY: f(pg_ic<PG_ACT_NONE>{}, pg_ic<PG_ACT_LEAKY>{}); break;
+            case PG_ACT_RELU: f(pg_ic<PG_ACT_NONE>{}, pg_ic<PG_ACT_RELU>{}); break;
+            case PG_ACT_TANH: f(pg_ic<PG_ACT_NONE>{}, pg_ic<PG_ACT_TANH>{}); break;
+            case PG_ACT_SIGMOID: f(pg_ic<PG_ACT_NONE>{}, pg_ic<PG_ACT_SIGMOID>{}); break;
+            default: f(pg_ic<PG_ACT_NONE>{}, pg_ic<PG_ACT_NONE>{}); break;
+        }
+    } else {
+        switch (act) {
+            case PG_ACT_LEAKY: f(pg_ic<PG_ACT_LEAKY>{}, pg_ic<PG_ACT_NONE>{}); break;
+            case PG_ACT_RELU: f(pg_ic<PG_ACT_RELU>{}, pg_ic<PG_ACT_NONE>{}); break;
+            case PG_ACT_TANH: f(pg_ic<PG_ACT_TANH>{}, pg_ic<PG_ACT_NONE>{}); break;
+            case PG_ACT_SIGMOID: f(pg_ic<PG_ACT_SIGMOID>{}, pg_ic<PG_ACT_NONE>{}); break;
+            default: f(pg_ic<PG_ACT_NONE>{}, pg_ic<PG_ACT_NONE>{}); break;
+        }
+    }
 }
 
 __device__ __forceinline__ unsigned pack2(float x, float y) {
@@ -331,6 +374,8 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(OC
         mok[i] = m < Mc;
     }
     if constexpr (STATS) __syncthreads();                          // the operand tiles in LDS are dead: the statistics reuse the space
+    auto body = [&](auto act_tag, auto mact_tag) {
+    constexpr int ACT = decltype(act_tag)::value, MACT = decltype(mact_tag)::value;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int nb = n0 + (wn * NR + j) * 32;
@@ -351,7 +396,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(OC
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x = acc[i][j][4 * q + e];
-                    v[q][e] = fin ? act_epi(x + bv[e], act) : x;
+                    v[q][e] = fin ? act_sel<ACT>(x + bv[e], act) : x;
                 }
                 if constexpr (MUL) {           // data gradient times the activation derivative of the layer below (t: its output)
                     const long tidx = (mok[i] ? opix[i] : 0L) * mul.ld + min(ch, Cout - 4);
@@ -364,7 +409,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(OC
                         tv = *reinterpret_cast<const f32x4*>((const char*)mul.t + tidx * 4);
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[q][e] *= pg_act_grad_sel(tv[e], mul.act);
+                    for (int e = 0; e < 4; ++e) v[q][e] *= act_grad_c<MACT>(tv[e], mul.act);
                 }
                 if constexpr (STATS) {         // what InstanceNorm will read back: the bf16-rounded value
 #pragma unroll
@@ -424,6 +469,8 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(OC
             __syncthreads();
         }
     }
+    };
+    epi_dispatch<MUL>(fin ? act : PG_ACT_NONE, mul.act, body);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -443,6 +490,13 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(OC
 //     exposed waits above.
 // DRC 0: big -> small; DRC 1: small -> big, class = blockIdx.z % 4; both take weights with K contiguous per output channel (dir 1: the
 // per-tap transposed pack, pg_bf16x_pack dir 1).
+#ifdef PG_TRACE_R
+// Diagnostics build only (make trace -> libpatchgan_hip_trace.so, tools/trace_r.py): per wave, real-time-clock (100 MHz) stamps of the phases of
+// k_conv_bf16r -- entry, first barrier passed, time spent waiting at the later chunk starts, time issuing a chunk's MFMAs, epilogue
+// start, end -- into a buffer set with pg_debug_trace_set.  Not part of the product library.
+__device__ unsigned long long* pg_trace_buf = nullptr;
+#define PG_TR_NOW() __builtin_amdgcn_s_memrealtime()      // 100 MHz, the same on every XCD
+#endif
 template <int MR, int NR, int WM, int WN, int DRC, bool MUL = false, bool STATS = false, int OCC = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_conv_bf16r(
     const __bf16* __restrict__ in, int ld_in, const __bf16* __restrict__ W, void* __restrict__ out, int ld_out, long slab_stride, XGeom g,
@@ -586,6 +640,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     //   t = 0: request fragments(s0 + 3), window(mi + 1)
     //   t >= 1: request fragments(s0 + t + 3); fragments(s0 + t) are in once <= 3 NB + WP remain
     constexpr int NB = NR * 4;
+#ifdef PG_TRACE_R
+    const unsigned long long tr_t0 = PG_TR_NOW();
+    unsigned long long tr_t1 = 0, tr_w = 0, tr_m = 0;
+#endif
     if (nsteps > 0) {
         issue_window(0);
         load_b(0, breg[0]);
@@ -595,8 +653,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll 1
     for (int mi = 0; 4 * mi < nsteps; ++mi) {
         const int s0 = 4 * mi;
+#ifdef PG_TRACE_R
+        const unsigned long long tr_a = PG_TR_NOW();
+#endif
         wait_vmcnt<2 * NB>();
         __builtin_amdgcn_s_barrier();                              // this chunk's window is complete; everyone is done with the other buffer
+#ifdef PG_TRACE_R
+        const unsigned long long tr_b = PG_TR_NOW();
+        if (mi == 0) tr_t1 = tr_b;
+        else tr_w += tr_b - tr_a;
+#endif
         load_b(s0 + 3, breg[3]);
         issue_window(mi + 1);
         multiply(s0, breg[0]);
@@ -609,9 +675,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         load_b(s0 + 6, breg[2]);
         wait_vmcnt<3 * NB + WP>();
         multiply(s0 + 3, breg[3]);
+#ifdef PG_TRACE_R
+        tr_m += PG_TR_NOW() - tr_b;
+#endif
     }
     wait_vmcnt<0>();                                               // the killed tail loads / pieces drain before the kernel ends
     __syncthreads();
+#ifdef PG_TRACE_R
+    const unsigned long long tr_t2 = PG_TR_NOW();
+#endif
 
     // ---- epilogue (as k_conv_bf16x): lane = pixel lrow of tile i; register r = channel (r & 3) + 8 * (r >> 2) + 4 * lh of tile j
     const bool fin = (slab_stride == 0);
@@ -626,6 +698,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         opix[i] = (DRC == 0) ? (long)((nsmp * g.Hs + ii) * g.Ws + jj) : (long)((nsmp * g.Hb + 2 * ii + ah) * g.Wb + 2 * jj + aw);
     }
     if constexpr (STATS) __syncthreads();
+    auto body = [&](auto act_tag, auto mact_tag) {                 // (one body per activation: see epi_dispatch)
+    constexpr int ACT = decltype(act_tag)::value, MACT = decltype(mact_tag)::value;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int nb = n0 + (wn * NR + j) * 32;
@@ -646,7 +720,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x = acc[i][j][4 * q + e];
-                    v[q][e] = fin ? act_epi(x + bv[e], act) : x;
+                    v[q][e] = fin ? act_sel<ACT>(x + bv[e], act) : x;
                 }
                 if constexpr (MUL) {
                     const long tidx = opix[i] * mul.ld + min(ch, Cout - 4);
@@ -659,7 +733,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                         tv = *reinterpret_cast<const f32x4*>((const char*)mul.t + tidx * 4);
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[q][e] *= pg_act_grad_sel(tv[e], mul.act);
+                    for (int e = 0; e < 4; ++e) v[q][e] *= act_grad_c<MACT>(tv[e], mul.act);
                 }
                 if constexpr (STATS) {
 #pragma unroll
@@ -713,6 +787,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             __syncthreads();
         }
     }
+    };
+    epi_dispatch<MUL>(fin ? act : PG_ACT_NONE, mul.act, body);
+#ifdef PG_TRACE_R
+    if (pg_trace_buf != nullptr && lane == 0) {
+        const unsigned long long tr_t3 = PG_TR_NOW();
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* const o = pg_trace_buf + ((size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 4 + wave) * 8;
+        o[0] = tr_t0;
+        o[1] = tr_t1;
+        o[2] = tr_w;
+        o[3] = tr_m;
+        o[4] = tr_t2;
+        o[5] = tr_t3;
+        o[6] = ((unsigned long long)xcc << 32) | hw;
+        o[7] = (unsigned long long)((nsteps + 3) / 4);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1298,3 +1392,10 @@ int pg_bf16x_wgrad(const void* small, int ld_small, long small_bytes, const void
 #undef PG_BF16X_WG
     return pg_launch_status();
 }
+
+#ifdef PG_TRACE_R
+extern "C" int pg_debug_trace_set(void* buf) {
+    unsigned long long* p = (unsigned long long*)buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(pg_trace_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -646,7 +646,11 @@ ChunkPlan chunk_plan(int N, int HW, int C, int vecw) {
     }();
     if (HW >= chunk_min) {
         const int PL = 256 / G;
-        long want = (1024 + (long)N * p.groups - 1) / ((long)N * p.groups);
+        static const int wgs = [] {
+            const char* e = pg_exp_env("PATCHGAN_IN_CHUNK_WGS");
+            return e ? atoi(e) : 1024;
+        }();
+        long want = (wgs + (long)N * p.groups - 1) / ((long)N * p.groups);
         long maxc = HW / (PL * 2);            // at least two pixels per lane per chunk
         if (want > maxc) want = maxc;
         if (want > 1024) want = 1024;
