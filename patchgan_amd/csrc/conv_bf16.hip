@@ -512,7 +512,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     // contiguous bytes -- 16 line requests per store instruction instead of 64 (lane = pixel, 16 bytes each): measured, the stores were
     // 2.2 us of a 256 x 64 tile's 3.6-us epilogue.  80-byte rows: conflict-free 8-byte writes, 16-byte aligned reads.
     constexpr int STG_RS = 80, STG_W = 32 * STG_RS, STG_OFF = STATB;
-    constexpr int SMEM = 2 * WBYTES > STG_OFF + 4 * STG_W ? 2 * WBYTES : STG_OFF + 4 * STG_W;
+    // MUL with a bf16 `t`: the tile's BM x BN slice of t is fetched by LDS-DMA DURING the last chunk (into the window buffer that chunk no
+    // longer needs, or an area of its own where a window is smaller than the slice) instead of by 16 scattered 8-byte loads per lane in
+    // the epilogue, whose latency nothing covered (measured: 7 of the 9.8 us of that epilogue, against 4.7 us of MFMA loop on the 128 -> 64
+    // channel data gradient).  Image: [pixel][16-byte slot], slot XOR-swizzled by the pixel (2-way instead of 16-way conflicts on the reads).
+    static_assert(!(MUL && STATS), "the multiplier and the statistics share LDS");
+    constexpr int TBYTES = BM * BN * 2, TP = TBYTES / 1024 / 4, NSL = BN / 8, PPP = 64 / NSL;
+    constexpr bool TDED = MUL && WBYTES < TBYTES;                              // the slice does not fit a window buffer: its own area
+    constexpr int SMEM0 = 2 * WBYTES + (TDED ? TBYTES : 0);
+    constexpr int SMEM = SMEM0 > STG_OFF + 4 * STG_W ? SMEM0 : STG_OFF + 4 * STG_W;
     __shared__ __attribute__((aligned(1024))) char smem[SMEM];
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, w_bytes, 0x00020000);
@@ -654,8 +662,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         load_b(1, breg[1]);
         load_b(2, breg[2]);
     }
-#pragma unroll 1
-    for (int mi = 0; 4 * mi < nsteps; ++mi) {
+    const int nmc = nsteps >> 2;                                   // macro chunks of this tile
+    const bool tpre = MUL && slab_stride == 0 && out_bf;          // t through LDS (bf16 t; an fp32 t keeps the loads in the epilogue)
+    const int t_off = TDED ? 2 * WBYTES : (nmc & 1) * WBYTES;     // the buffer the last chunk does not read
+    auto issue_t = [&]() {
+        if constexpr (MUL) {
+            const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)mul.t, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < TP; ++k) {
+                const int piece = wave * TP + k;
+                const int pl = piece * PPP + lane / NSL;           // pixel of the tile; the lane's granule holds slot (lane % NSL) ^ (pl % NSL)
+                const int sl = (lane % NSL) ^ (pl & (NSL - 1));
+                const int ii = r0 + (pl >> 4), jj = c0 + (pl & 15);
+                const long op = (DRC == 0) ? (long)((nsmp * g.Hs + ii) * g.Ws + jj) : (long)((nsmp * g.Hb + 2 * ii + ah) * g.Wb + 2 * jj + aw);
+                const int ch = n0 + sl * 8;
+                dma16(rt, smem + t_off + piece * 1024, ch < Cout ? (int)((op * mul.ld + ch) * 2) : (int)0x80000000u);
+            }
+        }
+    };
+    auto chunk = [&](int mi, auto xp_tag, auto t_tag) {            // XP: the pieces requested at tap 0 (the next window, or the slice of t)
+        constexpr int XP = decltype(xp_tag)::value;
+        constexpr bool TNOW = decltype(t_tag)::value;
         const int s0 = 4 * mi;
 #ifdef PG_TRACE_R
         const unsigned long long tr_a = PG_TR_NOW();
@@ -668,20 +695,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         else tr_w += tr_b - tr_a;
 #endif
         load_b(s0 + 3, breg[3]);
-        issue_window(mi + 1);
+        if constexpr (TNOW) issue_t();
+        else issue_window(mi + 1);
         multiply(s0, breg[0]);
         load_b(s0 + 4, breg[0]);
-        wait_vmcnt<3 * NB + WP>();
+        wait_vmcnt<3 * NB + XP>();
         multiply(s0 + 1, breg[1]);
         load_b(s0 + 5, breg[1]);
-        wait_vmcnt<3 * NB + WP>();
+        wait_vmcnt<3 * NB + XP>();
         multiply(s0 + 2, breg[2]);
         load_b(s0 + 6, breg[2]);
-        wait_vmcnt<3 * NB + WP>();
+        wait_vmcnt<3 * NB + XP>();
         multiply(s0 + 3, breg[3]);
 #ifdef PG_TRACE_R
         tr_m += PG_TR_NOW() - tr_b;
 #endif
+    };
+#pragma unroll 1
+    for (int mi = 0; mi + 1 < nmc; ++mi) chunk(mi, pg_ic<WP>{}, std::false_type{});
+    if (nmc > 0) {
+        if (MUL && tpre) chunk(nmc - 1, pg_ic<(MUL ? TP : WP)>{}, std::integral_constant<bool, MUL>{});
+        else chunk(nmc - 1, pg_ic<WP>{}, std::false_type{});
     }
     wait_vmcnt<0>();                                               // the killed tail loads / pieces drain before the kernel ends
     __syncthreads();
@@ -730,7 +764,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                     const long tidx = opix[i] * mul.ld + min(ch, Cout - 4);
                     f32x4 tv;
                     if (obf) {
-                        const u32x2 h = *reinterpret_cast<const u32x2*>((const char*)mul.t + tidx * 2);
+                        const int pl = (wm * MR + i) * 32 + lrow, sl = (wn * NR + j) * 4 + q;       // tile pixel, 16-byte slot of the slice in LDS
+                        const u32x2 h = *reinterpret_cast<const u32x2*>(smem + t_off + ((pl * NSL + (sl ^ (pl & (NSL - 1)))) << 4) + lh * 8);
                         tv = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
                                    __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
                     } else {
@@ -749,7 +784,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                 }
             }
             if (obf) {
-                char* const stg = smem + STG_OFF + wave * STG_W;
+                char* const stg = smem + (MUL && !TDED ? ((nmc - 1) & 1) * WBYTES : STG_OFF) + wave * STG_W;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const u32x2 pk = {pack2(v[q][0], v[q][1]), pack2(v[q][2], v[q][3])};
