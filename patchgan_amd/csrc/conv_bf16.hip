@@ -1312,12 +1312,9 @@ int pg_bf16x_conv(int dir, const void* in, int ld_in, long in_bytes, const void*
 #undef PG_BF16W_K
         return pg_launch_status();
     }
-    static const bool occ2 = pg_exp_env("PATCHGAN_BF16X_OCC2") != nullptr;      // A/B: the 64-accumulator tiles at two workgroups per CU
-#define PG_BF16X_K(MR, NR, WM, WN, D, KB, MUL, ST, BT)                                                                          \
-    do {                                                                                                                       \
-        if (occ2) hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB, MUL, ST, BT, 2>), grid, dim3(WM * WN * 64), 0, st, PG_BF16X_ARGS); \
-        else hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB, MUL, ST, BT>), grid, dim3(WM * WN * 64), 0, st, PG_BF16X_ARGS);     \
-    } while (0)
+    // (the 64-accumulator tiles at four workgroups per CU: the two-per-CU A/B of round 4, 6.94 vs 6.35 ms per cfg4 step, is in EXPERIMENTS.md)
+#define PG_BF16X_K(MR, NR, WM, WN, D, KB, MUL, ST, BT) \
+    hipLaunchKernelGGL((k_conv_bf16x<MR, NR, WM, WN, D, KB, MUL, ST, BT>), grid, dim3(WM * WN * 64), 0, st, PG_BF16X_ARGS)
 #define PG_BF16X_LAUNCH(MR, NR, WM, WN)                                                                                      \
     do {                                                                                                                     \
         if (dir == 1 && !p->ring && bt) {                                                                                    \
@@ -1424,14 +1421,9 @@ int pg_bf16x_wgrad(const void* small, int ld_small, long small_bytes, const void
     const float inv_hw = 1.0f / (float)(Hs * Ws), inv_w = 1.0f / (float)Ws;
     const __bf16* S = (const __bf16*)small;
     const __bf16* B = (const __bf16*)big;
-    static const bool wocc2 = pg_exp_env("PATCHGAN_BF16X_OCC2") != nullptr;
 #define PG_BF16X_WG(MR, NR, WM, WN, TN)                                                                                      \
-    do {                                                                                                                     \
-        if (wocc2) hipLaunchKernelGGL((k_wgrad_bf16x<MR, NR, WM, WN, TN, 2>), grid, dim3(256), 0, st, S, ld_small, B, ld_big, out, slab_stride, g, p->cps, \
-                                      (int)small_bytes, (int)big_bytes, p->tiles_n, ntiles, inv_hw, inv_w);                  \
-        else hipLaunchKernelGGL((k_wgrad_bf16x<MR, NR, WM, WN, TN>), grid, dim3(256), 0, st, S, ld_small, B, ld_big, out, slab_stride, g, p->cps, \
-                                (int)small_bytes, (int)big_bytes, p->tiles_n, ntiles, inv_hw, inv_w);                        \
-    } while (0)
+    hipLaunchKernelGGL((k_wgrad_bf16x<MR, NR, WM, WN, TN>), grid, dim3(256), 0, st, S, ld_small, B, ld_big, out, slab_stride, g, p->cps, \
+                       (int)small_bytes, (int)big_bytes, p->tiles_n, ntiles, inv_hw, inv_w)
     switch (p->tile) {
         case 0: PG_BF16X_WG(4, 2, 2, 2, false); break;
         case 1: PG_BF16X_WG(2, 2, 2, 2, false); break;
