@@ -184,30 +184,32 @@ def e2e_training(dev, batches=48, files=192):
     out = {'workload': f'cfg2 fed by DataLoader: {files} synthetic 256x256 JPEG + PNG files (repeated to {batches} batches of 16 per epoch), '
                        f'{workers} workers, pin_memory, shuffle; Trainer.train, 2 epochs, the second one timed from its 6th batch',
            'unit': 'images/sec', 'host_cpus': cores, 'workers': workers}
+    import contextlib
     try:
-        _write_coco_like(folder, files, cfg['size'])
-        for fmt in ('float', 'u8_device_pipeline'):
-            torch.manual_seed(1234)
-            G = pg.UNet(3, 1, cfg['nf'], use_dropout=False, activation=cfg['activation'], final_act=cfg['final_act']).to(dev)
-            D = pg.Discriminator(4, cfg['ndf'], n_layers=cfg['n_layers']).to(dev)
-            tr = pg.Trainer(G, D, os.path.join(folder, 'ckpt_' + fmt))
-            tr.loss_type, tr.seg_alpha = cfg['loss_type'], 200
-            tr.graph = tr.gc_freeze = True          # as the patchgan_train entry point sets them
-            if fmt != 'float':
-                tr.label_values = [1]
-            ds = COCOStuffDataset(os.path.join(folder, 'img'), os.path.join(folder, 'mask'), labels=[1], size=cfg['size'],
-                                  augmentation='resize', device_pipeline=(fmt != 'float'))
-            ds = ConcatDataset([ds] * ((batches * cfg['batch'] + files - 1) // files))
-            dl = _Stamped(DataLoader(ds, batch_size=cfg['batch'], shuffle=True, pin_memory=True, drop_last=True, num_workers=workers,
-                                     persistent_workers=True, prefetch_factor=4))
-            tr.train(dl, [], 2, dsc_learning_rate=1e-3, gen_learning_rate=1e-3, save_freq=1000)
-            torch.cuda.synchronize()
-            t_end = time.perf_counter()
-            st = dl.stamps[1]              # second epoch of the training loader (stamps[0] = first)
-            n = len(st) - 5
-            out[fmt] = {'value': round(n * cfg['batch'] / (t_end - st[5]), 1), 'steps_timed': n,
-                        'h2d_bytes_per_image': (3 * 4 + 1 * 4) * cfg['size'] ** 2 if fmt == 'float' else (3 + 1) * cfg['size'] ** 2}
-            del dl, tr, G, D
+      with contextlib.redirect_stdout(sys.stderr):        # the dataset and Trainer.train print their progress: stdout carries the ONE JSON line only
+          _write_coco_like(folder, files, cfg['size'])
+          for fmt in ('float', 'u8_device_pipeline'):
+              torch.manual_seed(1234)
+              G = pg.UNet(3, 1, cfg['nf'], use_dropout=False, activation=cfg['activation'], final_act=cfg['final_act']).to(dev)
+              D = pg.Discriminator(4, cfg['ndf'], n_layers=cfg['n_layers']).to(dev)
+              tr = pg.Trainer(G, D, os.path.join(folder, 'ckpt_' + fmt))
+              tr.loss_type, tr.seg_alpha = cfg['loss_type'], 200
+              tr.graph = tr.gc_freeze = True          # as the patchgan_train entry point sets them
+              if fmt != 'float':
+                  tr.label_values = [1]
+              ds = COCOStuffDataset(os.path.join(folder, 'img'), os.path.join(folder, 'mask'), labels=[1], size=cfg['size'],
+                                    augmentation='resize', device_pipeline=(fmt != 'float'))
+              ds = ConcatDataset([ds] * ((batches * cfg['batch'] + files - 1) // files))
+              dl = _Stamped(DataLoader(ds, batch_size=cfg['batch'], shuffle=True, pin_memory=True, drop_last=True, num_workers=workers,
+                                       persistent_workers=True, prefetch_factor=4))
+              tr.train(dl, [], 2, dsc_learning_rate=1e-3, gen_learning_rate=1e-3, save_freq=1000)
+              torch.cuda.synchronize()
+              t_end = time.perf_counter()
+              st = dl.stamps[1]              # second epoch of the training loader (stamps[0] = first)
+              n = len(st) - 5
+              out[fmt] = {'value': round(n * cfg['batch'] / (t_end - st[5]), 1), 'steps_timed': n,
+                          'h2d_bytes_per_image': (3 * 4 + 1 * 4) * cfg['size'] ** 2 if fmt == 'float' else (3 + 1) * cfg['size'] ** 2}
+              del dl, tr, G, D
     finally:
         shutil.rmtree(folder, ignore_errors=True)
     return out

@@ -21,8 +21,8 @@ def _bench(extra_args, extra_env, timeout=900, extras=False, cpu=False):
                        + ([] if cpu else ['--no-cpu-baseline']) + ([] if extras else ['--no-extra']) + extra_args,
                        env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, p.stdout
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), p.stdout      # stdout carries the ONE JSON line and nothing else
     return json.loads(lines[0])
 
 
