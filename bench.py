@@ -277,6 +277,12 @@ def spawn_ranks(n, argv, script=None, timeout=None, grace=5.0):
 
 
 def main():
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print there (RCCL's version banner at communicator
+    # creation, the dataset and Trainer.train in the loader-fed leg) goes to stderr -- file descriptor 1 is pointed at stderr for the
+    # whole run and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -366,7 +372,8 @@ def main():
         if world == 1 and not use_dist and not args.no_extra and args.config == 'cfg2' and args.dtype == 'f32':
             del m
             out['extra_configs'] = extra_configs(dev, cpu=not args.no_cpu_baseline)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(out) + '\n').encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
