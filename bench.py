@@ -280,9 +280,6 @@ def main():
     # stdout carries the ONE JSON line and nothing else: whatever libraries print there (RCCL's version banner at communicator
     # creation, the dataset and Trainer.train in the loader-fed leg) goes to stderr -- file descriptor 1 is pointed at stderr for the
     # whole run and the line is written to the saved descriptor at the end
-    sys.stdout.flush()
-    line_fd = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -306,7 +303,10 @@ def main():
     GFLOP_PER_IMAGE, BATCH_PER_GPU, SIZE = CFG['gflop_per_image'], CFG['batch'], CFG['size']
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        return spawn_ranks(args.gpus, sys.argv[1:])
+        return spawn_ranks(args.gpus, sys.argv[1:])        # (forwards rank 0's stdout: that rank's one line)
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
