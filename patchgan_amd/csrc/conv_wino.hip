@@ -970,6 +970,10 @@ __global__ __launch_bounds__(256) void k_wino2_v(const float* __restrict__ big, 
                      tile * K + ph * Cb + c0);
 }
 
+#ifdef PG_TRACE_R
+// diagnostics build only (make trace): phase stamps of k_wino_bgemm, as in conv_bf16.hip
+__device__ unsigned long long* pg_trace_buf_w = nullptr;
+#endif
 // NZ independent row GEMMs: C[z][m][n] = sum_k A[z][m][k] * B[z][n][k]; rows of A and B are K contiguous floats (K % 32 == 0)
 template <int MR, int NR, int WM, int WN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wino_bgemm(const float* __restrict__ A, const float* __restrict__ B,
@@ -1026,11 +1030,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int j = 0; j < NR; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#ifdef PG_TRACE_R
+    const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tr_w = 0, tr_m = 0;
+#endif
     issue_loads(0, true);
     store_chunk();
     __syncthreads();
+#ifdef PG_TRACE_R
+    const unsigned long long tr_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int c = 0; c < nch; ++c) {
         const bool more = c + 1 < nch;
+#ifdef PG_TRACE_R
+        const unsigned long long tr_b = __builtin_amdgcn_s_memrealtime();
+#endif
         issue_loads(c + 1, more);
         __builtin_amdgcn_sched_barrier(0x386);
 #pragma unroll
@@ -1050,12 +1064,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     for (int j = 0; j < NR; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
+#ifdef PG_TRACE_R
+        const unsigned long long tr_c = __builtin_amdgcn_s_memrealtime();
+        tr_m += tr_c - tr_b;
+#endif
         __syncthreads();
         if (more) {
             store_chunk();
             __syncthreads();
         }
+#ifdef PG_TRACE_R
+        tr_w += __builtin_amdgcn_s_memrealtime() - tr_c;
+#endif
     }
+#ifdef PG_TRACE_R
+    const unsigned long long tr_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
     float* o = C + (long)z * Mrows * Ncols;
 #pragma unroll
     for (int i = 0; i < MR; ++i)
@@ -1069,6 +1093,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (m < Mrows && col < Ncols) o[(long)m * Ncols + col] = acc[i][j][r];
             }
         }
+#ifdef PG_TRACE_R
+    if (pg_trace_buf_w != nullptr && lane == 0 && blockIdx.x < 16384) {
+        unsigned long long* const ob = pg_trace_buf_w + ((size_t)blockIdx.x * 4 + wave) * 8;
+        ob[0] = tr_t0;
+        ob[1] = tr_t1;
+        ob[2] = tr_w;            // barriers + LDS staging between chunks
+        ob[3] = tr_m;            // issuing a chunk's loads, LDS reads and MFMAs
+        ob[4] = tr_t2;
+        ob[5] = __builtin_amdgcn_s_memrealtime();
+        ob[6] = 0;
+        ob[7] = (unsigned long long)nch;
+    }
+#endif
 }
 
 // Multi-batch variant: a workgroup owns one (m, n) tile position and runs `zb` consecutive batches z through ONE flattened (z, chunk) loop: the
@@ -2160,3 +2197,10 @@ int pg_wino2_s2b_zb(int N, int Hb, int Wb, int Cb) {
     const long tm = (T >= 1024) ? (T + 127) / 128 : (T + 63) / 64;
     return bgemm_zb(tm * ((4 * Cb + 127) / 128), (int)wino2_nxi());
 }
+
+#ifdef PG_TRACE_R
+extern "C" int pg_debug_trace_set_w(void* buf) {
+    unsigned long long* p = (unsigned long long*)buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(pg_trace_buf_w), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
