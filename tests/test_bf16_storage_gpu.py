@@ -422,3 +422,61 @@ def test_bf16_storage_other_configurations(cfg, tmp_path):
     print(f'{cfg}: output bf16 vs fp32 mode {e_out:.1e}, losses {rel.max(axis=1)}')
     assert e_out < 3e-2, e_out
     assert rel.max() < 5e-2, rel
+
+
+@pytest.mark.parametrize('geom', [(2, 32, 32, 128, 64, 2), (2, 32, 32, 128, 128, 2), (1, 17, 19, 64, 64, 1)], ids=lambda g: 'x'.join(map(str, g)))
+def test_bf16_conv_epilogue_bodies_every_activation(geom):
+    """The bf16 conv kernels dispatch the activation (and the data gradient's multiplier activation) once per tile into a body compiled
+    for that code (epi_dispatch in conv_bf16.hip).  Every code through both kernels -- the window-staged one on its two tilings (64 / 128
+    output channels) and the flat one (stride 1) -- with a bias, on bf16 and fp32 outputs, against float64: one bf16 ulp of the rounded
+    reference / 2e-5; then every multiplier activation with a bf16 t (window kernel: the slice of t through LDS) and an fp32 t."""
+    from patchgan_amd import engine as E, _lib as L
+    from tests.gpu_util import to_view, to_view_bf, empty_view, empty_view_bf, pack, rel_err
+    N, Hb, Wb, Ca, Cb, s = geom
+    big, small, Wt, Hs, Ws = _mk(*geom)
+    Wt = Wt.bfloat16().float()
+    P = pack(Wt)
+    op = E.ConvOp(*geom, L.ALGO_BF16)
+    names = set()
+
+    def check(got_view, want, out_bf, what):
+        got = got_view.to_nchw().double().cpu()
+        if out_bf:
+            ref = want.float().bfloat16().double()
+            assert ((got - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-5 * want.abs().max()).all(), (what, rel_err(got, ref))
+        else:
+            assert rel_err(got, want) < 2e-5, (what, rel_err(got, want))
+
+    for opcode in (0, 1):
+        cin, cout = (Cb, Ca) if opcode == 0 else (Ca, Cb)
+        names.add(op.describe(opcode, L.IO_MASK)[0].split('<')[0])
+        bias = torch.randn(cout)
+        if opcode == 0:
+            lin = F.conv2d(big.double(), Wt.double(), bias.double(), stride=s, padding=1)
+            src, oshape = to_view_bf(big), (N, Hs, Ws, Ca)
+        else:
+            lin = torch.nn.grad.conv2d_input((N, Cb, Hb, Wb), Wt.double(), small.double(), stride=s, padding=1) + bias.double().view(1, -1, 1, 1)
+            src, oshape = to_view_bf(small), (N, Hb, Wb, Cb)
+        call = op.big2small if opcode == 0 else op.small2big
+        for act in ('none', 'leakyrelu', 'relu', 'tanh', 'sigmoid'):
+            want = O.apply_act(lin, act)
+            for out_bf in (True, False):
+                out = (empty_view_bf if out_bf else empty_view)(*oshape, ld=cout + 8, off=8)
+                call(src, P, 0, bias.cuda(), 0, out, L.ACT_CODES[act])
+                torch.cuda.synchronize()
+                check(out, want, out_bf, (opcode, act, out_bf))
+        if opcode == 1:
+            lin0 = lin - bias.double().view(1, -1, 1, 1)
+            for mact in ('none', 'leakyrelu', 'relu', 'tanh', 'sigmoid'):
+                t64 = O.apply_act(torch.randn(N, Cb, Hb, Wb).double(), mact).float().bfloat16().double()     # an activation OUTPUT, bf16-representable
+                d = {'none': torch.ones_like(t64), 'leakyrelu': torch.where(t64 > 0, 1.0, 0.2).double(), 'relu': (t64 > 0).double(),
+                     'tanh': 1 - t64 * t64, 'sigmoid': t64 * (1 - t64)}[mact]
+                for out_bf in (True, False):
+                    tv = (to_view_bf if out_bf else to_view)(t64.float(), ld=Cb + 8, off=8)
+                    out = (empty_view_bf if out_bf else empty_view)(*oshape, ld=cout + 8, off=8)
+                    if not op.mul_ok(src, out, tv):
+                        continue
+                    op.small2big(src, P, 0, None, 0, out, mul=(tv, L.ACT_CODES[mact]))
+                    torch.cuda.synchronize()
+                    check(out, lin0 * d, out_bf, ('mul', mact, out_bf))
+    assert names <= {'k_conv_bf16r', 'k_conv_bf16x'} and (s == 1 or 'k_conv_bf16r' in names), names
