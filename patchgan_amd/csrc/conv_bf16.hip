@@ -953,7 +953,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifdef PG_TRACE_R
+    const unsigned long long tr_t0 = PG_TR_NOW();
+    unsigned long long tr_w = 0, tr_m = 0, tr_b2 = 0, tr_i = 0;
+#endif
     for (int c = c_begin; c < c_end; ++c) {
+#ifdef PG_TRACE_R
+        const unsigned long long tr_a = PG_TR_NOW();
+#endif
         const int pix0 = c * KP;
         const int a_uni = pix0 * ld_small * 2;
 #pragma unroll
@@ -978,8 +985,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             const int off = ((n * g.Hb + h) * g.Wb + w) * ld_big * 2 + (TAPN ? 0 : b_col[j]);
             dma16(rb, b_dst + j * 1024, ok ? off : (int)0x80000000u);
         }
+#ifdef PG_TRACE_R
+        const unsigned long long tr_i1 = PG_TR_NOW();
+        tr_i += tr_i1 - tr_a;
+#endif
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+#ifdef PG_TRACE_R
+        const unsigned long long tr_b = PG_TR_NOW();
+        tr_w += tr_b - tr_i1;
+#endif
 #pragma unroll
         for (int ks = 0; ks < KP / 16; ++ks) {
             bf16x8 af[MR], bf[NR];
@@ -993,8 +1008,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                 for (int j = 0; j < NR; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // D[b][a]
         }
+#ifdef PG_TRACE_R
+        const unsigned long long tr_c = PG_TR_NOW();
+        tr_m += tr_c - tr_b;
+#endif
         __syncthreads();
+#ifdef PG_TRACE_R
+        tr_b2 += PG_TR_NOW() - tr_c;
+#endif
     }
+#ifdef PG_TRACE_R
+    const unsigned long long tr_t2 = PG_TR_NOW();
+#endif
 
     // ---- epilogue: lane = channel a (lane & 31) of tile i; register r = channel b (r & 3) + 8 * (r >> 2) + 4 * lh of tile j
     float* const o = out + (long)slice * slab_stride + (long)tap * g.Ca * g.Cb;
@@ -1019,6 +1044,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             }
         }
     }
+#ifdef PG_TRACE_R
+    if (pg_trace_buf != nullptr && lane == 0 && blockIdx.x < 16384) {
+        unsigned long long* const ob = pg_trace_buf + ((size_t)blockIdx.x * 4 + wave) * 8;
+        ob[0] = tr_t0;
+        ob[1] = tr_i;            // issuing a chunk's DMA pieces (address arithmetic included)
+        ob[2] = tr_w;            // waiting for them + the barrier
+        ob[3] = tr_m;            // transposed reads + MFMAs
+        ob[4] = tr_t2;
+        ob[5] = PG_TR_NOW();
+        ob[6] = tr_b2;           // the barrier after the MFMAs
+        ob[7] = (unsigned long long)(c_end - c_begin);
+    }
+#endif
 }
 
 // P[tap][a][b] fp32 -> bf16, optionally transposing each tap to [b][a] (32 x 32 tiles through LDS).  blk / nblk: this workgroup's index
