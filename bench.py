@@ -194,7 +194,7 @@ def e2e_training(dev, batches=48, files=192):
               D = pg.Discriminator(4, cfg['ndf'], n_layers=cfg['n_layers']).to(dev)
               tr = pg.Trainer(G, D, os.path.join(folder, 'ckpt_' + fmt))
               tr.loss_type, tr.seg_alpha = cfg['loss_type'], 200
-              tr.graph = tr.gc_freeze = True          # as the patchgan_train entry point sets them
+              tr.graph, tr.gc_freeze = 'auto', True          # as the patchgan_train entry point sets them
               if fmt != 'float':
                   tr.label_values = [1]
               ds = COCOStuffDataset(os.path.join(folder, 'img'), os.path.join(folder, 'mask'), labels=[1], size=cfg['size'],
@@ -350,7 +350,9 @@ def main():
             'metric': f'train images/sec (G+D step) at {SIZE}x{SIZE} bs={BATCH_PER_GPU} per GPU', 'value': round(m['value'], 2),
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(m['ms_per_step'], 3), 'host_enqueue_ms_per_step': round(m['host_ms_per_step'], 3),
-            'step_launch': 'hipGraph replay of the captured step' if m['graph'] else 'launch by launch',
+            'step_launch': ('hipGraph replay of the captured step' if m['graph'] else
+                            'launch by launch, the weight gradients of each backward pass on a second stream' if m['two_streams'] else 'launch by launch')
+                           + (f" (auto: device {m['step_times'][0]:.2f} ms vs host enqueue {m['step_times'][1]:.2f} ms per step)" if m.get('step_times') else ''),
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'activation_storage': m['activation_storage'],
@@ -401,7 +403,9 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
     t = pg.Trainer(G, D, tempfile.mkdtemp(prefix='pgbench_'))
     t.loss_type, t.seg_alpha = cfg['loss_type'], 200
     t.gc_freeze = True            # as the patchgan_train entry point does (trainer._settle_gc): opt-in, process-global
-    t.graph = bool(graph) and not use_dist and not dropout     # the steady-state step replayed from a hipGraph (Trainer._batch_graph)
+    # as the patchgan_train entry point: a launch-bound steady-state step is replayed from a captured hipGraph, a device-bound one stays
+    # launch by launch with the fp32 weight gradients on a second stream (Trainer.graph = 'auto' measures and decides)
+    t.graph = 'auto' if (graph and not use_dist and not dropout) else False
     t.setup_optimizers(1e-3, 1e-3)
     G.train()
     D.train()
@@ -435,18 +439,24 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         n_ev = prof.limit if prof.limit is not None else int(per_step * steps)
         prof.reserve(2 * n_ev + 8)        # the events exist (and have been recorded once) before the timed region starts
     E.PROFILER = prof if events != 'none' else None
-    graphed = False
+    graphed = after = False
     if t.graph:
-        # untimed: more steps until the step runs from its captured graph (a kind of step is captured after Trainer.GRAPH_WARM_STEPS eager
-        # ones).  The timed steps are then replays of that graph and carry no per-launch events; the dominant kernel's launches are timed
-        # on eager steps of the same trainer right after the timed region (below)
+        # untimed: more steps until the trainer has decided how the step is launched (after Trainer.GRAPH_WARM_STEPS launch-by-launch
+        # ones): replayed from a captured graph, or left launch by launch on two streams.  Either way the timed steps carry no
+        # per-launch events (a capture cannot hold them; the launch profiler turns the second stream off); the dominant kernel's
+        # launches are timed on one-stream launch-by-launch steps of the same trainer right after the timed region (below)
         E.PROFILER = None
         for _ in range(t.GRAPH_WARM_STEPS + 3):
-            if t.graph_captured():
+            if t.graph_decided():
                 break
             t.batch(x, y, train=True)
-        graphed = t.graph_captured()
-        E.PROFILER = None if graphed else (prof if events != 'none' else None)
+        graphed, after = t.graph_captured(), t.graph_decided()
+        if after and not graphed:
+            # the first two-stream steps hold every backward operand until the streams join: the caching allocator grows for a few
+            # steps (device allocations synchronise) before the pattern settles -- outside the timed region, as any warm-up
+            for _ in range(8):
+                t.batch(x, y, train=True)
+        E.PROFILER = None if after else (prof if events != 'none' else None)
     pd = parallel.current()
     trace = bool(os.environ.get('PATCHGAN_BENCH_TRACE'))
     if trace:
@@ -475,8 +485,8 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
     sync()
     elapsed = time.perf_counter() - t0
     sample_note = 'every launch of the kernel in the first steps of the timed region (<= 96 launches), HIP events on the launch stream'
-    if graphed and events != 'none' and wsum:
-        # the timed steps were hipGraph replays (no per-launch events: the HIP runtime torch brings along refuses external event-record
+    if after and events != 'none' and wsum:
+        # the timed steps were hipGraph replays (or two-stream steps) (no per-launch events: the HIP runtime torch brings along refuses external event-record
         # nodes inside a capture, tools/graph_event_probe.py): the sample is taken on launch-by-launch steps of the same trainer, same
         # buffers, right after the timed region -- the same kernels with the same arguments, HIP events on the launch stream
         E.PROFILER = prof
@@ -484,8 +494,10 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         for _ in range(nsample):
             t.batch(x, y, train=True)
         torch.cuda.synchronize()
-        sample_note = (f'{nsample} launch-by-launch steps right after the timed region (the timed steps are hipGraph replays, which cannot '
-                       f'carry per-launch events on this runtime): every launch of the kernel, HIP events on the launch stream')
+        sample_note = (f'{nsample} one-stream launch-by-launch steps right after the timed region (the timed steps are '
+                       + ('hipGraph replays, which cannot carry per-launch events on this runtime' if graphed else
+                          'two-stream steps; the launch profiler keeps everything on one stream')
+                       + '): every launch of the kernel, HIP events on the launch stream')
     E.PROFILER = None
     comm = None
     if pd.on:
@@ -526,7 +538,8 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
-    res = {'comm': comm, 'elapsed': elapsed, 'graph': graphed}
+    res = {'comm': comm, 'elapsed': elapsed, 'graph': graphed, 'two_streams': after and not graphed and E.WGRAD_SIDE and not G.engine.act_bf,
+           'step_times': t.step_times}
     if rank != 0:
         return res
     value = batch * world * steps / elapsed
@@ -537,7 +550,7 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         d = dict(d, launches=d['launches'] * steps, ms=d['ms'] * steps, flops=d['flops'] * steps, kflops=d['kflops'] * steps,
                  uflops=d['uflops'] * steps)
     timed_steps = steps if (events != 'dominant' or prof.limit is None) else max(1, d['launches'] // max(1, int(wsum[sym]['launches'])))
-    if graphed and events != 'none' and wsum:
+    if after and events != 'none' and wsum:
         timed_steps = nsample
     per_step_all = wsum                      # every conv kernel, from the profiled warm-up step
     if not per_step_all:

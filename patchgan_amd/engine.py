@@ -132,8 +132,42 @@ class View:
 _WS = {}
 
 
+# Weight gradients on a second stream.  Inside a network's backward pass a layer's weight gradient and its data gradient both start
+# from dy and are independent of each other; enqueued on one stream their kernels run strictly one after the other, and every kernel
+# whose grid is one round of workgroups loses its ramp, its lock-step prologue / epilogue phases and its tail (EXPERIMENTS.md, "the fp32
+# polyphase GEMM's tile life": ~15-20 % of such a launch).  With the weight-gradient chain on a second stream (its own workspace) the
+# two chains' kernels fill each other's gaps: cfg2 fp32 8.85 -> 8.68 ms per step with only the encoder's and the discriminator's
+# weight gradients moved.  Same kernels, same order of every floating-point sum: bit-identical results.  The operands are referenced
+# until the streams join at the end of the backward pass (the caching allocator must not hand them out meanwhile).  Off under data
+# parallelism (the bucket all-reduce of a layer's gradient is launched as soon as that layer is done), under the launch profiler, for
+# bf16 networks and inside a hipGraph capture; it costs ~0.6 ms of host time per step (26 stream hand-overs), so it pays where the device
+# step is several times the host's enqueue time (Trainer.graph = 'auto' measures both and picks: cfg2 fp32 8.95 -> 8.65 ms, cfg4 fp32
+# 16.7 -> 16.5; cfg1's 2.9-ms step stays on the captured graph).
+_SIDE = {'enabled': False, 'allow': False, 'stream': None, 'keep': [], 'in': False}      # enabled: by the caller, per step (Trainer, 'auto')
+
+
+def side_stream():
+    """The second stream of a two-stream step (created on first use)."""
+    if _SIDE['stream'] is None:
+        _SIDE['stream'] = torch.cuda.Stream()
+    return _SIDE['stream']
+
+
+def _side_begin(allow):
+    # (not inside a hipGraph capture: a captured two-branch step replays SLOWER than the one-stream one, 9.03 vs 8.96 ms at cfg2)
+    _SIDE['allow'] = bool(allow) and _SIDE['enabled'] and WGRAD_SIDE and PROFILER is None and not torch.cuda.is_current_stream_capturing()
+
+
+def _side_join():
+    """The weight gradients enqueued on the second stream are complete for the current stream; their operands may be freed."""
+    _SIDE['allow'] = False
+    if _SIDE['keep']:
+        torch.cuda.current_stream().wait_stream(_SIDE['stream'])
+        _SIDE['keep'].clear()
+
+
 def _workspace(nbytes, device):
-    key = (device.type, device.index)
+    key = (device.type, device.index, _SIDE['in'])
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -389,6 +423,20 @@ class ConvOp:
                 L.check(L.load().pg_conv4x4_wgrad(*args), 'pg_conv4x4_wgrad')
             else:
                 L.check(L.load().pg_conv4x4_wgrad_x(*args, ctypes.byref(x)), 'pg_conv4x4_wgrad_x')
+        if _SIDE['allow']:
+            # on the second stream (see _SIDE): after everything enqueued so far (dy is ready), with that stream's own workspace
+            side = side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            _SIDE['keep'].append((small.t, big.t, v_pre, dP))
+            _SIDE['in'] = True
+            try:
+                with torch.cuda.stream(side):
+                    wp2, wn2 = self._ws(dP.device)
+                    args = args[:8] + (wp2, wn2, _stream())
+                    go()
+            finally:
+                _SIDE['in'] = False
+            return
         PROFILER.launch(self, 2, go, self._io(big, small)) if PROFILER is not None else go()
 
     def bwd_big(self, small, big, P, dP, p_off, dsmall, u_cache=None, u_valid=False):
@@ -548,6 +596,8 @@ CACHE_U = _exp_env('PATCHGAN_CACHE_U') != '0'                 # per-step cache o
 PREP_BATCH = _exp_env('PATCHGAN_PREP_BATCH') != '0'           # one batched weight-preparation launch per network and step
 FUSE_ACT_BWD = _exp_env('PATCHGAN_FUSE_ACT_BWD') != '0'       # activation backward in the data-gradient epilogue above it
 SEAM8 = _exp_env('PATCHGAN_SEAM8') != '0'       # bf16 storage: image-facing tensors in 8-channel bf16 pixels
+WGRAD_SIDE = _exp_env('PATCHGAN_WGRAD_SIDE') != '0'       # weight gradients of a backward pass on a second stream (_SIDE)
+SPLIT_BWD_BIG = _exp_env('PATCHGAN_SPLIT_BWD_BIG') != '0'       # with the second stream: the decoder's fused backward call as its two halves (8.83 -> 8.65 ms at cfg2)
 
 
 def instnorm_act_bwd(g1, g2, y, stats, dy, act, drop_p=0.0, seed=0):
@@ -925,6 +975,13 @@ class GeneratorEngine(_WeightPrep):
         def done(l):
             if on_ready is not None:
                 on_ready(l.p_off, l.p_off + 16 * l.a * l.b)
+        _side_begin(on_ready is None and not self.act_bf)       # (bf16: the two chains contend for the L1 path: 5.87 -> 5.94 ms at cfg4)
+        try:
+            return self._backward(flat, gflat, c, g1, g2, need_dx, done, ucache)
+        finally:
+            _side_join()
+
+    def _backward(self, flat, gflat, c, g1, g2, need_dx, done, ucache):
         N, dev = c.N, flat.device
         enc_ops, dec_ops = self.ops(c.N, c.H, c.W)
         act = L.ACT_CODES[self.activation]
@@ -956,7 +1013,7 @@ class GeneratorEngine(_WeightPrep):
             src = c.hidden if i == 0 else c.cat[i]
             dsrc = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=bf)
             u, uv = _ucache(ucache, ('d', i), 0, op, dev, dy, dsrc, l.p_off)
-            if u is not None and bf:      # bf16 tensors: the two halves as two calls, the data gradient on the forward's packed weights
+            if (u is not None and bf) or (SPLIT_BWD_BIG and _SIDE['allow']):      # bf16 tensors: the two halves as two calls, the data gradient on the forward's packed weights
                 op.wgrad(src, dy, gflat, l.p_off)
                 op.big2small(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
             else:
@@ -1098,6 +1155,13 @@ class DiscriminatorEngine(_WeightPrep):
     def backward(self, flat, gflat, c, gout, need_wgrad=True, need_dx=False, ucache=None):
         """gout: View of dL/d(out).  need_wgrad=False skips the weight gradients (the generator step's pass
         through D, whose D-gradients the reference zeroes at trainer.py:93-94).  ucache: as in forward."""
+        _side_begin(need_wgrad and not self.act_bf)
+        try:
+            return self._backward(flat, gflat, c, gout, need_wgrad, need_dx, ucache)
+        finally:
+            _side_join()
+
+    def _backward(self, flat, gflat, c, gout, need_wgrad, need_dx, ucache):
         ops = self.ops(c.N, c.H, c.W)
         dev = flat.device
         g = gout

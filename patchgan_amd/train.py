@@ -136,7 +136,7 @@ def patchgan_train(argv=None):
     checkpoint_path = config.get('checkpoint_path', './checkpoints/')
     trainer = Trainer(generator, discriminator, savefolder=checkpoint_path)
     trainer.gc_freeze = True      # this process is the training job: keep generation-2 collections out of the step loop
-    trainer.graph = True          # steady-state steps replayed from a captured hipGraph where that applies (one GPU, use_dropout: False)
+    trainer.graph = 'auto'        # launch-bound steady-state steps are replayed from a captured hipGraph (one GPU, use_dropout: False); device-bound ones stay launch by launch
     if dataset_kwargs.get('device_pipeline', False):
         trainer.label_values = [int(v) for v in np.sort(dataset_kwargs['labels'])]
     if config.get('load_last_checkpoint', False):

@@ -150,8 +150,13 @@ class Trainer:
     neptune_config = None
     label_values = None      # label list of the dataset, only for the uint8 (device-side) input path of batch()
     gc_freeze = False        # opt-in: gc.collect() + gc.freeze() after training steps 1 and 3 (_settle_gc; process-global)
-    graph = False            # opt-in: replay the steady-state training step from a captured hipGraph (_batch_graph)
+    graph = False            # opt-in: True = replay the steady-state training step from a captured hipGraph (_batch_graph); 'auto' = only where the step is launch-bound
     GRAPH_WARM_STEPS = 3     # eager steps of a given kind before it is captured (kernel plans, weight-cache plans, workspaces settle)
+    # graph = 'auto': the last eager warm step of a kind is timed on the device (one event pair, one wait for it) and on the host; the
+    # step is captured only if the device time is < AUTO_RATIO x the host's enqueue time (a launch-bound step: cfg1).  A device-bound
+    # step stays launch by launch, where fp32 networks run their weight gradients on a second stream (engine._SIDE): a captured
+    # two-stream step replays slower than a one-stream one, and the launch-by-launch two-stream step is faster than either.
+    AUTO_RATIO = 2.5
     MAX_GRAPHS = 2           # captured kinds of step kept (each holds its activations: ~4 GB at cfg2)
 
     def __init__(self, generator, discriminator, savefolder, device='cuda'):
@@ -173,6 +178,7 @@ class Trainer:
         self._pending_d = None
         self.bucket_bytes = 32 << 20   # all-reduce bucket size under data parallelism (parallel.GradReducer)
         self._graphs, self._graph_seen, self._adam_dev = {}, {}, None
+        self._graph_eager, self._probe, self.step_times, self._two_streams = set(), None, None, False      # graph = 'auto' (see AUTO_RATIO)
 
     # -------------------------------------------------------------------------------------- optimizers
     def setup_optimizers(self, gen_lr=1e-3, dsc_lr=1e-3):
@@ -182,6 +188,7 @@ class Trainer:
         self._adam = (torch.zeros_like(g), torch.zeros_like(g), torch.zeros_like(d), torch.zeros_like(d))
         self._t_g = self._t_d = 0
         self._graphs, self._graph_seen = {}, {}        # captured steps update the OLD moment buffers
+        self._graph_eager, self._probe = set(), None
 
     # -------------------------------------------------------------------------------------- one G+D step
     def batch(self, x, y, train=False):
@@ -217,10 +224,24 @@ class Trainer:
             self.setup_optimizers(self.gen_lr, self.dsc_lr)
         self._step += 1
         losses = None
+        self._two_streams = False
         if train and self._graph_eligible():
             losses = self._batch_graph(x, y, u8, (N, H, W, Cin, Cout))
         if losses is None:
-            losses = self._enqueue_step(x, y, u8, N, H, W, Cin, Cout, train)
+            probe = self._probe
+            if probe is not None and probe.get('e0') is None:      # 'auto': time this (the last warm) step on the device and on the host
+                probe['e0'], probe['e1'] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                probe['e0'].record()
+                t_p = time.perf_counter()
+                losses = self._enqueue_step(x, y, u8, N, H, W, Cin, Cout, train)
+                probe['host_ms'] = (time.perf_counter() - t_p) * 1e3
+                probe['e1'].record()
+            else:
+                E._SIDE['enabled'] = bool(train and self._two_streams)      # a device-bound step ('auto'): weight gradients on a second stream
+                try:
+                    losses = self._enqueue_step(x, y, u8, N, H, W, Cin, Cout, train)
+                finally:
+                    E._SIDE['enabled'] = False
         if train and self.gc_freeze:
             _settle_gc(self._step)
         self.host_ms = (time.perf_counter() - t_host0) * 1e3       # host time to enqueue the whole step (bench.py reports it)
@@ -386,9 +407,22 @@ class Trainer:
                 tuple(x.shape), tuple(y.shape), x.dtype, y.dtype)
         st = self._graphs.get(key)
         if st is None:
+            if key in self._graph_eager:
+                self._two_streams = True
+                return None
             seen = self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
             if seen <= self.GRAPH_WARM_STEPS:
+                if self.graph == 'auto' and seen == self.GRAPH_WARM_STEPS:
+                    self._probe = {'key': key}
                 return None
+            if self.graph == 'auto' and self._probe is not None and self._probe.get('key') == key and self._probe.get('e1') is not None:
+                pr, self._probe = self._probe, None
+                pr['e1'].synchronize()
+                dev_ms = pr['e0'].elapsed_time(pr['e1'])
+                self.step_times = (dev_ms, pr['host_ms'])
+                if dev_ms >= self.AUTO_RATIO * pr['host_ms']:
+                    self._graph_eager.add(key)          # device-bound: launch by launch (two streams in the backward passes)
+                    return None
             try:
                 st = self._capture(key, x, y, u8, dims)
             except Exception as e:          # a runtime that cannot capture this step: launch by launch from here on, loudly
@@ -438,6 +472,10 @@ class Trainer:
     def graph_captured(self):
         """True once some kind of training step runs from a captured graph (bench.py warms up until then)."""
         return bool(self._graphs)
+
+    def graph_decided(self):
+        """True once a kind of training step has been captured or ('auto') found device-bound and left launch by launch."""
+        return bool(self._graphs) or bool(self._graph_eager)
 
     # -------------------------------------------------------------------------------------- epoch driver
     def train(self, train_data, val_data, epochs, dsc_learning_rate=1.e-3, gen_learning_rate=1.e-3, save_freq=10,
