@@ -76,3 +76,34 @@ def test_graph_falls_back_where_it_cannot_apply(tmp_path):
     assert [float(l2[k]) for k in LOSS_KEYS] == [float(l2e[k]) for k in LOSS_KEYS]
     torch.cuda.synchronize()
     assert np.array_equal(t.generator.flat.cpu().numpy(), te.generator.flat.cpu().numpy())
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_auto_policy_both_outcomes_are_the_same_computation(tmp_path, precision, monkeypatch):
+    """Trainer.graph = 'auto': the last launch-by-launch warm step is timed on device and host; a device-bound step stays launch by
+    launch with the weight-gradient chain of each backward pass on a second stream (fp32 networks), a launch-bound one is captured.
+    Both outcomes, forced through AUTO_RATIO, against the plain one-stream step: bit-identical losses and weights."""
+    import patchgan_amd as pg
+    from patchgan_amd import engine as E
+    nf = 32 if precision == 'bf16' else 16
+    ref = _run(tmp_path, False, precision, 9, nf=nf, lr_change_at=6, tag='ref')
+    # device-bound by decree: never captured; from the 5th step of its kind on, two streams (fp32)
+    monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 0.0)
+    sides = []
+    orig = E._side_begin
+
+    def spy(allow):
+        orig(allow)
+        sides.append(bool(E._SIDE['allow']))
+    monkeypatch.setattr(E, '_side_begin', spy)
+    a = _run(tmp_path, 'auto', precision, 9, nf=nf, lr_change_at=6, tag='eager')
+    monkeypatch.setattr(E, '_side_begin', orig)
+    assert not any(a[3]) and a[4].graph_decided() and a[4].step_times is not None and a[4].step_times[0] > 0
+    assert any(sides) == (precision == 'fp32'), sides          # the second stream ran (fp32) / stayed off (bf16 networks)
+    assert np.array_equal(ref[0], a[0]) and np.array_equal(ref[1], a[1]) and np.array_equal(ref[2], a[2])
+    assert not E._SIDE['keep'] and not E._SIDE['enabled']
+    # launch-bound by decree: captured at the 4th step of its kind, as with graph = True
+    monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 1e9)
+    b = _run(tmp_path, 'auto', precision, 9, nf=nf, lr_change_at=6, tag='graph')
+    assert b[3][:3] == [False] * 3 and all(b[3][3:]), b[3]
+    assert np.array_equal(ref[0], b[0]) and np.array_equal(ref[1], b[1]) and np.array_equal(ref[2], b[2])
