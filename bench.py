@@ -452,10 +452,20 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
             t.batch(x, y, train=True)
         graphed, after = t.graph_captured(), t.graph_decided()
         if after and not graphed:
-            # the first two-stream steps hold every backward operand until the streams join: the caching allocator grows for a few
-            # steps (device allocations synchronise) before the pattern settles -- outside the timed region, as any warm-up
-            for _ in range(8):
-                t.batch(x, y, train=True)
+            # the first two-stream steps hold every backward operand until the streams join: the caching allocator grows for some
+            # steps (device allocations synchronise: 12-15 ms per step instead of 8.7) before the pattern settles -- outside the timed
+            # region, as any warm-up: groups of four steps until two consecutive groups take the same time (2 %), at most 48 steps
+            prev = None
+            for _ in range(12):
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+                for _ in range(4):
+                    t.batch(x, y, train=True)
+                torch.cuda.synchronize()
+                tg = time.perf_counter() - tg
+                if prev is not None and abs(tg - prev) <= 0.02 * prev:
+                    break
+                prev = tg
         E.PROFILER = None if after else (prof if events != 'none' else None)
     pd = parallel.current()
     trace = bool(os.environ.get('PATCHGAN_BENCH_TRACE'))
