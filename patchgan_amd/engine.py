@@ -158,6 +158,11 @@ def _side_begin(allow):
     _SIDE['allow'] = bool(allow) and _SIDE['enabled'] and WGRAD_SIDE and PROFILER is None and not torch.cuda.is_current_stream_capturing()
 
 
+def side_join():
+    """Join of a backward pass called with defer_join=True (no-op if nothing is pending)."""
+    _side_join()
+
+
 def _side_join():
     """The weight gradients enqueued on the second stream are complete for the current stream; their operands may be freed."""
     _SIDE['allow'] = False
@@ -967,7 +972,7 @@ class GeneratorEngine(_WeightPrep):
             src = cat
         return c
 
-    def backward(self, flat, gflat, c, g1, g2=None, need_dx=False, on_ready=None, ucache=None):
+    def backward(self, flat, gflat, c, g1, g2=None, need_dx=False, on_ready=None, ucache=None, defer_join=False):
         """g1 (+ g2): Views of dL/d(gen_out).  Writes every weight gradient into `gflat` (packed layout);
         returns dL/dx as a View if need_dx.  on_ready(lo, hi) is called after each layer's weight gradient has been
         enqueued with that layer's range of the flat buffer (last layer first): the hook data parallelism uses to
@@ -975,11 +980,19 @@ class GeneratorEngine(_WeightPrep):
         def done(l):
             if on_ready is not None:
                 on_ready(l.p_off, l.p_off + 16 * l.a * l.b)
+        # defer_join: the caller joins the second stream itself (side_join()) before it reads the weight gradients -- the trainer puts
+        # the discriminator's forward pass, which needs none of them, in between
         _side_begin(on_ready is None and not self.act_bf)       # (bf16: the two chains contend for the L1 path: 5.87 -> 5.94 ms at cfg4)
+        ok = False
         try:
-            return self._backward(flat, gflat, c, g1, g2, need_dx, done, ucache)
+            r = self._backward(flat, gflat, c, g1, g2, need_dx, done, ucache)
+            ok = True
+            return r
         finally:
-            _side_join()
+            if not (ok and defer_join):
+                _side_join()
+            else:
+                _SIDE['allow'] = False
 
     def _backward(self, flat, gflat, c, g1, g2, need_dx, done, ucache):
         N, dev = c.N, flat.device

@@ -295,7 +295,7 @@ class Trainer:
         o = dc.out
         gd = E.View.alloc(o.N, o.H, o.W, 1, dev) if train else None
         E.loss_value_and_grad(o, None, 1.0, L.LOSS_BCE, 1.0, gd, losses, 1, Bglobal)          # trainer.py:84
-        g_reducer = None
+        g_reducer, late_adam_g = None, False
         if train:
             gflat = G.ensure_grad_flat()
             ddin = de.backward(D.flat, None, dc, gd, need_wgrad=False, need_dx=True, ucache=ucache)   # dL/d(x|gen)
@@ -304,10 +304,16 @@ class Trainer:
                 # collective keeps running under the discriminator step below (which does not read G's new weights:
                 # gen_img.detach() is the pre-update output, trainer.py:98)
                 g_reducer = GradReducer(dist, gflat, self.bucket_bytes)
+            # two-stream step: G's weight gradients may still be running on the second stream when the pass returns; the
+            # discriminator's forward below needs neither them nor G's new weights (gen_img.detach() is the pre-update output,
+            # trainer.py:98), so the join and G's Adam update come after it
+            late_adam_g = bool(E._SIDE['enabled']) and g_reducer is None
             ge.backward(G.flat, gflat, gc, gseg, ddin.channels(Cin, Cout),                    # trainer.py:88-89
-                        on_ready=g_reducer.ready if g_reducer is not None else None, ucache=gcache)
+                        on_ready=g_reducer.ready if g_reducer is not None else None, ucache=gcache, defer_join=late_adam_g)
             ge.ucache_end(gcache)
-            if g_reducer is None:
+            if late_adam_g:
+                pass
+            elif g_reducer is None:
                 self._adam_step('g')                                                          # trainer.py:90
             else:
                 g_reducer.finish(launch_only=True)     # the last (first layers') bucket leaves as soon as backward has produced it
@@ -315,6 +321,9 @@ class Trainer:
 
         # ---- discriminator step: real and (pre-update, detached) fake in one 2N batch        trainer.py:96-99
         dc2 = de.forward(D.flat, din, ucache=ucache, keep_v=train)
+        if train and late_adam_g:
+            E.side_join()
+            self._adam_step('g')                                                              # trainer.py:90
         o2 = dc2.out
         god = E.View.alloc(o2.N, o2.H, o2.W, 1, dev) if train else None
         E.loss_value_and_grad(o2.samples(0, N), None, 1.0, L.LOSS_BCE, 0.5, god.samples(0, N) if train else None,
@@ -420,7 +429,8 @@ class Trainer:
                 pr['e1'].synchronize()
                 dev_ms = pr['e0'].elapsed_time(pr['e1'])
                 self.step_times = (dev_ms, pr['host_ms'])
-                if dev_ms >= self.AUTO_RATIO * pr['host_ms']:
+                ratio = float(os.environ['PATCHGAN_AUTO_RATIO']) if 'PATCHGAN_EXPERIMENT' in os.environ and 'PATCHGAN_AUTO_RATIO' in os.environ else self.AUTO_RATIO
+                if dev_ms >= ratio * pr['host_ms']:
                     self._graph_eager.add(key)          # device-bound: launch by launch (two streams in the backward passes)
                     return None
             try:
