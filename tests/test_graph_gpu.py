@@ -107,3 +107,14 @@ def test_auto_policy_both_outcomes_are_the_same_computation(tmp_path, precision,
     b = _run(tmp_path, 'auto', precision, 9, nf=nf, lr_change_at=6, tag='graph')
     assert b[3][:3] == [False] * 3 and all(b[3][3:]), b[3]
     assert np.array_equal(ref[0], b[0]) and np.array_equal(ref[1], b[1]) and np.array_equal(ref[2], b[2])
+
+
+def test_two_stream_step_at_full_width_is_bit_identical(tmp_path, monkeypatch):
+    """nf = ndf = 64 (the benchmark's widths: every Winograd path, the decoder's backward call as its two halves): the two-stream
+    launch-by-launch step against the one-stream one, 6 steps from the same start -- identical losses and weights, bit for bit."""
+    import patchgan_amd as pg
+    monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 0.0)
+    ref = _run(tmp_path, False, 'fp32', 6, nf=64, tag='w_ref')
+    two = _run(tmp_path, 'auto', 'fp32', 6, nf=64, tag='w_two')
+    assert two[4].graph_decided() and not any(two[3])
+    assert np.array_equal(ref[0], two[0]) and np.array_equal(ref[1], two[1]) and np.array_equal(ref[2], two[2])
