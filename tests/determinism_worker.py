@@ -8,6 +8,10 @@ import torch
 import patchgan_amd as pg
 
 prec = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+two_streams = prec == 'fp32-two-streams'          # fp32 with the weight gradients of each backward pass on a second stream (Trainer 'auto')
+if two_streams:
+    prec = 'fp32'
+    pg.Trainer.AUTO_RATIO = 0.0                   # every kind of step counts as device-bound: two streams from the 5th step on
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 do_clone = (sys.argv[4] if len(sys.argv) > 4 else '1') == '1'
@@ -28,6 +32,8 @@ for r in range(reps):
     g.cuda().set_precision(prec); d.cuda().set_precision(prec)
     t = pg.Trainer(g, d, tempfile.mkdtemp())
     t.loss_type = 'weighted_bce'
+    if two_streams:
+        t.graph = 'auto'
     t.setup_optimizers(1e-3, 1e-3)
     g.train(); d.train()
     rec = []

@@ -5,7 +5,8 @@ reproducible; this situation is where round 3's LDS-staged head-gradient kernel 
 early: EXPERIMENTS.md, "k_s2b_ca1_s1: cause"; the operand form itself is barred by tests/test_codeobj_cpu.py).
 Detection power: with that kernel 50 of 92 repetitions of 18 bf16 steps showed an event in this very situation, so 2 x 11 compared
 repetitions miss it with probability ~1e-7; for an effect ten times rarer the test would still catch it two times in three.
-Needs an MI355X."""
+'fp32-two-streams': the step with the weight gradients of each backward pass on a second stream (from its 5th step on): a missing
+dependency between the two streams would show as run-to-run differences exactly here.  Needs an MI355X."""
 import os
 import subprocess
 import sys
@@ -16,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+@pytest.mark.parametrize('precision', ['bf16', 'fp32', 'fp32-two-streams'])
 def test_two_concurrent_processes_are_each_bitwise_reproducible(precision):
     reps, steps = 12, 18
     cmd = [sys.executable, os.path.join(ROOT, 'tests', 'determinism_worker.py'), precision, str(reps), str(steps), '0']

@@ -8,12 +8,15 @@ import patchgan_amd as pg
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 precision = sys.argv[2] if len(sys.argv) > 2 else 'fp32'        # tools/soak.py 1000 bf16: bf16 kernels + bf16 activation storage
 torch.manual_seed(0)
-g = pg.UNet(3, 1, 64, use_dropout=True, activation='leakyrelu', final_act='sigmoid').cuda()
+g = pg.UNet(3, 1, 64, use_dropout=os.environ.get('SOAK_DROPOUT', '1') != '0', activation='leakyrelu', final_act='sigmoid').cuda()
 d = pg.Discriminator(4, 64, n_layers=3).cuda()
 g.set_precision(precision)
 d.set_precision(precision)
 t = pg.Trainer(g, d, tempfile.mkdtemp())
 t.gc_freeze = True
+t.graph = os.environ.get('SOAK_GRAPH', 'auto')          # 'auto' (dropout off: SOAK_DROPOUT=0) / '' = launch by launch on one stream
+if t.graph == '':
+    t.graph = False
 t.setup_optimizers(2e-4, 2e-4)
 g.train(); d.train()
 gen = torch.Generator(device='cuda').manual_seed(1)
@@ -29,7 +32,7 @@ for s in range(1, steps + 1):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         blocks.append({'step': s, 'img_per_s': round(1600 / dt, 1), 'gen': round(l['gen'], 4), 'disc': round(l['disc'], 4),
-                       'mem_GiB': round(torch.cuda.memory_allocated() / 2**30, 3), 'peak_GiB': round(torch.cuda.max_memory_allocated() / 2**30, 3)})
+                       'mem_GiB': round(torch.cuda.memory_allocated() / 2**30, 3), 'reserved_GiB': round(torch.cuda.memory_reserved() / 2**30, 3), 'peak_GiB': round(torch.cuda.max_memory_allocated() / 2**30, 3)})
         print(blocks[-1], flush=True)
         t0 = time.perf_counter()
 print(json.dumps({'finite': ok, 'blocks': len(blocks)}))
