@@ -106,6 +106,12 @@ def test_hot_kernels_keep_the_occupancy_they_were_tuned_at():
             if waves(k) < 4 or k['.private_segment_fixed_size'] > 0 or wgs * k['.group_segment_fixed_size'] > 160 * 1024:
                 bad[n] = (waves(k), 4, k['.private_segment_fixed_size'], k['.group_segment_fixed_size'])
             seen['bf16 OCC4'] = seen.get('bf16 OCC4', 0) + 1
+        # the window-staged bf16 kernel: two workgroups per CU -- <= 256 registers, NO scratch (its main loop keeps four fragment sets
+        # and 64 accumulators live: a spill lands in the loop), two workgroups' LDS within the CU's 160 KB
+        if 'k_conv_bf16r' in n:
+            if waves(k) < 2 or k['.private_segment_fixed_size'] > 0 or 2 * k['.group_segment_fixed_size'] > 160 * 1024:
+                bad[n] = (waves(k), 2, k['.private_segment_fixed_size'], k['.group_segment_fixed_size'])
+            seen['bf16 window'] = seen.get('bf16 window', 0) + 1
     assert all(v > 0 for v in seen.values()), seen
-    assert seen['bf16 OCC4'] >= 10, seen
+    assert seen['bf16 OCC4'] >= 10 and seen.get('bf16 window', 0) >= 10, seen
     assert not bad, bad
