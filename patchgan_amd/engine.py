@@ -143,7 +143,7 @@ _WS = {}
 # bf16 networks and inside a hipGraph capture; it costs ~0.6 ms of host time per step (26 stream hand-overs), so it pays where the device
 # step is several times the host's enqueue time (Trainer.graph = 'auto' measures both and picks: cfg2 fp32 8.95 -> 8.65 ms, cfg4 fp32
 # 16.7 -> 16.5; cfg1's 2.9-ms step stays on the captured graph).
-_SIDE = {'enabled': False, 'allow': False, 'stream': None, 'keep': [], 'in': False}      # enabled: by the caller, per step (Trainer, 'auto')
+_SIDE = {'enabled': False, 'allow': False, 'stream': None, 'keep': [], 'in': False, 'pending': False}      # enabled: by the caller, per step (Trainer, 'auto')
 
 
 def side_stream():
@@ -153,22 +153,45 @@ def side_stream():
     return _SIDE['stream']
 
 
+class on_side:
+    """`with on_side():` -- what is enqueued inside goes to the second stream (after everything enqueued so far), with that stream's
+    own workspace; the caller joins with side_join() before it reads the results on its own stream.  Tensors allocated inside belong
+    to the second stream's allocator pool: safe as long as every later use on the second stream is again behind such a hand-over
+    (it is: each one starts with wait_stream)."""
+    def __enter__(self):
+        side = side_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        self._ctx = torch.cuda.stream(side)
+        self._ctx.__enter__()
+        self._was = _SIDE['in']
+        _SIDE['in'] = _SIDE['pending'] = True
+        return side
+
+    def __exit__(self, *exc):
+        _SIDE['in'] = self._was
+        return self._ctx.__exit__(*exc)
+
+
 def _side_begin(allow):
     # (not inside a hipGraph capture: a captured two-branch step replays SLOWER than the one-stream one, 9.03 vs 8.96 ms at cfg2)
     _SIDE['allow'] = bool(allow) and _SIDE['enabled'] and WGRAD_SIDE and PROFILER is None and not torch.cuda.is_current_stream_capturing()
 
 
 def side_join():
-    """Join of a backward pass called with defer_join=True (no-op if nothing is pending)."""
-    _side_join()
+    """The caller's join: of a backward pass called with defer_join=True and of anything enqueued under on_side() (no-op if nothing
+    is pending)."""
+    _side_join(True)
 
 
-def _side_join():
-    """The weight gradients enqueued on the second stream are complete for the current stream; their operands may be freed."""
+def _side_join(explicit=False):
+    """The weight gradients enqueued on the second stream are complete for the current stream; their operands may be freed.  (The
+    join at the end of a backward pass does not wait for work the CALLER put on the second stream under on_side(): only the caller's
+    own side_join() does.)"""
     _SIDE['allow'] = False
-    if _SIDE['keep']:
+    if _SIDE['keep'] or (explicit and _SIDE['pending']):
         torch.cuda.current_stream().wait_stream(_SIDE['stream'])
         _SIDE['keep'].clear()
+        _SIDE['pending'] = False
 
 
 def _workspace(nbytes, device):

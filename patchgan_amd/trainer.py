@@ -32,6 +32,7 @@ from .parallel import current as _dist, GradReducer
 device = 'cuda' if torch.cuda.is_available() else 'cpu'
 
 _LOSS_MODES = {'tversky': L.LOSS_TVERSKY, 'weighted_bce': L.LOSS_WBCE, 'MAE': L.LOSS_MAE}
+EARLY_D_FWD = E._exp_env('PATCHGAN_EARLY_D_FWD') != '0'      # two-stream step: the discriminator step's forward under the generator step (A/B switch)
 
 
 _GC_FREEZES = 0
@@ -288,6 +289,13 @@ class Trainer:
         # D's weights do not change until the Adam step at the end of this call: its Winograd-transformed weights are computed
         # once per (layer, direction) and shared by the passes below through this per-step cache
         ucache = de.ucache_begin(D.flat, N, H, W, tag=bool(train))
+        # two-stream step: the discriminator step's forward over din[2N] (trainer.py:96-99) needs only the generator's OUTPUT and D's
+        # weights, both final here -- it is enqueued on the second stream now and runs under the rest of the generator step (same
+        # kernels, same 2N plan: bit-identical); joined where the discriminator step reads its output
+        dc2 = None
+        if train and E._SIDE['enabled'] and E.PROFILER is None and not dist.on and not de.act_bf and not ge.act_bf and EARLY_D_FWD:
+            with E.on_side():
+                dc2 = de.forward(D.flat, din, ucache=ucache, keep_v=True)
         dc = de.forward(D.flat, fake, ucache=ucache)                                          # trainer.py:66
         gseg = E.View.alloc(N, H, W, Cout, dev) if train else None
         E.loss_finish(seg_pending, _LOSS_MODES[self.loss_type], float(self.seg_alpha), gseg, losses, 0, Bglobal,
@@ -320,9 +328,11 @@ class Trainer:
         del dc
 
         # ---- discriminator step: real and (pre-update, detached) fake in one 2N batch        trainer.py:96-99
-        dc2 = de.forward(D.flat, din, ucache=ucache, keep_v=train)
-        if train and late_adam_g:
+        if dc2 is None:
+            dc2 = de.forward(D.flat, din, ucache=ucache, keep_v=train)
+        if train and (late_adam_g or E._SIDE['pending']):
             E.side_join()
+        if train and late_adam_g:
             self._adam_step('g')                                                              # trainer.py:90
         o2 = dc2.out
         god = E.View.alloc(o2.N, o2.H, o2.W, 1, dev) if train else None
