@@ -294,8 +294,13 @@ class Trainer:
         # kernels, same 2N plan: bit-identical); joined where the discriminator step reads its output
         dc2 = None
         if train and E._SIDE['enabled'] and E.PROFILER is None and not dist.on and not de.act_bf and not ge.act_bf and EARLY_D_FWD:
+            n_prepared = len(ucache)
             with E.on_side():
                 dc2 = de.forward(D.flat, din, ucache=ucache, keep_v=True)
+            if len(ucache) != n_prepared:
+                # (a transformed-weight entry the batched preparation did not cover was made by a kernel on the second stream -- the
+                #  first steps after a change of tuning: the passes below would take it as ready, so they wait for it this once)
+                E.side_join()
         dc = de.forward(D.flat, fake, ucache=ucache)                                          # trainer.py:66
         gseg = E.View.alloc(N, H, W, Cout, dev) if train else None
         E.loss_finish(seg_pending, _LOSS_MODES[self.loss_type], float(self.seg_alpha), gseg, losses, 0, Bglobal,
