@@ -351,7 +351,9 @@ def main():
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(m['ms_per_step'], 3), 'host_enqueue_ms_per_step': round(m['host_ms_per_step'], 3),
             'step_launch': ('hipGraph replay of the captured step' if m['graph'] else
-                            'launch by launch, the weight gradients of each backward pass on a second stream' if m['two_streams'] else 'launch by launch')
+                            'launch by launch, the weight gradients of each backward pass and the discriminator step\'s forward on a second stream'
+                            if m['two_streams'] == 'fp32' else
+                            'launch by launch, the discriminator step\'s forward on a second stream' if m['two_streams'] == 'bf16' else 'launch by launch')
                            + (f" (auto: device {m['step_times'][0]:.2f} ms vs host enqueue {m['step_times'][1]:.2f} ms per step)" if m.get('step_times') else ''),
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
@@ -548,7 +550,7 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
-    res = {'comm': comm, 'elapsed': elapsed, 'graph': graphed, 'two_streams': after and not graphed and E.WGRAD_SIDE and not G.engine.act_bf,
+    res = {'comm': comm, 'elapsed': elapsed, 'graph': graphed, 'two_streams': (after and not graphed) and ('fp32' if not G.engine.act_bf else 'bf16'),
            'step_times': t.step_times}
     if rank != 0:
         return res

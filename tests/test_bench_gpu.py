@@ -38,7 +38,7 @@ def test_bench_single_gpu_line():
         m = re.search(r'auto: device ([0-9.]+) ms vs host enqueue ([0-9.]+) ms', o['step_launch'])
         assert m, o['step_launch']
         eager = float(m.group(1)) >= 2.5 * float(m.group(2))
-        assert o['step_launch'].startswith('launch by launch, the weight gradients' if eager else 'hipGraph'), o['step_launch']
+        assert o['step_launch'].startswith('launch by launch, the weight gradients of each backward pass and the discriminator' if eager else 'hipGraph'), o['step_launch']
         return eager
     assert out['roofline']['launches_timed'] >= 8
     eager2 = decided(out)

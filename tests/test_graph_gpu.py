@@ -96,10 +96,19 @@ def test_auto_policy_both_outcomes_are_the_same_computation(tmp_path, precision,
         orig(allow)
         sides.append(bool(E._SIDE['allow']))
     monkeypatch.setattr(E, '_side_begin', spy)
+    forks = []
+    enter = E.on_side.__enter__
+
+    def spy_enter(self):
+        forks.append(1)
+        return enter(self)
+    monkeypatch.setattr(E.on_side, '__enter__', spy_enter)
     a = _run(tmp_path, 'auto', precision, 9, nf=nf, lr_change_at=6, tag='eager')
     monkeypatch.setattr(E, '_side_begin', orig)
+    monkeypatch.setattr(E.on_side, '__enter__', enter)
+    assert len(forks) >= 4, forks          # the discriminator step's forward went to the second stream (both precisions), steps 5..9
     assert not any(a[3]) and a[4].graph_decided() and a[4].step_times is not None and a[4].step_times[0] > 0
-    assert any(sides) == (precision == 'fp32'), sides          # the second stream ran (fp32) / stayed off (bf16 networks)
+    assert any(sides) == (precision == 'fp32'), sides          # weight gradients on the second stream: fp32 networks only
     assert np.array_equal(ref[0], a[0]) and np.array_equal(ref[1], a[1]) and np.array_equal(ref[2], a[2])
     assert not E._SIDE['keep'] and not E._SIDE['enabled']
     # launch-bound by decree: captured at the 4th step of its kind, as with graph = True
