@@ -405,9 +405,10 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
     t = pg.Trainer(G, D, tempfile.mkdtemp(prefix='pgbench_'))
     t.loss_type, t.seg_alpha = cfg['loss_type'], 200
     t.gc_freeze = True            # as the patchgan_train entry point does (trainer._settle_gc): opt-in, process-global
-    # as the patchgan_train entry point: a launch-bound steady-state step is replayed from a captured hipGraph, a device-bound one stays
-    # launch by launch with the fp32 weight gradients on a second stream (Trainer.graph = 'auto' measures and decides)
-    t.graph = 'auto' if (graph and not use_dist and not dropout) else False
+    # as the patchgan_train entry point: a launch-bound steady-state step is replayed from a captured hipGraph (one GPU, dropout off), a
+    # device-bound one stays launch by launch with the fp32 weight gradients on a second stream -- also with dropout and under data
+    # parallelism (Trainer.graph = 'auto' measures and decides per kind of step)
+    t.graph = 'auto' if graph else False
     t.setup_optimizers(1e-3, 1e-3)
     G.train()
     D.train()
@@ -453,7 +454,9 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
                 break
             t.batch(x, y, train=True)
         graphed, after = t.graph_captured(), t.graph_decided()
-        if after and not graphed:
+        two = 'eager2' in t.decided_modes()
+        after = graphed or two          # (decided 'eager1': nothing to settle, the timed steps carry the launch profiler as before)
+        if two:
             # the first two-stream steps hold every backward operand until the streams join: the caching allocator grows for some
             # steps (device allocations synchronise: 12-15 ms per step instead of 8.7) before the pattern settles -- outside the timed
             # region, as any warm-up: groups of four steps until two consecutive groups take the same time (2 %), at most 48 steps
@@ -551,7 +554,9 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     res = {'comm': comm, 'elapsed': elapsed, 'graph': graphed, 'two_streams': (after and not graphed) and ('fp32' if not G.engine.act_bf else 'bf16'),
-           'step_times': t.step_times}
+           'step_times': t.step_times, 'peak_vram_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 3)}
+    last_vals = {k: round(v, 5) for k, v in last.items()} if last is not None else None
+    t.release()                    # this trainer's captured steps, workspaces and second stream go back to the allocator
     if rank != 0:
         return res
     value = batch * world * steps / elapsed
@@ -578,7 +583,7 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
     res.update({
         'value': value, 'ms_per_step': elapsed / steps * 1e3, 'host_ms_per_step': host_ms / steps,
         'activation_storage': 'bf16' if (dtype == 'bf16' and G.engine.act_bf) else 'f32',
-        'last_losses': {k: round(v, 5) for k, v in last.items()},
+        'last_losses': last_vals,
         'roofline': {'bound': 'mfma', 'kernel': sym,
                      'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': round(achieved / peak, 4), 'achieved_useful': round(useful, 2), 'frac_useful': round(useful / peak, 4),
@@ -633,10 +638,27 @@ def extra_configs(dev, cpu=True):
     except Exception as e:          # the headline line must not be lost to an extra
         out['cfg4_bf16'] = {'error': f'{type(e).__name__}: {e}'}
     try:
-        import patchgan_amd as pg
-        from patchgan_amd.infer import predict_image
+        # the reference CLI's DEFAULT generator (train.py:92: use_dropout=True, unet.py:26-28,63-65) at cfg2 in fp32: per-layer dropout
+        # seeds are launch arguments, so the step cannot be captured -- it runs launch by launch on two streams like the headline
         gc.collect()
         torch.cuda.empty_cache()
+        m = measure_training(CONFIGS['cfg2'], 'f32', 10, 5, dev, dropout=True, events='none')
+        out['cfg2_dropout_on'] = {
+            'workload': CONFIGS['cfg2']['desc'] + ', dropout ON (nn.Dropout(0.2) in 7 encoder + 5 decoder blocks: the patchgan_train default)',
+            'metric': 'train images/sec (G+D step) at 256x256 bs=16 per GPU', 'value': round(m['value'], 2), 'unit': 'images/sec',
+            'steps': 10, 'warmup': 5, 'ms_per_step': round(m['ms_per_step'], 3), 'dtype': 'f32',
+            'step_launch': 'two streams' if m['two_streams'] else ('graph' if m['graph'] else 'one stream'), 'last_losses': m['last_losses']}
+        del m
+    except Exception as e:
+        out['cfg2_dropout_on'] = {'error': f'{type(e).__name__}: {e}'}
+    try:
+        import patchgan_amd as pg
+        from patchgan_amd import engine as E
+        from patchgan_amd.infer import predict_image
+        gc.collect()
+        E.release_workspaces()
+        torch.cuda.empty_cache()
+        base_GiB = torch.cuda.memory_allocated() / 2 ** 30          # what earlier legs still hold (0 when they released everything)
         torch.manual_seed(1234)
         G = pg.UNet(3, 1, 64, use_dropout=False, activation='leakyrelu', final_act='sigmoid').to(dev).eval()
         img = torch.rand(3, 1024, 1024, generator=torch.Generator().manual_seed(5)).to(dev)
@@ -655,6 +677,7 @@ def extra_configs(dev, cpu=True):
                        'metric': 'tiles/sec', 'value': round(25 / dt, 1), 'unit': 'tiles/sec', 'images': n,
                        'ms_per_image': round(dt * 1e3, 3), 'dtype': 'f32',
                        'peak_vram_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 3),
+                       'vram_held_by_earlier_legs_GiB': round(base_GiB, 3),
                        'mask_positive_fraction': round(float(mask.mean()), 4)}
         # the generator forward's direct-convolution work (190.589 GFLOP per 16 images of 256x256 at nf = 64) over the
         # whole predict_image call (gather, 25 forwards, blend, device -> host copy of the mask), against the fp32 MFMA peak

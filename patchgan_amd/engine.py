@@ -18,6 +18,7 @@ Nothing here touches autograd; `patchgan_amd.unet` / `.disc` wrap the engines in
 import ctypes
 import os
 import math
+import threading
 
 import numpy as np
 
@@ -127,30 +128,109 @@ class View:
 
 
 # ------------------------------------------------------------------------------------------------
-# workspace (split-K slabs): one growing buffer per device; all launches are stream-ordered
+# execution state: workspaces (split-K slabs) and the second stream, owned by whoever drives the engines
 # ------------------------------------------------------------------------------------------------
-_WS = {}
-
-
 # Weight gradients on a second stream.  Inside a network's backward pass a layer's weight gradient and its data gradient both start
 # from dy and are independent of each other; enqueued on one stream their kernels run strictly one after the other, and every kernel
 # whose grid is one round of workgroups loses its ramp, its lock-step prologue / epilogue phases and its tail (EXPERIMENTS.md, "the fp32
 # polyphase GEMM's tile life": ~15-20 % of such a launch).  With the weight-gradient chain on a second stream (its own workspace) the
 # two chains' kernels fill each other's gaps: cfg2 fp32 8.85 -> 8.68 ms per step with only the encoder's and the discriminator's
 # weight gradients moved.  Same kernels, same order of every floating-point sum: bit-identical results.  The operands are referenced
-# until the streams join at the end of the backward pass (the caching allocator must not hand them out meanwhile).  Off under data
-# parallelism (the bucket all-reduce of a layer's gradient is launched as soon as that layer is done), under the launch profiler, for
-# bf16 networks and inside a hipGraph capture; it costs ~0.6 ms of host time per step (26 stream hand-overs), so it pays where the device
-# step is several times the host's enqueue time (Trainer.graph = 'auto' measures both and picks: cfg2 fp32 8.95 -> 8.65 ms, cfg4 fp32
-# 16.7 -> 16.5; cfg1's 2.9-ms step stays on the captured graph).
-_SIDE = {'enabled': False, 'allow': False, 'stream': None, 'keep': [], 'in': False, 'pending': False}      # enabled: by the caller, per step (Trainer, 'auto')
+# until the streams join at the end of the backward pass (the caching allocator must not hand them out meanwhile).  Off under the
+# launch profiler, for bf16 networks' weight gradients and inside a hipGraph capture; it costs ~0.6 ms of host time per step (26 stream
+# hand-overs), so it pays where the device step is several times the host's enqueue time (the Trainer measures both and picks: cfg2
+# fp32 8.95 -> 8.65 ms, cfg4 fp32 16.7 -> 16.5; cfg1's 2.9-ms step stays on the captured graph).
 
 
-def side_stream():
-    """The second stream of a two-stream step (created on first use)."""
-    if _SIDE['stream'] is None:
-        _SIDE['stream'] = torch.cuda.Stream()
-    return _SIDE['stream']
+class Exec:
+    """Execution state of ONE driver of the engines (a Trainer; or a device's default for stand-alone module calls): the split-K
+    workspace per stream and the second stream of a two-stream step with its book-keeping.  Nothing in here is shared between
+    owners -- two Trainers (also on different GPUs, also on different threads) never see each other's stream, flags or buffers,
+    and everything is released with the owner (or by release()).
+
+      enabled   set by the owner per step: this step may use the second stream
+      allow     inside a backward pass: weight gradients go to the second stream
+      inside    what is enqueued right now goes to the second stream (its own workspace)
+      pending   something was enqueued under on_side() and has not been joined
+      keep      operands of second-stream launches, referenced until the join
+      ws_gen    counts workspace (re)allocations: a captured graph holds the buffers it was captured with (Trainer._capture)"""
+
+    def __init__(self, device=None):
+        self.device = torch.device(device) if device is not None else None
+        self.enabled = self.allow = self.inside = self.pending = False
+        self.stream = None
+        self.keep = []
+        self.keep_bytes = 0
+        self.ws = {}
+        self.ws_gen = 0
+
+    def side_stream(self):
+        """The second stream of a two-stream step, created on first use ON THE OWNER'S DEVICE."""
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=self.device)
+        return self.stream
+
+    def workspace(self, nbytes, device):
+        if self.device is not None and device != self.device:
+            raise RuntimeError(f'patchgan_amd: engine call on {device} under an execution state bound to {self.device}')
+        ws = self.ws.get(self.inside)
+        if ws is None or ws.numel() < nbytes:
+            ws = self.ws[self.inside] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self.ws_gen += 1
+        return ws
+
+    def buffers(self):
+        """The device buffers launches under this state write into besides their arguments (what a captured graph must keep alive)."""
+        return list(self.ws.values())
+
+    def release(self):
+        """Give the workspaces back to the allocator (the second stream is joined first)."""
+        if self.stream is not None and (self.keep or self.pending):
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self.keep.clear()
+        self.keep_bytes = 0
+        self.pending = self.allow = self.inside = False
+        self.ws.clear()
+        self.ws_gen += 1
+
+    def __enter__(self):
+        self._prev = getattr(_TLS, 'cur', None)
+        _TLS.cur = self
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.cur = self._prev
+        return False
+
+
+_TLS = threading.local()
+_DEFAULT_EXEC = {}       # device index -> Exec of stand-alone module calls (UNet(...)(x), predict_image): one workspace, never a second stream
+
+
+def cur_exec(device=None):
+    """The execution state of the running driver (`with exec:`), or the device's default one for stand-alone module calls."""
+    ex = getattr(_TLS, 'cur', None)
+    if ex is not None:
+        return ex
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    ex = _DEFAULT_EXEC.get(device.index)
+    if ex is None:
+        ex = _DEFAULT_EXEC[device.index] = Exec(device)
+    return ex
+
+
+def release_workspaces():
+    """Free the default execution states' workspaces (stand-alone module calls; a Trainer's go with the Trainer or by
+    Trainer.release())."""
+    for ex in _DEFAULT_EXEC.values():
+        ex.release()
+    _DEFAULT_EXEC.clear()
+
+
+# the owner joins every KEEP_LIMIT_BYTES of operands held for the second stream (ADVICE r4: with defer_join nearly all backward
+# temporaries of a pass were live at once; joining costs one stream wait, ~10 us)
+KEEP_LIMIT_BYTES = 3 << 30
 
 
 class on_side:
@@ -159,22 +239,24 @@ class on_side:
     to the second stream's allocator pool: safe as long as every later use on the second stream is again behind such a hand-over
     (it is: each one starts with wait_stream)."""
     def __enter__(self):
-        side = side_stream()
+        ex = self._ex = cur_exec()
+        side = ex.side_stream()
         side.wait_stream(torch.cuda.current_stream())
         self._ctx = torch.cuda.stream(side)
         self._ctx.__enter__()
-        self._was = _SIDE['in']
-        _SIDE['in'] = _SIDE['pending'] = True
+        self._was = ex.inside
+        ex.inside = ex.pending = True
         return side
 
     def __exit__(self, *exc):
-        _SIDE['in'] = self._was
+        self._ex.inside = self._was
         return self._ctx.__exit__(*exc)
 
 
 def _side_begin(allow):
     # (not inside a hipGraph capture: a captured two-branch step replays SLOWER than the one-stream one, 9.03 vs 8.96 ms at cfg2)
-    _SIDE['allow'] = bool(allow) and _SIDE['enabled'] and WGRAD_SIDE and PROFILER is None and not torch.cuda.is_current_stream_capturing()
+    ex = cur_exec()
+    ex.allow = bool(allow) and ex.enabled and WGRAD_SIDE and PROFILER is None and not torch.cuda.is_current_stream_capturing()
 
 
 def side_join():
@@ -187,20 +269,24 @@ def _side_join(explicit=False):
     """The weight gradients enqueued on the second stream are complete for the current stream; their operands may be freed.  (The
     join at the end of a backward pass does not wait for work the CALLER put on the second stream under on_side(): only the caller's
     own side_join() does.)"""
-    _SIDE['allow'] = False
-    if _SIDE['keep'] or (explicit and _SIDE['pending']):
-        torch.cuda.current_stream().wait_stream(_SIDE['stream'])
-        _SIDE['keep'].clear()
-        _SIDE['pending'] = False
+    ex = cur_exec()
+    ex.allow = False
+    if ex.keep or (explicit and ex.pending):
+        torch.cuda.current_stream().wait_stream(ex.stream)
+        ex.keep.clear()
+        ex.keep_bytes = 0
+        ex.pending = False
+
+
+def side_producers():
+    """Streams besides the current one that may still be writing weight gradients (data parallelism: the bucket all-reduce waits
+    for them too, parallel.Dist.all_reduce_side)."""
+    ex = cur_exec()
+    return [ex.stream] if (ex.stream is not None and (ex.keep or ex.pending)) else []
 
 
 def _workspace(nbytes, device):
-    key = (device.type, device.index, _SIDE['in'])
-    ws = _WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _WS[key] = ws
-    return ws
+    return cur_exec(device).workspace(nbytes, device)
 
 
 class LaunchProfiler:
@@ -451,19 +537,26 @@ class ConvOp:
                 L.check(L.load().pg_conv4x4_wgrad(*args), 'pg_conv4x4_wgrad')
             else:
                 L.check(L.load().pg_conv4x4_wgrad_x(*args, ctypes.byref(x)), 'pg_conv4x4_wgrad_x')
-        if _SIDE['allow']:
-            # on the second stream (see _SIDE): after everything enqueued so far (dy is ready), with that stream's own workspace
-            side = side_stream()
+        ex = cur_exec(dP.device)
+        if ex.allow:
+            # on the second stream (see Exec): after everything enqueued so far (dy is ready), with that stream's own workspace
+            side = ex.side_stream()
             side.wait_stream(torch.cuda.current_stream())
-            _SIDE['keep'].append((small.t, big.t, v_pre, dP))
-            _SIDE['in'] = True
+            ex.keep.append((small.t, big.t, v_pre, dP))
+            ex.keep_bytes += small.t.numel() * small.t.element_size() + big.t.numel() * big.t.element_size()
+            was, ex.inside = ex.inside, True
             try:
                 with torch.cuda.stream(side):
                     wp2, wn2 = self._ws(dP.device)
                     args = args[:8] + (wp2, wn2, _stream())
                     go()
             finally:
-                _SIDE['in'] = False
+                ex.inside = was
+            if ex.keep_bytes > KEEP_LIMIT_BYTES:
+                # bound what the second stream keeps alive: an intermediate join (the chains re-synchronise once; same results)
+                torch.cuda.current_stream().wait_stream(side)
+                ex.keep.clear()
+                ex.keep_bytes = 0
             return
         PROFILER.launch(self, 2, go, self._io(big, small)) if PROFILER is not None else go()
 
@@ -624,7 +717,7 @@ CACHE_U = _exp_env('PATCHGAN_CACHE_U') != '0'                 # per-step cache o
 PREP_BATCH = _exp_env('PATCHGAN_PREP_BATCH') != '0'           # one batched weight-preparation launch per network and step
 FUSE_ACT_BWD = _exp_env('PATCHGAN_FUSE_ACT_BWD') != '0'       # activation backward in the data-gradient epilogue above it
 SEAM8 = _exp_env('PATCHGAN_SEAM8') != '0'       # bf16 storage: image-facing tensors in 8-channel bf16 pixels
-WGRAD_SIDE = _exp_env('PATCHGAN_WGRAD_SIDE') != '0'       # weight gradients of a backward pass on a second stream (_SIDE)
+WGRAD_SIDE = _exp_env('PATCHGAN_WGRAD_SIDE') != '0'       # weight gradients of a backward pass on a second stream (Exec)
 SPLIT_BWD_BIG = _exp_env('PATCHGAN_SPLIT_BWD_BIG') != '0'       # with the second stream: the decoder's fused backward call as its two halves (8.83 -> 8.65 ms at cfg2)
 
 
@@ -1005,7 +1098,7 @@ class GeneratorEngine(_WeightPrep):
                 on_ready(l.p_off, l.p_off + 16 * l.a * l.b)
         # defer_join: the caller joins the second stream itself (side_join()) before it reads the weight gradients -- the trainer puts
         # the discriminator's forward pass, which needs none of them, in between
-        _side_begin(on_ready is None and not self.act_bf)       # (bf16: the two chains contend for the L1 path: 5.87 -> 5.94 ms at cfg4)
+        _side_begin(not self.act_bf)       # (bf16: the two chains contend for the L1 path: 5.87 -> 5.94 ms at cfg4)
         ok = False
         try:
             r = self._backward(flat, gflat, c, g1, g2, need_dx, done, ucache)
@@ -1015,7 +1108,7 @@ class GeneratorEngine(_WeightPrep):
             if not (ok and defer_join):
                 _side_join()
             else:
-                _SIDE['allow'] = False
+                cur_exec().allow = False
 
     def _backward(self, flat, gflat, c, g1, g2, need_dx, done, ucache):
         N, dev = c.N, flat.device
@@ -1049,7 +1142,7 @@ class GeneratorEngine(_WeightPrep):
             src = c.hidden if i == 0 else c.cat[i]
             dsrc = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=bf)
             u, uv = _ucache(ucache, ('d', i), 0, op, dev, dy, dsrc, l.p_off)
-            if (u is not None and bf) or (SPLIT_BWD_BIG and _SIDE['allow']):      # bf16 tensors: the two halves as two calls, the data gradient on the forward's packed weights
+            if (u is not None and bf) or (SPLIT_BWD_BIG and cur_exec().allow):      # bf16 tensors: the two halves as two calls, the data gradient on the forward's packed weights
                 op.wgrad(src, dy, gflat, l.p_off)
                 op.big2small(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
             else:

@@ -50,10 +50,11 @@ class Dist:
             self._comm = torch.cuda.Stream(device=device)
         return self._comm
 
-    def all_reduce_side(self, t):
-        """SUM all-reduce of `t` ordered after everything enqueued so far on the current stream, without holding that
-        stream up.  Returns wait(): call it (on the stream that consumes `t`) before the result is read.  Device
-        tensors go through the comm stream; host tensors (gloo CPU tests) through an async work handle."""
+    def all_reduce_side(self, t, producers=()):
+        """SUM all-reduce of `t` ordered after everything enqueued so far on the current stream (and on every stream in
+        `producers`: a two-stream step writes weight gradients on its second stream), without holding that stream up.
+        Returns wait(): call it (on the stream that consumes `t`) before the result is read.  Device tensors go through
+        the comm stream; host tensors (gloo CPU tests) through an async work handle."""
         if not self.on:
             return lambda: None
         if not t.is_cuda:
@@ -64,6 +65,8 @@ class Dist:
         ready.record()                                   # behind the producer kernels on the compute stream
         with torch.cuda.stream(comm):
             comm.wait_event(ready)
+            for p in producers:
+                comm.wait_stream(p)
             if self.timing is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -136,8 +139,9 @@ class GradReducer:
     """Bucketed, asynchronous SUM all-reduce of a flat gradient buffer that is filled from its END towards its START
     (backward visits layers last to first, and the flat buffer is laid out first layer to last)."""
 
-    def __init__(self, dist, flat, bucket_bytes=32 << 20):
-        self.dist, self.flat = dist, flat
+    def __init__(self, dist, flat, bucket_bytes=32 << 20, producers=None):
+        """producers(): streams besides the current one that may hold a ready range's last writes (engine.side_producers)."""
+        self.dist, self.flat, self.producers = dist, flat, producers
         self.bucket_elems = max(1, bucket_bytes // flat.element_size())
         self.hi = flat.numel()      # everything in [hi, numel) has been handed to a collective
         self.lo = flat.numel()      # everything in [lo, hi) is ready but not yet launched
@@ -155,7 +159,9 @@ class GradReducer:
 
     def _launch(self):
         if self.lo < self.hi:
-            self.waits.append(self.dist.all_reduce_side(self.flat[self.lo:self.hi]))
+            extra = self.producers() if (self.producers is not None and self.flat.is_cuda) else ()
+            self.waits.append(self.dist.all_reduce_side(self.flat[self.lo:self.hi], extra) if extra else
+                              self.dist.all_reduce_side(self.flat[self.lo:self.hi]))
             self.launched.append((self.lo, self.hi))
             self.hi = self.lo
 

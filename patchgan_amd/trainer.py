@@ -151,14 +151,23 @@ class Trainer:
     neptune_config = None
     label_values = None      # label list of the dataset, only for the uint8 (device-side) input path of batch()
     gc_freeze = False        # opt-in: gc.collect() + gc.freeze() after training steps 1 and 3 (_settle_gc; process-global)
-    graph = False            # opt-in: True = replay the steady-state training step from a captured hipGraph (_batch_graph); 'auto' = only where the step is launch-bound
-    GRAPH_WARM_STEPS = 3     # eager steps of a given kind before it is captured (kernel plans, weight-cache plans, workspaces settle)
-    # graph = 'auto': the last eager warm step of a kind is timed on the device (one event pair, one wait for it) and on the host; the
-    # step is captured only if the device time is < AUTO_RATIO x the host's enqueue time (a launch-bound step: cfg1).  A device-bound
-    # step stays launch by launch, where fp32 networks run their weight gradients on a second stream (engine._SIDE): a captured
-    # two-stream step replays slower than a one-stream one, and the launch-by-launch two-stream step is faster than either.
+    # How a step is launched (decided per KIND of step: shapes, loss settings, precision / tuning, train / eval):
+    #   graph        False | True | 'auto'  -- replay the steady-state TRAINING step from a captured hipGraph (_replay): 220 launches become
+    #                one hipGraphLaunch (host 1.9 -> 0.1 ms per step).  Only single-GPU steps without dropout can be captured.
+    #   two_streams  None | False | True | 'auto'  -- launch by launch with each backward pass's weight-gradient chain (fp32 networks) and
+    #                the discriminator step's forward pass on a second stream (engine.Exec).  Independent of capture: dropout, evaluation
+    #                passes and data-parallel steps take it too.  None = follows `graph` ('auto' with graph = 'auto', else off).
+    # 'auto': PROBE_STEPS warm steps of a kind are timed on the device (one event pair each) and on the host; a device-bound kind (device
+    # time >= AUTO_RATIO x the host's enqueue time: cfg2, cfg4) runs on two streams, a launch-bound one (cfg1: 2.94 vs 1.80 ms) is
+    # captured where capture applies.  A captured two-stream step replays slower than a one-stream one, and the launch-by-launch
+    # two-stream step is faster than either, hence never both.
+    graph = False
+    two_streams = None
+    GRAPH_WARM_STEPS = 3     # eager steps of a given kind before it is captured / decided (kernel plans, weight-cache plans, workspaces settle)
+    PROBE_STEPS = 2          # 'auto': the last PROBE_STEPS warm steps are timed; minimum host time and minimum device time decide
     AUTO_RATIO = 2.5
     MAX_GRAPHS = 2           # captured kinds of step kept (each holds its activations: ~4 GB at cfg2)
+    MAX_KINDS = 16           # kinds of step whose launch decision is remembered
 
     def __init__(self, generator, discriminator, savefolder, device='cuda'):
         generator.apply(weights_init)
@@ -178,8 +187,9 @@ class Trainer:
         self._step = 0
         self._pending_d = None
         self.bucket_bytes = 32 << 20   # all-reduce bucket size under data parallelism (parallel.GradReducer)
-        self._graphs, self._graph_seen, self._adam_dev = {}, {}, None
-        self._graph_eager, self._probe, self.step_times, self._two_streams = set(), None, None, False      # graph = 'auto' (see AUTO_RATIO)
+        self._graphs, self._adam_dev = {}, None
+        self._kinds, self.step_times, self.launch_mode = {}, None, None      # per kind of step: warm-step count, probe samples, decision
+        self._exec = None          # engine.Exec: this trainer's workspaces and second stream (created on the networks' device)
 
     # -------------------------------------------------------------------------------------- optimizers
     def setup_optimizers(self, gen_lr=1e-3, dsc_lr=1e-3):
@@ -188,8 +198,7 @@ class Trainer:
         g, d = self.generator.flat, self.discriminator.flat
         self._adam = (torch.zeros_like(g), torch.zeros_like(g), torch.zeros_like(d), torch.zeros_like(d))
         self._t_g = self._t_d = 0
-        self._graphs, self._graph_seen = {}, {}        # captured steps update the OLD moment buffers
-        self._graph_eager, self._probe = set(), None
+        self._graphs, self._kinds = {}, {}        # captured steps update the OLD moment buffers
 
     # -------------------------------------------------------------------------------------- one G+D step
     def batch(self, x, y, train=False):
@@ -224,25 +233,34 @@ class Trainer:
         if train and self._adam is None:
             self.setup_optimizers(self.gen_lr, self.dsc_lr)
         self._step += 1
-        losses = None
-        self._two_streams = False
-        if train and self._graph_eligible():
-            losses = self._batch_graph(x, y, u8, (N, H, W, Cin, Cout))
-        if losses is None:
-            probe = self._probe
-            if probe is not None and probe.get('e0') is None:      # 'auto': time this (the last warm) step on the device and on the host
-                probe['e0'], probe['e1'] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                probe['e0'].record()
+        ex = self._exec
+        if ex is None or ex.device != dev:
+            ex = self._exec = E.Exec(dev)
+        with ex:
+            dims = (N, H, W, Cin, Cout)
+            key = self._kind_key(x, y, u8, dims, train)
+            mode = self._launch_mode(key, train)
+            losses = None
+            if mode == 'graph':
+                losses = self._replay(key, x, y, u8, dims)          # None: this runtime cannot capture the step
+                if losses is None:
+                    mode = 'eager1'
+            if mode == 'probe':
+                # 'auto': this warm step is timed on the device (one event pair) and on the host; a step that raises leaves no sample
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 t_p = time.perf_counter()
                 losses = self._enqueue_step(x, y, u8, N, H, W, Cin, Cout, train)
-                probe['host_ms'] = (time.perf_counter() - t_p) * 1e3
-                probe['e1'].record()
-            else:
-                E._SIDE['enabled'] = bool(train and self._two_streams)      # a device-bound step ('auto'): weight gradients on a second stream
+                host_ms = (time.perf_counter() - t_p) * 1e3
+                e1.record()
+                self._kinds[key]['samples'].append((e0, e1, host_ms))
+            elif losses is None:
+                ex.enabled = mode == 'eager2'
                 try:
                     losses = self._enqueue_step(x, y, u8, N, H, W, Cin, Cout, train)
                 finally:
-                    E._SIDE['enabled'] = False
+                    ex.enabled = False
+            self.launch_mode = mode
         if train and self.gc_freeze:
             _settle_gc(self._step)
         self.host_ms = (time.perf_counter() - t_host0) * 1e3       # host time to enqueue the whole step (bench.py reports it)
@@ -259,6 +277,7 @@ class Trainer:
         dist = _dist()
         Bglobal = N * dist.world
         Cd = Cin + Cout
+        ex = E.cur_exec(dev)
 
         # discriminator input buffer: samples [0,N) real = x|y, [N,2N) fake = x|G(x)   (trainer.py:65,96,98)
         din = E.View.alloc(2 * N, H, W, Cd, dev)
@@ -293,10 +312,12 @@ class Trainer:
         # weights, both final here -- it is enqueued on the second stream now and runs under the rest of the generator step (same
         # kernels, same 2N plan: bit-identical); joined where the discriminator step reads its output
         dc2 = None
-        if train and E._SIDE['enabled'] and E.PROFILER is None and not dist.on and EARLY_D_FWD:      # (bf16 networks too: 5.93 -> 5.84 ms at cfg4)
+        # (evaluation passes and data-parallel steps too; under data parallelism D's deferred update of the previous step has been
+        #  applied by flush() above, and on_side() orders the second stream behind it)
+        if ex.enabled and E.PROFILER is None and EARLY_D_FWD:      # (bf16 networks too: 5.93 -> 5.84 ms at cfg4)
             n_prepared = len(ucache)
             with E.on_side():
-                dc2 = de.forward(D.flat, din, ucache=ucache, keep_v=True)
+                dc2 = de.forward(D.flat, din, ucache=ucache, keep_v=train)
             if len(ucache) != n_prepared:
                 # (a transformed-weight entry the batched preparation did not cover was made by a kernel on the second stream -- the
                 #  first steps after a change of tuning: the passes below would take it as ready, so they wait for it this once)
@@ -316,13 +337,15 @@ class Trainer:
                 # buckets of the flat G gradient are all-reduced on RCCL's stream as backward finishes them; the
                 # collective keeps running under the discriminator step below (which does not read G's new weights:
                 # gen_img.detach() is the pre-update output, trainer.py:98)
-                g_reducer = GradReducer(dist, gflat, self.bucket_bytes)
+                # (two-stream step: a bucket's weight gradients may sit on the second stream -- the collective waits for it as well)
+                g_reducer = GradReducer(dist, gflat, self.bucket_bytes, producers=E.side_producers)
             # two-stream step: G's weight gradients may still be running on the second stream when the pass returns; the
             # discriminator's forward below needs neither them nor G's new weights (gen_img.detach() is the pre-update output,
             # trainer.py:98), so the join and G's Adam update come after it
-            late_adam_g = bool(E._SIDE['enabled']) and g_reducer is None
+            two = bool(ex.enabled)
+            late_adam_g = two and g_reducer is None
             ge.backward(G.flat, gflat, gc, gseg, ddin.channels(Cin, Cout),                    # trainer.py:88-89
-                        on_ready=g_reducer.ready if g_reducer is not None else None, ucache=gcache, defer_join=late_adam_g)
+                        on_ready=g_reducer.ready if g_reducer is not None else None, ucache=gcache, defer_join=two)
             ge.ucache_end(gcache)
             if late_adam_g:
                 pass
@@ -335,7 +358,7 @@ class Trainer:
         # ---- discriminator step: real and (pre-update, detached) fake in one 2N batch        trainer.py:96-99
         if dc2 is None:
             dc2 = de.forward(D.flat, din, ucache=ucache, keep_v=train)
-        if train and (late_adam_g or E._SIDE['pending']):
+        if ex.pending or ex.keep:
             E.side_join()
         if train and late_adam_g:
             self._adam_step('g')                                                              # trainer.py:90
@@ -407,47 +430,94 @@ class Trainer:
             self._t_d += 1
             E.adam_step(net.flat, net.grad_flat, m, v, self._t_d, self.dsc_lr)
 
-    # -------------------------------------------------------------------------------------- the step as a hipGraph
+    # -------------------------------------------------------------------------------------- how a step is launched
     def _graph_eligible(self):
-        """Single GPU, dropout off (its per-layer seeds are launch arguments derived from the step number on the host), and no launch
-        profiler armed (its HIP events are per launch: the HIP runtime torch brings along refuses external event-record nodes inside a
-        capture, tools/graph_event_probe.py)."""
+        """Capture applies: single GPU, dropout off (its per-layer seeds are launch arguments derived from the step number on the
+        host), and no launch profiler armed (its HIP events are per launch: the HIP runtime torch brings along refuses external
+        event-record nodes inside a capture, tools/graph_event_probe.py)."""
         G = self.generator
         if not self.graph or os.environ.get('PATCHGAN_GRAPH', '1') == '0' or _dist().on or E.PROFILER is not None:
             return False
         return not (G.training and G.engine.use_dropout)
 
-    def _batch_graph(self, x, y, u8, dims):
-        """The training step replayed from a captured hipGraph: ~220 launches become one hipGraphLaunch (host enqueue 1.9 ms -> well
-        under 0.1 ms per step at cfg2; the step itself is unchanged -- same kernels, same arguments, bit-identical results).
-        A kind of step (shapes, loss settings, precision / tuning of both networks) is captured after GRAPH_WARM_STEPS eager steps of
-        that kind; until then, and for any step that is not eligible, None is returned and the caller
-        enqueues the step launch by launch.  Per replay the host copies the inputs into the graph's input buffers, writes Adam's two
-        step-dependent scalars per network (lr / bc1, sqrt(bc2): pg_adam_step_dev reads them from device memory) and launches."""
+    def _two_streams_setting(self):
+        ts = self.two_streams
+        if ts is None:
+            ts = 'auto' if self.graph == 'auto' else False
+        if E.PROFILER is not None or E._exp_env('PATCHGAN_TWO_STREAMS') == '0':
+            return False          # (the launch profiler's event pairs keep everything on one stream)
+        return ts
+
+    def _kind_key(self, x, y, u8, dims, train):
         G, D = self.generator, self.discriminator
-        key = (u8, dims, self.loss_type, float(self.seg_alpha), float(self.tversky_beta), float(self.tversky_gamma),
+        return (bool(train), u8, dims, self.loss_type, float(self.seg_alpha), float(self.tversky_beta), float(self.tversky_gamma),
                 tuple(self.label_values) if self.label_values is not None else None, G.training, D.training,
                 G.engine.algo, bool(G.engine.act_bf), D.engine.algo, bool(D.engine.act_bf), G.flat.data_ptr(), D.flat.data_ptr(),
-                tuple(x.shape), tuple(y.shape), x.dtype, y.dtype)
+                tuple(x.shape), tuple(y.shape), x.dtype, y.dtype, _dist().on)
+
+    def _launch_mode(self, key, train):
+        """'eager1' (launch by launch, one stream) | 'eager2' (launch by launch, two streams) | 'graph' (replay) | 'probe' (a timed
+        'eager1' step) for this step of kind `key`.  What the settings allow is re-read every step (a profiler armed later, a
+        group initialised later); what was measured is remembered per kind."""
+        want_graph = self.graph if (train and self._graph_eligible()) else False
+        ts = self._two_streams_setting()
+        if not want_graph and not ts:
+            return 'eager1'
+        if ts is True and want_graph is not True:
+            return 'eager2'                       # forced: no warm-up needed (entries a pass makes on the second stream are joined, _enqueue_step)
+        k = self._kinds.pop(key, None) or {'seen': 0, 'mode': None, 'samples': []}
+        self._kinds[key] = k                      # most recently used last
+        while len(self._kinds) > self.MAX_KINDS:
+            self._kinds.pop(next(iter(self._kinds)))
+        if k['mode'] is not None:
+            if (k['mode'] == 'graph' and not want_graph) or (k['mode'] == 'eager2' and not ts):
+                return 'eager1'
+            return k['mode']
+        k['seen'] += 1
+        auto = want_graph == 'auto' or ts == 'auto'
+        if k['seen'] <= self.GRAPH_WARM_STEPS:
+            return 'probe' if auto and k['seen'] > self.GRAPH_WARM_STEPS - self.PROBE_STEPS else 'eager1'
+        if not auto:
+            k['mode'] = 'graph' if want_graph else 'eager1'
+            return k['mode']
+        if not k['samples']:
+            return 'probe'                        # (every probe step so far raised: keep measuring)
+        k['samples'][-1][1].synchronize()
+        dev_ms = min(e0.elapsed_time(e1) for e0, e1, _ in k['samples'])
+        host_ms = min(h for _, _, h in k['samples'])
+        k['samples'] = []
+        self.step_times = (dev_ms, host_ms)
+        ratio = float(os.environ['PATCHGAN_AUTO_RATIO']) if 'PATCHGAN_EXPERIMENT' in os.environ and 'PATCHGAN_AUTO_RATIO' in os.environ else self.AUTO_RATIO
+        if dev_ms >= ratio * host_ms and ts:
+            k['mode'] = 'eager2'                  # device-bound: launch by launch on two streams
+        elif want_graph:
+            k['mode'] = 'graph'                   # launch-bound (or no second stream wanted): one hipGraphLaunch per step
+        else:
+            k['mode'] = 'eager1'
+        return k['mode']
+
+    def redecide(self):
+        """Forget every launch decision and captured step (the next steps of each kind warm up, are timed and decided again)."""
+        self._kinds, self._graphs = {}, {}
+
+    def release(self):
+        """Give this trainer's captured steps, workspaces and second stream back (they also go with the object)."""
+        self._graphs = {}
+        if self._exec is not None:
+            self._exec.release()
+
+    def _replay(self, key, x, y, u8, dims):
+        """The training step replayed from a captured hipGraph: ~220 launches become one hipGraphLaunch (host enqueue 1.9 ms -> well
+        under 0.1 ms per step at cfg2; the step itself is unchanged -- same kernels, same arguments, bit-identical results).
+        Captured on first use.  Per replay the host copies the inputs into the graph's input buffers, writes Adam's two
+        step-dependent scalars per network (lr / bc1, sqrt(bc2): pg_adam_step_dev reads them from device memory) and launches.
+        Returns None (after a warning) if this runtime cannot capture the step: the caller continues launch by launch."""
         st = self._graphs.get(key)
+        if st is not None and st.ptrs != self._graph_ptrs():
+            # the gradient / moment buffers the capture was made with were replaced (a network moved, .grad reset): capture again
+            del self._graphs[key]
+            st = None
         if st is None:
-            if key in self._graph_eager:
-                self._two_streams = True
-                return None
-            seen = self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
-            if seen <= self.GRAPH_WARM_STEPS:
-                if self.graph == 'auto' and seen == self.GRAPH_WARM_STEPS:
-                    self._probe = {'key': key}
-                return None
-            if self.graph == 'auto' and self._probe is not None and self._probe.get('key') == key and self._probe.get('e1') is not None:
-                pr, self._probe = self._probe, None
-                pr['e1'].synchronize()
-                dev_ms = pr['e0'].elapsed_time(pr['e1'])
-                self.step_times = (dev_ms, pr['host_ms'])
-                ratio = float(os.environ['PATCHGAN_AUTO_RATIO']) if 'PATCHGAN_EXPERIMENT' in os.environ and 'PATCHGAN_AUTO_RATIO' in os.environ else self.AUTO_RATIO
-                if dev_ms >= ratio * pr['host_ms']:
-                    self._graph_eager.add(key)          # device-bound: launch by launch (two streams in the backward passes)
-                    return None
             try:
                 st = self._capture(key, x, y, u8, dims)
             except Exception as e:          # a runtime that cannot capture this step: launch by launch from here on, loudly
@@ -471,11 +541,16 @@ class Trainer:
         self._last_gen = st.gen
         return st.losses
 
+    def _graph_ptrs(self):
+        G, D = self.generator, self.discriminator
+        return tuple(t.data_ptr() if t is not None else 0 for t in (G.grad_flat, D.grad_flat) + tuple(self._adam))
+
     def _capture(self, key, x, y, u8, dims):
         class _StepGraph:
             pass
         st = _StepGraph()
         dev = x.device
+        G, D = self.generator, self.discriminator
         st.x, st.y = torch.empty_like(x), torch.empty_like(y)
         st.scal = torch.zeros(4, dtype=torch.float32, device=dev)
         # (a ring: the copy of slot i to the device may still be queued when the host prepares the next steps; _publish's ring of
@@ -483,6 +558,8 @@ class Trainer:
         st.host, st.slot = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(8)], 0
         while len(self._graphs) >= self.MAX_GRAPHS:
             self._graphs.pop(next(iter(self._graphs)))
+        G.ensure_grad_flat()
+        D.ensure_grad_flat()
         st.graph = torch.cuda.CUDAGraph()
         self._adam_dev = st.scal
         try:
@@ -491,6 +568,14 @@ class Trainer:
                 st.gen = self._last_gen
         finally:
             self._adam_dev = None
+        # The graph has baked in the addresses of buffers it does not own: the workspace(s), the transformed / packed weight entries of
+        # both networks, the flat gradients and Adam's moments.  It keeps every one of them alive -- a workspace that grows for a larger
+        # extent, a weight-cache pool cleared by set_precision / set_tuning or trimmed by its plan limit replace THEIR reference, not this
+        # one, so a replay never writes into memory the allocator has handed to someone else -- and it is captured again if the
+        # buffers whose CONTENT matters outside the graph (gradients, moments) were replaced (_graph_ptrs).
+        st.hold = (E.cur_exec(dev).buffers() + list(G.engine.__dict__.get('_upool', {}).values())
+                   + list(D.engine.__dict__.get('_upool', {}).values()) + [G.grad_flat, D.grad_flat] + list(self._adam))
+        st.ptrs = self._graph_ptrs()
         self._graphs[key] = st
         return st
 
@@ -499,8 +584,12 @@ class Trainer:
         return bool(self._graphs)
 
     def graph_decided(self):
-        """True once a kind of training step has been captured or ('auto') found device-bound and left launch by launch."""
-        return bool(self._graphs) or bool(self._graph_eager)
+        """True once a kind of step has been captured or its launch mode decided ('auto')."""
+        return bool(self._graphs) or any(k['mode'] is not None for k in self._kinds.values())
+
+    def decided_modes(self):
+        """The launch modes decided so far, one per kind of step, most recently used last ('eager1' | 'eager2' | 'graph')."""
+        return [k['mode'] for k in self._kinds.values() if k['mode'] is not None]
 
     # -------------------------------------------------------------------------------------- epoch driver
     def train(self, train_data, val_data, epochs, dsc_learning_rate=1.e-3, gen_learning_rate=1.e-3, save_freq=10,

@@ -39,6 +39,20 @@ CONFIGS = {
     'e_wbce_c1': dict(in_nc=1, out_nc=1, nf=4, ndf=4, n_layers=3, norm=False, activation='leakyrelu',
                       final_act='sigmoid', loss_type='weighted_bce', B=2, size=256),
 }
+# The BENCHMARK configurations at full width, driven through the reference itself (round 5).  Initial weights are NOT stored
+# (41.8 M parameters): they are torch's default init under MODEL_SEED, which the build's modules reproduce bit for bit
+# (tests/test_cabi_cpu.py::test_default_init_equals_torch_module_init); the weight probes 'g0/...' pin that claim per tensor.
+WIDE_CONFIGS = {
+    # cfg2 = BASELINE.json configs[1], the headline: 256x256x3 -> 1 mask, bs 16, nf = ndf = 64
+    'w_cfg2': dict(in_nc=3, out_nc=1, nf=64, ndf=64, n_layers=3, norm=False, activation='leakyrelu',
+                   final_act='sigmoid', loss_type='tversky', B=16, size=256, steps=10),
+    # cfg1 = examples/train_coco.yaml:13-28 hyper-parameters at 256x256 (64x64 cannot run: SURVEY section 5), bs 4
+    'w_cfg1': dict(in_nc=3, out_nc=7, nf=32, ndf=16, n_layers=5, norm=False, activation='relu',
+                   final_act='sigmoid', loss_type='weighted_bce', B=4, size=256, steps=10),
+    # cfg4's shape: 512x512x3 -> 4 classes (softmax head, weighted BCE over C > 1), nf = ndf = 64, B = 2 of the 8 per GPU
+    'w_cfg4': dict(in_nc=3, out_nc=4, nf=64, ndf=64, n_layers=3, norm=False, activation='leakyrelu',
+                   final_act='softmax', loss_type='weighted_bce', B=2, size=512, steps=4),
+}
 NSTEPS = 10
 MODEL_SEED = 1234
 DATA_SEED = 7
@@ -62,7 +76,9 @@ def probe(t, nsamp=NSAMP):
     return np.concatenate([[f.sum().item(), f.abs().sum().item()], f[idx].numpy()])
 
 
-def run_config(name, cfg):
+def run_config(name, cfg, store_weights=True):
+    cfg = dict(cfg)
+    nsteps = cfg.pop('steps', NSTEPS)
     sys.path.insert(0, REF)
     from patchgan import UNet, Discriminator, Trainer
     torch.manual_seed(MODEL_SEED)
@@ -71,9 +87,9 @@ def run_config(name, cfg):
     d = Discriminator(cfg['in_nc'] + cfg['out_nc'], cfg['ndf'], n_layers=cfg['n_layers'], norm=cfg['norm'])
     out = {}
     for k, v in g.state_dict().items():
-        out['g0/' + k] = v.detach().numpy().copy()
+        out['g0/' + k] = v.detach().numpy().copy() if store_weights else probe(v)
     for k, v in d.state_dict().items():
-        out['d0/' + k] = v.detach().numpy().copy()
+        out['d0/' + k] = v.detach().numpy().copy() if store_weights else probe(v)
     with contextlib.redirect_stdout(io.StringIO()):
         t = Trainer(g, d, tempfile.mkdtemp(), device='cpu')
     t.loss_type = cfg['loss_type']
@@ -110,7 +126,7 @@ def run_config(name, cfg):
 
     # 10 training steps; gradient probes after step 1
     curve = []
-    for s in range(NSTEPS):
+    for s in range(nsteps):
         l = t.batch(x, y, train=True)
         curve.append([l[k] for k in ['gen', 'gen_loss', 'gdisc', 'discr', 'discf', 'disc']])
         if s == 0:
@@ -131,7 +147,8 @@ def run_config(name, cfg):
         out['gen_img10'] = probe(g(x))
     out['cfg_keys'] = np.array(list(cfg.keys()))
     out['cfg_vals'] = np.array([str(v) for v in cfg.values()])
-    out['meta'] = np.array([MODEL_SEED, DATA_SEED, NSTEPS, NSAMP])
+    out['meta'] = np.array([MODEL_SEED, DATA_SEED, nsteps, NSAMP])
+    out['threads'] = np.array([torch.get_num_threads()])
     np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
     print(name, 'loss[0]', curve[0][0], 'loss[-1]', curve[-1][0], flush=True)
 
@@ -247,7 +264,7 @@ def run_io_onehot():
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
-    which = sys.argv[1:] or (list(CONFIGS) + ['train_driver', 'infer_tiles', 'io_onehot'])
+    which = sys.argv[1:] or (list(CONFIGS) + list(WIDE_CONFIGS) + ['train_driver', 'infer_tiles', 'io_onehot'])
     for name in which:
         if name == 'io_onehot':
             run_io_onehot()
@@ -255,5 +272,7 @@ if __name__ == '__main__':
             run_infer_tiles()
         elif name == 'train_driver':
             run_train_driver()
+        elif name in WIDE_CONFIGS:
+            run_config(name, WIDE_CONFIGS[name], store_weights=False)
         else:
             run_config(name, CONFIGS[name])

@@ -85,14 +85,23 @@ def test_bench_rccl_path_one_rank():
     """backend "nccl" (= RCCL) really executes: a one-rank process group with the data-parallel path forced on runs every
     collective of the step (bucketed gradient all-reduces on the comm stream, loss terms, the deferred discriminator update)
     through RCCL and must reproduce the single-process losses."""
-    plain = _bench(['--no-graph'], {})      # launch by launch like the data-parallel path: the same number of steps before the last timed one
-    out = _bench([], {'PATCHGAN_DP_FORCE': '1', 'MASTER_PORT': '29631'})
+    plain = _bench(['--no-graph'], {})      # launch by launch on one stream: the same number of steps before the last timed one
+    out = _bench(['--no-graph'], {'PATCHGAN_DP_FORCE': '1', 'MASTER_PORT': '29631'})
     assert plain['step_launch'] == out['step_launch'] == 'launch by launch'
     assert out['comm']['backend'] == 'nccl' and out['comm']['ranks_in_group'] == 1
     assert out['comm']['collectives_per_step'] >= 7            # 6 x 32 MiB G buckets + D gradient + loss terms
     assert out['comm']['allreduce_MB_per_step'] > 170          # 167 MB + 11 MB of gradients
     for k, v in plain['last_losses'].items():
         assert abs(out['last_losses'][k] - v) <= 1e-5 * max(abs(v), 1e-3), (k, out['last_losses'], plain['last_losses'])
+    # the default launch policy under data parallelism: never a captured graph (collectives stay outside), and a device-bound step
+    # runs on two streams like the single-process one (the bucket all-reduce waits for the second stream's weight gradients)
+    import re
+    two = _bench([], {'PATCHGAN_DP_FORCE': '1', 'MASTER_PORT': '29632'})
+    assert not two['step_launch'].startswith('hipGraph') and two['comm']['collectives_per_step'] >= 7
+    m = re.search(r'auto: device ([0-9.]+) ms vs host enqueue ([0-9.]+) ms', two['step_launch'])
+    assert m, two['step_launch']
+    if float(m.group(1)) >= 2.5 * float(m.group(2)):
+        assert two['step_launch'].startswith('launch by launch, the weight gradients of each backward pass'), two['step_launch']
 
 
 def test_bench_spawns_its_own_ranks_gloo_rehearsal():

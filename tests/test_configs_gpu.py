@@ -54,32 +54,48 @@ def _relrows(a, b):
 
 @pytest.fixture(scope='module')
 def cfg4_reference():
-    """Oracle trajectories of the cfg4-shaped problem (B = 2 keeps the CPU oracle to ~15 s per step): fp32 on the CPU (the
-    reference's own arithmetic) and float64 on the GPU (torch double ops), two training steps each."""
-    g, d, gw, dw = _models(4, 'softmax')
-    x, y = _inputs(2, 4, 512)
+    """Trajectories of the cfg4-shaped problem (B = 2 keeps the CPU side to seconds per step), from the seeds of the fixture the
+    REFERENCE produced at this shape (tests/golden/w_cfg4.npz: 4 steps of patchgan/trainer.py:50-115 on torch-CPU): the reference's
+    curve itself, the fp32 CPU oracle (the same torch kernels), and the oracle in float64 on the GPU (torch double ops), 10 steps."""
+    from tests.golden_util import Golden
+    gold = Golden('w_cfg4')
+    c = gold.cfg
+    assert (c['size'], c['out_nc'], c['B'], c['final_act'], c['loss_type']) == (512, 4, 2, 'softmax', 'weighted_bce')
+    g, d = gold.seeded_modules()                 # holds the seeded init to the reference's weight probes
+    gw = {k: v.clone() for k, v in g.state_dict().items()}
+    dw = {k: v.clone() for k, v in d.state_dict().items()}
+    x, y = gold.inputs()
     kw = dict(activation='leakyrelu', final_act='softmax', n_layers=3, norm=False, loss_type='weighted_bce')
     c64 = _curve(O.OracleTrainer({k: v.cuda() for k, v in gw.items()}, {k: v.cuda() for k, v in dw.items()},
-                                 dtype=torch.float64, **kw), x.cuda(), y.cuda(), 2)
-    c32 = _curve(O.OracleTrainer(gw, dw, **kw), x, y, 2)
+                                 dtype=torch.float64, **kw), x.cuda(), y.cuda(), 10)
+    c32 = _curve(O.OracleTrainer(gw, dw, **kw), x, y, gold.nsteps)
     with torch.no_grad():
         out0 = O.unet_forward(gw, x, 'leakyrelu', 'softmax')
-    return dict(gw=gw, dw=dw, x=x, y=y, c32=c32, c64=c64, out0=out0)
+    return dict(gw=gw, dw=dw, x=x, y=y, c32=c32, c64=c64, out0=out0, ref=gold.z['losses'], gold=gold)
+
+
+# Stated bounds of the cfg4-shaped curves = 1.5 x the maxima measured on the round-5 build (printed by the tests).
+# (round 5, per step: fp32 vs the reference 2.1e-7 1.4e-5 5.9e-6 1.3e-4, vs float64 6.1e-8 9.0e-6 3.8e-6 1.8e-4; the reference vs float64
+#  1.7e-7 5.2e-6 5.5e-6 6.1e-5; the CPU oracle on the GPU box's host -- the reference's own kernels, another thread count -- vs the
+#  reference's curve 2.1e-7 1.3e-5 6.2e-5 9.9e-5; bf16 vs float64 4.4e-5 1.9e-3 3.8e-3 4.1e-3 3.5e-3 4.9e-3 7.8e-3 4.2e-3 4.6e-2 1.6e-2)
+CFG4_FP32_REF_BOUND = 2.0e-4        # fp32, 4 steps, vs the reference's curve
+CFG4_FP32_F64_BOUND = 2.7e-4        # fp32, 4 steps, vs float64
+CFG4_BF16_F64_BOUND = 7e-2          # bf16, 10 steps, vs float64 ...
+CFG4_BF16_F64_BOUND_8 = 1.2e-2      # ... and its first 8 steps
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-def test_cfg4_shape_two_steps_vs_oracle(cfg4_reference, precision, tmp_path):
-    """Stated tolerances.  fp32: generator output at the initial weights within 2e-4 (max-norm) of the CPU oracle; each of
-    the six loss scalars of both steps within 1e-4 of the float64 trajectory, and within max(1e-4, 4 x E) of the fp32 CPU
-    oracle, E = that oracle's own distance from float64 (at 512x512 oneDNN's fp32 trajectory leaves float64 by ~3e-4 at
-    step 2, more than the HIP path does).  bf16 (bf16 multiplies, fp32 accumulation / statistics / master weights): output
-    within 2e-2, losses within 5e-2 of float64."""
+def test_cfg4_shape_vs_reference_and_float64(cfg4_reference, precision, tmp_path):
+    """fp32: generator output at the initial weights within 2e-4 (max-norm) of the CPU oracle; the 4 steps of the REFERENCE's curve
+    (w_cfg4.npz) within CFG4_FP32_REF_BOUND and the float64 trajectory within CFG4_FP32_F64_BOUND -- at 512 x 512 oneDNN's own fp32
+    trajectory on ANOTHER host (the CPU oracle on the GPU box: the reference's kernels, 16 threads) is 1e-4 from the reference's curve
+    by step 4, as far as the HIP path is; the first three steps agree to 1.4e-5 everywhere.
+    bf16 (bf16 multiplies, fp32 accumulation / statistics / master weights; bf16 activation storage): output within 2e-2; a TEN-step
+    curve against float64 within CFG4_BF16_F64_BOUND, every step printed."""
     import patchgan_amd as pg
     from patchgan_amd import _lib as L
     r = cfg4_reference
-    g, d, _, _ = _models(4, 'softmax')
-    g.load_state_dict(r['gw'])
-    d.load_state_dict(r['dw'])
+    g, d = r['gold'].seeded_modules()
     g.cuda()
     d.cuda()
     if precision == 'bf16':
@@ -101,17 +117,25 @@ def test_cfg4_shape_two_steps_vs_oracle(cfg4_reference, precision, tmp_path):
     t.loss_type = 'weighted_bce'
     t.setup_optimizers(1e-3, 1e-3)
     d.train()
-    got = _curve(t, r['x'], r['y'], 2)
-    e64, e32, env = _relrows(got, r['c64']), _relrows(got, r['c32']), _relrows(r['c32'], r['c64'])
-    print(f'cfg4-shaped {precision}: output vs CPU oracle {e_out:.2e}; losses vs float64 {e64}, vs fp32 CPU {e32}; '
-          f'fp32 CPU oracle vs float64 {env}')
+    nref = len(r['ref'])
+    steps = nref if precision == 'fp32' else 10
+    got = _curve(t, r['x'], r['y'], steps)
+    e64 = _relrows(got, r['c64'][:steps])
+    np.set_printoptions(precision=2, linewidth=200)
+    print(f'cfg4-shaped {precision}: output vs CPU oracle {e_out:.2e}; losses vs float64 per step {e64}')
     if precision == 'fp32':
+        eref, ref64, o_ref = _relrows(got, r['ref']), _relrows(r['ref'], r['c64'][:nref]), _relrows(r['c32'], r['ref'])
+        print(f'   vs the REFERENCE curve {eref}; REFERENCE vs float64 {ref64}; CPU oracle vs REFERENCE {o_ref}')
         assert e_out < 2e-4
-        assert (e64 <= 1e-4).all(), e64
-        assert (e32 <= np.maximum(1e-4, 4 * env)).all(), (e32, env)
+        # (the oracle is BIT-equal to the reference on the fixture's host and thread count, tests/test_oracle_golden.py; on another
+        #  host oneDNN sums in another order and the curves part like any two fp32 evaluations: 1e-4 by step 4 on the GPU box)
+        assert o_ref[0] <= 1e-6, o_ref
+        assert e64.max() <= CFG4_FP32_F64_BOUND, e64
+        assert eref.max() <= CFG4_FP32_REF_BOUND, eref
+        assert eref[:3].max() <= 3e-5 and e64[:3].max() <= 3e-5, (eref, e64)
     else:
         assert 1e-6 < e_out < 2e-2
-        assert (e64 <= 5e-2).all(), e64
+        assert e64.max() <= CFG4_BF16_F64_BOUND and e64[:8].max() <= CFG4_BF16_F64_BOUND_8, e64
 
 
 def test_cfg5_tiled_inference_1024_vs_oracle():
@@ -290,35 +314,47 @@ def test_cfg2_layer_local_generator_gradients_at_bench_batch():
 _CFG1 = dict(nf=32, ndf=16, n_layers=5, out_nc=7, activation='relu', final_act='sigmoid', loss_type='weighted_bce', batch=4)
 
 
-def test_cfg1_coco_hyperparameters_two_steps_vs_oracle(tmp_path):
-    """BASELINE config 1 on the HIP path: two training steps at the COCO yaml's exact hyper-parameters (dropout off: the CPU's
-    dropout stream cannot be reproduced) against the CPU oracle (fp32) and its float64 run.
+# 1.5 x measured (round 5, maxima over 10 steps: HIP vs the reference 1.71e-4, vs float64 3.85e-4; the reference vs float64 3.45e-4; the CPU
+# oracle on the GPU box's host -- the reference's own kernels -- vs the reference's curve 4.2e-4: ReLU + weighted BCE + a 5-layer D)
+CFG1_REF_BOUND = 2.6e-4
+CFG1_F64_BOUND = 5.8e-4
 
-    Stated tolerances: generator output at the initial weights within 2e-4 (max-norm) of the CPU oracle; each of the six loss
-    scalars of both steps within max(1e-4, 4 x E) of the float64 trajectory, E = the fp32 CPU oracle's own distance from float64
-    at that step (ReLU + weighted BCE + a 5-layer discriminator amplify fp32 rounding quickly: SURVEY / DESIGN section 4); step-1
+
+def test_cfg1_coco_hyperparameters_vs_reference_and_oracle(tmp_path):
+    """BASELINE config 1 on the HIP path at the COCO yaml's exact hyper-parameters (dropout off: the CPU's dropout stream cannot be
+    reproduced), from the seeds of the fixture the REFERENCE produced (tests/golden/w_cfg1.npz: 10 steps of
+    patchgan/trainer.py:50-115): the reference's own curve, the CPU oracle (fp32) and its float64 run.
+
+    Stated tolerances: generator output at the initial weights within 2e-4 (max-norm) of the CPU oracle; the first two steps within
+    max(1e-4, 4 x E) of the float64 trajectory, E = the REFERENCE's own distance from float64 at that step (ReLU + weighted BCE + a
+    5-layer discriminator amplify fp32 rounding quickly: SURVEY / DESIGN section 4); all ten steps within CFG1_REF_BOUND of the
+    reference's curve and CFG1_F64_BOUND of float64 (every step printed next to the reference's own distance from float64); step-1
     parameter gradients of the discriminator within 2e-4 (relative max-norm) of float64, of the generator within 2e-2 in
     relative L2 and 8 x the fp32 oracle's own distance + 1e-3 (conditioning, as at cfg2)."""
     import patchgan_amd as pg
+    from tests.golden_util import Golden
     c = _CFG1
-    torch.manual_seed(1234)
-    g = pg.UNet(3, c['out_nc'], c['nf'], use_dropout=False, activation=c['activation'], final_act=c['final_act'])
-    d = pg.Discriminator(3 + c['out_nc'], c['ndf'], n_layers=c['n_layers'])
+    gold = Golden('w_cfg1')
+    gc = gold.cfg
+    assert (gc['nf'], gc['ndf'], gc['n_layers'], gc['out_nc'], gc['activation'], gc['loss_type'], gc['B']) == \
+        (c['nf'], c['ndf'], c['n_layers'], c['out_nc'], c['activation'], c['loss_type'], c['batch'])
+    g, d = gold.seeded_modules()
     gw = {k: v.clone() for k, v in g.state_dict().items()}
     dw = {k: v.clone() for k, v in d.state_dict().items()}
-    x, y = _inputs(c['batch'], c['out_nc'], 256)
+    x, y = gold.inputs()
+    steps = gold.nsteps
     kw = dict(activation=c['activation'], final_act=c['final_act'], n_layers=c['n_layers'], norm=False, loss_type=c['loss_type'])
     o64 = O.OracleTrainer({k: v.cuda() for k, v in gw.items()}, {k: v.cuda() for k, v in dw.items()}, dtype=torch.float64, **kw)
     o32 = O.OracleTrainer(gw, dw, **kw)
     c64, c32, grads64, grads32 = [], [], None, None
-    for step in range(2):
+    for step in range(steps):
         l64, l32 = o64.batch(x.cuda(), y.cuda(), train=True), o32.batch(x, y, train=True)
         c64.append([float(l64[k]) for k in LOSS_KEYS])
         c32.append([float(l32[k]) for k in LOSS_KEYS])
         if step == 0:
             grads64 = {n: {k: v.clone() for k, v in o64.last[n].items()} for n in ('g_grads', 'd_grads')}
             grads32 = {n: {k: v.clone() for k, v in o32.last[n].items()} for n in ('g_grads', 'd_grads')}
-    c64, c32 = np.array(c64), np.array(c32)
+    c64, c32, ref = np.array(c64), np.array(c32), gold.z['losses']
     with torch.no_grad():
         out0 = O.unet_forward(gw, x, c['activation'], c['final_act'])
     g.cuda()
@@ -335,17 +371,21 @@ def test_cfg1_coco_hyperparameters_two_steps_vs_oracle(tmp_path):
     t.setup_optimizers(1e-3, 1e-3)
     d.train()
     got = []
-    for step in range(2):
+    for step in range(steps):
         l = t.batch(x, y, train=True)
         got.append([float(l[k]) for k in LOSS_KEYS])
         if step == 0:
             gg = {k: p.grad.clone() for k, p in g.named_parameters()}
             dg = {k: p.grad.clone() for k, p in d.named_parameters()}
     got = np.array(got)
-    e64, e32, env = _relrows(got, c64), _relrows(got, c32), _relrows(c32, c64)
-    print(f'cfg1: output vs CPU oracle {e_out:.2e}; losses vs float64 {e64}, vs fp32 CPU {e32}; fp32 CPU oracle vs float64 {env}')
+    e64, eref, ref64, o_ref = _relrows(got, c64), _relrows(got, ref), _relrows(ref, c64), _relrows(c32, ref)
+    np.set_printoptions(precision=2, linewidth=200)
+    print(f'cfg1: output vs CPU oracle {e_out:.2e}; per step: HIP vs REFERENCE {eref}; HIP vs float64 {e64}; REFERENCE vs float64 {ref64}; '
+          f'CPU oracle vs REFERENCE {o_ref}')
     assert e_out < 2e-4
-    assert (e64 <= np.maximum(1e-4, 4 * env)).all(), (e64, env)
+    assert o_ref[0] <= 1e-6, o_ref          # (bit-equal on the fixture's host; another host's oneDNN order parts from it like any fp32 evaluation)
+    assert (e64[:2] <= np.maximum(1e-4, 4 * ref64[:2])).all(), (e64, ref64)
+    assert eref.max() <= CFG1_REF_BOUND and e64.max() <= CFG1_F64_BOUND, (eref, e64)
 
     def l2(a, b):
         a, b = a.double().cpu(), b.double().cpu()

@@ -41,11 +41,16 @@ def _collect(q, procs, timeout=300.0):
     return sorted(out, key=lambda r: r[0])
 
 
-def _worker(rank, world, port, q, name, nsteps, dropout=False):
+def _worker(rank, world, port, q, name, nsteps, dropout=False, two_streams=None, backend='gloo'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    if backend == 'nccl':
+        os.environ['PATCHGAN_DP_FORCE'] = '1'          # a one-rank RCCL group with the data-parallel path on
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(4)
     import tempfile
     import patchgan_amd as pg
@@ -63,6 +68,7 @@ def _worker(rank, world, port, q, name, nsteps, dropout=False):
     t = pg.Trainer(g, d, tempfile.mkdtemp())
     t.loss_type = c['loss_type']
     t.bucket_bytes = 64 << 10          # several buckets even for the nf=4 generator
+    t.two_streams = two_streams
     t.setup_optimizers(1e-3, 1e-3)
     g.train()
     d.train()
@@ -104,6 +110,38 @@ def test_two_rank_step_matches_single_process_golden(name):
     err = np.abs(c0 - want) / np.maximum(np.abs(want), 1e-6)
     print(name, 'dp2 vs single-process golden: max rel err per step', err.max(axis=1))
     assert err.max() < 1e-4, err
+
+
+def _spawn(world, nsteps, name, **kw):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, name, nsteps), kwargs=kw) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect(q, procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize('backend,world', [('gloo', 2), ('nccl', 1)])
+def test_two_stream_data_parallel_step_is_bit_identical_to_the_one_stream_one(backend, world):
+    """Under data parallelism the weight-gradient chain of each backward pass may run on the second stream as well: a bucket's
+    all-reduce then waits for that stream too (parallel.Dist.all_reduce_side(producers=...)), the discriminator step's forward runs
+    early on it, and the operands stay referenced until the join.  Same kernels, same order of every sum, same collectives in the
+    same order: losses and weights bit-identical to the one-stream data-parallel step -- two ranks over gloo on the one GPU (with
+    dropout, several buckets), and a one-rank RCCL group (the collectives really are RCCL's, on the comm stream)."""
+    name, nsteps = 'a_lrelu_tversky', 5
+    one = _spawn(world, nsteps, name, dropout=True, two_streams=False, backend=backend)
+    two = _spawn(world, nsteps, name, dropout=True, two_streams=True, backend=backend)
+    for a, b in zip(one, two):
+        assert np.array_equal(a[1], b[1]), (a[1] - b[1])
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
 
 
 def test_two_rank_dropout_masks_are_those_of_the_global_batch(tmp_path):

@@ -10,7 +10,7 @@ from tests.golden_util import LOSS_KEYS
 pytestmark = pytest.mark.gpu
 
 
-def _run(tmp_path, graph, precision, steps, nf=16, lr_change_at=None, use_dropout=False, tag=''):
+def _run(tmp_path, graph, precision, steps, nf=16, lr_change_at=None, use_dropout=False, tag='', two_streams=None, eval_at=()):
     import patchgan_amd as pg
     torch.manual_seed(99)
     g = pg.UNet(3, 1, nf, use_dropout=use_dropout, activation='leakyrelu', final_act='sigmoid')
@@ -22,6 +22,7 @@ def _run(tmp_path, graph, precision, steps, nf=16, lr_change_at=None, use_dropou
         d.set_precision('bf16')
     t = pg.Trainer(g, d, str(tmp_path / f'ck_{graph}_{precision}{tag}'))
     t.graph = graph
+    t.two_streams = two_streams
     t.setup_optimizers(1e-3, 2e-3)
     g.train()
     d.train()
@@ -32,6 +33,11 @@ def _run(tmp_path, graph, precision, steps, nf=16, lr_change_at=None, use_dropou
         y = (torch.rand(2, 1, 256, 256, generator=gen) > 0.7).float()
         if lr_change_at is not None and s == lr_change_at:
             t.gen_lr, t.dsc_lr = 5e-4, 1e-4                    # ExponentialLR / plateau steps change these between epochs
+        if s in eval_at:                                       # an evaluation pass in between (its own kind of step)
+            g.eval(), d.eval()
+            ev = t.batch(x, y, train=False)
+            rows.append([float(ev[k]) for k in LOSS_KEYS])
+            g.train(), d.train()
         l = t.batch(x, y, train=True)
         rows.append([float(l[k]) for k in LOSS_KEYS])
         used.append(t.graph_captured())
@@ -94,7 +100,7 @@ def test_auto_policy_both_outcomes_are_the_same_computation(tmp_path, precision,
 
     def spy(allow):
         orig(allow)
-        sides.append(bool(E._SIDE['allow']))
+        sides.append(bool(E.cur_exec().allow))
     monkeypatch.setattr(E, '_side_begin', spy)
     forks = []
     enter = E.on_side.__enter__
@@ -110,7 +116,9 @@ def test_auto_policy_both_outcomes_are_the_same_computation(tmp_path, precision,
     assert not any(a[3]) and a[4].graph_decided() and a[4].step_times is not None and a[4].step_times[0] > 0
     assert any(sides) == (precision == 'fp32'), sides          # weight gradients on the second stream: fp32 networks only
     assert np.array_equal(ref[0], a[0]) and np.array_equal(ref[1], a[1]) and np.array_equal(ref[2], a[2])
-    assert not E._SIDE['keep'] and not E._SIDE['enabled']
+    ex = a[4]._exec
+    assert not ex.keep and not ex.enabled and not ex.pending and ex.device == torch.device('cuda', torch.cuda.current_device())
+    assert getattr(E._TLS, 'cur', None) is None          # the trainer's execution state is current only inside batch()
     # launch-bound by decree: captured at the 4th step of its kind, as with graph = True
     monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 1e9)
     b = _run(tmp_path, 'auto', precision, 9, nf=nf, lr_change_at=6, tag='graph')
@@ -127,3 +135,148 @@ def test_two_stream_step_at_full_width_is_bit_identical(tmp_path, monkeypatch):
     two = _run(tmp_path, 'auto', 'fp32', 6, nf=64, tag='w_two')
     assert two[4].graph_decided() and not any(two[3])
     assert np.array_equal(ref[0], two[0]) and np.array_equal(ref[1], two[1]) and np.array_equal(ref[2], two[2])
+
+
+def test_dropout_and_eval_steps_take_the_second_stream_and_stay_bit_identical(tmp_path, monkeypatch):
+    """The reference CLI's default generator has dropout on (train.py:92, unet.py:26-28,63-65): such a step cannot be captured
+    (per-layer seeds are launch arguments) but the two-stream schedule applies to it like to any other -- seeds do not care which
+    stream a launch is on.  Same for evaluation passes (the discriminator step's forward on the second stream).  nf = ndf = 64, six
+    training steps with an evaluation pass before steps 3 and 5: forced two-stream and 'auto' (device-bound by decree) against the
+    one-stream trainer -- identical losses and weights, bit for bit; and the second stream really was used."""
+    import patchgan_amd as pg
+    from patchgan_amd import engine as E
+    ref = _run(tmp_path, False, 'fp32', 6, nf=64, use_dropout=True, tag='d_ref', eval_at=(2, 4))
+    assert len(ref[0]) == 8
+    forks = []
+    enter = E.on_side.__enter__
+
+    def spy_enter(self):
+        forks.append(E.cur_exec().enabled)
+        return enter(self)
+    monkeypatch.setattr(E.on_side, '__enter__', spy_enter)
+    two = _run(tmp_path, False, 'fp32', 6, nf=64, use_dropout=True, tag='d_two', two_streams=True, eval_at=(2, 4))
+    assert len(forks) == 8 and all(forks), forks           # every step, the evaluation passes included
+    assert two[4].launch_mode == 'eager2' and not any(two[3])
+    assert np.array_equal(ref[0], two[0]) and np.array_equal(ref[1], two[1]) and np.array_equal(ref[2], two[2])
+    monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 0.0)
+    del forks[:]
+    auto = _run(tmp_path, 'auto', 'fp32', 6, nf=64, use_dropout=True, tag='d_auto', eval_at=(2, 4))
+    assert not any(auto[3]) and auto[4].launch_mode == 'eager2' and len(forks) >= 3, forks      # training steps 4..6 (probes on steps 2, 3)
+    assert np.array_equal(ref[0], auto[0]) and np.array_equal(ref[1], auto[1]) and np.array_equal(ref[2], auto[2])
+    # launch-bound by decree: dropout rules capture out, so the step stays on one stream
+    monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 1e9)
+    one = _run(tmp_path, 'auto', 'fp32', 5, nf=16, use_dropout=True, tag='d_one')
+    assert not any(one[3]) and one[4].launch_mode == 'eager1' and one[4].graph_decided()
+
+
+def test_probe_survives_a_failing_step_and_can_be_redone(tmp_path, monkeypatch):
+    """'auto' decides from the minimum host time and the minimum device time of the timed warm steps; a step that raises while it is
+    being timed leaves no sample behind (the decision is then taken from the others, or postponed), and redecide() starts over."""
+    import patchgan_amd as pg
+    monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 1e9)
+    torch.manual_seed(3)
+    g = pg.UNet(3, 1, 16, use_dropout=False, activation='leakyrelu', final_act='sigmoid').cuda()
+    d = pg.Discriminator(4, 16, n_layers=3).cuda()
+    t = pg.Trainer(g, d, str(tmp_path / 'p'))
+    t.graph = 'auto'
+    t.setup_optimizers(1e-3, 1e-3)
+    g.train(), d.train()
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 256, 256, generator=gen)
+    y = (torch.rand(2, 1, 256, 256, generator=gen) > 0.7).float()
+    t.batch(x, y, train=True)
+    orig = t._enqueue_step
+    calls = []
+
+    def boom(*a, **k):
+        calls.append(1)
+        raise RuntimeError('injected')
+    t._enqueue_step = boom
+    with pytest.raises(RuntimeError, match='injected'):
+        t.batch(x, y, train=True)                  # step 2 of its kind: a probe step that raises
+    t._enqueue_step = orig
+    kind = next(iter(t._kinds.values()))
+    assert kind['samples'] == [] and kind['mode'] is None and not t._exec.enabled
+    t.batch(x, y, train=True)                      # step 3: probe
+    assert len(kind['samples']) == 1
+    t.batch(x, y, train=True)                      # step 4: decided from the one good sample -> launch-bound -> captured
+    assert t.graph_captured() and t.launch_mode == 'graph' and t.step_times[0] > 0 and t.step_times[1] > 0
+    t.redecide()
+    assert not t.graph_decided()
+    for _ in range(4):
+        t.batch(x, y, train=True)
+    assert t.graph_captured()
+
+
+def test_replay_after_the_buffers_it_baked_in_were_replaced(tmp_path):
+    """A captured step holds the addresses of buffers it does not own: the trainer's workspace, both networks' transformed-weight
+    pools, the flat gradients, Adam's moments.  Capture; then (1) a training step of a larger extent (the workspace grows and is
+    replaced), (2) set_tuning to other kernels and back (the weight pools are dropped and rebuilt), (3) a streamed inference pass
+    through the generator on the default execution state -- and replay: the captured step keeps its own buffers alive, so the replay
+    computes exactly what an eager trainer computes after the same sequence, bit for bit."""
+    import patchgan_amd as pg
+    from patchgan_amd import _lib as L
+    from patchgan_amd.infer import predict_image
+    gen = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 3, 256, 256, generator=gen)
+    y = (torch.rand(2, 1, 256, 256, generator=gen) > 0.7).float()
+    xb = torch.rand(6, 3, 256, 256, generator=gen)
+    yb = (torch.rand(6, 1, 256, 256, generator=gen) > 0.7).float()
+    img = torch.rand(3, 512, 512, generator=gen).cuda()
+    outs = []
+    for graph in (True, False):
+        rows, gw, dw, used, t = _run(tmp_path, graph, 'fp32', 5, nf=32, tag=f'rep{int(graph)}')
+        assert used[-1] == bool(graph)
+        G, D = t.generator, t.discriminator
+        ws_before = [b.data_ptr() for b in t._exec.buffers()]
+        seq = []
+        seq.append(t.batch(xb, yb, train=True))                       # (1) larger extent: eager, the workspace may grow ...
+        t._exec.release()                                              # ... and is certainly replaced after this
+        G.set_tuning(L.TUNE_WINO_OFF), D.set_tuning(L.TUNE_WINO_OFF)   # (2) other kernels (another kind of step) ...
+        seq.append(t.batch(x, y, train=True))
+        G.set_tuning(0), D.set_tuning(0)                               # ... and back: the captured kind's key matches again
+        G.eval()
+        m = predict_image(G, img, 256, 0.9, 0.0)                        # (3) inference on the default execution state
+        G.train()
+        seq.append(t.batch(x, y, train=True))                          # replay (graph=True) / eager
+        seq.append(t.batch(x, y, train=True))
+        if graph:
+            assert t.launch_mode == 'graph'
+            assert [b.data_ptr() for b in t._exec.buffers()] != ws_before          # the workspace really was replaced after the capture
+        torch.cuda.synchronize()
+        outs.append(([[float(l[k]) for k in LOSS_KEYS] for l in seq], G.flat.cpu().numpy().copy(), D.flat.cpu().numpy().copy(), m))
+    assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
+
+
+def test_two_trainers_do_not_share_execution_state(tmp_path):
+    """engine.Exec is per trainer: two trainers alternating steps (one on two streams, one on one) give what each gives alone, and
+    releasing one leaves the other's buffers alone."""
+    from patchgan_amd import engine as E
+    alone = _run(tmp_path, False, 'fp32', 4, nf=16, tag='al', two_streams=True)
+    import patchgan_amd as pg
+    ts = []
+    for i, two in enumerate((True, False)):
+        torch.manual_seed(99)
+        g = pg.UNet(3, 1, 16, use_dropout=False, activation='leakyrelu', final_act='sigmoid').cuda()
+        d = pg.Discriminator(4, 16, n_layers=3).cuda()
+        t = pg.Trainer(g, d, str(tmp_path / f'pair{i}'))
+        t.two_streams = two
+        t.setup_optimizers(1e-3, 2e-3)
+        g.train(), d.train()
+        ts.append(t)
+    gen = torch.Generator().manual_seed(5)
+    rows = [[], []]
+    for s in range(4):
+        x = torch.rand(2, 3, 256, 256, generator=gen)
+        y = (torch.rand(2, 1, 256, 256, generator=gen) > 0.7).float()
+        for i, t in enumerate(ts):
+            l = t.batch(x, y, train=True)
+            rows[i].append([float(l[k]) for k in LOSS_KEYS])
+    torch.cuda.synchronize()
+    assert ts[0]._exec is not ts[1]._exec and ts[0]._exec.stream is not None and ts[1]._exec.stream is None
+    assert np.array_equal(np.array(rows[0]), alone[0]) and np.array_equal(np.array(rows[1]), alone[0])
+    ptrs = [b.data_ptr() for b in ts[1]._exec.buffers()]
+    ts[0].release()
+    assert ts[0]._exec.buffers() == [] and [b.data_ptr() for b in ts[1]._exec.buffers()] == ptrs
+    E.release_workspaces()

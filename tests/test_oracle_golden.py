@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import patchgan_oracle as O
-from tests.golden_util import Golden, CONFIG_NAMES, LOSS_KEYS, probe
+from tests.golden_util import Golden, CONFIG_NAMES, WIDE_NAMES, LOSS_KEYS, probe
 
 
 def make_trainer(gold):
@@ -68,6 +68,42 @@ def test_loss_curve_and_grads(name):
                 np.testing.assert_allclose(probe(t.gw[k]), want, rtol=1e-5, atol=1e-7, err_msg=k)
     curve = np.array(curve)
     # the oracle uses the same torch kernels as the reference: expect (near) bit equality
+    np.testing.assert_allclose(curve, gold.z['losses'], rtol=1e-5, atol=1e-5)
+    for k, want in gold.probes('g10').items():
+        np.testing.assert_allclose(probe(t.gw[k]), want, rtol=1e-4, atol=1e-6, err_msg=k)
+    for k, want in gold.probes('d10').items():
+        np.testing.assert_allclose(probe(t.dw[k]), want, rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('name', WIDE_NAMES)
+def test_wide_benchmark_configs_vs_reference(name):
+    """The oracle at the BENCHMARK configurations against fixtures the reference itself produced at full width (cfg2: nf = ndf = 64,
+    bs 16, 10 steps; cfg1: the COCO yaml's hyper-parameters, 10 steps; cfg4's shape at B = 2, 4 steps): the seeded default init is
+    the reference's bit for bit (weight probes), and the evaluation losses, every loss of every step, the step-1 gradient probes and
+    the final weight probes agree.  The oracle runs the same torch-CPU kernels as the reference: with the thread count the fixtures
+    were made with (8) the curves are BIT-EQUAL (asserted); with another count oneDNN may sum in another order (1e-5 then)."""
+    gold = Golden(name)
+    c = gold.cfg
+    g, d = gold.seeded_modules()                     # asserts the weight probes
+    gw = {k: v.clone() for k, v in g.state_dict().items()}
+    dw = {k: v.clone() for k, v in d.state_dict().items()}
+    x, y = gold.inputs()
+    t = O.OracleTrainer(gw, dw, activation=c['activation'], final_act=c['final_act'], n_layers=c['n_layers'], norm=c['norm'],
+                        loss_type=c['loss_type'], seg_alpha=200, gen_lr=1e-3, dsc_lr=1e-3)
+    same_threads = torch.get_num_threads() == int(gold.z['threads'][0])
+    ev = t.batch(x, y, train=False)
+    np.testing.assert_allclose([ev[k] for k in LOSS_KEYS], gold.z['eval_losses'], rtol=1e-6)
+    curve = []
+    for s in range(gold.nsteps):
+        l = t.batch(x, y, train=True)
+        curve.append([l[k] for k in LOSS_KEYS])
+        if s == 0:
+            for kind, grads in (('ggrad1', t.last['g_grads']), ('dgrad1', t.last['d_grads'])):
+                for k, want in gold.probes(kind).items():
+                    np.testing.assert_allclose(probe(grads[k]), want, rtol=2e-5, atol=1e-6 * max(abs(want[1]), 1e-12), err_msg=k)
+    curve = np.array(curve)
+    if same_threads:
+        assert np.array_equal(curve, gold.z['losses']), np.abs(curve - gold.z['losses']).max()
     np.testing.assert_allclose(curve, gold.z['losses'], rtol=1e-5, atol=1e-5)
     for k, want in gold.probes('g10').items():
         np.testing.assert_allclose(probe(t.gw[k]), want, rtol=1e-4, atol=1e-6, err_msg=k)

@@ -434,25 +434,28 @@ def E_views(flat, module):
 
 
 def test_cfg2_loss_curve_10_steps_vs_oracle(tmp_path):
-    """The north-star parity statement at the BENCHMARK configuration itself (cfg2: bs 16, 256x256, nf = ndf = 64, every
-    kernel the bench runs incl. the Winograd stride-1 layer): 10 training steps against the fp32 CPU oracle on the same
-    inputs and initial weights.
+    """The north-star parity statement at the BENCHMARK configuration itself (cfg2: bs 16, 256x256, nf = ndf = 64, every kernel the
+    bench runs incl. the Winograd layers): 10 training steps against THE REFERENCE'S OWN CURVE at this configuration
+    (tests/golden/w_cfg2.npz: patchgan/trainer.py:50-115 on torch-CPU, generated by tests/golden/make_golden.py), on the same seeded
+    initial weights (held to the reference's weight probes) and inputs.
 
-    At this size the G/D dynamics amplify fp32 rounding quickly (gdisc swings between 4 and 0.005 within these steps):
-    the CPU oracle itself is 6e-5..8e-5 away from its own float64 run by steps 3-5.  Stated tolerance, as for the small
-    configurations: each of the 6 loss scalars of each step within max(1e-4, 10 x E_s) relative of the fp32 CPU oracle,
-    E_s = running max of the CPU oracle's fp32-vs-fp64 gap; and the HIP path no further from the float64 run than
-    max(1e-4, 4 x E_s).  The float64 run is the same oracle code on torch's GPU double ops (minutes per step on the CPU)."""
+    Stated tolerance: every loss scalar of every step within 1e-4 relative of the reference's curve (CFG2_REF_BOUND: the north star's
+    gate; measured 7.84e-5) and within CFG2_F64_BOUND of the same algorithm in float64 (torch double ops on the GPU; measured
+    1.43e-4, the reference itself 1.31e-4).  What those distances are made of is measured by tools/parity_attribution.py
+    (DESIGN.md section 4): at this size the G/D dynamics amplify rounding (gdisc swings between 4 and 0.005 within these steps) --
+    in pure float64 arithmetic, initial weights moved by ONE fp32 ulp move the curve by 1e-5 .. 8.4e-5; rounding ONE stage to fp32
+    inside the float64 run moves it by 9.0e-5 (convolutions), 9.2e-5 (InstanceNorm), 1.3e-4 (activations); the reference's own
+    kernels on another host (the CPU oracle below, 16 threads instead of 8) end up 1.6e-4 from the reference's curve."""
     import patchgan_amd as pg
     B, steps = 16, 10
-    torch.manual_seed(1234)
-    g = pg.UNet(3, 1, 64, use_dropout=False, activation='leakyrelu', final_act='sigmoid')
-    d = pg.Discriminator(4, 64, n_layers=3)
+    # the same seeds / recipe as the fixture the REFERENCE produced at this configuration (tests/golden/w_cfg2.npz): seeded_modules()
+    # holds the initial weights to the reference's, tensor by tensor
+    ref_gold = Golden('w_cfg2')
+    assert (ref_gold.cfg['B'], ref_gold.cfg['nf'], ref_gold.cfg['ndf'], ref_gold.nsteps) == (B, 64, 64, steps)
+    g, d = ref_gold.seeded_modules()
     gw = {k: v.clone() for k, v in g.state_dict().items()}
     dw = {k: v.clone() for k, v in d.state_dict().items()}
-    gen = torch.Generator().manual_seed(7)
-    x = torch.rand(B, 3, 256, 256, generator=gen)
-    y = (torch.rand(B, 1, 256, 256, generator=gen) > 0.7).float()
+    x, y = ref_gold.inputs()
     kw = dict(activation='leakyrelu', final_act='sigmoid', n_layers=3, norm=False, loss_type='tversky')
 
     def run(trainer, xx, yy):
@@ -489,19 +492,39 @@ def test_cfg2_loss_curve_10_steps_vs_oracle(tmp_path):
     def rel(a, b):
         return (np.abs(a - b) / np.maximum(np.abs(b), 1e-3)).max(axis=1)
 
+    ref = ref_gold.z['losses']                   # the reference's own curve (patchgan/trainer.py:50-115 on torch-CPU, 8 threads)
     env = np.maximum.accumulate(rel(c32, c64))
     err, err64, err64_nw = rel(got, c32), rel(got, c64), rel(got_nw, c64)
-    print('cfg2 bs16 per step: HIP vs fp32 CPU oracle', err, 'HIP vs fp64', err64, 'fp32 CPU oracle vs fp64 (running max)', env)
-    print('cfg2 bs16 per step: HIP without Winograd vs fp64', err64_nw)
-    print(f'cfg2 bs16 maxima over 10 steps: HIP default vs fp64 {err64.max():.3e}, HIP no-Winograd vs fp64 {err64_nw.max():.3e}, '
-          f'fp32 CPU oracle vs fp64 {env.max():.3e}, HIP default vs fp32 CPU oracle {err.max():.3e}')
-    assert (err <= np.maximum(LOSS_RTOL, 10 * env)).all(), (err, env)
-    assert (err64 <= np.maximum(LOSS_RTOL, 4 * env)).all(), (err64, env)
+    err_ref, ref64, oracle_ref = rel(got, ref), rel(ref, c64), rel(c32, ref)
+    np.set_printoptions(precision=2, linewidth=200)
+    print('cfg2 bs16, relative distance per step (max over the 6 loss scalars):')
+    print('   HIP default  vs REFERENCE golden', err_ref)
+    print('   HIP default  vs float64         ', err64)
+    print('   HIP no-Wino  vs float64         ', err64_nw)
+    print('   REFERENCE    vs float64         ', ref64)
+    print('   CPU oracle   vs REFERENCE       ', oracle_ref, '(same torch-CPU kernels: 0 with the fixture\'s thread count)')
+    print('   HIP default | REFERENCE per step:')
+    for s_ in range(steps):
+        print(f'     step {s_ + 1:2d}  ' + '  '.join(f'{k} {got[s_, i]:.6f} | {ref[s_, i]:.6f}' for i, k in enumerate(LOSS_KEYS) if k != 'gen_loss'))
+    print(f'cfg2 bs16 maxima over 10 steps: HIP default vs REFERENCE {err_ref.max():.3e}, vs fp64 {err64.max():.3e}, HIP no-Winograd vs fp64 '
+          f'{err64_nw.max():.3e}, REFERENCE vs fp64 {ref64.max():.3e}, HIP default vs fp32 CPU oracle {err.max():.3e}')
+    # the oracle is BIT-equal to the reference on the fixture's host and thread count (tests/test_oracle_golden.py); on this host
+    # oneDNN may sum in another order, and from step 2 on the two curves part like any two fp32 evaluations
+    assert oracle_ref[0] <= 1e-6, oracle_ref
+    # Stated bounds = 1.5 x the maxima MEASURED on the round-5 build (deterministic kernels: the same numbers on every box):
+    #   vs the reference's curve CFG2_REF_BOUND (= the north star's 1e-4: measured 7.84e-5), vs float64 CFG2_F64_BOUND (measured 1.43e-4;
+    #   the reference itself: 1.31e-4); steps 1-2, before the G/D dynamics amplify rounding, 4.2e-5 (measured 1.6e-5 / 2.8e-5).
+    assert err_ref.max() <= CFG2_REF_BOUND and err64.max() <= CFG2_F64_BOUND, (err_ref, err64)
+    assert err_ref[:2].max() <= 4.2e-5 and err64[:2].max() <= 4.2e-5, (err_ref[:2], err64[:2])
     # Winograd's price in parity: the default path may sit at most 2x as far from float64 as the exact-GEMM path of the same
     # library, compared on the running maxima (either path's single-step error is noise around its own drift)
     run64, run64_nw = np.maximum.accumulate(err64), np.maximum.accumulate(err64_nw)
     assert (run64 <= np.maximum(LOSS_RTOL, 2 * run64_nw)).all(), (run64, run64_nw)
 
+
+# 1.5 x measured (round 5; tools/parity_attribution.py prints the table and what each stage's fp32 rounding is worth)
+CFG2_REF_BOUND = 1.0e-4
+CFG2_F64_BOUND = 2.15e-4
 
 _FULL_SIZE_ORACLE = {}
 
