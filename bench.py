@@ -357,7 +357,7 @@ def main():
                            + (f" (auto: device {m['step_times'][0]:.2f} ms vs host enqueue {m['step_times'][1]:.2f} ms per step)" if m.get('step_times') else ''),
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'activation_storage': m['activation_storage'],
+            'activation_storage': m['activation_storage'], 'peak_vram_GiB': m['peak_vram_GiB'],
             'config': {'workload': CFG['desc'] + ', dropout ' + ('on' if args.dropout else 'off'),
                        'global_batch': BATCH_PER_GPU * world, 'parallelism': f'dp{world}'},
             'last_losses': m['last_losses'],
@@ -395,6 +395,7 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
     from patchgan_amd import engine as E
     from patchgan_amd import parallel
     batch, size = cfg['batch'], cfg['size']
+    torch.cuda.reset_peak_memory_stats()
     torch.manual_seed(1234)
     G = pg.UNet(3, cfg['out_nc'], cfg['nf'], use_dropout=dropout, activation=cfg['activation'],
                 final_act=cfg['final_act']).to(dev)
@@ -628,7 +629,8 @@ def extra_configs(dev, cpu=True):
             'workload': CONFIGS['cfg4']['desc'] + ', bf16 MFMA kernels, '
                         + m['activation_storage'] + ' activation storage, dropout off',
             'metric': 'train images/sec (G+D step) at 512x512 bs=8 per GPU', 'value': round(m['value'], 2), 'unit': 'images/sec',
-            'steps': 10, 'warmup': 5, 'ms_per_step': round(m['ms_per_step'], 3), 'dtype': 'bf16',
+            'steps': 10, 'warmup': 5, 'ms_per_step': round(m['ms_per_step'], 3), 'dtype': 'bf16', 'peak_vram_GiB': m['peak_vram_GiB'],
+            'step_launch': 'two streams' if m['two_streams'] else ('graph' if m['graph'] else 'one stream'),
             'roofline': {k: r[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'achieved_useful', 'frac_useful', 'traffic',
                                            'traffic_source', 'launches_per_step', 'avg_launch_ms', 'kernel_share_of_step', 'all_conv_kernels_TFLOPs',
                                            'step_frac_of_mfma_roofline')},
@@ -646,7 +648,7 @@ def extra_configs(dev, cpu=True):
         out['cfg2_dropout_on'] = {
             'workload': CONFIGS['cfg2']['desc'] + ', dropout ON (nn.Dropout(0.2) in 7 encoder + 5 decoder blocks: the patchgan_train default)',
             'metric': 'train images/sec (G+D step) at 256x256 bs=16 per GPU', 'value': round(m['value'], 2), 'unit': 'images/sec',
-            'steps': 10, 'warmup': 5, 'ms_per_step': round(m['ms_per_step'], 3), 'dtype': 'f32',
+            'steps': 10, 'warmup': 5, 'ms_per_step': round(m['ms_per_step'], 3), 'dtype': 'f32', 'peak_vram_GiB': m['peak_vram_GiB'],
             'step_launch': 'two streams' if m['two_streams'] else ('graph' if m['graph'] else 'one stream'), 'last_losses': m['last_losses']}
         del m
     except Exception as e:

@@ -10,6 +10,36 @@ class FlatParamModule(nn.Module):
     the reference, each a strided view of the flat buffer -- so state_dict()/load_state_dict()/parameters()/
     to()/apply() behave like the reference's modules while kernels, Adam and all-reduce see one buffer."""
 
+    # set by a Trainer: completes an update of this module that is still in flight (Trainer.flush) before its weights or gradients are
+    # read through the module's own surface (state_dict, parameters, forward, .to()).  `flat` / `grad_flat` are the raw buffers the
+    # engines work on: whoever reads those directly calls Trainer.flush() first.
+    _access_hook = None
+
+    def _pre_access(self):
+        hook = self._access_hook
+        if hook is not None:
+            hook()
+
+    def state_dict(self, *args, **kwargs):
+        self._pre_access()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._pre_access()
+        return super().load_state_dict(*args, **kwargs)
+
+    def parameters(self, *args, **kwargs):
+        self._pre_access()
+        return super().parameters(*args, **kwargs)
+
+    def named_parameters(self, *args, **kwargs):
+        self._pre_access()
+        return super().named_parameters(*args, **kwargs)
+
+    def get_parameter(self, target):
+        self._pre_access()
+        return super().get_parameter(target)
+
     def _init_flat(self, layers, nparams):
         self._layers = layers
         flat = torch.zeros(nparams, dtype=torch.float32)
@@ -38,6 +68,7 @@ class FlatParamModule(nn.Module):
 
     def _apply(self, fn, recurse=True):
         # .to()/.cuda()/.cpu(): move the flat buffer, then re-point every parameter at its view of it
+        self._pre_access()
         new_flat = fn(self.flat.detach())
         if new_flat.dtype != torch.float32:
             raise TypeError("patchgan_amd networks are fp32 only")

@@ -48,5 +48,6 @@ class Discriminator(FlatParamModule, Transferable):
         self._init_flat(self.engine.layers, self.engine.nparams)
 
     def forward(self, input):
+        self._pre_access()
         params = [self.get_parameter(k) for k in self._param_keys]
         return _DiscFn.apply(self, input, *params)

@@ -163,6 +163,7 @@ class Exec:
         self.keep_bytes = 0
         self.ws = {}
         self.ws_gen = 0
+        self._prev = []
 
     def side_stream(self):
         """The second stream of a two-stream step, created on first use ON THE OWNER'S DEVICE."""
@@ -194,12 +195,12 @@ class Exec:
         self.ws_gen += 1
 
     def __enter__(self):
-        self._prev = getattr(_TLS, 'cur', None)
+        self._prev.append(getattr(_TLS, 'cur', None))          # (a stack: flush() inside batch() enters the same state again)
         _TLS.cur = self
         return self
 
     def __exit__(self, *exc):
-        _TLS.cur = self._prev
+        _TLS.cur = self._prev.pop()
         return False
 
 
@@ -256,7 +257,9 @@ class on_side:
 def _side_begin(allow):
     # (not inside a hipGraph capture: a captured two-branch step replays SLOWER than the one-stream one, 9.03 vs 8.96 ms at cfg2)
     ex = cur_exec()
-    ex.allow = bool(allow) and ex.enabled and WGRAD_SIDE and PROFILER is None and not torch.cuda.is_current_stream_capturing()
+    # (nor inside on_side(): a pass the caller has put on the second stream as a whole runs its chains one after the other there)
+    ex.allow = (bool(allow) and ex.enabled and not ex.inside and WGRAD_SIDE and PROFILER is None
+                and not torch.cuda.is_current_stream_capturing())
 
 
 def side_join():
@@ -718,6 +721,7 @@ PREP_BATCH = _exp_env('PATCHGAN_PREP_BATCH') != '0'           # one batched weig
 FUSE_ACT_BWD = _exp_env('PATCHGAN_FUSE_ACT_BWD') != '0'       # activation backward in the data-gradient epilogue above it
 SEAM8 = _exp_env('PATCHGAN_SEAM8') != '0'       # bf16 storage: image-facing tensors in 8-channel bf16 pixels
 WGRAD_SIDE = _exp_env('PATCHGAN_WGRAD_SIDE') != '0'       # weight gradients of a backward pass on a second stream (Exec)
+BF16_WGRAD_SIDE = _exp_env('PATCHGAN_BF16_WGRAD_SIDE', '0') == '1'       # bf16 networks' weight gradients on the second stream too (A/B switch; off)
 SPLIT_BWD_BIG = _exp_env('PATCHGAN_SPLIT_BWD_BIG') != '0'       # with the second stream: the decoder's fused backward call as its two halves (8.83 -> 8.65 ms at cfg2)
 
 
@@ -1098,7 +1102,7 @@ class GeneratorEngine(_WeightPrep):
                 on_ready(l.p_off, l.p_off + 16 * l.a * l.b)
         # defer_join: the caller joins the second stream itself (side_join()) before it reads the weight gradients -- the trainer puts
         # the discriminator's forward pass, which needs none of them, in between
-        _side_begin(not self.act_bf)       # (bf16: the two chains contend for the L1 path: 5.87 -> 5.94 ms at cfg4)
+        _side_begin(not self.act_bf or BF16_WGRAD_SIDE)       # (bf16: the two chains contend for the L1 path: 5.87 -> 5.94 ms at cfg4)
         ok = False
         try:
             r = self._backward(flat, gflat, c, g1, g2, need_dx, done, ucache)
@@ -1284,7 +1288,7 @@ class DiscriminatorEngine(_WeightPrep):
     def backward(self, flat, gflat, c, gout, need_wgrad=True, need_dx=False, ucache=None):
         """gout: View of dL/d(out).  need_wgrad=False skips the weight gradients (the generator step's pass
         through D, whose D-gradients the reference zeroes at trainer.py:93-94).  ucache: as in forward."""
-        _side_begin(need_wgrad and not self.act_bf)
+        _side_begin(need_wgrad and (not self.act_bf or BF16_WGRAD_SIDE))
         try:
             return self._backward(flat, gflat, c, gout, need_wgrad, need_dx, ucache)
         finally:

@@ -136,7 +136,10 @@ def patchgan_train(argv=None):
     checkpoint_path = config.get('checkpoint_path', './checkpoints/')
     trainer = Trainer(generator, discriminator, savefolder=checkpoint_path)
     trainer.gc_freeze = True      # this process is the training job: keep generation-2 collections out of the step loop
-    trainer.graph = 'auto'        # launch-bound steady-state steps are replayed from a captured hipGraph (one GPU, use_dropout: False); device-bound ones stay launch by launch
+    # per kind of step the trainer times two warm steps and decides: a launch-bound one is replayed from a captured hipGraph (one GPU,
+    # use_dropout: False); a device-bound one stays launch by launch on two streams -- also with use_dropout: True (the default,
+    # reference train.py:92), in the validation loop and under data parallelism
+    trainer.graph = 'auto'
     if dataset_kwargs.get('device_pipeline', False):
         trainer.label_values = [int(v) for v in np.sort(dataset_kwargs['labels'])]
     if config.get('load_last_checkpoint', False):

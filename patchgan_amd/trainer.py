@@ -33,6 +33,8 @@ device = 'cuda' if torch.cuda.is_available() else 'cpu'
 
 _LOSS_MODES = {'tversky': L.LOSS_TVERSKY, 'weighted_bce': L.LOSS_WBCE, 'MAE': L.LOSS_MAE}
 EARLY_D_FWD = E._exp_env('PATCHGAN_EARLY_D_FWD') != '0'      # two-stream step: the discriminator step's forward under the generator step (A/B switch)
+ADAM_G_BESIDE = E._exp_env('PATCHGAN_ADAM_G_BESIDE') != '0'      # ... and G's Adam update behind that fork (A/B switch)
+DEFER_D_BWD = E._exp_env('PATCHGAN_DEFER_D_BWD') != '0'      # two-stream step: the discriminator's backward pass + Adam(D) under the NEXT step's generator forward (A/B switch)
 
 
 _GC_FREEZES = 0
@@ -174,6 +176,11 @@ class Trainer:
         discriminator.apply(weights_init)
         self.generator = generator
         self.discriminator = discriminator
+        # (a discriminator update may be in flight on the second stream / in a collective when batch() returns: anything that reads the
+        #  module's weights through its own surface completes it first)
+        import weakref
+        me = weakref.ref(self)
+        discriminator._access_hook = lambda: me() is not None and me().flush()
         self.device = device
         if savefolder[-1] != '/':
             savefolder += '/'
@@ -186,6 +193,7 @@ class Trainer:
         self._t_g = self._t_d = 0  # Adam step counts
         self._step = 0
         self._pending_d = None
+        self._deferred = None      # operands of a discriminator backward pass still running on the second stream (flush())
         self.bucket_bytes = 32 << 20   # all-reduce bucket size under data parallelism (parallel.GradReducer)
         self._graphs, self._adam_dev = {}, None
         self._kinds, self.step_times, self.launch_mode = {}, None, None      # per kind of step: warm-step count, probe samples, decision
@@ -360,7 +368,8 @@ class Trainer:
             dc2 = de.forward(D.flat, din, ucache=ucache, keep_v=train)
         if ex.pending or ex.keep:
             E.side_join()
-        if train and late_adam_g:
+        adam_g_behind_fork = bool(train and late_adam_g and ex.enabled and E.PROFILER is None and DEFER_D_BWD and ADAM_G_BESIDE)
+        if train and late_adam_g and not adam_g_behind_fork:
             self._adam_step('g')                                                              # trainer.py:90
         o2 = dc2.out
         god = E.View.alloc(o2.N, o2.H, o2.W, 1, dev) if train else None
@@ -377,16 +386,37 @@ class Trainer:
             wait_losses = dist.all_reduce_side(losses)
         if train:
             dflat = D.ensure_grad_flat()
-            de.backward(D.flat, dflat, dc2, god, need_wgrad=True, need_dx=False, ucache=ucache)   # trainer.py:106
-            if g_reducer is not None:
-                # D's gradient (11 MB at ndf=64) is all-reduced asynchronously and applied by flush() at the first use of
-                # D's weights -- after the NEXT step's generator forward, which does not read them (trainer.py:63-66); handed to
-                # the comm stream BEFORE the compute stream waits for G's buckets, so it is queued behind them without a gap
-                self._pending_d = dist.all_reduce_side(dflat)
-                g_reducer.finish()                     # G's buckets have been in flight since the generator backward
-                self._adam_step('g')
+            if ex.enabled and E.PROFILER is None and DEFER_D_BWD:
+                # two-stream step: the discriminator's whole backward pass and its Adam update go to the second stream and run under the
+                # NEXT step's generator forward, which reads neither D's weights nor its gradients (trainer.py:63; the next use of D is
+                # trainer.py:66) and has no second chain of its own -- the same kernels with the same arguments, so the results are
+                # bit-identical; flush() joins before anything reads D's weights (the next step's D passes, save / load, the end of train,
+                # state_dict() / forward of the module).  The pass's operands stay referenced until then.
+                with E.on_side():
+                    de.backward(D.flat, dflat, dc2, god, need_wgrad=True, need_dx=False, ucache=ucache)   # trainer.py:106
+                    if g_reducer is not None:
+                        self._pending_d = dist.all_reduce_side(dflat)      # (behind the pass on the second stream; Adam(D) in flush())
+                    else:
+                        self._adam_step('d')                                                      # trainer.py:107
+                self._deferred = (dc2, god, ucache, dflat)
+                if adam_g_behind_fork:
+                    # G's Adam update (1.2 GB at the memory rate, 0.2 ms alone on the chip) beside the first kernels of D's backward pass
+                    # instead of in front of them: it only has to precede the next step's generator forward
+                    self._adam_step('g')                                                          # trainer.py:90
+                if g_reducer is not None:
+                    g_reducer.finish()                     # G's buckets have been in flight since the generator backward
+                    self._adam_step('g')
             else:
-                self._adam_step('d')                                                          # trainer.py:107
+                de.backward(D.flat, dflat, dc2, god, need_wgrad=True, need_dx=False, ucache=ucache)   # trainer.py:106
+                if g_reducer is not None:
+                    # D's gradient (11 MB at ndf=64) is all-reduced asynchronously and applied by flush() at the first use of
+                    # D's weights -- after the NEXT step's generator forward, which does not read them (trainer.py:63-66); handed to
+                    # the comm stream BEFORE the compute stream waits for G's buckets, so it is queued behind them without a gap
+                    self._pending_d = dist.all_reduce_side(dflat)
+                    g_reducer.finish()                     # G's buckets have been in flight since the generator backward
+                    self._adam_step('g')
+                else:
+                    self._adam_step('d')                                                          # trainer.py:107
         de.ucache_end(ucache)
         if wait_losses is not None:
             wait_losses()
@@ -410,8 +440,16 @@ class Trainer:
         return out
 
     def flush(self):
-        """Apply a discriminator update whose gradient all-reduce is still in flight (data parallelism only).  Called
-        before anything reads the discriminator's weights: the next step's D forward, save(), load(), the end of train()."""
+        """Complete a discriminator update that is still in flight: under data parallelism its gradient all-reduce (Adam(D) is applied
+        here), in a two-stream step the backward pass + Adam(D) running on the second stream under the next generator forward.  Called
+        before anything reads the discriminator's weights: the next step's D passes, save(), load(), the end of train(), and -- through
+        the modules' access hook -- state_dict() / forward() / .to() of the discriminator itself."""
+        if self._deferred is not None:
+            ex = self._exec
+            if ex is not None and (ex.pending or ex.keep):
+                with ex:
+                    E.side_join()
+            self._deferred = None
         wait = getattr(self, '_pending_d', None)
         if wait is not None:
             self._pending_d = None
@@ -502,6 +540,7 @@ class Trainer:
 
     def release(self):
         """Give this trainer's captured steps, workspaces and second stream back (they also go with the object)."""
+        self.flush()
         self._graphs = {}
         if self._exec is not None:
             self._exec.release()
@@ -512,6 +551,7 @@ class Trainer:
         Captured on first use.  Per replay the host copies the inputs into the graph's input buffers, writes Adam's two
         step-dependent scalars per network (lr / bc1, sqrt(bc2): pg_adam_step_dev reads them from device memory) and launches.
         Returns None (after a warning) if this runtime cannot capture the step: the caller continues launch by launch."""
+        self.flush()
         st = self._graphs.get(key)
         if st is not None and st.ptrs != self._graph_ptrs():
             # the gradient / moment buffers the capture was made with were replaced (a network moved, .grad reset): capture again

@@ -1,4 +1,4 @@
-"""Back-to-back repetitions of K training steps (bf16 network of tools/debug_repro.py, N = 1), device clones of the step's end-of-step
+"""Back-to-back repetitions of K training steps (bf16 network of the determinism hunt (tools/forensics/), N = 1), device clones of the step's end-of-step
 tensors after every step (no host synchronisation inside a repetition beyond the step's own loss read-back), compared with repetition 0
 at the end.  Run two of these at once on one GPU (tests/test_determinism_gpu.py does).
 usage: python tests/determinism_worker.py [precision] [reps] [steps] [clone: 0|1]"""
@@ -40,12 +40,14 @@ for r in range(reps):
     for s in range(steps):
         l = t.batch(x, y, train=True)
         if do_clone:
+            t.flush()          # (a two-stream step leaves the discriminator's update running on the second stream: flat buffers are raw)
             rec.append((f'step {s + 1} gen image', t._last_gen.t.clone()))
             rec.append((f'step {s + 1} G grad', g.grad_flat.clone()))
             rec.append((f'step {s + 1} D grad', d.grad_flat.clone()))
             rec.append((f'step {s + 1} G weights', g.flat.clone()))
             rec.append((f'step {s + 1} D weights', d.flat.clone()))
         rec.append((f'step {s + 1} losses', torch.tensor([l[k] for k in ('gen', 'gen_loss', 'gdisc', 'discr', 'discf', 'disc')], dtype=torch.float64)))
+    t.flush()
     rec.append(('final G weights', g.flat.clone()))
     rec.append(('final D weights', d.flat.clone()))
     runs.append(rec)

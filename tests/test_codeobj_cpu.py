@@ -39,7 +39,7 @@ OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
 def test_no_packed_f32_low_half_from_the_odd_register_of_a_fresh_lds_pair(tmp_path):
     """Cause of round 3's open issue (k_s2b_ca1_s1 returning different values next to a second process on the GPU): `acc += x * w`
     with x read from LDS compiled to v_pk_mul_f32 ... op_sel:[0,1] straight off a ds_read2_b32 pair; lanes 48-63 of the low half
-    then used the register's old content although s_waitcnt lgkmcnt was satisfied (one tap of the sum dropped; tools/debug_cc5.py,
+    then used the register's old content although s_waitcnt lgkmcnt was satisfied (one tap of the sum dropped; tools/forensics/debug_cc5.py,
     two processes: an event in 50 of 92 repetitions of 18 steps; with the values passed through v_readfirstlane / v_mov_b32 first:
     0 of 92).  No kernel of the library may contain that operand form."""
     import subprocess

@@ -186,7 +186,7 @@ def test_cfg2_full_width_gradients_vs_oracle(tmp_path):
     sign flip at an output within an ulp of zero is worth 2e-4 there: see the comment at the assertion).  Generator: relative L2 2e-2 and no worse than 8 x the fp32
     CPU oracle's own relative-L2 distance + 1e-3 -- at this width the generator's backward chain amplifies fp32 rounding so
     much that EXACT fp32 evaluations (the one-thread-per-output kernels, the implicit GEMM, oneDNN on the CPU) sit 3e-4 .. 7e-3
-    in relative L2 and up to 1e-1 in max-norm from float64 (tools/debug_grads_full.py prints the table), so a max-norm bound
+    in relative L2 and up to 1e-1 in max-norm from float64 (tools/forensics/debug_grads_full.py prints the table), so a max-norm bound
     would test the conditioning of the network, not the kernels; the per-kernel tests carry the 2e-5 statements."""
     import patchgan_amd as pg
     g, d, gw, dw = _models(1, 'sigmoid')
@@ -215,7 +215,7 @@ def test_cfg2_full_width_gradients_vs_oracle(tmp_path):
         # model.0.* sit behind the LeakyReLU kink of 8.4 M first-layer outputs: ONE output within an ulp of zero whose fp32 sign
         # differs from float64's changes its dy by a factor 5 and moves model.0.bias by 1.8e-4 / model.0.weight by 5.9e-5 of their
         # max-norm (measured with the persistent first-layer kernel, whose output is 4.9e-7 from float64 with exactly one such
-        # flip; the one-shot kernel had none on these inputs and sits at 3e-6: tools/debug_flips.py, tools/debug_dgrads.py)
+        # flip; the one-shot kernel had none on these inputs and sits at 3e-6: tools/forensics/debug_flips.py, tools/forensics/debug_dgrads.py)
         assert e < (1e-3 if k.startswith('model.0.') else 1e-4), (k, e)
     for k, p in g.named_parameters():
         e, noise = l2(p.grad, o64.last['g_grads'][k]), l2(ot.last['g_grads'][k], o64.last['g_grads'][k])

@@ -117,6 +117,9 @@ def test_auto_policy_both_outcomes_are_the_same_computation(tmp_path, precision,
     assert any(sides) == (precision == 'fp32'), sides          # weight gradients on the second stream: fp32 networks only
     assert np.array_equal(ref[0], a[0]) and np.array_equal(ref[1], a[1]) and np.array_equal(ref[2], a[2])
     ex = a[4]._exec
+    assert ex.pending and a[4]._deferred is not None          # the last step's discriminator backward pass is still on the second stream ...
+    a[4].flush()                                              # ... until something needs the discriminator's weights
+    assert a[4]._deferred is None
     assert not ex.keep and not ex.enabled and not ex.pending and ex.device == torch.device('cuda', torch.cuda.current_device())
     assert getattr(E._TLS, 'cur', None) is None          # the trainer's execution state is current only inside batch()
     # launch-bound by decree: captured at the 4th step of its kind, as with graph = True
@@ -155,7 +158,8 @@ def test_dropout_and_eval_steps_take_the_second_stream_and_stay_bit_identical(tm
         return enter(self)
     monkeypatch.setattr(E.on_side, '__enter__', spy_enter)
     two = _run(tmp_path, False, 'fp32', 6, nf=64, use_dropout=True, tag='d_two', two_streams=True, eval_at=(2, 4))
-    assert len(forks) == 8 and all(forks), forks           # every step, the evaluation passes included
+    # every step, the evaluation passes included, forks the discriminator step's forward; every training step also its backward pass
+    assert len(forks) == 8 + 6 and all(forks), forks
     assert two[4].launch_mode == 'eager2' and not any(two[3])
     assert np.array_equal(ref[0], two[0]) and np.array_equal(ref[1], two[1]) and np.array_equal(ref[2], two[2])
     monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 0.0)
@@ -280,3 +284,40 @@ def test_two_trainers_do_not_share_execution_state(tmp_path):
     ts[0].release()
     assert ts[0]._exec.buffers() == [] and [b.data_ptr() for b in ts[1]._exec.buffers()] == ptrs
     E.release_workspaces()
+
+
+def test_discriminator_update_in_flight_is_completed_by_whatever_reads_its_weights(tmp_path):
+    """In a two-stream step the discriminator's backward pass and Adam update are still running on the second stream when batch()
+    returns (they run under the next step's generator forward).  Reading the discriminator through its own surface -- state_dict(),
+    forward(), save() -- completes the update first (the modules' access hook -> Trainer.flush), with NO device synchronize by the
+    caller: the values are those of the one-stream trainer, bit for bit."""
+    import patchgan_amd as pg
+    outs = []
+    for two in (True, False):
+        torch.manual_seed(21)
+        g = pg.UNet(3, 1, 32, use_dropout=False, activation='leakyrelu', final_act='sigmoid').cuda()
+        d = pg.Discriminator(4, 32, n_layers=3).cuda()
+        t = pg.Trainer(g, d, str(tmp_path / f'h{int(two)}'))
+        t.two_streams = two
+        t.setup_optimizers(1e-3, 1e-3)
+        g.train(), d.train()
+        gen = torch.Generator().manual_seed(5)
+        x = torch.rand(4, 3, 256, 256, generator=gen)
+        y = (torch.rand(4, 1, 256, 256, generator=gen) > 0.7).float()
+        for _ in range(3):
+            t.batch(x, y, train=True)
+        if two:
+            assert t._deferred is not None
+        sd = {k: v.clone() for k, v in d.state_dict().items()}          # (no synchronize: the hook joins the streams)
+        assert t._deferred is None
+        t.batch(x, y, train=True)
+        with torch.no_grad():
+            out = d(torch.cat((x, y), 1).cuda())                         # the module's own forward: the 4th update is in place
+        t.batch(x, y, train=True)
+        t.save(1)                                                         # save() flushes too
+        ck = torch.load(str(tmp_path / f'h{int(two)}' / 'discriminator_ep_001.pth'))
+        outs.append((sd, out.cpu(), ck))
+    for k in outs[0][0]:
+        assert torch.equal(outs[0][0][k].cpu(), outs[1][0][k].cpu()), k
+        assert torch.equal(outs[0][2][k].cpu(), outs[1][2][k].cpu()), k
+    assert torch.equal(outs[0][1], outs[1][1])

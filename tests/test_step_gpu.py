@@ -615,7 +615,7 @@ def test_full_size_cfg2_matches_oracle(tmp_path, tuning):
             # D gradients are well conditioned: relative max-norm 1e-4 against float64 (measured <= 1.2e-5, Winograd layers
             # included).  G gradients at this width are not: the backward chain amplifies fp32 rounding so much that EXACT fp32
             # evaluations (one-thread-per-output kernels, implicit GEMM, the CPU oracle) sit 3e-4 .. 7e-3 (relative L2) and
-            # up to 1e-1 (max-norm) from float64 (tools/debug_grads_full.py), so they get a relative-L2 bound of 2e-2.
+            # up to 1e-1 (max-norm) from float64 (tools/forensics/debug_grads_full.py), so they get a relative-L2 bound of 2e-2.
             for key in ('model.6.weight', 'model.4.weight', 'model.2.weight'):
                 assert _rel(d.get_parameter(key).grad.cpu(), r['grads64'][1][key]) < 1e-4, key
             for key in ('encoder.3.model.DownConv3.weight', 'decoder.3.model.UpConv3.weight', 'encoder.1.model.DownConv1.weight',

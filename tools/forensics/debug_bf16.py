@@ -1,6 +1,6 @@
 """Debug aid (GPU box): per-layer deviation of the bf16 path from the fp32 path on a golden config."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, tempfile
 import patchgan_amd as pg
 from patchgan_amd import engine as E

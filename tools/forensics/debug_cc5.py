@@ -5,7 +5,7 @@ content from an earlier call), a neighbour's value, the un-multiplied accumulato
 With PATCHGAN_EXPERIMENT=1 PATCHGAN_CA1S1_BF16=1 the LDS-staged kernel runs on bf16 outputs.  Two of these at once.
 usage: python tools/debug_cc5.py [reps] [steps]"""
 import os, sys, tempfile
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import patchgan_amd as pg
 from patchgan_amd import engine as E, _lib as L

@@ -1,7 +1,7 @@
 """Per-key loss-curve error of the HIP trainer against the float64 oracle for one golden config (fp32 oracle noise beside it).
 usage: [PATCHGAN_ALGO=direct|mfma] python tools/debug_curve.py d_softmax_tversky"""
 import sys, os, tempfile
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from tests.golden_util import Golden, LOSS_KEYS

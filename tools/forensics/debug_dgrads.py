@@ -1,6 +1,6 @@
 """Debug: step-1 discriminator gradients vs the float64 oracle at cfg2 width (B = 4), per parameter."""
 import sys, os, tempfile
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import patchgan_amd as pg
 from oracle import patchgan_oracle as O

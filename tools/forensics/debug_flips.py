@@ -1,6 +1,6 @@
 """Debug: LeakyReLU sign flips of d0's output between fp32 kernels and float64 at the cfg2 full-width test's inputs (B = 4)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F
 import patchgan_amd as pg
 from patchgan_amd import engine as E, _lib as L

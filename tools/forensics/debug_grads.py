@@ -1,6 +1,6 @@
 """Debug aid (GPU box): per-parameter gradient error of the HIP step vs the fp64 / fp32 CPU oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, tempfile
 torch.set_num_threads(16)
 from oracle import patchgan_oracle as O

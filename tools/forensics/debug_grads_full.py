@@ -1,7 +1,7 @@
 """Debug aid (GPU box): per-parameter step-1 gradient error of the HIP step at full width (nf = ndf = 64, 256x256, B from argv)
 against the float64 oracle (torch double ops on the GPU), next to the fp32 CPU oracle's own error; for several tunings."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, tempfile
 torch.set_num_threads(16)
 from oracle import patchgan_oracle as O

@@ -2,7 +2,7 @@
 fp32 oracle's own distance beside them (which parameter's gradient carries more rounding noise than torch's fp32 run?).
 usage: python tools/debug_step1.py d_softmax_tversky"""
 import sys, os, tempfile, pathlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from oracle import patchgan_oracle as O

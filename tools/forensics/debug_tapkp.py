@@ -1,6 +1,6 @@
 """Debug: k_b2s_tapkp vs float64 on the d0 geometry at several batch sizes; prints max abs error and its location."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F
 from patchgan_amd import engine as E, _lib as L
 dev = 'cuda'

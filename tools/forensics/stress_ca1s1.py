@@ -3,7 +3,7 @@ ITERS launches on fixed operands, every output compared ON THE DEVICE with the f
 process (CHURN=1: empty_cache + fresh allocations between launches, what a starting process does).  Run two at once.
 usage: [PATCHGAN_EXPERIMENT=1 PATCHGAN_CA1S1_BF16=1] python tools/stress_ca1s1.py [iters] [N]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from patchgan_amd import engine as E, _lib as L
 
