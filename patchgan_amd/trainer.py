@@ -34,6 +34,8 @@ device = 'cuda' if torch.cuda.is_available() else 'cpu'
 _LOSS_MODES = {'tversky': L.LOSS_TVERSKY, 'weighted_bce': L.LOSS_WBCE, 'MAE': L.LOSS_MAE}
 EARLY_D_FWD = E._exp_env('PATCHGAN_EARLY_D_FWD') != '0'      # two-stream step: the discriminator step's forward under the generator step (A/B switch)
 ADAM_G_BESIDE = E._exp_env('PATCHGAN_ADAM_G_BESIDE') != '0'      # ... and G's Adam update behind that fork (A/B switch)
+# (under data parallelism the deferral measured SLOWER -- one-rank RCCL group, same box: 9.06 vs 8.89 ms -- and stays off there)
+DEFER_D_BWD_DP = E._exp_env('PATCHGAN_DEFER_D_BWD_DP', '0') == '1'
 DEFER_D_BWD = E._exp_env('PATCHGAN_DEFER_D_BWD') != '0'      # two-stream step: the discriminator's backward pass + Adam(D) under the NEXT step's generator forward (A/B switch)
 
 
@@ -386,7 +388,7 @@ class Trainer:
             wait_losses = dist.all_reduce_side(losses)
         if train:
             dflat = D.ensure_grad_flat()
-            if ex.enabled and E.PROFILER is None and DEFER_D_BWD:
+            if ex.enabled and E.PROFILER is None and DEFER_D_BWD and (g_reducer is None or DEFER_D_BWD_DP):
                 # two-stream step: the discriminator's whole backward pass and its Adam update go to the second stream and run under the
                 # NEXT step's generator forward, which reads neither D's weights nor its gradients (trainer.py:63; the next use of D is
                 # trainer.py:66) and has no second chain of its own -- the same kernels with the same arguments, so the results are
