@@ -238,6 +238,7 @@ def spawn_ranks(n, argv, script=None, timeout=None, grace=5.0):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('GPU_MAX_HW_QUEUES', '8')          # (patchgan_amd/__init__.py: one hardware queue per stream of the step)
         env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cpus() // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
@@ -307,6 +308,7 @@ def main():
     sys.stdout.flush()
     line_fd = os.dup(1)
     os.dup2(2, 1)
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime initialises (patchgan_amd/__init__.py says why)
 
     import torch
     import torch.distributed as dist

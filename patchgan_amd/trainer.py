@@ -34,8 +34,10 @@ device = 'cuda' if torch.cuda.is_available() else 'cpu'
 _LOSS_MODES = {'tversky': L.LOSS_TVERSKY, 'weighted_bce': L.LOSS_WBCE, 'MAE': L.LOSS_MAE}
 EARLY_D_FWD = E._exp_env('PATCHGAN_EARLY_D_FWD') != '0'      # two-stream step: the discriminator step's forward under the generator step (A/B switch)
 ADAM_G_BESIDE = E._exp_env('PATCHGAN_ADAM_G_BESIDE') != '0'      # ... and G's Adam update behind that fork (A/B switch)
-# (under data parallelism the deferral measured SLOWER -- one-rank RCCL group, same box: 9.06 vs 8.89 ms -- and stays off there)
-DEFER_D_BWD_DP = E._exp_env('PATCHGAN_DEFER_D_BWD_DP', '0') == '1'
+# (under data parallelism too -- with the runtime's default of 4 hardware queues it measured SLOWER there, 9.06 vs 8.89 ms with a one-rank
+#  RCCL group: the compute stream shared a hardware queue with a stream waiting for the deferred pass; patchgan_amd/__init__.py asks
+#  for 8 queues: 8.51)
+DEFER_D_BWD_DP = E._exp_env('PATCHGAN_DEFER_D_BWD_DP') != '0'
 DEFER_D_BWD = E._exp_env('PATCHGAN_DEFER_D_BWD') != '0'      # two-stream step: the discriminator's backward pass + Adam(D) under the NEXT step's generator forward (A/B switch)
 
 
@@ -276,6 +278,14 @@ class Trainer:
         self.host_ms = (time.perf_counter() - t_host0) * 1e3       # host time to enqueue the whole step (bench.py reports it)
         return self._publish(losses)
 
+    marks = None             # diagnostics (tools/step_phases.py): a list -> every _mark(name) records an event on the current stream
+
+    def _mark(self, name):
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((name, ev, time.perf_counter()))
+
     def _enqueue_step(self, x, y, u8, N, H, W, Cin, Cout, train):
         """Every launch of one step on the current stream, from the device-resident inputs to the four loss scalars (returned as a
         device tensor).  Nothing in here reads the device; the only step-dependent HOST values are the dropout seed (self._step) and
@@ -288,6 +298,7 @@ class Trainer:
         Bglobal = N * dist.world
         Cd = Cin + Cout
         ex = E.cur_exec(dev)
+        self._mark('start')
 
         # discriminator input buffer: samples [0,N) real = x|y, [N,2N) fake = x|G(x)   (trainer.py:65,96,98)
         din = E.View.alloc(2 * N, H, W, Cd, dev)
@@ -311,7 +322,9 @@ class Trainer:
         # one batched launch (from the second step on; engine._WeightPrep), shared by forward and backward where one copy serves both
         gcache = ge.ucache_begin(G.flat, N, H, W) if train else None
         gc = ge.forward(G.flat, xin, gen, G.training, seed, sample0=dist.rank * N, keep_v=train, ucache=gcache)   # trainer.py:63
+        self._mark('G fwd done')
         self.flush()          # D's deferred all-reduce + Adam from the previous step ran under this G forward
+        self._mark('flushed')
         # seg loss, phase 1 (per-sample reductions); under data parallelism its two batch-global terms are summed across
         # ranks on the comm stream while the discriminator's forward pass over the fake batch runs
         seg_pending = E.loss_begin(gen, yv, 0.0, self.tversky_beta, allred)
@@ -328,6 +341,7 @@ class Trainer:
             n_prepared = len(ucache)
             with E.on_side():
                 dc2 = de.forward(D.flat, din, ucache=ucache, keep_v=train)
+                self._mark('side: dc2 fwd done')
             if len(ucache) != n_prepared:
                 # (a transformed-weight entry the batched preparation did not cover was made by a kernel on the second stream -- the
                 #  first steps after a change of tuning: the passes below would take it as ready, so they wait for it this once)
@@ -340,9 +354,11 @@ class Trainer:
         gd = E.View.alloc(o.N, o.H, o.W, 1, dev) if train else None
         E.loss_value_and_grad(o, None, 1.0, L.LOSS_BCE, 1.0, gd, losses, 1, Bglobal)          # trainer.py:84
         g_reducer, late_adam_g = None, False
+        self._mark('D(fake) fwd + losses done')
         if train:
             gflat = G.ensure_grad_flat()
             ddin = de.backward(D.flat, None, dc, gd, need_wgrad=False, need_dx=True, ucache=ucache)   # dL/d(x|gen)
+            self._mark('D dgrad done')
             if dist.on:
                 # buckets of the flat G gradient are all-reduced on RCCL's stream as backward finishes them; the
                 # collective keeps running under the discriminator step below (which does not read G's new weights:
@@ -357,6 +373,7 @@ class Trainer:
             ge.backward(G.flat, gflat, gc, gseg, ddin.channels(Cin, Cout),                    # trainer.py:88-89
                         on_ready=g_reducer.ready if g_reducer is not None else None, ucache=gcache, defer_join=two)
             ge.ucache_end(gcache)
+            self._mark('G bwd (main chain) done')
             if late_adam_g:
                 pass
             elif g_reducer is None:
@@ -370,6 +387,7 @@ class Trainer:
             dc2 = de.forward(D.flat, din, ucache=ucache, keep_v=train)
         if ex.pending or ex.keep:
             E.side_join()
+        self._mark('joined')
         adam_g_behind_fork = bool(train and late_adam_g and ex.enabled and E.PROFILER is None and DEFER_D_BWD and ADAM_G_BESIDE)
         if train and late_adam_g and not adam_g_behind_fork:
             self._adam_step('g')                                                              # trainer.py:90
@@ -400,14 +418,18 @@ class Trainer:
                         self._pending_d = dist.all_reduce_side(dflat)      # (behind the pass on the second stream; Adam(D) in flush())
                     else:
                         self._adam_step('d')                                                      # trainer.py:107
+                    self._mark('side: D bwd done')
                 self._deferred = (dc2, god, ucache, dflat)
                 if adam_g_behind_fork:
                     # G's Adam update (1.2 GB at the memory rate, 0.2 ms alone on the chip) beside the first kernels of D's backward pass
                     # instead of in front of them: it only has to precede the next step's generator forward
                     self._adam_step('g')                                                          # trainer.py:90
                 if g_reducer is not None:
+                    self._mark('forked')
                     g_reducer.finish()                     # G's buckets have been in flight since the generator backward
+                    self._mark('G buckets waited')
                     self._adam_step('g')
+                    self._mark('Adam(G) done')
             else:
                 de.backward(D.flat, dflat, dc2, god, need_wgrad=True, need_dx=False, ucache=ucache)   # trainer.py:106
                 if g_reducer is not None:
@@ -422,6 +444,7 @@ class Trainer:
         de.ucache_end(ucache)
         if wait_losses is not None:
             wait_losses()
+        self._mark('end')
         self._last_gen = gen
         return losses
 
