@@ -656,6 +656,21 @@ def extra_configs(dev, cpu=True):
     except Exception as e:
         out['cfg2_dropout_on'] = {'error': f'{type(e).__name__}: {e}'}
     try:
+        # BASELINE config 1 (examples/train_coco.yaml hyper-parameters at 256 x 256, bs 4): a launch-bound step -- the trainer's decision
+        # for it is the captured hipGraph (dropout off here, as in the capture's precondition)
+        gc.collect()
+        torch.cuda.empty_cache()
+        m = measure_training(CONFIGS['cfg1'], 'f32', 20, 5, dev, events='none')
+        out['cfg1'] = {
+            'workload': CONFIGS['cfg1']['desc'] + ', dropout off', 'metric': 'train images/sec (G+D step) at 256x256 bs=4 per GPU',
+            'value': round(m['value'], 2), 'unit': 'images/sec', 'steps': 20, 'warmup': 5, 'ms_per_step': round(m['ms_per_step'], 3),
+            'host_enqueue_ms_per_step': round(m['host_ms_per_step'], 3), 'dtype': 'f32', 'peak_vram_GiB': m['peak_vram_GiB'],
+            'step_launch': 'two streams' if m['two_streams'] else ('graph' if m['graph'] else 'one stream'),
+            'step_times_device_host_ms': [round(v, 3) for v in m['step_times']] if m.get('step_times') else None}
+        del m
+    except Exception as e:
+        out['cfg1'] = {'error': f'{type(e).__name__}: {e}'}
+    try:
         import patchgan_amd as pg
         from patchgan_amd import engine as E
         from patchgan_amd.infer import predict_image

@@ -74,6 +74,11 @@ def test_bench_extra_configs_ride_on_the_headline_line():
     assert x5['roofline']['peak'] == 157.3 and 0.05 < x5['roofline']['frac'] < 1.0
     r = out['roofline']
     assert 0 < r['frac_useful'] <= r['frac'] < 1.0
+    xd, x1 = out['extra_configs']['cfg2_dropout_on'], out['extra_configs']['cfg1']
+    assert 'error' not in xd and 'error' not in x1, (xd, x1)
+    # the reference CLI's default generator (dropout on) rides the same schedule as the headline: within 10 % of it in this short run
+    assert xd['value'] > 0.9 * out['value'] and xd['step_launch'] in ('two streams', 'one stream')
+    assert x1['value'] > 100 and x1['step_launch'] in ('graph', 'two streams', 'one stream')
     e = out['extra_configs']['e2e_cfg2']
     assert 'error' not in e, e
     for fmt in ('float', 'u8_device_pipeline'):

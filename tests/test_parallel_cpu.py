@@ -97,6 +97,44 @@ def test_grad_reducer_waits_once_for_in_order_collectives():
         assert sorted(r.launched) == [(0, 100), (100, 400), (400, 700), (700, 1000)]
 
 
+def test_grad_reducer_hands_the_collective_every_producer_stream():
+    """Two-stream step under data parallelism: a bucket's weight gradients may have been written on the second stream, so the reducer
+    passes `producers()` on to all_reduce_side for device tensors (the comm stream then waits for those streams too) -- and calls the
+    plain one-argument form when there is nothing to add or the tensor lives on the host."""
+    from patchgan_amd.parallel import GradReducer
+
+    class Flat:
+        """a stand-in with the three things GradReducer touches"""
+        def __init__(self, n, cuda):
+            self.n, self.is_cuda = n, cuda
+
+        def numel(self):
+            return self.n
+
+        def element_size(self):
+            return 4
+
+        def __getitem__(self, sl):
+            return (sl.start, sl.stop)
+
+    class FakeDist:
+        def __init__(self):
+            self.calls = []
+
+        def all_reduce_side(self, t, producers=None):
+            self.calls.append((t, producers))
+            return lambda: None
+
+    side = object()
+    for cuda, prod, want in ((True, lambda: [side], [side]), (True, lambda: [], None), (False, lambda: [side], None), (True, None, None)):
+        d = FakeDist()
+        r = GradReducer(d, Flat(1000, cuda), bucket_bytes=4 * 500, producers=prod)
+        r.ready(500, 1000)
+        r.ready(0, 500)
+        r.finish()
+        assert d.calls == [((500, 1000), want), ((0, 500), want)], (cuda, d.calls)
+
+
 def test_grad_reducer_world2():
     port = _free_port()
     ctx = mp.get_context('spawn')

@@ -36,3 +36,59 @@ def test_plateau_equals_torch_reduce_on_plateau(name, lr0):
         assert mine.lr == lr0
     if name == 'long_flat' and lr0 == 1e-3:
         assert mine.lr < 1e-8 * 1.2           # reductions stopped once a step would change the rate by less than eps
+
+
+def test_execution_state_is_per_owner_and_per_thread():
+    """engine.Exec (workspaces, second stream, book-keeping of a two-stream step) belongs to ONE driver: `with exec:` makes it current on
+    the calling thread only, nests (Trainer.flush() inside Trainer.batch() enters the same state again) and restores what was current
+    before; another thread sees its own state or none.  No GPU needed: nothing here allocates."""
+    import threading
+    from patchgan_amd import engine as E
+    a, b = E.Exec(), E.Exec()
+    assert getattr(E._TLS, 'cur', None) is None
+    seen = {}
+    with a:
+        assert E._TLS.cur is a
+        with a:                                   # re-entered by the same owner
+            with b:
+                assert E._TLS.cur is b
+            assert E._TLS.cur is a
+        assert E._TLS.cur is a
+
+        def other():
+            seen['before'] = getattr(E._TLS, 'cur', None)
+            with b:
+                seen['inside'] = E._TLS.cur
+            seen['after'] = getattr(E._TLS, 'cur', None)
+        th = threading.Thread(target=other)
+        th.start()
+        th.join()
+        assert E._TLS.cur is a                    # the other thread's `with b:` did not touch this thread's current state
+    assert getattr(E._TLS, 'cur', None) is None
+    assert seen == {'before': None, 'inside': b, 'after': None}
+    assert not a.keep and not a.pending and a.buffers() == [] and a.stream is None
+    a.release()                                    # nothing to join, nothing to free: no GPU call
+    assert a.ws_gen == 1
+
+
+def test_launch_mode_policy_without_a_gpu():
+    """Trainer._launch_mode is host logic: what `graph` / `two_streams` allow, the warm-up count, forced modes.  (The timed 'auto'
+    decision needs device events: tests/test_graph_gpu.py.)"""
+    import types
+    from patchgan_amd.trainer import Trainer
+    t = Trainer.__new__(Trainer)
+    t._kinds, t._graphs, t.step_times = {}, {}, None
+    t.generator = types.SimpleNamespace(training=True, engine=types.SimpleNamespace(use_dropout=False))
+    t.graph, t.two_streams = False, None
+    assert [t._launch_mode('k', True) for _ in range(5)] == ['eager1'] * 5 and t._kinds == {}
+    t.two_streams = True
+    assert t._launch_mode('k', True) == 'eager2' and t._launch_mode('e', False) == 'eager2'      # forced: no warm-up, eval passes too
+    t.graph, t.two_streams = True, None
+    assert [t._launch_mode('k', True) for _ in range(5)] == ['eager1'] * 3 + ['graph'] * 2        # captured at the 4th step of its kind
+    assert t._launch_mode('e', False) == 'eager1'                                                # never an evaluation pass
+    t.generator.engine.use_dropout = True                                                        # dropout: launch arguments change per step
+    assert t._launch_mode('k', True) == 'eager1' and t._launch_mode('d', True) == 'eager1'
+    t.generator.engine.use_dropout = False
+    t.graph, t._kinds = 'auto', {}
+    assert [t._launch_mode('k', True) for _ in range(3)] == ['eager1', 'probe', 'probe']         # the 2nd and 3rd warm step are timed
+    assert t.decided_modes() == [] and not t.graph_decided()
