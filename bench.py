@@ -356,7 +356,7 @@ def main():
                             'launch by launch, the weight gradients of each backward pass and the discriminator step\'s forward on a second stream'
                             if m['two_streams'] == 'fp32' else
                             'launch by launch, the discriminator step\'s forward on a second stream' if m['two_streams'] == 'bf16' else 'launch by launch')
-                           + (f" (auto: device {m['step_times'][0]:.2f} ms vs host enqueue {m['step_times'][1]:.2f} ms per step)" if m.get('step_times') else ''),
+                           + (' (auto, measured ms per step: ' + ', '.join(f'{k} {v:.2f}' if v is not None else f'{k} not tried' for k, v in m['step_times'].items() if k != 'host_enqueue') + ')' if m.get('step_times') else ''),
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'activation_storage': m['activation_storage'], 'peak_vram_GiB': m['peak_vram_GiB'],
@@ -452,7 +452,7 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         # per-launch events (a capture cannot hold them; the launch profiler turns the second stream off); the dominant kernel's
         # launches are timed on one-stream launch-by-launch steps of the same trainer right after the timed region (below)
         E.PROFILER = None
-        for _ in range(t.GRAPH_WARM_STEPS + 3):
+        for _ in range(3 * (t.TRIAL_STEPS + 2) + 4):
             if t.graph_decided():
                 break
             t.batch(x, y, train=True)
@@ -666,7 +666,7 @@ def extra_configs(dev, cpu=True):
             'value': round(m['value'], 2), 'unit': 'images/sec', 'steps': 20, 'warmup': 5, 'ms_per_step': round(m['ms_per_step'], 3),
             'host_enqueue_ms_per_step': round(m['host_ms_per_step'], 3), 'dtype': 'f32', 'peak_vram_GiB': m['peak_vram_GiB'],
             'step_launch': 'two streams' if m['two_streams'] else ('graph' if m['graph'] else 'one stream'),
-            'step_times_device_host_ms': [round(v, 3) for v in m['step_times']] if m.get('step_times') else None}
+            'auto_measured_ms_per_step': {k: (round(v, 3) if isinstance(v, float) else v) for k, v in m['step_times'].items() if k != 'host_enqueue'} if m.get('step_times') else None}
         del m
     except Exception as e:
         out['cfg1'] = {'error': f'{type(e).__name__}: {e}'}

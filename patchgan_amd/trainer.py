@@ -163,15 +163,19 @@ class Trainer:
     #   two_streams  None | False | True | 'auto'  -- launch by launch with each backward pass's weight-gradient chain (fp32 networks) and
     #                the discriminator step's forward pass on a second stream (engine.Exec).  Independent of capture: dropout, evaluation
     #                passes and data-parallel steps take it too.  None = follows `graph` ('auto' with graph = 'auto', else off).
-    # 'auto': PROBE_STEPS warm steps of a kind are timed on the device (one event pair each) and on the host; a device-bound kind (device
-    # time >= AUTO_RATIO x the host's enqueue time: cfg2, cfg4) runs on two streams, a launch-bound one (cfg1: 2.94 vs 1.80 ms) is
-    # captured where capture applies.  A captured two-stream step replays slower than a one-stream one, and the launch-by-launch
-    # two-stream step is faster than either, hence never both.
+    # 'auto': a tournament per kind of step.  After one untimed warm step every way of launching that the settings allow -- one stream,
+    # two streams, the captured graph -- runs for TRIAL_STEPS steps while an event is recorded at the start of each step; a candidate's
+    # score is the SHORTEST start-to-start period it reached (the step time as the caller sees it: host-bound or device-bound, whatever
+    # binds; the minimum is robust against a loader hiccup or a GC pause in one of the steps), and the fastest candidate is kept.  All
+    # candidates are the same computation, bit for bit, so the trials are ordinary training steps.  Measured at cfg2 / cfg4 two streams
+    # win (8.3 vs 8.9 ms), at cfg1 too (2.49 ms against 2.92 for the graph: its 219 short kernels leave gaps a second chain fills), a
+    # tiny network ends on the graph.  AUTO_FORCE (tests, experiments) decrees the outcome instead of measuring it.
     graph = False
     two_streams = None
-    GRAPH_WARM_STEPS = 3     # eager steps of a given kind before it is captured / decided (kernel plans, weight-cache plans, workspaces settle)
-    PROBE_STEPS = 2          # 'auto': the last PROBE_STEPS warm steps are timed; minimum host time and minimum device time decide
-    AUTO_RATIO = 2.5
+    GRAPH_WARM_STEPS = 3     # graph = True: eager steps of a given kind before it is captured (kernel plans, weight-cache plans, workspaces settle)
+    TRIAL_STEPS = 4          # 'auto': timed steps per candidate
+    GRAPH_TRIAL_RATIO = 1.25 # 'auto': the captured graph enters the tournament only if the one-stream step takes < this x its own host enqueue time
+    AUTO_FORCE = None        # 'eager1' | 'eager2' | 'graph': 'auto' takes this outcome (where the settings allow it) after the warm steps
     MAX_GRAPHS = 2           # captured kinds of step kept (each holds its activations: ~4 GB at cfg2)
     MAX_KINDS = 16           # kinds of step whose launch decision is remembered
 
@@ -200,7 +204,7 @@ class Trainer:
         self._deferred = None      # operands of a discriminator backward pass still running on the second stream (flush())
         self.bucket_bytes = 32 << 20   # all-reduce bucket size under data parallelism (parallel.GradReducer)
         self._graphs, self._adam_dev = {}, None
-        self._kinds, self.step_times, self.launch_mode = {}, None, None      # per kind of step: warm-step count, probe samples, decision
+        self._kinds, self.step_times, self.launch_mode = {}, None, None      # per kind of step: warm-step count, the tournament, the decision; step_times = the last tournament's ms per step per candidate
         self._exec = None          # engine.Exec: this trainer's workspaces and second stream (created on the networks' device)
 
     # -------------------------------------------------------------------------------------- optimizers
@@ -253,29 +257,30 @@ class Trainer:
             key = self._kind_key(x, y, u8, dims, train)
             mode = self._launch_mode(key, train)
             losses = None
-            if mode == 'graph':
-                losses = self._replay(key, x, y, u8, dims)          # None: this runtime cannot capture the step
+            try:
+                if mode == 'graph':
+                    losses = self._replay(key, x, y, u8, dims)          # None: this runtime cannot capture the step
+                    if losses is None:
+                        mode = 'eager1'
                 if losses is None:
-                    mode = 'eager1'
-            if mode == 'probe':
-                # 'auto': this warm step is timed on the device (one event pair) and on the host; a step that raises leaves no sample
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                t_p = time.perf_counter()
-                losses = self._enqueue_step(x, y, u8, N, H, W, Cin, Cout, train)
-                host_ms = (time.perf_counter() - t_p) * 1e3
-                e1.record()
-                self._kinds[key]['samples'].append((e0, e1, host_ms))
-            elif losses is None:
-                ex.enabled = mode == 'eager2'
-                try:
-                    losses = self._enqueue_step(x, y, u8, N, H, W, Cin, Cout, train)
-                finally:
-                    ex.enabled = False
+                    ex.enabled = mode == 'eager2'
+                    try:
+                        losses = self._enqueue_step(x, y, u8, N, H, W, Cin, Cout, train)
+                    finally:
+                        ex.enabled = False
+            except BaseException:
+                kind = self._kinds.get(key)
+                if kind is not None:
+                    kind['trial'] = None          # a step that raised must not score in a running tournament: it starts over
+                raise
             self.launch_mode = mode
         if train and self.gc_freeze:
             _settle_gc(self._step)
         self.host_ms = (time.perf_counter() - t_host0) * 1e3       # host time to enqueue the whole step (bench.py reports it)
+        kind = self._kinds.get(key)
+        if kind is not None and kind.get('trial') is not None:
+            h = kind['trial']['host']
+            h[mode] = min(h.get(mode, 1e30), self.host_ms)
         return self._publish(losses)
 
     marks = None             # diagnostics (tools/step_phases.py): a list -> every _mark(name) records an event on the current stream
@@ -519,16 +524,16 @@ class Trainer:
                 tuple(x.shape), tuple(y.shape), x.dtype, y.dtype, _dist().on)
 
     def _launch_mode(self, key, train):
-        """'eager1' (launch by launch, one stream) | 'eager2' (launch by launch, two streams) | 'graph' (replay) | 'probe' (a timed
-        'eager1' step) for this step of kind `key`.  What the settings allow is re-read every step (a profiler armed later, a
-        group initialised later); what was measured is remembered per kind."""
+        """'eager1' (launch by launch, one stream) | 'eager2' (launch by launch, two streams) | 'graph' (replay) for this step of kind
+        `key`.  What the settings allow is re-read every step (a profiler armed later, a group initialised later); what was measured
+        is remembered per kind."""
         want_graph = self.graph if (train and self._graph_eligible()) else False
         ts = self._two_streams_setting()
         if not want_graph and not ts:
             return 'eager1'
         if ts is True and want_graph is not True:
             return 'eager2'                       # forced: no warm-up needed (entries a pass makes on the second stream are joined, _enqueue_step)
-        k = self._kinds.pop(key, None) or {'seen': 0, 'mode': None, 'samples': []}
+        k = self._kinds.pop(key, None) or {'seen': 0, 'mode': None, 'trial': None}
         self._kinds[key] = k                      # most recently used last
         while len(self._kinds) > self.MAX_KINDS:
             self._kinds.pop(next(iter(self._kinds)))
@@ -537,26 +542,48 @@ class Trainer:
                 return 'eager1'
             return k['mode']
         k['seen'] += 1
-        auto = want_graph == 'auto' or ts == 'auto'
-        if k['seen'] <= self.GRAPH_WARM_STEPS:
-            return 'probe' if auto and k['seen'] > self.GRAPH_WARM_STEPS - self.PROBE_STEPS else 'eager1'
-        if not auto:
-            k['mode'] = 'graph' if want_graph else 'eager1'
+        if want_graph is True:                    # capture, no questions: after the warm steps
+            if k['seen'] <= self.GRAPH_WARM_STEPS:
+                return 'eager1'
+            k['mode'] = 'graph'
+            return 'graph'
+        cands = ['eager1'] + (['eager2'] if ts else []) + (['graph'] if want_graph else [])
+        forced = os.environ.get('PATCHGAN_AUTO_FORCE') if 'PATCHGAN_EXPERIMENT' in os.environ else None
+        forced = forced or self.AUTO_FORCE
+        if forced is not None:                    # by decree (tests, A/B runs): after the warm steps, no trials
+            if k['seen'] <= self.GRAPH_WARM_STEPS:
+                return 'eager1'
+            k['mode'] = forced if forced in cands else 'eager1'
             return k['mode']
-        if not k['samples']:
-            return 'probe'                        # (every probe step so far raised: keep measuring)
-        k['samples'][-1][1].synchronize()
-        dev_ms = min(e0.elapsed_time(e1) for e0, e1, _ in k['samples'])
-        host_ms = min(h for _, _, h in k['samples'])
-        k['samples'] = []
-        self.step_times = (dev_ms, host_ms)
-        ratio = float(os.environ['PATCHGAN_AUTO_RATIO']) if 'PATCHGAN_EXPERIMENT' in os.environ and 'PATCHGAN_AUTO_RATIO' in os.environ else self.AUTO_RATIO
-        if dev_ms >= ratio * host_ms and ts:
-            k['mode'] = 'eager2'                  # device-bound: launch by launch on two streams
-        elif want_graph:
-            k['mode'] = 'graph'                   # launch-bound (or no second stream wanted): one hipGraphLaunch per step
-        else:
-            k['mode'] = 'eager1'
+        if k['seen'] == 1:
+            return 'eager1'                       # untimed: kernel plans, weight-cache plans, workspaces
+        tr = k['trial']
+        if tr is None or tr['cands'] != cands:    # (the settings changed under a running tournament, or a step raised: start over)
+            tr = k['trial'] = {'cands': cands, 'i': 0, 'starts': [], 'ms': {}, 'host': {}}
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()                               # the start of this step on the compute stream
+        tr['starts'].append(ev)
+        if len(tr['starts']) <= self.TRIAL_STEPS + 1:
+            return tr['cands'][tr['i']]
+        # TRIAL_STEPS + 1 starts of this candidate and the start of the step that follows them: its periods are known once that last
+        # event has been reached (one wait per candidate, during warm-up)
+        ev.synchronize()
+        st = tr['starts']
+        tr['ms'][tr['cands'][tr['i']]] = min(st[j].elapsed_time(st[j + 1]) for j in range(1, len(st) - 1))      # (the first period holds the switch)
+        tr['i'] += 1
+        tr['starts'] = [ev]
+        if tr['i'] < len(cands) and cands[tr['i']] == 'graph' and tr['ms']['eager1'] > self.GRAPH_TRIAL_RATIO * tr['host'].get('eager1', 0.0):
+            # a replay removes host time only: where the one-stream step is well clear of being host-bound the capture (which would
+            # hold a second copy of the step's activations, ~4 GB at cfg2) cannot win and is not tried
+            tr['ms']['graph'] = None
+            tr['i'] += 1
+        if tr['i'] < len(cands):
+            return cands[tr['i']]
+        self.step_times = dict(tr['ms'], host_enqueue=dict(tr['host']))
+        k['mode'] = min((m for m in cands if tr['ms'][m] is not None), key=lambda m: tr['ms'][m])
+        k['trial'] = None
+        if k['mode'] != 'graph':
+            self._graphs.pop(key, None)           # the losing capture's buffers go back to the allocator
         return k['mode']
 
     def redecide(self):

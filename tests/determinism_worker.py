@@ -11,7 +11,7 @@ prec = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 two_streams = prec == 'fp32-two-streams'          # fp32 with the weight gradients of each backward pass on a second stream (Trainer 'auto')
 if two_streams:
     prec = 'fp32'
-    pg.Trainer.AUTO_RATIO = 0.0                   # every kind of step counts as device-bound: two streams from the 5th step on
+    pg.Trainer.AUTO_FORCE = 'eager2'              # by decree: two streams from the 4th step of a kind on
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 do_clone = (sys.argv[4] if len(sys.argv) > 4 else '1') == '1'

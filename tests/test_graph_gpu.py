@@ -88,13 +88,13 @@ def test_graph_falls_back_where_it_cannot_apply(tmp_path):
 def test_auto_policy_both_outcomes_are_the_same_computation(tmp_path, precision, monkeypatch):
     """Trainer.graph = 'auto': the last launch-by-launch warm step is timed on device and host; a device-bound step stays launch by
     launch with the weight-gradient chain of each backward pass on a second stream (fp32 networks), a launch-bound one is captured.
-    Both outcomes, forced through AUTO_RATIO, against the plain one-stream step: bit-identical losses and weights."""
+    Both outcomes, decreed through AUTO_FORCE, against the plain one-stream step: bit-identical losses and weights."""
     import patchgan_amd as pg
     from patchgan_amd import engine as E
     nf = 32 if precision == 'bf16' else 16
     ref = _run(tmp_path, False, precision, 9, nf=nf, lr_change_at=6, tag='ref')
     # device-bound by decree: never captured; from the 5th step of its kind on, two streams (fp32)
-    monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 0.0)
+    monkeypatch.setattr(pg.Trainer, 'AUTO_FORCE', 'eager2')
     sides = []
     orig = E._side_begin
 
@@ -113,7 +113,7 @@ def test_auto_policy_both_outcomes_are_the_same_computation(tmp_path, precision,
     monkeypatch.setattr(E, '_side_begin', orig)
     monkeypatch.setattr(E.on_side, '__enter__', enter)
     assert len(forks) >= 4, forks          # the discriminator step's forward went to the second stream (both precisions), steps 5..9
-    assert not any(a[3]) and a[4].graph_decided() and a[4].step_times is not None and a[4].step_times[0] > 0
+    assert not any(a[3]) and a[4].graph_decided() and a[4].decided_modes() == ['eager2']
     assert any(sides) == (precision == 'fp32'), sides          # weight gradients on the second stream: fp32 networks only
     assert np.array_equal(ref[0], a[0]) and np.array_equal(ref[1], a[1]) and np.array_equal(ref[2], a[2])
     ex = a[4]._exec
@@ -123,7 +123,7 @@ def test_auto_policy_both_outcomes_are_the_same_computation(tmp_path, precision,
     assert not ex.keep and not ex.enabled and not ex.pending and ex.device == torch.device('cuda', torch.cuda.current_device())
     assert getattr(E._TLS, 'cur', None) is None          # the trainer's execution state is current only inside batch()
     # launch-bound by decree: captured at the 4th step of its kind, as with graph = True
-    monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 1e9)
+    monkeypatch.setattr(pg.Trainer, 'AUTO_FORCE', 'graph')
     b = _run(tmp_path, 'auto', precision, 9, nf=nf, lr_change_at=6, tag='graph')
     assert b[3][:3] == [False] * 3 and all(b[3][3:]), b[3]
     assert np.array_equal(ref[0], b[0]) and np.array_equal(ref[1], b[1]) and np.array_equal(ref[2], b[2])
@@ -133,7 +133,7 @@ def test_two_stream_step_at_full_width_is_bit_identical(tmp_path, monkeypatch):
     """nf = ndf = 64 (the benchmark's widths: every Winograd path, the decoder's backward call as its two halves): the two-stream
     launch-by-launch step against the one-stream one, 6 steps from the same start -- identical losses and weights, bit for bit."""
     import patchgan_amd as pg
-    monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 0.0)
+    monkeypatch.setattr(pg.Trainer, 'AUTO_FORCE', 'eager2')
     ref = _run(tmp_path, False, 'fp32', 6, nf=64, tag='w_ref')
     two = _run(tmp_path, 'auto', 'fp32', 6, nf=64, tag='w_two')
     assert two[4].graph_decided() and not any(two[3])
@@ -162,54 +162,56 @@ def test_dropout_and_eval_steps_take_the_second_stream_and_stay_bit_identical(tm
     assert len(forks) == 8 + 6 and all(forks), forks
     assert two[4].launch_mode == 'eager2' and not any(two[3])
     assert np.array_equal(ref[0], two[0]) and np.array_equal(ref[1], two[1]) and np.array_equal(ref[2], two[2])
-    monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 0.0)
+    monkeypatch.setattr(pg.Trainer, 'AUTO_FORCE', 'eager2')
     del forks[:]
     auto = _run(tmp_path, 'auto', 'fp32', 6, nf=64, use_dropout=True, tag='d_auto', eval_at=(2, 4))
     assert not any(auto[3]) and auto[4].launch_mode == 'eager2' and len(forks) >= 3, forks      # training steps 4..6 (probes on steps 2, 3)
     assert np.array_equal(ref[0], auto[0]) and np.array_equal(ref[1], auto[1]) and np.array_equal(ref[2], auto[2])
     # launch-bound by decree: dropout rules capture out, so the step stays on one stream
-    monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 1e9)
+    monkeypatch.setattr(pg.Trainer, 'AUTO_FORCE', 'graph')
     one = _run(tmp_path, 'auto', 'fp32', 5, nf=16, use_dropout=True, tag='d_one')
     assert not any(one[3]) and one[4].launch_mode == 'eager1' and one[4].graph_decided()
 
 
-def test_probe_survives_a_failing_step_and_can_be_redone(tmp_path, monkeypatch):
-    """'auto' decides from the minimum host time and the minimum device time of the timed warm steps; a step that raises while it is
-    being timed leaves no sample behind (the decision is then taken from the others, or postponed), and redecide() starts over."""
+def test_auto_tournament_measures_every_candidate_and_is_the_same_computation(tmp_path):
+    """Trainer.graph = 'auto' without a decree: after one warm step each candidate (one stream, two streams, and -- where the one-stream
+    step is close to host-bound -- the captured graph) runs TRIAL_STEPS timed steps, the fastest is kept.  Every candidate is the same
+    computation: 24 steps that pass through all of them equal 24 one-stream steps bit for bit.  A step that raises inside the
+    tournament does not score (the tournament starts over), and redecide() forgets the outcome."""
     import patchgan_amd as pg
-    monkeypatch.setattr(pg.Trainer, 'AUTO_RATIO', 1e9)
-    torch.manual_seed(3)
-    g = pg.UNet(3, 1, 16, use_dropout=False, activation='leakyrelu', final_act='sigmoid').cuda()
-    d = pg.Discriminator(4, 16, n_layers=3).cuda()
-    t = pg.Trainer(g, d, str(tmp_path / 'p'))
-    t.graph = 'auto'
-    t.setup_optimizers(1e-3, 1e-3)
-    g.train(), d.train()
+    ref = _run(tmp_path, False, 'fp32', 24, nf=16, tag='t_ref')
+    auto = _run(tmp_path, 'auto', 'fp32', 24, nf=16, tag='t_auto')
+    t = auto[4]
+    assert t.graph_decided() and t.decided_modes()[0] in ('eager1', 'eager2', 'graph')
+    ms = {k: v for k, v in t.step_times.items() if k != 'host_enqueue'}
+    assert set(ms) == {'eager1', 'eager2', 'graph'} and ms['eager1'] > 0 and ms['eager2'] > 0, t.step_times
+    tried = {k: v for k, v in ms.items() if v is not None}
+    assert t.decided_modes()[0] == min(tried, key=tried.get), (t.decided_modes(), ms)
+    if t.decided_modes()[0] != 'graph':
+        assert not t.graph_captured()                  # a losing capture is released
+    assert np.array_equal(ref[0], auto[0]) and np.array_equal(ref[1], auto[1]) and np.array_equal(ref[2], auto[2])
+    # a raising step inside a tournament
+    t.redecide()
+    assert not t.graph_decided()
     gen = torch.Generator().manual_seed(5)
     x = torch.rand(2, 3, 256, 256, generator=gen)
     y = (torch.rand(2, 1, 256, 256, generator=gen) > 0.7).float()
-    t.batch(x, y, train=True)
+    for _ in range(3):
+        t.batch(x, y, train=True)
+    kind = next(iter(t._kinds.values()))
+    assert kind['trial'] is not None and len(kind['trial']['starts']) == 2
     orig = t._enqueue_step
-    calls = []
 
     def boom(*a, **k):
-        calls.append(1)
         raise RuntimeError('injected')
     t._enqueue_step = boom
     with pytest.raises(RuntimeError, match='injected'):
-        t.batch(x, y, train=True)                  # step 2 of its kind: a probe step that raises
-    t._enqueue_step = orig
-    kind = next(iter(t._kinds.values()))
-    assert kind['samples'] == [] and kind['mode'] is None and not t._exec.enabled
-    t.batch(x, y, train=True)                      # step 3: probe
-    assert len(kind['samples']) == 1
-    t.batch(x, y, train=True)                      # step 4: decided from the one good sample -> launch-bound -> captured
-    assert t.graph_captured() and t.launch_mode == 'graph' and t.step_times[0] > 0 and t.step_times[1] > 0
-    t.redecide()
-    assert not t.graph_decided()
-    for _ in range(4):
         t.batch(x, y, train=True)
-    assert t.graph_captured()
+    t._enqueue_step = orig
+    assert kind['trial'] is None and kind['mode'] is None and not t._exec.enabled
+    for _ in range(3 * (t.TRIAL_STEPS + 2)):
+        t.batch(x, y, train=True)
+    assert t.graph_decided()
 
 
 def test_replay_after_the_buffers_it_baked_in_were_replaced(tmp_path):

@@ -89,6 +89,9 @@ def test_launch_mode_policy_without_a_gpu():
     t.generator.engine.use_dropout = True                                                        # dropout: launch arguments change per step
     assert t._launch_mode('k', True) == 'eager1' and t._launch_mode('d', True) == 'eager1'
     t.generator.engine.use_dropout = False
-    t.graph, t._kinds = 'auto', {}
-    assert [t._launch_mode('k', True) for _ in range(3)] == ['eager1', 'probe', 'probe']         # the 2nd and 3rd warm step are timed
-    assert t.decided_modes() == [] and not t.graph_decided()
+    t.graph, t._kinds, t.AUTO_FORCE = 'auto', {}, 'eager2'                                       # 'auto' by decree: after the warm steps
+    assert [t._launch_mode('k', True) for _ in range(5)] == ['eager1'] * 3 + ['eager2'] * 2 and t.decided_modes() == ['eager2']
+    t._kinds, t.AUTO_FORCE = {}, 'graph'
+    assert [t._launch_mode('k', True) for _ in range(4)] == ['eager1'] * 3 + ['graph']
+    assert [t._launch_mode('e', False) for _ in range(4)] == ['eager1'] * 4                       # an evaluation pass cannot be captured
+    assert t.decided_modes() == ['graph', 'eager1'] and t.graph_decided()
