@@ -75,12 +75,11 @@ def oracle_curves(gold, dtype):
 def test_loss_curve_vs_golden(name, tmp_path):
     """10-step loss curves against the fixtures generated from the reference.
 
-    Stated tolerance (fp32): every one of the 6 loss scalars of every step within
-        max(1e-4, 10 x E_s) relative,
-    where E_s is the reference algorithm's OWN fp32 rounding envelope at step s: the running max of the relative gap
-    between the fp32 and fp64 runs of the CPU oracle.  For the cfg2-shaped config (a_lrelu_tversky) E_s < 1e-6, so the
-    bound is the plain 1e-4 of the north star; relu/MAE/5-layer-D configs are chaotic in fp32 (the reference itself
-    drifts ~1e-3 from its fp64 run by step 10) and no fp32 implementation can track them tighter than that."""
+    Stated tolerance (fp32): every one of the 6 loss scalars of every step within SMALL_CURVE_BOUND[name] relative of the reference's
+    value -- 1.5 x the maximum MEASURED on the round-5 build (the kernels are deterministic: the same numbers on every box).  The
+    cfg2-shaped configuration (a_lrelu_tversky) and e_wbce_c1 sit at 6e-6 / 3e-6, far inside the north star's 1e-4; the relu / MAE /
+    5-layer-D and softmax / normed-D configurations are chaotic in fp32 -- the reference's own fp32 run drifts 1.2e-3 / 4.6e-5 from its
+    float64 run by step 10 (the envelope printed below), and no fp32 implementation tracks them tighter than that."""
     gold = Golden(name)
     g, d, t = build(gold, tmp_path)
     x, y = gold.inputs()
@@ -101,9 +100,14 @@ def test_loss_curve_vs_golden(name, tmp_path):
     c64, _ = oracle_curves(gold, torch.float64)
     env = np.maximum.accumulate((np.abs(c32 - c64) / np.maximum(np.abs(c64), 1e-6)).max(axis=1))
     print(name, 'HIP-vs-golden rel err per step', err, 'fp32 envelope', env)
-    assert (err <= np.maximum(LOSS_RTOL, 10 * env)).all(), (err, env)
+    assert err.max() <= SMALL_CURVE_BOUND[name], (err, SMALL_CURVE_BOUND[name])
     if name in ('a_lrelu_tversky', 'e_wbce_c1'):
         assert err.max() < LOSS_RTOL
+
+
+# 1.5 x the maxima measured over the 10 steps on the round-5 build: 6.1e-6, 1.04e-6, 1.12e-3, 2.60e-4, 3.24e-6
+SMALL_CURVE_BOUND = {'a_lrelu_tversky': 9.2e-6, 'b_tanh_wbce_norm': 1.6e-6, 'c_relu_mae_l5': 1.7e-3, 'd_softmax_tversky': 3.9e-4,
+                     'e_wbce_c1': 4.9e-6}
 
 
 @pytest.mark.parametrize('name', CONFIG_NAMES)
@@ -406,9 +410,9 @@ def test_device_input_kernels_vs_reference_fixture():
 
 
 def test_bf16_precision_tracks_fp32(tmp_path):
-    """f2: bf16-multiply / fp32-accumulate convolutions.  Stated tolerance: every loss scalar of the first 5 steps within
-    2e-3 relative of the fp32 golden curve (bf16 has an 8-bit significand; products are rounded once, sums stay fp32;
-    measured 2e-5 on this configuration)."""
+    """f2: bf16-multiply / fp32-accumulate convolutions (nf = 4: the bf16 kernels on fp32-stored activations).  Stated tolerance: every
+    loss scalar of the first 5 steps within 1.6e-4 relative of the reference's fp32 curve = 1.5 x measured (per step: 2.4e-7 1.6e-5
+    4.4e-5 8.5e-5 1.07e-4; bf16 has an 8-bit significand; products are rounded once, sums stay fp32)."""
     gold = Golden('a_lrelu_tversky')
     g, d, t = build(gold, tmp_path)
     g.set_precision('bf16')
@@ -424,7 +428,7 @@ def test_bf16_precision_tracks_fp32(tmp_path):
     want = gold.z['losses'][:5]
     err = np.abs(curve - want) / np.maximum(np.abs(want), 1e-6)
     print('bf16 vs fp32 golden, max rel err per step', err.max(axis=1))
-    assert err.max() < 2e-3
+    assert err.max() < 1.6e-4
     assert err.max() > 1e-7          # it really is a different arithmetic
 
 
