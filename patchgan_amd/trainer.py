@@ -586,6 +586,14 @@ class Trainer:
             self._graphs.pop(key, None)           # the losing capture's buffers go back to the allocator
         return k['mode']
 
+    def __del__(self):
+        # a discriminator update still running on the second stream references this trainer's tensors: join before they are freed
+        try:
+            if self._deferred is not None:
+                self.flush()
+        except Exception:
+            pass
+
     def redecide(self):
         """Forget every launch decision and captured step (the next steps of each kind warm up, are timed and decided again)."""
         self._kinds, self._graphs = {}, {}

@@ -323,3 +323,23 @@ def test_discriminator_update_in_flight_is_completed_by_whatever_reads_its_weigh
         assert torch.equal(outs[0][0][k].cpu(), outs[1][0][k].cpu()), k
         assert torch.equal(outs[0][2][k].cpu(), outs[1][2][k].cpu()), k
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_bounded_operand_holding_joins_early_and_changes_nothing(tmp_path, monkeypatch):
+    """engine.KEEP_LIMIT_BYTES bounds what the second stream keeps referenced inside a backward pass: past it the streams join in the
+    middle of the pass (and the held operands are dropped).  With the limit at 1 MiB every layer joins: same losses and weights as the
+    one-stream step, bit for bit -- and the early joins really happened."""
+    from patchgan_amd import engine as E
+    ref = _run(tmp_path, False, 'fp32', 5, nf=32, tag='k_ref')
+    monkeypatch.setattr(E, 'KEEP_LIMIT_BYTES', 1 << 20)
+    peaks = []
+    orig = E.ConvOp.wgrad
+
+    def spy(self, *a, **k):
+        r = orig(self, *a, **k)
+        peaks.append(E.cur_exec().keep_bytes)
+        return r
+    monkeypatch.setattr(E.ConvOp, 'wgrad', spy)
+    two = _run(tmp_path, False, 'fp32', 5, nf=32, tag='k_two', two_streams=True)
+    assert peaks and max(peaks) <= (1 << 20) and peaks.count(0) > len(peaks) // 2, peaks[:20]
+    assert np.array_equal(ref[0], two[0]) and np.array_equal(ref[1], two[1]) and np.array_equal(ref[2], two[2])
