@@ -452,25 +452,38 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         # per-launch events (a capture cannot hold them; the launch profiler turns the second stream off); the dominant kernel's
         # launches are timed on one-stream launch-by-launch steps of the same trainer right after the timed region (below)
         E.PROFILER = None
-        for _ in range(3 * (t.TRIAL_STEPS + 2) + 4):
-            if t.graph_decided():
+        # (under data parallelism every rank must run the SAME number of steps -- each step holds collectives -- so nothing below may
+        #  depend on a rank's own clock: the tournament has a fixed length, the settling loop a fixed count, and the flags that steer
+        #  the rest of this function are agreed on across ranks)
+        n_decide = 3 * (t.TRIAL_STEPS + 2) + 4
+        for _ in range(n_decide):
+            if t.graph_decided() and not use_dist:
                 break
             t.batch(x, y, train=True)
         graphed, after = t.graph_captured(), t.graph_decided()
         two = 'eager2' in t.decided_modes()
+        if use_dist:
+            flags = torch.tensor([int(two), int(graphed)], dtype=torch.int32, device=dev)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+            two, graphed = bool(flags[0].item()), bool(flags[1].item())
         after = graphed or two          # (decided 'eager1': nothing to settle, the timed steps carry the launch profiler as before)
         if two:
             # the first two-stream steps hold every backward operand until the streams join: the caching allocator grows for some
             # steps (device allocations synchronise: 12-15 ms per step instead of 8.7) before the pattern settles -- outside the timed
             # region, as any warm-up: groups of four steps until two consecutive groups take the same time (2 %), at most 48 steps
+            # (data parallel: a fixed 16 steps)
             prev = None
-            for _ in range(12):
+            for grp in range(12):
                 torch.cuda.synchronize()
                 tg = time.perf_counter()
                 for _ in range(4):
                     t.batch(x, y, train=True)
                 torch.cuda.synchronize()
                 tg = time.perf_counter() - tg
+                if use_dist:
+                    if grp == 3:
+                        break
+                    continue
                 if prev is not None and abs(tg - prev) <= 0.02 * prev:
                     break
                 prev = tg
@@ -509,6 +522,8 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         # buffers, right after the timed region -- the same kernels with the same arguments, HIP events on the launch stream
         E.PROFILER = prof
         nsample = max(1, prof.limit // max(1, int(per_step))) if prof.limit else min(steps, 4)
+        if use_dist:
+            nsample = min(steps, 4)          # (rank-independent: every step holds collectives)
         for _ in range(nsample):
             t.batch(x, y, train=True)
         torch.cuda.synchronize()
