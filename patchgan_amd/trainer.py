@@ -10,6 +10,11 @@ Per-step schedule (reference trainer.py:50-115):
    one device->host copy of the loss scalars.
    Under data parallelism: G's gradient buckets are all-reduced asynchronously from inside G bwd and Adam(G) moves behind
    the D backward; D's gradient is all-reduced asynchronously and Adam(D) moves behind the next step's G forward (flush()).
+   On two streams (a device-bound kind of step; engine.Exec) the same launches are spread over two in-order chains: the weight
+   gradients of each backward pass, the D forward over din[2N] (enqueued as soon as G's output exists) and the whole D backward pass +
+   Adam(D) (which then run under the NEXT step's G forward) go to the second stream; flush() joins before D's weights are read.
+   How a kind of step is launched -- one stream, two streams, a replay of the captured hipGraph -- is measured, not guessed
+   (_launch_mode: a tournament over the candidates the settings allow).
 
 Data parallelism: one process per GPU (torch.distributed, backend "nccl" = RCCL).  InstanceNorm is per sample,
 so the only exchanges are the SUM all-reduce of the flat gradient buffers and of two loss-normalisation terms
