@@ -722,6 +722,7 @@ FUSE_ACT_BWD = _exp_env('PATCHGAN_FUSE_ACT_BWD') != '0'       # activation backw
 SEAM8 = _exp_env('PATCHGAN_SEAM8') != '0'       # bf16 storage: image-facing tensors in 8-channel bf16 pixels
 WGRAD_SIDE = _exp_env('PATCHGAN_WGRAD_SIDE') != '0'       # weight gradients of a backward pass on a second stream (Exec)
 BF16_WGRAD_SIDE = _exp_env('PATCHGAN_BF16_WGRAD_SIDE', '0') == '1'       # bf16 networks' weight gradients on the second stream too (A/B switch; off)
+SHARE_DY_V = _exp_env('PATCHGAN_SHARE_DY_V') != '0'       # ... and the two halves share the transformed dy (A/B switch)
 SPLIT_BWD_BIG = _exp_env('PATCHGAN_SPLIT_BWD_BIG') != '0'       # with the second stream: the decoder's fused backward call as its two halves (8.83 -> 8.65 ms at cfg2)
 
 
@@ -1147,8 +1148,16 @@ class GeneratorEngine(_WeightPrep):
             dsrc = View.alloc(N, op.Hs, op.Ws, l.a, dev, bf=bf)
             u, uv = _ucache(ucache, ('d', i), 0, op, dev, dy, dsrc, l.p_off)
             if (u is not None and bf) or (SPLIT_BWD_BIG and cur_exec().allow):      # bf16 tensors: the two halves as two calls, the data gradient on the forward's packed weights
-                op.wgrad(src, dy, gflat, l.p_off)
-                op.big2small(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
+                vb = op.v_bytes() if (SHARE_DY_V and not bf and KEEP_V and ConvOp._aligned(dy, dsrc, src) and ConvOp.fits(dy, dsrc, src)) else 0
+                if vb:
+                    # both halves start from the polyphase transform of dy: the data gradient keeps it (v_keep), the weight gradient --
+                    # on the second stream, behind this layer's data gradient instead of beside it -- takes it over (v_pre)
+                    vk = torch.empty(vb, dtype=torch.uint8, device=dev)
+                    op.big2small(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv, v_keep=vk)
+                    op.wgrad(src, dy, gflat, l.p_off, v_pre=vk)
+                else:
+                    op.wgrad(src, dy, gflat, l.p_off)
+                    op.big2small(dy, flat, l.p_off, None, 0, dsrc, u_cache=u, u_valid=uv)
             else:
                 op.bwd_big(src, dy, flat, gflat, l.p_off, dsrc, u_cache=u, u_valid=uv)
             done(l)
