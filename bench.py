@@ -455,7 +455,7 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
         # (under data parallelism every rank must run the SAME number of steps -- each step holds collectives -- so nothing below may
         #  depend on a rank's own clock: the tournament has a fixed length, the settling loop a fixed count, and the flags that steer
         #  the rest of this function are agreed on across ranks)
-        n_decide = 3 * (t.TRIAL_STEPS + 2) + 4
+        n_decide = 3 * (2 * t.TRIAL_STEPS + 2) + 4
         for _ in range(n_decide):
             if t.graph_decided() and not use_dist:
                 break

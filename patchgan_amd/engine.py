@@ -168,7 +168,11 @@ class Exec:
     def side_stream(self):
         """The second stream of a two-stream step, created on first use ON THE OWNER'S DEVICE."""
         if self.stream is None:
-            self.stream = torch.cuda.Stream(device=self.device)
+            dev = self.device if self.device is not None else torch.device('cuda', torch.cuda.current_device())
+            st = _SECOND_STREAMS.get(dev.index)
+            if st is None:
+                st = _SECOND_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+            self.stream = st
         return self.stream
 
     def workspace(self, nbytes, device):
@@ -205,6 +209,12 @@ class Exec:
 
 
 _TLS = threading.local()
+# ONE second stream per device for every owner on it.  A stream is a device resource: torch hands out streams from a fixed pool and the HIP
+# runtime maps each onto one of its hardware queues -- a process that went through several trainers (bench.py's legs) otherwise ended up
+# with a second stream sharing the compute stream's hardware queue: the fourth trainer's two-stream step took 6.9 ms instead of 2.5.
+# In-order sharing is harmless: every hand-over to / from it is a stream wait, and owners' flags, held operands and workspaces stay
+# their own.
+_SECOND_STREAMS = {}
 _DEFAULT_EXEC = {}       # device index -> Exec of stand-alone module calls (UNet(...)(x), predict_image): one workspace, never a second stream
 
 

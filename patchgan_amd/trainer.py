@@ -169,7 +169,7 @@ class Trainer:
     #                the discriminator step's forward pass on a second stream (engine.Exec).  Independent of capture: dropout, evaluation
     #                passes and data-parallel steps take it too.  None = follows `graph` ('auto' with graph = 'auto', else off).
     # 'auto': a tournament per kind of step.  After one untimed warm step every way of launching that the settings allow -- one stream,
-    # two streams, the captured graph -- runs for TRIAL_STEPS steps while an event is recorded at the start of each step; a candidate's
+    # two streams, the captured graph -- runs for 2 x TRIAL_STEPS steps (the first half settles: allocator growth for the new pattern) while an event is recorded at the start of each step; a candidate's
     # score is the SHORTEST start-to-start period it reached (the step time as the caller sees it: host-bound or device-bound, whatever
     # binds; the minimum is robust against a loader hiccup or a GC pause in one of the steps), and the fastest candidate is kept.  All
     # candidates are the same computation, bit for bit, so the trials are ordinary training steps.  Measured at cfg2 / cfg4 two streams
@@ -178,7 +178,7 @@ class Trainer:
     graph = False
     two_streams = None
     GRAPH_WARM_STEPS = 3     # graph = True: eager steps of a given kind before it is captured (kernel plans, weight-cache plans, workspaces settle)
-    TRIAL_STEPS = 4          # 'auto': timed steps per candidate
+    TRIAL_STEPS = 4          # 'auto': per candidate, this many settling steps and then this many timed ones
     GRAPH_TRIAL_RATIO = 1.25 # 'auto': the captured graph enters the tournament only if the one-stream step takes < this x its own host enqueue time
     AUTO_FORCE = None        # 'eager1' | 'eager2' | 'graph': 'auto' takes this outcome (where the settings allow it) after the warm steps
     MAX_GRAPHS = 2           # captured kinds of step kept (each holds its activations: ~4 GB at cfg2)
@@ -568,13 +568,15 @@ class Trainer:
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()                               # the start of this step on the compute stream
         tr['starts'].append(ev)
-        if len(tr['starts']) <= self.TRIAL_STEPS + 1:
+        if len(tr['starts']) <= 2 * self.TRIAL_STEPS + 1:
             return tr['cands'][tr['i']]
-        # TRIAL_STEPS + 1 starts of this candidate and the start of the step that follows them: its periods are known once that last
-        # event has been reached (one wait per candidate, during warm-up)
+        # 2 x TRIAL_STEPS + 1 starts of this candidate and the start of the step that follows them: its periods are known once that last
+        # event has been reached (one wait per candidate, during warm-up).  The first TRIAL_STEPS periods do not score: they hold the
+        # switch and the caching allocator's growth for the new launch pattern (a second stream allocates from a pool of its own:
+        # device allocations synchronise -- seen at 2-3 x the settled step time for the first steps)
         ev.synchronize()
         st = tr['starts']
-        tr['ms'][tr['cands'][tr['i']]] = min(st[j].elapsed_time(st[j + 1]) for j in range(1, len(st) - 1))      # (the first period holds the switch)
+        tr['ms'][tr['cands'][tr['i']]] = min(st[j].elapsed_time(st[j + 1]) for j in range(self.TRIAL_STEPS, len(st) - 1))
         tr['i'] += 1
         tr['starts'] = [ev]
         if tr['i'] < len(cands) and cands[tr['i']] == 'graph' and tr['ms']['eager1'] > self.GRAPH_TRIAL_RATIO * tr['host'].get('eager1', 0.0):

@@ -176,11 +176,11 @@ def test_dropout_and_eval_steps_take_the_second_stream_and_stay_bit_identical(tm
 def test_auto_tournament_measures_every_candidate_and_is_the_same_computation(tmp_path):
     """Trainer.graph = 'auto' without a decree: after one warm step each candidate (one stream, two streams, and -- where the one-stream
     step is close to host-bound -- the captured graph) runs TRIAL_STEPS timed steps, the fastest is kept.  Every candidate is the same
-    computation: 24 steps that pass through all of them equal 24 one-stream steps bit for bit.  A step that raises inside the
+    computation: 36 steps that pass through all of them equal 36 one-stream steps bit for bit.  A step that raises inside the
     tournament does not score (the tournament starts over), and redecide() forgets the outcome."""
     import patchgan_amd as pg
-    ref = _run(tmp_path, False, 'fp32', 24, nf=16, tag='t_ref')
-    auto = _run(tmp_path, 'auto', 'fp32', 24, nf=16, tag='t_auto')
+    ref = _run(tmp_path, False, 'fp32', 36, nf=16, tag='t_ref')
+    auto = _run(tmp_path, 'auto', 'fp32', 36, nf=16, tag='t_auto')
     t = auto[4]
     assert t.graph_decided() and t.decided_modes()[0] in ('eager1', 'eager2', 'graph')
     ms = {k: v for k, v in t.step_times.items() if k != 'host_enqueue'}
@@ -209,7 +209,7 @@ def test_auto_tournament_measures_every_candidate_and_is_the_same_computation(tm
         t.batch(x, y, train=True)
     t._enqueue_step = orig
     assert kind['trial'] is None and kind['mode'] is None and not t._exec.enabled
-    for _ in range(3 * (t.TRIAL_STEPS + 2)):
+    for _ in range(3 * (2 * t.TRIAL_STEPS + 2)):
         t.batch(x, y, train=True)
     assert t.graph_decided()
 
