@@ -144,9 +144,10 @@ class View:
 
 class Exec:
     """Execution state of ONE driver of the engines (a Trainer; or a device's default for stand-alone module calls): the split-K
-    workspace per stream and the second stream of a two-stream step with its book-keeping.  Nothing in here is shared between
-    owners -- two Trainers (also on different GPUs, also on different threads) never see each other's stream, flags or buffers,
-    and everything is released with the owner (or by release()).
+    workspace per stream and the book-keeping of a two-stream step.  Nothing in here is shared between owners -- two Trainers (also on
+    different GPUs, also on different threads) never see each other's flags, held operands or buffers, and everything is released with
+    the owner (or by release()).  The second STREAM is the device's (one per device, _SECOND_STREAMS): owners on one device use it in
+    order, each behind its own hand-overs.
 
       enabled   set by the owner per step: this step may use the second stream
       allow     inside a backward pass: weight gradients go to the second stream

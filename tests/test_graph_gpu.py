@@ -256,8 +256,8 @@ def test_replay_after_the_buffers_it_baked_in_were_replaced(tmp_path):
 
 
 def test_two_trainers_do_not_share_execution_state(tmp_path):
-    """engine.Exec is per trainer: two trainers alternating steps (one on two streams, one on one) give what each gives alone, and
-    releasing one leaves the other's buffers alone."""
+    """engine.Exec is per trainer (flags, held operands, workspaces; the second stream itself is the device's): two trainers
+    alternating steps (one on two streams, one on one) give what each gives alone, and releasing one leaves the other's buffers alone."""
     from patchgan_amd import engine as E
     alone = _run(tmp_path, False, 'fp32', 4, nf=16, tag='al', two_streams=True)
     import patchgan_amd as pg
