@@ -1,6 +1,10 @@
 import os
 import sys
 
+# before anything initialises the HIP runtime (the collection hook below asks torch for a GPU): the setting the package ships with
+# (patchgan_amd/__init__.py: one hardware queue per stream of the step)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
