@@ -358,7 +358,10 @@ def main():
                             'launch by launch, the discriminator step\'s forward on a second stream' if m['two_streams'] == 'bf16' else 'launch by launch')
                            + (' (auto, measured ms per step: ' + ', '.join(f'{k} {v:.2f}' if v is not None else f'{k} not tried' for k, v in m['step_times'].items() if k != 'host_enqueue') + ')' if m.get('step_times') else ''),
             'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'vs_baseline': None,
+            'dtype': args.dtype + (' (fp32 tensors and accumulation; polyphase Winograd GEMMs in bf16x3 split form: six bf16 MFMA products per '
+                                   'fp32 product)' if (args.dtype == 'f32' and m.get('split_bf16')) else ''),
+            'data': 'synthetic',
             'activation_storage': m['activation_storage'], 'peak_vram_GiB': m['peak_vram_GiB'],
             'config': {'workload': CFG['desc'] + ', dropout ' + ('on' if args.dropout else 'off'),
                        'global_batch': BATCH_PER_GPU * world, 'parallelism': f'dp{world}'},
@@ -597,16 +600,27 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
     achieved = d['kflops'] / (d['ms'] * 1e-3) / 1e12
     useful = d['uflops'] / (d['ms'] * 1e-3) / 1e12      # ... without the padding of ragged edge tiles to whole tiles
     peak = FP32_MFMA_PEAK_TFLOPS if dtype == 'f32' else 2500.0     # dense MFMA peak of the multiply dtype
+    # a split-bf16 kernel (k_*_s3: every fp32 product as six bf16 products, fp32 accumulate) runs on the bf16 matrix pipe: it is priced
+    # against THAT pipe's dense peak with the bf16 FLOPs it issues (6 x its fp32-equivalent count); the fp32-equivalent rate is quoted too
+    s3_dom = '_s3<' in sym
+    fp32_equiv = achieved
+    if s3_dom:
+        achieved, useful, peak = 6.0 * achieved, 6.0 * useful, 2500.0
+    s3_any = any('_s3<' in k for k in per_step_all)
     traffic, traffic_src = pmc_traffic(sym)
     res.update({
         'value': value, 'ms_per_step': elapsed / steps * 1e3, 'host_ms_per_step': host_ms / steps,
         'activation_storage': 'bf16' if (dtype == 'bf16' and G.engine.act_bf) else 'f32',
-        'last_losses': last_vals,
+        'last_losses': last_vals, 'split_bf16': s3_any,
         'roofline': {'bound': 'mfma', 'kernel': sym,
                      'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': round(achieved / peak, 4), 'achieved_useful': round(useful, 2), 'frac_useful': round(useful / peak, 4),
                      'frac_note': 'frac = FLOPs the kernel executes on the MFMA pipe (ragged Winograd edge tiles count as whole tiles) / time / '
-                                  'peak; frac_useful = the same algorithm on the exact extents (no tile padding)',
+                                  'peak; frac_useful = the same algorithm on the exact extents (no tile padding)'
+                                  + ('; split-bf16 kernel: six bf16 MFMA products per fp32 product, priced in issued bf16 FLOPs against the '
+                                     'dense bf16 MFMA peak' if s3_dom else ''),
+                     'achieved_fp32_equivalent': round(fp32_equiv, 2),
+                     'fp32_equivalent_over_fp32_mfma_peak': round(fp32_equiv / FP32_MFMA_PEAK_TFLOPS, 4),
                      'traffic': traffic,
                      'traffic_source': (f'{traffic_src} (committed rocprofv3 --pmc pass of the same command; not measured '
                                         'in this run)') if traffic_src else None,
@@ -617,7 +631,8 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
                      'all_conv_kernels_TFLOPs': round(sum(v['kflops'] for v in per_step_all.values()) * steps / (conv_ms * 1e-3) / 1e12, 2),
                      'all_conv_kernels_direct_conv_TFLOPs': round(sum(v['flops'] for v in per_step_all.values()) * steps / (conv_ms * 1e-3) / 1e12, 2),
                      'all_conv_share_of_step': round(conv_ms / steps / (elapsed / steps * 1e3), 4),
-                     'step_frac_of_mfma_roofline': round(value / world * cfg['gflop_per_image'] / 1e3 / peak, 4)},
+                     'step_frac_of_mfma_roofline': round(value / world * cfg['gflop_per_image'] / 1e3
+                                                         / (FP32_MFMA_PEAK_TFLOPS if dtype == 'f32' else 2500.0), 4)},
         'conv_kernels': {k: {'launches_per_step': v['launches'], 'ms_per_step': round(v['ms'], 4),
                              'TFLOPs': round(v['kflops'] / (v['ms'] * 1e-3) / 1e12, 2),
                              'useful_TFLOPs': round(v['uflops'] / (v['ms'] * 1e-3) / 1e12, 2),

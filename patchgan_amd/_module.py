@@ -12,7 +12,8 @@ class FlatParamModule(nn.Module):
 
     # set by a Trainer: completes an update of this module that is still in flight (Trainer.flush) before its weights or gradients are
     # read through the module's own surface (state_dict, parameters, forward, .to()).  `flat` / `grad_flat` are the raw buffers the
-    # engines work on: whoever reads those directly calls Trainer.flush() first.
+    # engines work on: whoever reads those directly calls Trainer.flush() first.  So does whoever keeps a reference to a CHILD's parameter
+    # (module.model[i].weight, an optimizer built earlier) across batch() calls: attribute access on a child is not intercepted.
     _access_hook = None
 
     def _pre_access(self):
@@ -39,6 +40,10 @@ class FlatParamModule(nn.Module):
     def get_parameter(self, target):
         self._pre_access()
         return super().get_parameter(target)
+
+    def apply(self, fn):
+        self._pre_access()
+        return super().apply(fn)
 
     def _init_flat(self, layers, nparams):
         self._layers = layers

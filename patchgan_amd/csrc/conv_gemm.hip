@@ -3383,6 +3383,7 @@ struct Tune {
     int dma;        // stride-1 GEMM staging: 0 registers, 1 LDS-DMA ring for F(3x3,4x4), 2 also for 64-tile F(2x2,4x4)
     bool bf16x;     // PG_ALGO_BF16 on bf16 tensors: the LDS-DMA kernels of conv_bf16.hip (off: the register-staged k_*_bf16)
     int bf16ring;   // ... their staging: 1 three-stage ring of 32-wide chunks, 0 one buffer of 64-wide chunks, -1 per-layer default
+    bool s3;        // polyphase Winograd GEMMs in split-bf16 form (k_wino_bgemm_s3) instead of v_mfma_f32_32x32x2_f32 (k_wino_bgemm)
 };
 inline int env_int(const char* name, int dflt) {
     const char* e = pg_exp_env(name);
@@ -3399,6 +3400,7 @@ inline Tune tune_of(int algo) {
         t.dma = pg_wino_dma_mode();
         t.bf16x = env_int("PATCHGAN_NO_BF16X", 0) != 1;
         t.bf16ring = -1;      // (pinned only per call: PG_TUNE_BF16X_RING / _FLAT)
+        t.s3 = env_int("PATCHGAN_S3", 1) != 0;
         return t;
     }();
     Tune t = env;
@@ -3414,11 +3416,12 @@ inline Tune tune_of(int algo) {
     if (algo & PG_TUNE_BF16X_OFF) t.bf16x = false;
     if (algo & PG_TUNE_BF16X_RING) t.bf16ring = 1;
     if (algo & PG_TUNE_BF16X_FLAT) t.bf16ring = 0;
+    if (algo & PG_TUNE_S3_OFF) t.s3 = false;
     if (force_generic()) t.wino = false;
     return t;
 }
 // every path on, for sizing a workspace that serves any tuning
-inline Tune tune_widest(int mo1) { return Tune{true, true, 1, 1, mo1, 0, true, -1}; }
+inline Tune tune_widest(int mo1) { return Tune{true, true, 1, 1, mo1, 0, true, -1, true}; }
 
 // stride-1 layers only: forward is a pad-1 correlation big -> small, the data gradient a pad-2 correlation small -> big
 inline bool wino_b2s_ok(const Geom& g, const Tune& t) {
@@ -3757,17 +3760,18 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
         if (workgroups) *workgroups = (((long)g->N * g->Hs * g->Ws + tmk - 1) / tmk) * ((g->Ca + 63) / 64);
         return PG_OK;
     }
-    // 70 / 71: polyphase Winograd of a stride-2 layer (k_wino_bgemm<2,2,2,2> / <1,2,2,2>); 72 / 73: k_wino_bgemm_mz
+    // 70 / 71: polyphase Winograd of a stride-2 layer (k_wino_bgemm_s3<2,2,2,2,2> / <1,2,2,2,3>; under PG_TUNE_S3_OFF k_wino_bgemm<2,2,2,2> /
+    // <1,2,2,2>, 72 / 73: k_wino_bgemm_mz)
     if (algo == PG_ALGO_AUTO && op == 0 && wino2_b2s_ok(gq, tune) && ws_bytes >= pg_wino2_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
         const long T = pg_wino2_tiles_b2s(g->N, g->Hs, g->Ws), X = (long)(pg_wino2_mo() + 1) * (pg_wino2_mo() + 1);
-        if (tile_id) *tile_id = (T >= 1024 ? 70 : 71) + (pg_wino2_b2s_zb(g->N, g->Hs, g->Ws, g->Ca) > 1 ? 2 : 0);
+        if (tile_id) *tile_id = (T >= 1024 ? 70 : 71) + ((!tune.s3 && pg_wino2_b2s_zb(g->N, g->Hs, g->Ws, g->Ca) > 1) ? 2 : 0);
         if (split) *split = 1;
         if (workgroups) *workgroups = X * ((T + (T >= 1024 ? 127 : 63)) / (T >= 1024 ? 128 : 64)) * ((g->Ca + 127) / 128);
         return PG_OK;
     }
     if (algo == PG_ALGO_AUTO && op == 1 && wino2_s2b_ok(gq, tune) && ws_bytes >= pg_wino2c_ws_bytes(gq.N, gq.Hb, gq.Wb, gq.Ca, gq.Cb)) {
         const long T = pg_wino2_tiles_s2b(g->N, g->Hb, g->Wb), X = (long)(pg_wino2_mo() + 1) * (pg_wino2_mo() + 1);
-        if (tile_id) *tile_id = (T >= 1024 ? 70 : 71) + (pg_wino2_s2b_zb(g->N, g->Hb, g->Wb, g->Cb) > 1 ? 2 : 0);
+        if (tile_id) *tile_id = (T >= 1024 ? 70 : 71) + ((!tune.s3 && pg_wino2_s2b_zb(g->N, g->Hb, g->Wb, g->Cb) > 1) ? 2 : 0);
         if (split) *split = 1;
         if (workgroups) *workgroups = X * ((T + (T >= 1024 ? 127 : 63)) / (T >= 1024 ? 128 : 64)) * ((4 * g->Cb + 127) / 128);
         return PG_OK;
@@ -3842,7 +3846,10 @@ static int conv_kernel_impl(const pg_conv_geom* g, int op, size_t ws_bytes, char
         snprintf(buf, sizeof buf, (tid <= 4 && tapkp_enabled()) ? "k_b2s_tapkp<%d>" : "k_b2s_tapk<%d>", tid);
         sp = 1;
     } else if (mode == 7) {          // polyphase Winograd of a stride-2 layer
-        snprintf(buf, sizeof buf, "k_wino_bgemm%s<%s>", tid >= 2 ? "_mz" : "", (tid & 1) ? "1,2,2,2" : "2,2,2,2");
+        if (tune.s3)       // split-bf16 form (the default): 128-row tiles at two waves per SIMD, 64-row tiles at three
+            snprintf(buf, sizeof buf, "k_wino_bgemm_s3<%s>", (tid & 1) ? "1,2,2,2,3" : "2,2,2,2,2");
+        else
+            snprintf(buf, sizeof buf, "k_wino_bgemm%s<%s>", tid >= 2 ? "_mz" : "", (tid & 1) ? "1,2,2,2" : "2,2,2,2");
         const int mo = pg_wino2_mo();
         fl = (oc == 0) ? 2.0 * (mo + 1) * (mo + 1) * g->N * cd(g->Hs, mo) * cd(g->Ws, mo) * 4.0 * g->Cb * g->Ca
                        : 2.0 * 4 * (mo + 1) * (mo + 1) * g->N * cd(cd(g->Hb, 2) + 1, mo) * cd(cd(g->Wb, 2) + 1, mo) * (double)g->Ca * g->Cb;
@@ -3963,7 +3970,7 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
         if (part && pg_wino2_b2s_stats_chunks(g.N, g.Hs, g.Ws, g.Ca) == 0) return PG_EINVAL;
         if (x.v_keep && pg_wino2_mo() != 3) return PG_EINVAL;
         return pg_wino2_b2s(big, ld_big, P, bias, small, ld_small, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, nullptr,
-                            part, x.v_keep, x.u_cache, x.u_valid);
+                            part, x.v_keep, x.u_cache, x.u_valid, tune.s3);
     }
     if (bf16x_ok(g, 0, algo | io, tune) && !x.v_keep) {
         const int rc = bf16x_run(0, big, ld_big, P, bias, small, ld_small, g, act, io & PG_IO_SMALL_BF16, ws, ws_bytes, st, x, tune.bf16ring);
@@ -4190,7 +4197,7 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
         if (part && pg_wino2_s2b_stats_chunks(g.N, g.Hb, g.Wb, g.Cb) == 0) return PG_EINVAL;
         if (mul.t && (!aligned16(mul.t) || mul.ld % 4)) return PG_EINVAL;
         return pg_wino2_s2b(small, ld_small, P, bias, big, ld_big, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, act, ws, st, e0, e1, part,
-                            x.u_cache, x.u_valid, mul);
+                            x.u_cache, x.u_valid, mul, tune.s3);
     }
     if (s2b_tapnf_bf_ok(g, algo | io, tune) && !part && !x.u_cache && !mul.t && (ld_small % 8 == 0) && aligned16(small) &&
         tensor_bytes((long)g.N * g.Hs * g.Ws, ld_small, g.Ca, true) < FAST_LIMIT && tensor_bytes((long)g.N * g.Hb * g.Wb, ld_big, g.Cb) < FAST_LIMIT)
@@ -4644,7 +4651,7 @@ int pg_conv4x4_bwd_big_x(const float* small, int ld_small, const float* big, int
     rc = pg_wino2_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, rest, st, e0, e1, V);
     if (rc != PG_OK) return rc;
     return pg_wino2_b2s(big, ld_big, P, nullptr, dsmall, ld_dsmall, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, PG_ACT_NONE, rest, st, e2,
-                        e3, V, nullptr, nullptr, Uext, u_valid);
+                        e3, V, nullptr, nullptr, Uext, u_valid, tune.s3);
 }
 
 }  // extern "C"

@@ -72,7 +72,9 @@ size_t pg_wino2_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
 // Vpre (optional, F(3x3,2x2) only): the transformed input already computed by pg_wino2_v; ws then holds U | M only
 int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                 const float* Vpre, double* part, float* Vkeep, float* Uext, int u_valid);
+                 const float* Vpre, double* part, float* Vkeep, float* Uext, int u_valid, int s3);
+// s3 (both directions): != 0 runs the batched GEMM in split-bf16 form (k_wino_bgemm_s3: fp32 operands split into three bf16 pieces while they
+// are staged, six bf16 MFMAs per 16 k, fp32 accumulate), 0 on v_mfma_f32_32x32x2_f32 (k_wino_bgemm)
 // part (optional, both directions): the output transform also writes per-sample partial sums / sums of squares of the output,
 // part[((n * chunks + chunk) * C + c) * 2 + {0,1}] (fp64), chunks = pg_wino2_*_stats_chunks(...) (0: not available)
 int pg_wino2_b2s_stats_chunks(int N, int Hs, int Ws, int Ca);
@@ -85,7 +87,7 @@ bool pg_wino2c_geom_ok(int N, int Hb, int Wb, int Ca, int Cb);
 size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb);
 int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                 double* part, float* Uext, int u_valid, pg_epi_mul mul = pg_epi_mul{nullptr, 0, 0});
+                 double* part, float* Uext, int u_valid, pg_epi_mul mul, int s3);
 
 // weight gradient of the stride-2 layers, polyphase F(2x2, 3x3): V (16*tiles*4Cb) | DY (16*tiles*Ca) | S (slices*16*Ca*4Cb)
 bool pg_wino2_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);

@@ -32,6 +32,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KC = 32;
 constexpr int LDK = KC + 4;
 
+
 // Toom-Cook matrices for F(2, 4), points {0, 1, -1, 2, inf}
 __device__ __constant__ float c_BT[5][5] = {{2, -1, -2, 1, 0}, {0, -2, -1, 1, 0}, {0, 2, -3, 1, 0}, {0, -1, 0, 1, 0},
                                             {0, 2, -1, -2, 1}};
@@ -1108,6 +1109,167 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #endif
 }
 
+// ---- split-bf16 form of the same batched row GEMM (the default; PG_TUNE_S3_OFF selects the fp32-MFMA kernel above) ----
+// fp32 products on the bf16 matrix pipe: every operand value a is split, while it is staged into LDS, into three bf16 pieces
+// a = a1 + a2 + a3 (a1 = RNE_bf16(a), a2 = RNE_bf16(a - a1), a3 = a - a1 - a2: exact, 8 + 8 + 8 significand bits cover fp32's 24), and the six
+// products a_i b_j with i + j <= 4 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (a product of two bf16 values is exact in fp32; the
+// dropped terms a2 b3 + a3 b2 + a3 b3 are <= 2^-25 |a b|, below the rounding of the fp32 accumulation itself).  Six MFMAs of 32 cycles per 16 k
+// instead of eight fp32 MFMAs of 64: 2.67x fewer matrix-pipe cycles for fp32-grade results (measured per kernel against float64: the same
+// 1e-6-level errors as the fp32-MFMA kernel, tests/test_bench_layers_gpu.py).  Operands stay fp32 in HBM: the split costs VALU work per
+// staged value, not bytes.  Inf / NaN operands: a - RNE_bf16(a) is NaN for an infinite a, so an infinity in an operand gives NaN where
+// the fp32 kernel gives +-inf or NaN -- both poison the step.
+typedef __bf16 s3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 s3_bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void s3_split(const f32x4 v, s3_bf16x4& h, s3_bf16x4& m, s3_bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 a = (__bf16)v[e];
+        const float r1 = v[e] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        const float r2 = r1 - (float)b;
+        h[e] = a;
+        m[e] = b;
+        l[e] = (__bf16)r2;
+    }
+}
+
+// Structure: K chunks of 16, two LDS buffers, ONE barrier per chunk.  While the MFMAs of chunk c run out of buffer c & 1, the same wave
+// splits chunk c + 1 (loaded two chunks earlier into one of two register sets) and writes it into the other buffer: the split's VALU work and
+// the LDS writes sit between the MFMAs of the wave's own instruction stream instead of in a phase of their own (a two-phase form with
+// 32-wide chunks measured 0.65 us of MFMAs and 1.6-1.9 us of waiting + splitting + writing per chunk: EXPERIMENTS.md, round 6).
+// LDS row = [a1: 16 k | a2: 16 k | a3: 16 k | pad] = 112 bytes = 7 x 16: conflict-free ds_read_b128 fragments of 8 consecutive k.
+constexpr int S3_KC = 16, S3_LDR = 3 * S3_KC + 8;
+template <int MR, int NR, int WM, int WN, int WPE, int VAR = 1>      // VAR: order of the six products (1 = largest first, the shipped one; others: PATCHGAN_S3_VAR, experiment)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_bgemm_s3(const float* __restrict__ A, const float* __restrict__ B,
+                                                    float* __restrict__ C, int Mrows, int Ncols, int K, int a_bytes,
+                                                    int b_bytes, int tiles_m, int tiles_n) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32, AI = BM / 64, BI = BN / 64, BUF = (BM + BN) * S3_LDR;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * BUF];
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    int w = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (w % tiles_n) * BN;
+    w /= tiles_n;
+    const int m0 = (w % tiles_m) * BM, z = w / tiles_m;
+    const int nch = K / S3_KC;
+    const int kq = tid & 3, r0 = tid >> 2;      // four lanes per 16-wide row piece, 64 rows per pass
+    int a_off[AI], b_off[BI];
+    bool a_ok[AI], b_ok[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        a_ok[i] = m < Mrows;
+        a_off[i] = (z * Mrows + min(m, Mrows - 1)) * K + kq * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int n = n0 + r0 + 64 * i;
+        b_ok[i] = n < Ncols;
+        b_off[i] = (z * Ncols + min(n, Ncols - 1)) * K + kq * 4;
+    }
+    auto issue_loads = [&](f32x4 (&ra)[AI], f32x4 (&rb)[BI], int c) {
+        const bool on = c < nch;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) ra[i] = bload4(rA, voff(a_off[i] + c * S3_KC, on && a_ok[i]));
+#pragma unroll
+        for (int i = 0; i < BI; ++i) rb[i] = bload4(rB, voff(b_off[i] + c * S3_KC, on && b_ok[i]));
+    };
+    auto stage = [&](const f32x4 (&ra)[AI], const f32x4 (&rb)[BI], __bf16* buf) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            s3_bf16x4 h, m, l;
+            s3_split(ra[i], h, m, l);
+            __bf16* row = &buf[(r0 + 64 * i) * S3_LDR + kq * 4];
+            *reinterpret_cast<s3_bf16x4*>(row) = h;
+            *reinterpret_cast<s3_bf16x4*>(row + S3_KC) = m;
+            *reinterpret_cast<s3_bf16x4*>(row + 2 * S3_KC) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            s3_bf16x4 h, m, l;
+            s3_split(rb[i], h, m, l);
+            __bf16* row = &buf[(BM + r0 + 64 * i) * S3_LDR + kq * 4];
+            *reinterpret_cast<s3_bf16x4*>(row) = h;
+            *reinterpret_cast<s3_bf16x4*>(row + S3_KC) = m;
+            *reinterpret_cast<s3_bf16x4*>(row + 2 * S3_KC) = l;
+        }
+    };
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto compute = [&](const __bf16* buf) {
+        s3_bf16x8 bf[NR][3], af[MR][3];
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                bf[j][p] = *reinterpret_cast<const s3_bf16x8*>(&buf[(BM + (wn * NR + j) * 32 + lrow) * S3_LDR + p * S3_KC + lh * 8]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                af[i][p] = *reinterpret_cast<const s3_bf16x8*>(&buf[((wm * MR + i) * 32 + lrow) * S3_LDR + p * S3_KC + lh * 8]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+#define S3_MM(pa, pb) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0)
+                if constexpr (VAR == 1) {          // largest terms first
+                    S3_MM(0, 0); S3_MM(0, 1); S3_MM(1, 0); S3_MM(1, 1); S3_MM(0, 2); S3_MM(2, 0);
+                } else if constexpr (VAR == 2) {   // eight products, smallest first
+                    S3_MM(2, 1); S3_MM(1, 2); S3_MM(2, 0); S3_MM(0, 2); S3_MM(1, 1); S3_MM(1, 0); S3_MM(0, 1); S3_MM(0, 0);
+                } else if constexpr (VAR == 3) {   // a-major order
+                    S3_MM(2, 0); S3_MM(1, 1); S3_MM(1, 0); S3_MM(0, 2); S3_MM(0, 1); S3_MM(0, 0);
+                } else {                           // smallest terms first
+                    S3_MM(2, 0); S3_MM(0, 2); S3_MM(1, 1); S3_MM(1, 0); S3_MM(0, 1); S3_MM(0, 0);
+                }
+#undef S3_MM
+            }
+    };
+    __bf16* const buf0 = smem;
+    __bf16* const buf1 = smem + BUF;
+    f32x4 ra0[AI], rb0[BI], ra1[AI], rb1[BI];
+    issue_loads(ra0, rb0, 0);
+    issue_loads(ra1, rb1, 1);
+    stage(ra0, rb0, buf0);
+    issue_loads(ra0, rb0, 2);
+    __syncthreads();
+    // invariant at the top of step c: buf[c & 1] = chunk c; set (c + 1) & 1 = chunk c + 1; set c & 1 = chunk c + 2 (both in flight / landed)
+    // (K % 32 == 0: an even number of chunks; loads beyond the last chunk are masked to zero and staged into a buffer nobody reads, so the
+    //  body has no branch and the compiler interleaves the split with the MFMAs)
+    for (int c = 0; c < nch; c += 2) {
+        stage(ra1, rb1, buf1);
+        compute(buf0);
+        issue_loads(ra1, rb1, c + 3);
+        __syncthreads();
+        stage(ra0, rb0, buf0);
+        compute(buf1);
+        issue_loads(ra0, rb0, c + 4);
+        __syncthreads();
+    }
+    float* o = C + (long)z * Mrows * Ncols;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + (wm * MR + i) * 32 + row;
+                if (m < Mrows && col < Ncols) o[(long)m * Ncols + col] = acc[i][j][r];
+            }
+        }
+}
+
 // Multi-batch variant: a workgroup owns one (m, n) tile position and runs `zb` consecutive batches z through ONE flattened (z, chunk) loop: the
 // loads of the next batch's first chunk are in flight during the last MFMAs of the current one and the tile stores are
 // fire-and-forget, so the short K loops of these layers (4..32 chunks) do not pay a prologue and an epilogue each.
@@ -1855,11 +2017,11 @@ int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big
     if (pg_wino_wgrad_tile64(Ca, Cb)) {
         const int tilesA = (Ca + 63) / 64, tilesB = (Cb + 63) / 64;
         hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB * X * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                           Cb, cps, tilesA, tilesB, X, (int)((long)X * T * Ca * 4), (int)((long)X * T * Cb * 4));
+                       Cb, cps, tilesA, tilesB, X, (int)((long)X * T * Ca * 4), (int)((long)X * T * Cb * 4));
     } else {
         const int tilesA = (Ca + 127) / 128, tilesB = (Cb + 127) / 128;
         hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB * X * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                           Cb, cps, tilesA, tilesB, X, (int)((long)X * T * Ca * 4), (int)((long)X * T * Cb * 4));
+                       Cb, cps, tilesA, tilesB, X, (int)((long)X * T * Ca * 4), (int)((long)X * T * Cb * 4));
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
@@ -1875,6 +2037,21 @@ int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big
 // OFF by default since round 4 (PATCHGAN_BGEMM_MZ=1 enables it): measured in the cfg2 step on one box, the multi-batch kernel as hipcc
 // built it until then (196 VGPRs + 64 AGPRs: ONE wave per SIMD) 9.07 ms, the same kernel held to two waves per SIMD 8.95, the single-batch
 // kernel (126 registers, four waves per SIMD, four workgroups per CU covering each other's prologues) 8.90.
+// the split-bf16 batched GEMM: 128-row tiles at two waves per SIMD (194 registers), 64-row tiles at three (118)
+static void bgemm_s3_launch(int big_rows, dim3 grid, hipStream_t st, const float* A, const float* B, float* C, int Mrows, int Ncols, int K,
+                            int a_bytes, int b_bytes, int tm, int tn) {
+    static const int var = [] {      // PATCHGAN_S3_VAR (experiment): order of the six products, see k_wino_bgemm_s3
+        const char* e = pg_exp_env("PATCHGAN_S3_VAR");
+        return e ? atoi(e) : 1;
+    }();
+#define S3_GO(MR, WPE, VAR) hipLaunchKernelGGL((k_wino_bgemm_s3<MR, 2, 2, 2, WPE, VAR>), grid, dim3(256), 0, st, A, B, C, Mrows, Ncols, K, a_bytes, b_bytes, tm, tn)
+    if (var == 0) { if (big_rows) S3_GO(2, 2, 0); else S3_GO(1, 3, 0); }
+    else if (var == 2) { if (big_rows) S3_GO(2, 2, 2); else S3_GO(1, 3, 2); }
+    else if (var == 3) { if (big_rows) S3_GO(2, 2, 3); else S3_GO(1, 3, 3); }
+    else if (big_rows) S3_GO(2, 2, 1);
+    else S3_GO(1, 3, 1);
+#undef S3_GO
+}
 static int bgemm_zb(long tiles_mn, int X) {
     static const bool on = [] {
         const char* e = pg_exp_env("PATCHGAN_BGEMM_MZ");
@@ -1920,7 +2097,7 @@ size_t pg_wino2_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb) {
 template <int MO>
 static int wino2_b2s_run(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N,
                          int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0,
-                         hipEvent_t ev1, const float* Vpre, double* part, float* Vkeep, float* Uext, int u_valid) {
+                         hipEvent_t ev1, const float* Vpre, double* part, float* Vkeep, float* Uext, int u_valid, int s3) {
     constexpr int X = (MO + 1) * (MO + 1);
     const int TH = (Hs + MO - 1) / MO, TW = (Ws + MO - 1) / MO, K = 4 * Cb;
     const long T = (long)N * TH * TW;
@@ -1946,9 +2123,11 @@ static int wino2_b2s_run(const float* big, int ld_big, const float* P, const flo
     {
         const int big_rows = T >= 1024;
         const int tm = (int)(big_rows ? (T + 127) / 128 : (T + 63) / 64), tn = (Ca + 127) / 128;
-        const int zb = bgemm_zb((long)tm * tn, X);
+        const int zb = s3 ? 1 : bgemm_zb((long)tm * tn, X);
         const dim3 grid((unsigned)(tm * tn * (X / zb)));
-        if (big_rows && zb > 1)
+        if (s3)
+            bgemm_s3_launch(big_rows, grid, st, V, U, M, (int)T, Ca, K, a_bytes, b_bytes, tm, tn);
+        else if (big_rows && zb > 1)
             hipLaunchKernelGGL((k_wino_bgemm_mz<2, 2, 2, 2>), grid, dim3(256), 0, st, V, U, M, (int)T, Ca, K, zb, a_bytes, b_bytes, tm, tn);
         else if (big_rows)
             hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), grid, dim3(256), 0, st, V, U, M, (int)T, Ca, K, a_bytes, b_bytes, tm, tn);
@@ -1970,12 +2149,12 @@ static int wino2_b2s_run(const float* big, int ld_big, const float* P, const flo
 
 int pg_wino2_b2s(const float* big, int ld_big, const float* P, const float* bias, float* small, int ld_small, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                 const float* Vpre, double* part, float* Vkeep, float* Uext, int u_valid) {
+                 const float* Vpre, double* part, float* Vkeep, float* Uext, int u_valid, int s3) {
     if (pg_wino2_mo() == 4)
         return wino2_b2s_run<4>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, nullptr, part,
-                                nullptr, Uext, u_valid);
+                                nullptr, Uext, u_valid, s3);
     return wino2_b2s_run<3>(big, ld_big, P, bias, small, ld_small, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, Vpre, part, Vkeep,
-                            Uext, u_valid);
+                            Uext, u_valid, s3);
 }
 int pg_wino_prep_batch(int n, const pg_wino_prep* items, hipStream_t st) {
     if (n <= 0) return PG_OK;
@@ -2062,7 +2241,7 @@ size_t pg_wino2c_ws_bytes(int N, int Hb, int Wb, int Ca, int Cb) {
 template <int MO>
 static int wino2_s2b_run(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N,
                          int Hb, int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0,
-                         hipEvent_t ev1, double* part, float* Uext, int u_valid, pg_epi_mul mul) {
+                         hipEvent_t ev1, double* part, float* Uext, int u_valid, pg_epi_mul mul, int s3) {
     constexpr int X = (MO + 1) * (MO + 1);
     const int TH = ((Hb + 1) / 2 + 1 + MO - 1) / MO, TW = ((Wb + 1) / 2 + 1 + MO - 1) / MO, NC = 4 * Cb;
     const long T = (long)N * TH * TW;
@@ -2082,9 +2261,11 @@ static int wino2_s2b_run(const float* small, int ld_small, const float* P, const
     {
         const int big_rows = T >= 1024;
         const int tm = (int)(big_rows ? (T + 127) / 128 : (T + 63) / 64), tn = (NC + 127) / 128;
-        const int zb = bgemm_zb((long)tm * tn, X);
+        const int zb = s3 ? 1 : bgemm_zb((long)tm * tn, X);
         const dim3 grid((unsigned)(tm * tn * (X / zb)));
-        if (big_rows && zb > 1)
+        if (s3)
+            bgemm_s3_launch(big_rows, grid, st, V, U, M, (int)T, NC, Ca, a_bytes, b_bytes, tm, tn);
+        else if (big_rows && zb > 1)
             hipLaunchKernelGGL((k_wino_bgemm_mz<2, 2, 2, 2>), grid, dim3(256), 0, st, V, U, M, (int)T, NC, Ca, zb, a_bytes, b_bytes, tm, tn);
         else if (big_rows)
             hipLaunchKernelGGL((k_wino_bgemm<2, 2, 2, 2>), grid, dim3(256), 0, st, V, U, M, (int)T, NC, Ca, a_bytes, b_bytes, tm, tn);
@@ -2106,11 +2287,11 @@ static int wino2_s2b_run(const float* small, int ld_small, const float* P, const
 
 int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* bias, float* big, int ld_big, int N, int Hb,
                  int Wb, int Hs, int Ws, int Ca, int Cb, int act, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                 double* part, float* Uext, int u_valid, pg_epi_mul mul) {
+                 double* part, float* Uext, int u_valid, pg_epi_mul mul, int s3) {
     if (part && mul.t) return PG_EINVAL;
     if (pg_wino2_mo() == 4)
-        return wino2_s2b_run<4>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part, Uext, u_valid, mul);
-    return wino2_s2b_run<3>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part, Uext, u_valid, mul);
+        return wino2_s2b_run<4>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part, Uext, u_valid, mul, s3);
+    return wino2_s2b_run<3>(small, ld_small, P, bias, big, ld_big, N, Hb, Wb, Hs, Ws, Ca, Cb, act, ws, st, ev0, ev1, part, Uext, u_valid, mul, s3);
 }
 
 // ---- weight gradient of the stride-2 layers (polyphase F(2x2, 3x3)) ----

@@ -161,6 +161,7 @@ class Exec:
         self.enabled = self.allow = self.inside = self.pending = False
         self.stream = None
         self.keep = []
+        self.keep_ptrs = set()
         self.keep_bytes = 0
         self.ws = {}
         self.ws_gen = 0
@@ -194,6 +195,7 @@ class Exec:
         if self.stream is not None and (self.keep or self.pending):
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
         self.keep.clear()
+        self.keep_ptrs.clear()
         self.keep_bytes = 0
         self.pending = self.allow = self.inside = False
         self.ws.clear()
@@ -288,6 +290,7 @@ def _side_join(explicit=False):
     if ex.keep or (explicit and ex.pending):
         torch.cuda.current_stream().wait_stream(ex.stream)
         ex.keep.clear()
+        ex.keep_ptrs.clear()
         ex.keep_bytes = 0
         ex.pending = False
 
@@ -557,7 +560,12 @@ class ConvOp:
             side = ex.side_stream()
             side.wait_stream(torch.cuda.current_stream())
             ex.keep.append((small.t, big.t, v_pre, dP))
-            ex.keep_bytes += small.t.numel() * small.t.element_size() + big.t.numel() * big.t.element_size()
+            # what this call adds to the bytes held alive: each backing storage once (the skip buffers are shared by several
+            # layers' views), plus the transformed input handed over from the forward pass
+            for t in (small.t, big.t, v_pre):
+                if t is not None and t.data_ptr() not in ex.keep_ptrs:
+                    ex.keep_ptrs.add(t.data_ptr())
+                    ex.keep_bytes += t.numel() * t.element_size()
             was, ex.inside = ex.inside, True
             try:
                 with torch.cuda.stream(side):
@@ -570,6 +578,7 @@ class ConvOp:
                 # bound what the second stream keeps alive: an intermediate join (the chains re-synchronise once; same results)
                 torch.cuda.current_stream().wait_stream(side)
                 ex.keep.clear()
+                ex.keep_ptrs.clear()
                 ex.keep_bytes = 0
             return
         PROFILER.launch(self, 2, go, self._io(big, small)) if PROFILER is not None else go()

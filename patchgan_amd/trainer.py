@@ -185,15 +185,25 @@ class Trainer:
     MAX_KINDS = 16           # kinds of step whose launch decision is remembered
 
     def __init__(self, generator, discriminator, savefolder, device='cuda'):
+        # (networks that an earlier Trainer drove may still have a discriminator update in flight: complete it before anything here
+        #  touches their weights -- the modules' apply() does that through the access hook)
         generator.apply(weights_init)
         discriminator.apply(weights_init)
         self.generator = generator
         self.discriminator = discriminator
         # (a discriminator update may be in flight on the second stream / in a collective when batch() returns: anything that reads the
-        #  module's weights through its own surface completes it first)
+        #  module's weights through its own surface completes it first.  Hooks chain: an earlier trainer's stays in front of this one's)
         import weakref
         me = weakref.ref(self)
-        discriminator._access_hook = lambda: me() is not None and me().flush()
+        earlier = getattr(discriminator, '_access_hook', None)
+
+        def hook():
+            if earlier is not None:
+                earlier()
+            t = me()
+            if t is not None:
+                t.flush()
+        discriminator._access_hook = hook
         self.device = device
         if savefolder[-1] != '/':
             savefolder += '/'
@@ -215,6 +225,7 @@ class Trainer:
     # -------------------------------------------------------------------------------------- optimizers
     def setup_optimizers(self, gen_lr=1e-3, dsc_lr=1e-3):
         """Fresh Adam state (the reference re-creates both optimizers on every train() call, trainer.py:169-172)."""
+        self.flush()              # an Adam(D) still running on the second stream reads and writes the OLD moments
         self.gen_lr, self.dsc_lr = gen_lr, dsc_lr
         g, d = self.generator.flat, self.discriminator.flat
         self._adam = (torch.zeros_like(g), torch.zeros_like(g), torch.zeros_like(d), torch.zeros_like(d))
@@ -256,6 +267,7 @@ class Trainer:
         self._step += 1
         ex = self._exec
         if ex is None or ex.device != dev:
+            self.flush()          # (a deferred pass is joined on the Exec it was enqueued on, before that one is let go)
             ex = self._exec = E.Exec(dev)
         with ex:
             dims = (N, H, W, Cin, Cout)
@@ -429,7 +441,7 @@ class Trainer:
                     else:
                         self._adam_step('d')                                                      # trainer.py:107
                     self._mark('side: D bwd done')
-                self._deferred = (dc2, god, ucache, dflat)
+                self._deferred = (ex, dc2, god, ucache, dflat)
                 if adam_g_behind_fork:
                     # G's Adam update (1.2 GB at the memory rate, 0.2 ms alone on the chip) beside the first kernels of D's backward pass
                     # instead of in front of them: it only has to precede the next step's generator forward
@@ -480,7 +492,7 @@ class Trainer:
         before anything reads the discriminator's weights: the next step's D passes, save(), load(), the end of train(), and -- through
         the modules' access hook -- state_dict() / forward() / .to() of the discriminator itself."""
         if self._deferred is not None:
-            ex = self._exec
+            ex = self._deferred[0]          # the execution state the pass was enqueued on (self._exec may have been replaced since)
             if ex is not None and (ex.pending or ex.keep):
                 with ex:
                     E.side_join()
@@ -603,6 +615,7 @@ class Trainer:
 
     def redecide(self):
         """Forget every launch decision and captured step (the next steps of each kind warm up, are timed and decided again)."""
+        self.flush()
         self._kinds, self._graphs = {}, {}
 
     def release(self):
