@@ -444,7 +444,7 @@ def test_cfg2_loss_curve_10_steps_vs_oracle(tmp_path):
     initial weights (held to the reference's weight probes) and inputs.
 
     Stated tolerance: every loss scalar of every step within 1e-4 relative of the reference's curve (CFG2_REF_BOUND: the north star's
-    gate; measured 7.84e-5) and within CFG2_F64_BOUND of the same algorithm in float64 (torch double ops on the GPU; measured
+    gate; measured 7.84e-5) and within CFG2_F64_FACTOR x the reference's own distance from float64 of the same algorithm in float64 (torch double ops on the GPU; measured
     1.43e-4, the reference itself 1.31e-4).  What those distances are made of is measured by tools/parity_attribution.py
     (DESIGN.md section 4): at this size the G/D dynamics amplify rounding (gdisc swings between 4 and 0.005 within these steps) --
     in pure float64 arithmetic, initial weights moved by ONE fp32 ulp move the curve by 1e-5 .. 8.4e-5; rounding ONE stage to fp32
@@ -515,10 +515,12 @@ def test_cfg2_loss_curve_10_steps_vs_oracle(tmp_path):
     # the oracle is BIT-equal to the reference on the fixture's host and thread count (tests/test_oracle_golden.py); on this host
     # oneDNN may sum in another order, and from step 2 on the two curves part like any two fp32 evaluations
     assert oracle_ref[0] <= 1e-6, oracle_ref
-    # Stated bounds = 1.5 x the maxima MEASURED on the round-5 build (deterministic kernels: the same numbers on every box):
-    #   vs the reference's curve CFG2_REF_BOUND (= the north star's 1e-4: measured 7.84e-5), vs float64 CFG2_F64_BOUND (measured 1.43e-4;
-    #   the reference itself: 1.31e-4); steps 1-2, before the G/D dynamics amplify rounding, 4.2e-5 (measured 1.6e-5 / 2.8e-5).
-    assert err_ref.max() <= CFG2_REF_BOUND and err64.max() <= CFG2_F64_BOUND, (err_ref, err64)
+    # Stated bounds: vs the reference's curve CFG2_REF_BOUND = the north star's 1e-4 (measured, round 6: 7.84e-5 -- a chaotic quantity:
+    # profiles/r06_parity_attribution.txt lists what every summation-order variant of the same kernels draws); vs float64
+    # CFG2_F64_FACTOR x the REFERENCE'S OWN largest distance from float64 in the fixture (1.31e-4; measured 1.24e-4): a bound from the
+    # fixture, not from this build's output; steps 1-2, before the G/D dynamics amplify rounding, 4.2e-5 (measured 5.2e-6 / 1.7e-5).
+    assert err_ref.max() <= CFG2_REF_BOUND, err_ref
+    assert err64.max() <= max(1e-4, CFG2_F64_FACTOR * ref64.max()), (err64, ref64)
     assert err_ref[:2].max() <= 4.2e-5 and err64[:2].max() <= 4.2e-5, (err_ref[:2], err64[:2])
     # Winograd's price in parity: the default path may sit at most 2x as far from float64 as the exact-GEMM path of the same
     # library, compared on the running maxima (either path's single-step error is noise around its own drift)
@@ -526,9 +528,9 @@ def test_cfg2_loss_curve_10_steps_vs_oracle(tmp_path):
     assert (run64 <= np.maximum(LOSS_RTOL, 2 * run64_nw)).all(), (run64, run64_nw)
 
 
-# 1.5 x measured (round 5; tools/parity_attribution.py prints the table and what each stage's fp32 rounding is worth)
-CFG2_REF_BOUND = 1.0e-4
-CFG2_F64_BOUND = 2.15e-4
+# (tools/parity_attribution.py prints the table and what each stage's fp32 rounding is worth)
+CFG2_REF_BOUND = 1.0e-4        # the north star's gate
+CFG2_F64_FACTOR = 3.0          # x the reference's own largest distance from float64 (tests/test_configs_gpu.py: fp32_curve_bounds)
 
 _FULL_SIZE_ORACLE = {}
 
