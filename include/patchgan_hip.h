@@ -378,6 +378,10 @@ int pg_adam_step_dev(float* p, const float* g, float* m, float* v, long n, float
 /* ---- layout (the reference is NCHW end to end; trainer.py:55-66) ---------------------------------- */
 int pg_nchw_to_nhwc(const float* src, float* dst, int ld_dst, int N, int C, int H, int W, void* stream);
 int pg_nhwc_to_nchw(const float* src, int ld_src, float* dst, int N, int C, int H, int W, void* stream);
+/* The discriminator's two concatenated inputs in one pass (trainer.py:65-66,96-99: torch.cat((x, y), 1) and torch.cat((x, gen_img), 1)):
+ * real[n][hw][0 .. ld) = x[n] | y[n] | 0-pad, fake[n][hw][0 .. ld) = x[n] | 0 (the generator's output is written into channels Cx ..
+ * Cx + Cy - 1 of `fake` later); x, y contiguous NCHW fp32, real / fake NHWC with pixel stride ld (Cx + Cy <= ld <= 8). */
+int pg_din_fill(const float* x, const float* y, float* real, float* fake, int ld, int N, int Cx, int Cy, int H, int W, void* stream);
 /* dst[pix*ld_dst + c] = src[pix*ld_src + c] for c < C  (channel-slice copy; C need not be a multiple of 4) */
 int pg_copy_channels(const float* src, int ld_src, float* dst, int ld_dst, long npix, int C, void* stream);
 int pg_fill(float* dst, long n, float value, void* stream);

@@ -113,6 +113,7 @@ SIGNATURES = {
     'pg_copy_channels': (_i, [_p, _i, _p, _i, _l, _i, _p]),
     'pg_fill': (_i, [_p, _l, _f, _p]),
     'pg_pad8_bf16': (_i, [_p, _i, _p, _l, _i, _p]),
+    'pg_din_fill': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'pg_u8_to_f32': (_i, [_p, _p, _i, _l, _i, _f, _p]),
     'pg_labels_to_onehot': (_i, [_p, _p, _i, _l, _p, _i, _i, _p]),
     'pg_tiles_count': (_i, [_i, _i, _i]),

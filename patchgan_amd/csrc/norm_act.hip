@@ -33,10 +33,13 @@ inline TPtr tp(const void* p, bool bf) { return TPtr{(const char*)p, bf ? 1 : 0}
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
-template <int VEC>
+// KD: the storage type where the instantiation knows it (0 fp32, 1 bf16; -1 = read t.bf at run time).  VEC = 8 is bf16 by construction
+// (v8_ok below).  A known type leaves no branch around the access, so the loads of an unrolled loop are issued back to back.
+template <int VEC, int KD = -1>
 __device__ __forceinline__ Vec<VEC> vload(TPtr t) {
     Vec<VEC> r;
-    if (t.bf) {
+    const bool is_bf = (VEC == 8 || KD == 1) ? true : (KD == 0 ? false : (bool)t.bf);
+    if (is_bf) {
         if constexpr (VEC == 8) {          // 16 bytes per lane on a bf16 tensor
             const uint4 u = *reinterpret_cast<const uint4*>(t.p);
             r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
@@ -64,10 +67,11 @@ __device__ __forceinline__ Vec<VEC> vload(TPtr t) {
     }
     return r;
 }
-template <int VEC>
+template <int VEC, int KD = -1>
 __device__ __forceinline__ void vstore(TPtr t, const Vec<VEC>& r) {
     char* q = const_cast<char*>(t.p);
-    if (t.bf) {
+    const bool is_bf = (VEC == 8 || KD == 1) ? true : (KD == 0 ? false : (bool)t.bf);
+    if (is_bf) {
         if constexpr (VEC == 8) {
             uint4 u;
             u.x = (unsigned)f2bf(r.v[0]) | ((unsigned)f2bf(r.v[1]) << 16);
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256) void k_instnorm_bwd(TPtr g1, int ld_g1,
 // grid-stride elementwise kernel.  fp64 sum / sum-of-squares (squares of fp32 are exact in fp64) replaces the
 // two-pass variance: relative error ~1e-16 * mean^2/var.
 // ------------------------------------------------------------------------------------------------
-template <int VEC, bool BWD>
+template <int VEC, bool BWD, int KD = -1, bool HG2 = false>      // HG2: a second gradient source g2 (the skip connection's) is summed in
 __global__ __launch_bounds__(256) void k_in_partial(TPtr y, int ld_y,
                                                     TPtr g1, int ld_g1,
                                                     TPtr g2, int ld_g2,
@@ -315,37 +319,60 @@ __global__ __launch_bounds__(256) void k_in_partial(TPtr y, int ld_y,
     double s1[VEC], s2[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) s1[k] = s2[k] = 0.0;
-    if (on)
-        for (int pix = p_begin + pl; pix < p_end; pix += PL) {
-            Vec<VEC> v = vload<VEC>(y + (long)((nb + pix) * ld_y + c0));
-            if (!BWD) {
+    // one pixel's contribution, added in pixel order (the unrolled loop below only ISSUES the loads of UNR pixels together: a thread with one
+    // load pair in flight per iteration ran this pass at the latency of a load, 2.5-3.5 TB/s; the sums and their order are unchanged)
+    auto accumulate = [&](int pix, const Vec<VEC>& v, Vec<VEC> g, const Vec<VEC>& h) {
+        if (!BWD) {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    const double d = (double)v.v[k];
-                    s1[k] += d;
-                    s2[k] += d * d;
-                }
-            } else {
-                Vec<VEC> g = vload<VEC>(g1 + (long)((nb + pix) * ld_g1 + c0));
-                if (g2) {
-                    Vec<VEC> h = vload<VEC>(g2 + (long)((nb + pix) * ld_g2 + c0));
+            for (int k = 0; k < VEC; ++k) {
+                const double d = (double)v.v[k];
+                s1[k] += d;
+                s2[k] += d * d;
+            }
+        } else {
+            if (HG2) {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) g.v[k] += h.v[k];
-                }
+                for (int k = 0; k < VEC; ++k) g.v[k] += h.v[k];
+            }
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    float gg = g.v[k];
-                    if (drop_p > 0.f) {
-                        const uint64_t e = ((uint64_t)n * HW + pix) * C + c0 + k;
-                        gg = pg_dropout_keep(seed, e, drop_p) ? gg * keep_scale : 0.f;
-                    }
-                    const float z = __fadd_rn(__fmul_rn(v.v[k], rstd[k]), -mean[k] * rstd[k]);
-                    const float dz = gg * pg_norm_act_grad(z, act);
-                    s1[k] += (double)dz;
-                    s2[k] += (double)dz * (double)(v.v[k] - mean[k]);
+            for (int k = 0; k < VEC; ++k) {
+                float gg = g.v[k];
+                if (drop_p > 0.f) {
+                    const uint64_t e = ((uint64_t)n * HW + pix) * C + c0 + k;
+                    gg = pg_dropout_keep(seed, e, drop_p) ? gg * keep_scale : 0.f;
                 }
+                const float z = __fadd_rn(__fmul_rn(v.v[k], rstd[k]), -mean[k] * rstd[k]);
+                const float dz = gg * pg_norm_act_grad(z, act);
+                s1[k] += (double)dz;
+                s2[k] += (double)dz * (double)(v.v[k] - mean[k]);
             }
         }
+    };
+    if (on) {
+        constexpr int UNR = 4;
+        int pix = p_begin + pl;
+        for (; pix + (UNR - 1) * PL < p_end; pix += UNR * PL) {
+            Vec<VEC> v[UNR], g[UNR], h[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                v[u] = vload<VEC, KD>(y + (long)((nb + pix + u * PL) * ld_y + c0));
+                if (BWD) {
+                    g[u] = vload<VEC, KD>(g1 + (long)((nb + pix + u * PL) * ld_g1 + c0));
+                    if (HG2) h[u] = vload<VEC, KD>(g2 + (long)((nb + pix + u * PL) * ld_g2 + c0));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) accumulate(pix + u * PL, v[u], g[u], h[u]);
+        }
+        for (; pix < p_end; pix += PL) {
+            Vec<VEC> v = vload<VEC, KD>(y + (long)((nb + pix) * ld_y + c0)), g, h;
+            if (BWD) {
+                g = vload<VEC, KD>(g1 + (long)((nb + pix) * ld_g1 + c0));
+                if (HG2) h = vload<VEC, KD>(g2 + (long)((nb + pix) * ld_g2 + c0));
+            }
+            accumulate(pix, v, g, h);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         red[k][tid] = s1[k];
@@ -371,8 +398,20 @@ __global__ void k_in_merge(const double* __restrict__ part, int nchunk, int NC, 
     const int n = i / C, c = i - n * C;
     double s1 = 0.0, s2 = 0.0;
     const double2* p2 = reinterpret_cast<const double2*>(part) + ((long)n * nchunk) * C + c;
+    // chunk order, 32 loads in flight (the adds stay sequential: same sums; with 8 in flight a merge over 128 chunks took 8.5 us)
+    int k = 0;
+    for (; k + 32 <= nchunk; k += 32) {
+        double2 v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = p2[(long)(k + u) * C];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            s1 += v[u].x;
+            s2 += v[u].y;
+        }
+    }
 #pragma unroll 8
-    for (int k = 0; k < nchunk; ++k) {
+    for (; k < nchunk; ++k) {
         const double2 v = p2[(long)k * C];
         s1 += v.x;
         s2 += v.y;
@@ -394,7 +433,7 @@ __global__ void k_in_merge(const double* __restrict__ part, int nchunk, int NC, 
 // for the whole launch -- its statistics / coefficients live in registers and the pixel index advances by a constant: no division and
 // no per-element reload of the statistics in the loop (the flat form spent two 64-bit divisions and 16 scalar-indexed loads per
 // 16 bytes of payload and ran at 3 TB/s).  Other channel counts: the flat form within the sample, 32-bit.
-template <int VEC, bool BWD>
+template <int VEC, bool BWD, int KD = -1, bool HG2 = false>
 __global__ __launch_bounds__(256) void k_in_apply(TPtr y, int ld_y, TPtr g1, int ld_g1,
                            TPtr g2, int ld_g2, const float* __restrict__ stats,
                            const float* __restrict__ coef, TPtr out, int ld_out, int N, int HW, int C,
@@ -427,15 +466,8 @@ __global__ __launch_bounds__(256) void k_in_apply(TPtr y, int ld_y, TPtr g1, int
     const int first = fixed ? blockIdx.x * PL + (int)(threadIdx.x / cq) : blockIdx.x * 256 + (int)threadIdx.x;
     const int step = fixed ? gridDim.x * PL : gridDim.x * 256;
     const int limit = fixed ? HW : HW * cq;
-    for (int i = first; i < limit; i += step) {
-        int p = i;
-        if (!fixed) {
-            p = i / cq;
-            c0 = (i - p * cq) * VEC;
-            load_coef();
-        }
-        const long pix = nb + p;
-        Vec<VEC> v = vload<VEC>(y + (long)(pix * ld_y + c0)), o;
+    auto one = [&](long pix, const Vec<VEC>& v, Vec<VEC> g, const Vec<VEC>& h) {
+        Vec<VEC> o;
         if (!BWD) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
@@ -444,9 +476,7 @@ __global__ __launch_bounds__(256) void k_in_apply(TPtr y, int ld_y, TPtr g1, int
                 o.v[k] = a;
             }
         } else {
-            Vec<VEC> g = vload<VEC>(g1 + (long)(pix * ld_g1 + c0));
-            if (g2) {
-                Vec<VEC> h = vload<VEC>(g2 + (long)(pix * ld_g2 + c0));
+            if (HG2) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) g.v[k] += h.v[k];
             }
@@ -459,7 +489,41 @@ __global__ __launch_bounds__(256) void k_in_apply(TPtr y, int ld_y, TPtr g1, int
                 o.v[k] = (dz - cf0[k] - (v.v[k] - mf[k]) * cf1[k]) * rs[k];
             }
         }
-        vstore<VEC>(out + (long)(pix * ld_out + c0), o);
+        vstore<VEC, KD>(out + (long)(pix * ld_out + c0), o);
+    };
+    int i = first;
+    if (fixed) {
+        // the loads of UNR pixels are issued together (one load set in flight per thread left this pass at the latency of a load)
+        constexpr int UNR = 4;
+        for (; i + (UNR - 1) * step < limit; i += UNR * step) {
+            Vec<VEC> v[UNR], g[UNR], h[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const long pix = nb + i + u * step;
+                v[u] = vload<VEC, KD>(y + (long)(pix * ld_y + c0));
+                if (BWD) {
+                    g[u] = vload<VEC, KD>(g1 + (long)(pix * ld_g1 + c0));
+                    if (HG2) h[u] = vload<VEC, KD>(g2 + (long)(pix * ld_g2 + c0));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) one(nb + i + u * step, v[u], g[u], h[u]);
+        }
+    }
+    for (; i < limit; i += step) {
+        int p = i;
+        if (!fixed) {
+            p = i / cq;
+            c0 = (i - p * cq) * VEC;
+            load_coef();
+        }
+        const long pix = nb + p;
+        Vec<VEC> v = vload<VEC, KD>(y + (long)(pix * ld_y + c0)), g, h;
+        if (BWD) {
+            g = vload<VEC, KD>(g1 + (long)(pix * ld_g1 + c0));
+            if (HG2) h = vload<VEC, KD>(g2 + (long)(pix * ld_g2 + c0));
+        }
+        one(pix, v, g, h);
     }
 }
 
@@ -699,6 +763,24 @@ static inline bool v8_ok(const void* p, int ld, bool bf) {
     return !off && bf && (ld % 8 == 0) && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
 }
 
+// launch dispatch of the chunked kernels on what the call knows: all tensors fp32 (dt == 0: loads without a storage-type branch), a second
+// gradient source present (backward)
+#define IN_GO_G2(K, V, KD, ...)                                                       \
+    do {                                                                              \
+        if (g2) hipLaunchKernelGGL((K<V, true, KD, true>), __VA_ARGS__);              \
+        else hipLaunchKernelGGL((K<V, true, KD, false>), __VA_ARGS__);                \
+    } while (0)
+#define IN_GO_DT_G2(K, V, ...)                                                        \
+    do {                                                                              \
+        if (dt == 0) IN_GO_G2(K, V, 0, __VA_ARGS__);                                  \
+        else IN_GO_G2(K, V, -1, __VA_ARGS__);                                         \
+    } while (0)
+#define IN_GO_DT(K, V, ...)                                                           \
+    do {                                                                              \
+        if (dt == 0) hipLaunchKernelGGL((K<V, false, 0>), __VA_ARGS__);               \
+        else hipLaunchKernelGGL((K<V, false>), __VA_ARGS__);                          \
+    } while (0)
+
 int pg_instnorm_act_fwd_t(const void* y, int ld_y, void* out, int ld_out, float* stats, int N, int HW, int C, int act, float eps,
                           float drop_p, uint64_t seed, void* ws, size_t ws_bytes, void* stream, int dt) {
     if (!y || !out || !stats || N <= 0 || HW <= 0 || C <= 0 || ld_y < C || ld_out < C) return PG_EINVAL;
@@ -716,11 +798,9 @@ int pg_instnorm_act_fwd_t(const void* y, int ld_y, void* out, int ld_out, float*
             hipLaunchKernelGGL((k_in_partial<8, false>), grid, dim3(256), 0, st, ty, ld_y, none, 0, none, 0, (const float*)nullptr, part,
                                HW, C, cp.G, cp.ppc, act, drop_p, seed);
         else if (vec)
-            hipLaunchKernelGGL((k_in_partial<4, false>), grid, dim3(256), 0, st, ty, ld_y, none, 0, none, 0, (const float*)nullptr, part,
-                               HW, C, cp.G, cp.ppc, act, drop_p, seed);
+            IN_GO_DT(k_in_partial, 4, grid, dim3(256), 0, st, ty, ld_y, none, 0, none, 0, (const float*)nullptr, part, HW, C, cp.G, cp.ppc, act, drop_p, seed);
         else
-            hipLaunchKernelGGL((k_in_partial<1, false>), grid, dim3(256), 0, st, ty, ld_y, none, 0, none, 0, (const float*)nullptr, part,
-                               HW, C, cp.G, cp.ppc, act, drop_p, seed);
+            IN_GO_DT(k_in_partial, 1, grid, dim3(256), 0, st, ty, ld_y, none, 0, none, 0, (const float*)nullptr, part, HW, C, cp.G, cp.ppc, act, drop_p, seed);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         hipLaunchKernelGGL((k_in_merge<false>), dim3((N * C + 255) / 256), dim3(256), 0, st, part, cp.nchunk, N * C, C, HW, eps,
                            stats, (float*)nullptr);
@@ -729,11 +809,9 @@ int pg_instnorm_act_fwd_t(const void* y, int ld_y, void* out, int ld_out, float*
             hipLaunchKernelGGL((k_in_apply<8, false>), in_apply_grid(N, HW, C / 8), dim3(256), 0, st, ty, ld_y, none, 0,
                                none, 0, stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
         else if (vec)
-            hipLaunchKernelGGL((k_in_apply<4, false>), in_apply_grid(N, HW, C / 4), dim3(256), 0, st, ty, ld_y, none, 0,
-                               none, 0, stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
+            IN_GO_DT(k_in_apply, 4, in_apply_grid(N, HW, C / 4), dim3(256), 0, st, ty, ld_y, none, 0, none, 0, stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
         else
-            hipLaunchKernelGGL((k_in_apply<1, false>), in_apply_grid(N, HW, C), dim3(256), 0, st, ty, ld_y, none, 0, none, 0,
-                               stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
+            IN_GO_DT(k_in_apply, 1, in_apply_grid(N, HW, C), dim3(256), 0, st, ty, ld_y, none, 0, none, 0, stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
         return pg_launch_status();
     }
     if (vec) {
@@ -767,11 +845,9 @@ int pg_instnorm_act_fwd_parts_t(const void* y, int ld_y, void* out, int ld_out, 
         hipLaunchKernelGGL((k_in_apply<8, false>), in_apply_grid(N, HW, C / 8), dim3(256), 0, st, ty, ld_y, none, 0, none,
                            0, stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
     else if (vec)
-        hipLaunchKernelGGL((k_in_apply<4, false>), in_apply_grid(N, HW, C / 4), dim3(256), 0, st, ty, ld_y, none, 0, none,
-                           0, stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
+        IN_GO_DT(k_in_apply, 4, in_apply_grid(N, HW, C / 4), dim3(256), 0, st, ty, ld_y, none, 0, none, 0, stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
     else
-        hipLaunchKernelGGL((k_in_apply<1, false>), in_apply_grid(N, HW, C), dim3(256), 0, st, ty, ld_y, none, 0, none, 0,
-                           stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
+        IN_GO_DT(k_in_apply, 1, in_apply_grid(N, HW, C), dim3(256), 0, st, ty, ld_y, none, 0, none, 0, stats, (const float*)nullptr, to, ld_out, N, HW, C, act, drop_p, seed);
     return pg_launch_status();
 }
 
@@ -798,27 +874,21 @@ int pg_instnorm_act_bwd_t(const void* g1, int ld_g1, const void* g2, int ld_g2, 
         float* coef = (float*)((char*)ws + cp.part_bytes);
         dim3 grid(cp.groups, cp.nchunk, N);
         if (vec8)
-            hipLaunchKernelGGL((k_in_partial<8, true>), grid, dim3(256), 0, st, ty, ld_y, tg1, ld_g1, tg2, ld_g2, stats, part, HW,
-                               C, cp.G, cp.ppc, act, drop_p, seed);
+            IN_GO_G2(k_in_partial, 8, -1, grid, dim3(256), 0, st, ty, ld_y, tg1, ld_g1, tg2, ld_g2, stats, part, HW, C, cp.G, cp.ppc, act, drop_p, seed);
         else if (vec)
-            hipLaunchKernelGGL((k_in_partial<4, true>), grid, dim3(256), 0, st, ty, ld_y, tg1, ld_g1, tg2, ld_g2, stats, part, HW,
-                               C, cp.G, cp.ppc, act, drop_p, seed);
+            IN_GO_DT_G2(k_in_partial, 4, grid, dim3(256), 0, st, ty, ld_y, tg1, ld_g1, tg2, ld_g2, stats, part, HW, C, cp.G, cp.ppc, act, drop_p, seed);
         else
-            hipLaunchKernelGGL((k_in_partial<1, true>), grid, dim3(256), 0, st, ty, ld_y, tg1, ld_g1, tg2, ld_g2, stats, part, HW,
-                               C, cp.G, cp.ppc, act, drop_p, seed);
+            IN_GO_DT_G2(k_in_partial, 1, grid, dim3(256), 0, st, ty, ld_y, tg1, ld_g1, tg2, ld_g2, stats, part, HW, C, cp.G, cp.ppc, act, drop_p, seed);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         hipLaunchKernelGGL((k_in_merge<true>), dim3((N * C + 255) / 256), dim3(256), 0, st, part, cp.nchunk, N * C, C, HW, 0.f,
                            const_cast<float*>(stats), coef);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         if (vec8)
-            hipLaunchKernelGGL((k_in_apply<8, true>), in_apply_grid(N, HW, C / 8), dim3(256), 0, st, ty, ld_y, tg1,
-                               ld_g1, tg2, ld_g2, stats, coef, tdy, ld_dy, N, HW, C, act, drop_p, seed);
+            IN_GO_G2(k_in_apply, 8, -1, in_apply_grid(N, HW, C / 8), dim3(256), 0, st, ty, ld_y, tg1, ld_g1, tg2, ld_g2, stats, coef, tdy, ld_dy, N, HW, C, act, drop_p, seed);
         else if (vec)
-            hipLaunchKernelGGL((k_in_apply<4, true>), in_apply_grid(N, HW, C / 4), dim3(256), 0, st, ty, ld_y, tg1,
-                               ld_g1, tg2, ld_g2, stats, coef, tdy, ld_dy, N, HW, C, act, drop_p, seed);
+            IN_GO_DT_G2(k_in_apply, 4, in_apply_grid(N, HW, C / 4), dim3(256), 0, st, ty, ld_y, tg1, ld_g1, tg2, ld_g2, stats, coef, tdy, ld_dy, N, HW, C, act, drop_p, seed);
         else
-            hipLaunchKernelGGL((k_in_apply<1, true>), in_apply_grid(N, HW, C), dim3(256), 0, st, ty, ld_y, tg1, ld_g1,
-                               tg2, ld_g2, stats, coef, tdy, ld_dy, N, HW, C, act, drop_p, seed);
+            IN_GO_DT_G2(k_in_apply, 1, in_apply_grid(N, HW, C), dim3(256), 0, st, ty, ld_y, tg1, ld_g1, tg2, ld_g2, stats, coef, tdy, ld_dy, N, HW, C, act, drop_p, seed);
         return pg_launch_status();
     }
     if (vec) {

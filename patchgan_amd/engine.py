@@ -127,6 +127,17 @@ class View:
         return self
 
 
+def din_fill(x, y, real, fake):
+    """real = x | y, fake = x | 0 (NHWC fp32 views of one pixel stride, x / y contiguous NCHW): the discriminator's concatenated inputs
+    (trainer.py:65,96,98) in one launch; the generator's head writes its output into fake's mask channels later in the step."""
+    N, Cx, H, W = x.shape
+    Cy = y.shape[1]
+    assert tuple(y.shape) == (N, Cy, H, W) and (real.N, real.H, real.W, real.C) == (N, H, W, Cx + Cy) == (fake.N, fake.H, fake.W, fake.C)
+    assert real.ld == fake.ld and not real.bf and not fake.bf
+    x, y = x.contiguous(), y.contiguous()
+    L.check(L.load().pg_din_fill(x.data_ptr(), y.data_ptr(), real.ptr(), fake.ptr(), real.ld, N, Cx, Cy, H, W, _stream()), 'pg_din_fill')
+
+
 # ------------------------------------------------------------------------------------------------
 # execution state: workspaces (split-K slabs) and the second stream, owned by whoever drives the engines
 # ------------------------------------------------------------------------------------------------

@@ -323,12 +323,16 @@ class Trainer:
         self._mark('start')
 
         # discriminator input buffer: samples [0,N) real = x|y, [N,2N) fake = x|G(x)   (trainer.py:65,96,98)
-        din = E.View.alloc(2 * N, H, W, Cd, dev)
+        # (bf16 networks read it through pg_pad8_bf16: 8-float pixels there, so that pass and the fill below move whole 16-byte pieces)
+        ld_din = 8 if (4 < Cd < 8 and (de.algo & L.ALGO_MASK) == L.ALGO_BF16) else Cd
+        din = E.View(torch.empty(2 * N * H * W * ld_din, dtype=torch.float32, device=dev), 0, ld_din, 2 * N, H, W, Cd)
         real, fake = din.samples(0, N), din.samples(N, N)
         if u8:
             real.channels(0, Cin).from_u8(x)
             fake.channels(0, Cin).from_u8(x)
             real.channels(Cin, Cout).from_labels(y, self.label_values)
+        elif Cd <= 8:
+            E.din_fill(x, y, real, fake)       # both halves' x | y (and the fake half's zeroed mask channels) in one launch
         else:
             real.channels(0, Cin).from_nchw(x)
             fake.channels(0, Cin).from_nchw(x)
