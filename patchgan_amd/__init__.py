@@ -7,6 +7,15 @@ import os as _os
 # streams than queues two of them share a queue and run strictly one after the other -- measured under data parallelism: the compute
 # stream stood still behind the discriminator's backward pass on the second stream (9.07 instead of 8.51 ms per step at cfg2,
 # tools/step_phases.py).  Read when the runtime initialises (the first HIP call), so it is set here, at import; an explicit setting wins.
+# If the embedding process has already initialised HIP (torch.cuda used before this import) the setting comes too late and is silently
+# ignored by the runtime: remembered here, and the trainer warns once when a data-parallel step would need the queues (HWQ_LATE).
+HWQ_LATE = False
+if 'GPU_MAX_HW_QUEUES' not in _os.environ:
+    try:
+        import torch as _torch
+        HWQ_LATE = bool(_torch.cuda.is_initialized())
+    except Exception:
+        HWQ_LATE = False
 _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 from .unet import UNet

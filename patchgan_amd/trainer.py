@@ -183,6 +183,7 @@ class Trainer:
     AUTO_FORCE = None        # 'eager1' | 'eager2' | 'graph': 'auto' takes this outcome (where the settings allow it) after the warm steps
     MAX_GRAPHS = 2           # captured kinds of step kept (each holds its activations: ~4 GB at cfg2)
     MAX_KINDS = 16           # kinds of step whose launch decision is remembered
+    _hwq_warned = False      # (process-wide: the late GPU_MAX_HW_QUEUES warning is given once)
 
     def __init__(self, generator, discriminator, savefolder, device='cuda'):
         # (networks that an earlier Trainer drove may still have a discriminator update in flight: complete it before anything here
@@ -221,6 +222,7 @@ class Trainer:
         self._graphs, self._adam_dev = {}, None
         self._kinds, self.step_times, self.launch_mode = {}, None, None      # per kind of step: warm-step count, the tournament, the decision; step_times = the last tournament's ms per step per candidate
         self._exec = None          # engine.Exec: this trainer's workspaces and second stream (created on the networks' device)
+        self._oom_kinds, self.oom_fallbacks = set(), 0      # kinds of step pinned to one stream after an out-of-memory two-stream step
 
     # -------------------------------------------------------------------------------------- optimizers
     def setup_optimizers(self, gen_lr=1e-3, dsc_lr=1e-3):
@@ -281,7 +283,17 @@ class Trainer:
                         mode = 'eager1'
                 if losses is None:
                     ex.enabled = mode == 'eager2'
+                    t_g0, t_d0 = self._t_g, self._t_d
                     try:
+                        losses = self._enqueue_step(x, y, u8, N, H, W, Cin, Cout, train)
+                    except torch.cuda.OutOfMemoryError:
+                        # the two-stream step holds ~2x the one-stream step's memory (second workspace, the early discriminator forward
+                        # beside the generator's saved activations): where it does not fit, this KIND of step runs on one stream from
+                        # now on.  Safe to run again only while nothing of this step was committed (no optimizer update enqueued).
+                        if mode != 'eager2' or _dist().on or (self._t_g, self._t_d) != (t_g0, t_d0):
+                            raise
+                        self._two_stream_oom(ex, key)
+                        mode = 'eager1'
                         losses = self._enqueue_step(x, y, u8, N, H, W, Cin, Cout, train)
                     finally:
                         ex.enabled = False
@@ -317,6 +329,14 @@ class Trainer:
         ge, de = G.engine, D.engine
         dev = G.flat.device
         dist = _dist()
+        if dist.on and not Trainer._hwq_warned:
+            Trainer._hwq_warned = True
+            import patchgan_amd
+            if patchgan_amd.HWQ_LATE:
+                import warnings
+                warnings.warn('patchgan_amd: HIP was initialised before `import patchgan_amd`, so GPU_MAX_HW_QUEUES=8 could not take effect; '
+                              'the data-parallel step keeps five streams busy and loses ~0.6 ms per step at cfg2 with the default 4 hardware '
+                              'queues -- import patchgan_amd first or export GPU_MAX_HW_QUEUES=8')
         Bglobal = N * dist.world
         Cd = Cin + Cout
         ex = E.cur_exec(dev)
@@ -550,6 +570,8 @@ class Trainer:
         is remembered per kind."""
         want_graph = self.graph if (train and self._graph_eligible()) else False
         ts = self._two_streams_setting()
+        if key in self._oom_kinds:
+            ts = False                            # (did not fit in device memory: _two_stream_oom)
         if not want_graph and not ts:
             return 'eager1'
         if ts is True and want_graph is not True:
@@ -580,9 +602,14 @@ class Trainer:
             return 'eager1'                       # untimed: kernel plans, weight-cache plans, workspaces
         tr = k['trial']
         if tr is None or tr['cands'] != cands:    # (the settings changed under a running tournament, or a step raised: start over)
-            tr = k['trial'] = {'cands': cands, 'i': 0, 'starts': [], 'ms': {}, 'host': {}}
+            tr = k['trial'] = {'cands': cands, 'i': 0, 'starts': [], 'ms': {}, 'host': {}, 'step': -1}
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()                               # the start of this step on the compute stream
+        if tr['starts'] and tr['step'] != self._step - 1:
+            # a step of ANOTHER kind ran since this kind's last one (validation batches, a ragged last batch, an evaluation pass): the
+            # period would span it -- this candidate's trial starts over
+            tr['starts'] = []
+        tr['step'] = self._step
         tr['starts'].append(ev)
         if len(tr['starts']) <= 2 * self.TRIAL_STEPS + 1:
             return tr['cands'][tr['i']]
@@ -602,12 +629,44 @@ class Trainer:
             tr['i'] += 1
         if tr['i'] < len(cands):
             return cands[tr['i']]
+        dist = _dist()
+        if dist.on:
+            # every rank keeps the same way of launching: the slowest rank's time per candidate decides (ranks reach this point at the
+            # same step: trials and their restarts depend on the step sequence only)
+            dev = self.generator.flat.device
+            t = torch.tensor([tr['ms'][m] if tr['ms'][m] is not None else 1e30 for m in cands], dtype=torch.float64,
+                             device=dev if dist.backend == 'nccl' else 'cpu')
+            dist.dist.all_reduce(t, op=dist.dist.ReduceOp.MAX)
+            for m, v in zip(cands, t.tolist()):
+                if tr['ms'][m] is not None:
+                    tr['ms'][m] = v
         self.step_times = dict(tr['ms'], host_enqueue=dict(tr['host']))
         k['mode'] = min((m for m in cands if tr['ms'][m] is not None), key=lambda m: tr['ms'][m])
         k['trial'] = None
         if k['mode'] != 'graph':
             self._graphs.pop(key, None)           # the losing capture's buffers go back to the allocator
         return k['mode']
+
+    def _two_stream_oom(self, ex, key):
+        """A two-stream step ran out of device memory before anything was committed: join and drop the second stream's state, give the
+        workspaces and the allocator's cache back, and pin this kind of step to one stream (redecide() forgets the pin)."""
+        import warnings
+        ex.enabled = False
+        try:
+            E.side_join()
+        except Exception:
+            pass
+        torch.cuda.synchronize(ex.device)
+        self._deferred = None
+        ex.release()
+        torch.cuda.empty_cache()
+        self._oom_kinds.add(key)
+        k = self._kinds.get(key)
+        if k is not None:
+            k['mode'], k['trial'] = 'eager1', None
+        self.oom_fallbacks += 1
+        warnings.warn('patchgan_amd: the two-stream step ran out of device memory (it holds about twice what the one-stream step '
+                      'does: INTEGRATION.md, "Memory"); this kind of step runs on one stream from here on')
 
     def __del__(self):
         # a discriminator update still running on the second stream references this trainer's tensors: join before they are freed
@@ -621,6 +680,7 @@ class Trainer:
         """Forget every launch decision and captured step (the next steps of each kind warm up, are timed and decided again)."""
         self.flush()
         self._kinds, self._graphs = {}, {}
+        self._oom_kinds = set()
 
     def release(self):
         """Give this trainer's captured steps, workspaces and second stream back (they also go with the object)."""

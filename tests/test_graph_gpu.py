@@ -343,3 +343,100 @@ def test_bounded_operand_holding_joins_early_and_changes_nothing(tmp_path, monke
     two = _run(tmp_path, False, 'fp32', 5, nf=32, tag='k_two', two_streams=True)
     assert peaks and max(peaks) <= (1 << 20) and peaks.count(0) > len(peaks) // 2, peaks[:20]
     assert np.array_equal(ref[0], two[0]) and np.array_equal(ref[1], two[1]) and np.array_equal(ref[2], two[2])
+
+
+def test_two_stream_step_that_runs_out_of_memory_falls_back_to_one_stream(tmp_path):
+    """The two-stream step holds about twice the one-stream step's device memory.  Under a memory cap between the two it raises
+    torch.cuda.OutOfMemoryError inside the step, before anything is committed: the trainer joins and drops the second stream's state,
+    warns once, runs THAT step again on one stream and pins the kind to one stream -- same losses and weights as the one-stream trainer."""
+    import warnings
+    import patchgan_amd as pg
+    from patchgan_amd import engine as E
+    E.release_workspaces()
+    torch.cuda.empty_cache()
+
+    def peak(two, tag, steps=3):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        r = _run(tmp_path, False, 'fp32', steps, nf=32, tag=tag, two_streams=two)
+        m = torch.cuda.max_memory_reserved()
+        r[4].release()
+        return r, m
+    one, m1 = peak(False, 'oom1')
+    two, m2 = peak(True, 'oom2')
+    assert np.array_equal(one[0], two[0])
+    assert m2 > m1 * 1.2, (m1, m2)                 # (the premise: two streams need visibly more)
+    del two
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_reserved()
+    total = torch.cuda.get_device_properties(0).total_memory
+    cap = base + m1 + (m2 - m1) // 3
+    torch.cuda.set_per_process_memory_fraction(min(1.0, cap / total))
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            capped = _run(tmp_path, False, 'fp32', 3, nf=32, tag='oom3', two_streams=True)
+        t = capped[4]
+        assert t.oom_fallbacks == 1 and len(t._oom_kinds) == 1, (t.oom_fallbacks, m1, m2, cap)
+        assert any('out of device memory' in str(x.message) for x in w), [str(x.message) for x in w]
+        assert t.launch_mode == 'eager1'
+        assert np.array_equal(one[0], capped[0]) and np.array_equal(one[1], capped[1]) and np.array_equal(one[2], capped[2])
+        t.redecide()
+        assert not t._oom_kinds
+    finally:
+        torch.cuda.set_per_process_memory_fraction(1.0)
+        E.release_workspaces()
+        torch.cuda.empty_cache()
+
+
+def test_tournament_periods_do_not_span_steps_of_another_kind(tmp_path):
+    """'auto' scores a candidate by start-to-start periods of consecutive steps of ONE kind.  With evaluation passes between the
+    training steps no period of the training kind is clean: its trial keeps starting over (no decision from periods that contain another
+    kind's step), the steps run on the candidate under trial, and the results stay those of the one-stream trainer."""
+    ref = _run(tmp_path, False, 'fp32', 8, nf=16, tag='ik_ref', eval_at=range(8))
+    auto = _run(tmp_path, 'auto', 'fp32', 8, nf=16, tag='ik_auto', eval_at=range(8))
+    t = auto[4]
+    assert not t.graph_decided()
+    for kind in t._kinds.values():
+        assert kind['mode'] is None and (kind['trial'] is None or len(kind['trial']['starts']) <= 1), kind
+    assert np.array_equal(ref[0], auto[0]) and np.array_equal(ref[1], auto[1]) and np.array_equal(ref[2], auto[2])
+
+
+def test_optimizer_reset_and_a_second_trainer_wait_for_the_update_in_flight(tmp_path):
+    """setup_optimizers() (every train() call re-creates Adam, trainer.py:169-172) and a second Trainer built on the same networks both
+    touch state that a discriminator update still running on the second stream reads and writes: both complete it first.  Same
+    weights as the one-stream trainer doing the same thing."""
+    import patchgan_amd as pg
+    outs = []
+    for two in (True, False):
+        torch.manual_seed(21)
+        g = pg.UNet(3, 1, 16, use_dropout=False, activation='leakyrelu', final_act='sigmoid').cuda()
+        d = pg.Discriminator(4, 16, n_layers=3).cuda()
+        t = pg.Trainer(g, d, str(tmp_path / f'o{int(two)}'))
+        t.two_streams = two
+        t.setup_optimizers(1e-3, 1e-3)
+        g.train(), d.train()
+        gen = torch.Generator().manual_seed(5)
+        x = torch.rand(4, 3, 256, 256, generator=gen)
+        y = (torch.rand(4, 1, 256, 256, generator=gen) > 0.7).float()
+        for _ in range(3):
+            t.batch(x, y, train=True)
+        if two:
+            assert t._deferred is not None
+        t.setup_optimizers(5e-4, 5e-4)                 # fresh moments while Adam(D) of step 3 may still be running
+        assert t._deferred is None
+        for _ in range(2):
+            t.batch(x, y, train=True)
+        if two:
+            assert t._deferred is not None
+        t2 = pg.Trainer(g, d, str(tmp_path / f'o{int(two)}b'))      # a second driver of the same networks
+        assert t._deferred is None
+        t2.two_streams = two
+        t2.setup_optimizers(1e-3, 1e-3)
+        t2.batch(x, y, train=True)
+        t2.flush()
+        torch.cuda.synchronize()
+        outs.append((g.flat.cpu().clone(), d.flat.cpu().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

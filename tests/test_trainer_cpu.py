@@ -77,10 +77,14 @@ def test_launch_mode_policy_without_a_gpu():
     import types
     from patchgan_amd.trainer import Trainer
     t = Trainer.__new__(Trainer)
-    t._kinds, t._graphs, t.step_times = {}, {}, None
+    t._kinds, t._graphs, t.step_times, t._oom_kinds = {}, {}, None, set()
     t.generator = types.SimpleNamespace(training=True, engine=types.SimpleNamespace(use_dropout=False))
     t.graph, t.two_streams = False, None
     assert [t._launch_mode('k', True) for _ in range(5)] == ['eager1'] * 5 and t._kinds == {}
+    # a kind that ran out of device memory on two streams stays on one stream whatever the setting says
+    t.two_streams, t._oom_kinds = True, {'k'}
+    assert t._launch_mode('k', True) == 'eager1' and t._launch_mode('other', True) == 'eager2'
+    t.two_streams, t._oom_kinds = None, set()
     t.two_streams = True
     assert t._launch_mode('k', True) == 'eager2' and t._launch_mode('e', False) == 'eager2'      # forced: no warm-up, eval passes too
     t.graph, t.two_streams = True, None
