@@ -3384,6 +3384,8 @@ struct Tune {
     bool bf16x;     // PG_ALGO_BF16 on bf16 tensors: the LDS-DMA kernels of conv_bf16.hip (off: the register-staged k_*_bf16)
     int bf16ring;   // ... their staging: 1 three-stage ring of 32-wide chunks, 0 one buffer of 64-wide chunks, -1 per-layer default
     bool s3;        // polyphase Winograd GEMMs in split-bf16 form (k_wino_bgemm_s3) instead of v_mfma_f32_32x32x2_f32 (k_wino_bgemm)
+    bool s3w;       // the Winograd weight-gradient GEMMs likewise (k_wino_wgrad_gemm_s3 instead of k_wino_wgrad_gemm)
+    bool s3r;       // the row-fused stride-1 F(3x3,4x4) GEMM likewise (k_wino_gemm_row_s3 instead of k_wino_gemm_row)
 };
 inline int env_int(const char* name, int dflt) {
     const char* e = pg_exp_env(name);
@@ -3401,6 +3403,8 @@ inline Tune tune_of(int algo) {
         t.bf16x = env_int("PATCHGAN_NO_BF16X", 0) != 1;
         t.bf16ring = -1;      // (pinned only per call: PG_TUNE_BF16X_RING / _FLAT)
         t.s3 = env_int("PATCHGAN_S3", 1) != 0;
+        t.s3w = env_int("PATCHGAN_S3W", 1) != 0;
+        t.s3r = env_int("PATCHGAN_S3R", 1) != 0;
         return t;
     }();
     Tune t = env;
@@ -3416,12 +3420,12 @@ inline Tune tune_of(int algo) {
     if (algo & PG_TUNE_BF16X_OFF) t.bf16x = false;
     if (algo & PG_TUNE_BF16X_RING) t.bf16ring = 1;
     if (algo & PG_TUNE_BF16X_FLAT) t.bf16ring = 0;
-    if (algo & PG_TUNE_S3_OFF) t.s3 = false;
+    if (algo & PG_TUNE_S3_OFF) t.s3 = t.s3w = t.s3r = false;
     if (force_generic()) t.wino = false;
     return t;
 }
 // every path on, for sizing a workspace that serves any tuning
-inline Tune tune_widest(int mo1) { return Tune{true, true, 1, 1, mo1, 0, true, -1, true}; }
+inline Tune tune_widest(int mo1) { return Tune{true, true, 1, 1, mo1, 0, true, -1, true, true, true}; }
 
 // stride-1 layers only: forward is a pad-1 correlation big -> small, the data gradient a pad-2 correlation small -> big
 inline bool wino_b2s_ok(const Geom& g, const Tune& t) {
@@ -3779,19 +3783,19 @@ int pg_conv_describe(const pg_conv_geom* g, int op, size_t ws_bytes, int* tile_i
     // 61 / 62: polyphase F(2x2, 3x3) weight gradient of a stride-2 layer (k_wino_wgrad_gemm<2,2,2,2> / <1,1,2,2>)
     if (algo == PG_ALGO_AUTO && op == 2 && wino2_wgrad_ok(gq, tune) &&
         ws_bytes >= reserved + pg_wino2_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
-        const int sl = pg_wino2_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb);
-        if (tile_id) *tile_id = pg_wino2_wgrad_tile64(gq.Ca, gq.Cb) ? 62 : 61;
+        const int sl = pg_wino2_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb, tune.s3w);
+        if (tile_id) *tile_id = pg_wino2_wgrad_tile64(gq.Ca, gq.Cb, tune.s3w) ? 62 : 61;
         if (split) *split = sl;
         if (workgroups) *workgroups = 16L * ((g->Ca + 127) / 128) * ((4 * g->Cb + 127) / 128) * sl;
         return PG_OK;
     }
     // 60 / 63: Winograd F(4x4, 2x2) weight gradient (k_wino_wgrad_gemm<2,2,2,2> / <1,1,2,2>); split = its K slices
     if (algo == PG_ALGO_AUTO && op == 2 && wino_wgrad_ok(gq, tune) && ws_bytes >= reserved + pg_wino_wgrad_ws_bytes(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb)) {
-        const bool t64 = pg_wino_wgrad_tile64(gq.Ca, gq.Cb);
+        const bool t64 = pg_wino_wgrad_tile64(gq.Ca, gq.Cb, tune.s3w);
         const int tt = t64 ? 64 : 128;
         if (tile_id) *tile_id = t64 ? 63 : 60;
-        if (split) *split = pg_wino_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb);
-        if (workgroups) *workgroups = 25L * ((g->Ca + tt - 1) / tt) * ((g->Cb + tt - 1) / tt) * pg_wino_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb);
+        if (split) *split = pg_wino_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb, tune.s3w);
+        if (workgroups) *workgroups = 25L * ((g->Ca + tt - 1) / tt) * ((g->Cb + tt - 1) / tt) * pg_wino_wgrad_slices(gq.N, gq.Hs, gq.Ws, gq.Ca, gq.Cb, tune.s3w);
         return PG_OK;
     }
     if (split) *split = p.split;
@@ -3836,7 +3840,8 @@ static int conv_kernel_impl(const pg_conv_geom* g, int op, size_t ws_bytes, char
     } else if (algo == PG_ALGO_DIRECT) {
         snprintf(buf, sizeof buf, "%s", oc == 0 ? "k_big2small_direct" : oc == 1 ? "k_small2big_direct" : "k_wgrad_direct");
     } else if (mode == 6) {          // Winograd weight gradients: 60 / 63 stride 1 (F(4x4,2x2)), 61 / 62 polyphase stride 2
-        snprintf(buf, sizeof buf, "k_wino_wgrad_gemm<%s>", (tid == 2 || tid == 3) ? "1,1,2,2" : "2,2,2,2");
+        if (tune.s3w) snprintf(buf, sizeof buf, "k_wino_wgrad_gemm_s3<%s>", (tid == 2 || tid == 3) ? "1,1,2,2,2,3" : "2,2,2,2,1,2");
+        else snprintf(buf, sizeof buf, "k_wino_wgrad_gemm<%s>", (tid == 2 || tid == 3) ? "1,1,2,2" : "2,2,2,2");
         fl = (g->stride == 1) ? pg_wino_wgrad_flops(g->N, g->Hs, g->Ws, g->Ca, g->Cb)
                               : 2.0 * 16 * g->N * cd(g->Hs, 3) * cd(g->Ws, 3) * g->Ca * 4.0 * g->Cb;
         const int wr = pg_wino_wgrad_r(g->N, g->Hs, g->Ws);
@@ -3861,7 +3866,8 @@ static int conv_kernel_impl(const pg_conv_geom* g, int op, size_t ws_bytes, char
         const int dm = tune.dma;
         if (mode == 9 && dm) snprintf(buf, sizeof buf, "k_wino_gemm_dma<3,4,2>");
         else if (mode == 5 && dm == 2) snprintf(buf, sizeof buf, "k_wino_gemm_dma<2,3,3>");
-        else if (mode == 9 && pg_wino_row_on()) snprintf(buf, sizeof buf, "k_wino_gemm_row<4,1>");
+        else if (mode == 9 && pg_wino_row_on())
+            snprintf(buf, sizeof buf, (tune.s3r && (oc == 0 ? g->Cb : g->Ca) % 32 == 0) ? "k_wino_gemm_row_s3<2>" : "k_wino_gemm_row<4,1>");
         else snprintf(buf, sizeof buf, "k_wino_gemm<%s>", mode == 9 ? "1,1,2,2,2,3" : mode == 4 ? "2,1,2,2,2,2" : "1,1,2,2,4,2");
         const int ho = oc == 0 ? g->Hs : g->Hb, wo = oc == 0 ? g->Ws : g->Wb;
         fl = 2.0 * (mo + 3) * (mo + 3) * g->N * cd(ho, mo) * cd(wo, mo) * (double)g->Ca * g->Cb;
@@ -3954,7 +3960,7 @@ static int b2s_impl(const float* big, int ld_big, const float* P, const float* b
         {
             TimedLaunch timed(st);
             rc = pg_wino_gemm(bias, small, ld_small, g.N, g.Cb, g.Hs, g.Ws, g.Ca, act, ws, st, tune.mo1, tune.dma, x.u_cache,
-                              pg_epi_mul{nullptr, 0, 0}, x.v_keep);
+                              pg_epi_mul{nullptr, 0, 0}, x.v_keep, tune.s3r);
         }
         if (rc != PG_OK || nsl == 1) return rc;
         const long pix = (long)g.N * g.Hs * g.Ws;
@@ -4181,7 +4187,7 @@ static int s2b_impl(const float* small, int ld_small, const float* P, const floa
                             ? 1 : pg_wino_gemm_slices(g.N, g.Hb, g.Wb, g.Ca, g.Cb, tune.mo1);
         {
             TimedLaunch timed(st);
-            rc = pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st, tune.mo1, tune.dma, x.u_cache, mul);
+            rc = pg_wino_gemm(bias, big, ld_big, g.N, g.Ca, g.Hb, g.Wb, g.Cb, act, ws, st, tune.mo1, tune.dma, x.u_cache, mul, nullptr, tune.s3r);
         }
         if (rc != PG_OK || nsl == 1) return rc;
         const long pix = (long)g.N * g.Hb * g.Wb;
@@ -4484,7 +4490,7 @@ static int wgrad_impl(const float* small, int ld_small, const float* big, int ld
         t_ev1 = nullptr;
         if (v_pre && !pg_wino_wgrad_v_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb, tune.mo1)) return PG_EINVAL;
         return pg_wino_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, (char*)ws + reserved, st,
-                             e0, e1, v_pre);
+                             e0, e1, v_pre, tune.s3w);
     }
     if (algo == PG_ALGO_AUTO && wino2_wgrad_ok(g, tune) && (ld_small % 4 == 0) && (ld_big % 4 == 0) && aligned16(small) &&
         aligned16(big) && aligned16(ws) && aligned16(dP) && ws_bytes >= reserved + pg_wino2_wgrad_ws_bytes(g.N, g.Hs, g.Ws, g.Ca, g.Cb)) {
@@ -4492,7 +4498,7 @@ static int wgrad_impl(const float* small, int ld_small, const float* big, int ld
         t_ev0 = nullptr;
         t_ev1 = nullptr;
         return pg_wino2_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, (char*)ws + reserved, st,
-                              e0, e1, v_pre);
+                              e0, e1, v_pre, tune.s3w);
     }
     if (v_pre) return PG_EINVAL;     // pg_conv_v_bytes said 0 for this call: there is no transformed operand to reuse
     if (bf16x_wgrad_ok(g, algo | io, tune) && (g.Cb > 8 || ld_big == 8) && aligned_bf_view(small, ld_small, true) &&
@@ -4648,7 +4654,7 @@ int pg_conv4x4_bwd_big_x(const float* small, int ld_small, const float* big, int
     void* rest = (char*)ws + vb;
     int rc = pg_wino2_v(big, ld_big, V, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Cb, st);
     if (rc != PG_OK) return rc;
-    rc = pg_wino2_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, rest, st, e0, e1, V);
+    rc = pg_wino2_wgrad(small, ld_small, big, ld_big, dP, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, rest, st, e0, e1, V, tune.s3w);
     if (rc != PG_OK) return rc;
     return pg_wino2_b2s(big, ld_big, P, nullptr, dsmall, ld_dsmall, g.N, g.Hb, g.Wb, g.Hs, g.Ws, g.Ca, g.Cb, PG_ACT_NONE, rest, st, e2,
                         e3, V, nullptr, nullptr, Uext, u_valid, tune.s3);

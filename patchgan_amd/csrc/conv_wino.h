@@ -44,7 +44,8 @@ int pg_wino_dma_mode();   // process default (PATCHGAN_WINO_DMA): 0 register-sta
 // the batched GEMM with fused output transform, bias and activation
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
                  void* ws, hipStream_t st, int mo_forced, int dma_mode, const float* Uext, pg_epi_mul mul = pg_epi_mul{nullptr, 0, 0},
-                 const float* Vext = nullptr);
+                 const float* Vext = nullptr, int s3 = 0);
+// s3: the row-fused F(3x3,4x4) GEMM in split-bf16 form (k_wino_gemm_row_s3 instead of k_wino_gemm_row; Cin % 32 == 0)
 // Vext (both): the transformed input lives in a caller-owned buffer (pg_wino_wgrad_v_bytes) instead of the workspace -- the forward
 // call keeps it for the layer's weight gradient (Vpre of pg_wino_wgrad), F(3x3,4x4) forward + F(4x4,3x3) weight gradient only
 
@@ -52,12 +53,13 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
 bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
 int pg_wino_wgrad_r(int N, int Hs, int Ws);      // dy-tile edge: 2 = F(4x4,2x2), 3 = F(4x4,3x3)
 double pg_wino_wgrad_flops(int N, int Hs, int Ws, int Ca, int Cb);      // FLOPs its GEMM executes
-int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb);
-bool pg_wino_wgrad_tile64(int Ca, int Cb);      // k_wino_wgrad_gemm<1,1,2,2> instead of <2,2,2,2>
+int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb, int s3);
+bool pg_wino_wgrad_tile64(int Ca, int Cb, int s3);      // k_wino_wgrad_gemm<1,1,2,2> instead of <2,2,2,2>; s3: for the split-bf16 form
 size_t pg_wino_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
 // ev0 / ev1 (optional) are recorded around the GEMM kernel
 int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
-                  int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const float* Vpre = nullptr);
+                  int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const float* Vpre = nullptr, int s3 = 0);
+// s3 (both weight gradients): != 0 runs the GEMM in split-bf16 form (k_wino_wgrad_gemm_s3; same tiles, slices and workspace)
 size_t pg_wino_wgrad_v_bytes(int N, int Hs, int Ws, int Ca, int Cb, int fwd_mo_forced);     // 0: the two calls do not share a transform
 
 // stride-2 layers, polyphase F(MO x MO, 2x2), MO = pg_wino2_mo() (3, or 4 with PATCHGAN_WINO2_TILE=4), X = (MO+1)^2:
@@ -91,9 +93,9 @@ int pg_wino2_s2b(const float* small, int ld_small, const float* P, const float* 
 
 // weight gradient of the stride-2 layers, polyphase F(2x2, 3x3): V (16*tiles*4Cb) | DY (16*tiles*Ca) | S (slices*16*Ca*4Cb)
 bool pg_wino2_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb);
-int pg_wino2_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb);
-bool pg_wino2_wgrad_tile64(int Ca, int Cb);     // k_wino_wgrad_gemm<1,1,2,2> (64x64 output tiles) instead of <2,2,2,2>
+int pg_wino2_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb, int s3);
+bool pg_wino2_wgrad_tile64(int Ca, int Cb, int s3);     // k_wino_wgrad_gemm<1,1,2,2> (64x64 output tiles) instead of <2,2,2,2>
 size_t pg_wino2_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb);
 // Vpre (optional): as for pg_wino2_b2s; ws then holds DY | S only
 int pg_wino2_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
-                   int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const float* Vpre);
+                   int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const float* Vpre, int s3 = 0);

@@ -1270,6 +1270,268 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         }
 }
 
+// ---- split-bf16 form of the weight-gradient GEMM (k_wino_wgrad_gemm above): S[slice][xi][a][b] = sum_{tile in slice} DY[xi][tile][a] V[xi][tile][b] ----
+// Both operands are K-major here (K = the Winograd tile index; a row of DY / V holds one tile's channels), while a bf16 MFMA operand is 8
+// consecutive K of one channel: the transposition happens in registers on the way to LDS.  A staging thread owns a 4 (tiles) x 4 (channels)
+// block -- four 16-byte loads from four consecutive tile rows -- and writes, per channel, the three bf16 pieces of its 4 consecutive tiles:
+// the same twelve 8-byte LDS stores per 16 values as k_wino_bgemm_s3, the same [channel][piece][16 k] rows, the same fragment reads and the
+// same six products per fp32 product (largest first).  KS k-steps of 16 tiles per barrier: 1 for the 128 x 128 tile (256 staging threads =
+// 128 + 128 channel rows x 4 tile groups), 2 for the 64 x 64 tile.  Tiles beyond T (the last chunk, the slice's end) are masked to zero.
+template <int MR, int NR, int WM, int WN, int KS, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_wgrad_gemm_s3(const float* __restrict__ DY, const float* __restrict__ V,
+                                                         float* __restrict__ S, int T, int Ca, int Cb, int chunks_per_slice,
+                                                         int tilesA, int tilesB, int NX, int dy_bytes, int v_bytes) {
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32, KCH = 16 * KS, ROW = KS * 48 + 8, BUF = (BM + BN) * ROW;
+    static_assert((BM + BN) * KS == 256, "one 4 x 4 block per staging thread");
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    int w = pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_b = w % tilesB;
+    w /= tilesB;
+    const int tile_a = w % tilesA;
+    w /= tilesA;
+    const int xi = w % NX, slice = w / NX;
+    const int m0 = tile_a * BM, n0 = tile_b * BN;
+    // chunks_per_slice counts 32-tile chunks (the fp32 kernel's KC) so that both kernels cut K into the same slices
+    const int k_begin = slice * chunks_per_slice * KC, k_end = min(T, k_begin + chunks_per_slice * KC);
+    const int nch = (max(k_end - k_begin, 0) + KCH - 1) / KCH;
+    // staging role (wave-uniform, so that the buffer descriptor stays in scalar registers): items 0 .. BM * KS - 1 stage DY, the rest V
+    const bool is_a = __builtin_amdgcn_readfirstlane(tid >> 6) < BM * KS / 64;
+    const int it = is_a ? tid : tid - BM * KS, BX = is_a ? BM : BN;
+    const int kg = it & 3, mq = (it >> 2) % (BX / 4), ks = it / BX;
+    const int ld = is_a ? Ca : Cb, c0 = (is_a ? m0 : n0) + mq * 4;
+    const bool c_in = c0 < ld;
+    const __amdgpu_buffer_rsrc_t rS = is_a ? __builtin_amdgcn_make_buffer_rsrc((void*)DY, 0, dy_bytes, 0x00020000)
+                                           : __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, v_bytes, 0x00020000);
+    const int base = xi * T * ld + c0;                           // + tile * ld
+    const int krow = ks * 16 + kg * 4;                           // first of this thread's four tiles within a chunk
+    const int wr_off = ((is_a ? 0 : BM) + mq * 4) * ROW + ks * 48 + kg * 4;
+    auto issue_loads = [&](f32x4 (&r)[4], int c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k_begin + c * KCH + krow + j;
+            r[j] = bload4(rS, voff(base + k * ld, c < nch && c_in && k < k_end));
+        }
+    };
+    auto stage = [&](const f32x4 (&r)[4], __bf16* buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 v = {r[0][e], r[1][e], r[2][e], r[3][e]};          // channel c0 + e of four consecutive tiles
+            s3_bf16x4 h, m, l;
+            s3_split(v, h, m, l);
+            __bf16* row = &buf[wr_off + e * ROW];
+            *reinterpret_cast<s3_bf16x4*>(row) = h;
+            *reinterpret_cast<s3_bf16x4*>(row + 16) = m;
+            *reinterpret_cast<s3_bf16x4*>(row + 32) = l;
+        }
+    };
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto compute = [&](const __bf16* buf) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            s3_bf16x8 bf[NR][3], af[MR][3];
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bf[j][p] = *reinterpret_cast<const s3_bf16x8*>(&buf[(BM + (wn * NR + j) * 32 + lrow) * ROW + s * 48 + p * 16 + lh * 8]);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[i][p] = *reinterpret_cast<const s3_bf16x8*>(&buf[((wm * MR + i) * 32 + lrow) * ROW + s * 48 + p * 16 + lh * 8]);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+#define S3_MM(pa, pb) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0)
+                    S3_MM(0, 0); S3_MM(0, 1); S3_MM(1, 0); S3_MM(1, 1); S3_MM(0, 2); S3_MM(2, 0);
+#undef S3_MM
+                }
+        }
+    };
+    __bf16* const buf0 = smem;
+    __bf16* const buf1 = smem + BUF;
+    f32x4 r0[4], r1[4];
+    issue_loads(r0, 0);
+    issue_loads(r1, 1);
+    stage(r0, buf0);
+    issue_loads(r0, 2);
+    __syncthreads();
+    // as k_wino_bgemm_s3: buf[c & 1] = chunk c, the two register sets hold chunks c + 1 and c + 2; an odd chunk count runs one masked chunk
+    for (int c = 0; c < nch; c += 2) {
+        stage(r1, buf1);
+        compute(buf0);
+        issue_loads(r1, c + 3);
+        __syncthreads();
+        stage(r0, buf0);
+        compute(buf1);
+        issue_loads(r0, c + 4);
+        __syncthreads();
+    }
+    float* o = S + ((long)slice * NX + xi) * Ca * Cb;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int a = m0 + (wm * MR + i) * 32 + row;
+                if (a < Ca && col < Cb) o[(long)a * Cb + col] = acc[i][j][r];
+            }
+        }
+}
+
+// ---- split-bf16 form of k_wino_gemm_row (F(3x3,4x4), output transform cut in two) ----
+// The same work split -- a workgroup owns ONE ROW i of the 6 x 6 products of its tiles x channels and folds the column transform
+// T_i[c] = sum_j M_ij AT[c][j] -- on the bf16 matrix pipe: 128 tiles x 64 channels per workgroup (a wave: 64 x 32 = two accumulator sets for M_ij
+// + six for T_i), operands split into three bf16 pieces while they are staged (s3_split), 16-wide K chunks, two LDS buffers and two register
+// sets of loads as in k_wino_bgemm_s3, one flattened (j, chunk) loop.  Ci % 32 == 0 (an even number of chunks per j).
+template <int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_gemm_row_s3(
+    const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ Tout, int T, int Ci, int Co, int v_bytes, int u_bytes,
+    int tiles_n) {
+    constexpr int NP = 6, BM = 128, BN = 64, MR = 2, BUF = (BM + BN) * S3_LDR;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * BUF];
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, v_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, u_bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lh = lane >> 5;
+    int w = pg_xcd_remap(blockIdx.x, gridDim.x);             // (work order as k_wino_gemm_row: an XCD stays on one row of products)
+    const int n0 = (w % tiles_n) * BN;
+    w /= tiles_n;
+    const int tiles_m = (T + BM - 1) / BM;
+    const int xrow = w / tiles_m;
+    const int m0 = (w % tiles_m) * BM;
+    const int nch = Ci / S3_KC, total = NP * nch;
+    const int kq = tid & 3, r0 = tid >> 2;
+    int a_off[2], b_off;
+    bool a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        a_ok[i] = m < T;
+        a_off[i] = min(m, T - 1) * Ci + kq * 4;
+    }
+    {
+        const int co = n0 + r0;
+        b_off = (co < Co) ? co * Ci + kq * 4 : 0x10000000;
+    }
+    const int v_xi = T * Ci, u_xi = Co * Ci;
+    int ld_j = 0, ld_ch = 0;
+    auto issue_loads = [&](f32x4 (&ra)[2], f32x4& rb) {         // the next (j, chunk) in order; beyond the last one: masked
+        const bool on = ld_j < NP;
+        const int xi = xrow * NP + ld_j;
+        const int av = xi * v_xi + ld_ch * S3_KC, bu = xi * u_xi + ld_ch * S3_KC;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = bload4(rV, voff(a_off[i] + av, on && a_ok[i]));
+        rb = bload4(rU, voff(b_off + bu, on));
+        const bool wrap = ld_ch + 1 >= nch;
+        ld_ch = wrap ? 0 : ld_ch + 1;
+        ld_j = wrap ? ld_j + 1 : ld_j;
+    };
+    auto stage = [&](const f32x4 (&ra)[2], const f32x4& rb, __bf16* buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            s3_bf16x4 h, m, l;
+            s3_split(ra[i], h, m, l);
+            __bf16* row = &buf[(r0 + 64 * i) * S3_LDR + kq * 4];
+            *reinterpret_cast<s3_bf16x4*>(row) = h;
+            *reinterpret_cast<s3_bf16x4*>(row + S3_KC) = m;
+            *reinterpret_cast<s3_bf16x4*>(row + 2 * S3_KC) = l;
+        }
+        s3_bf16x4 h, m, l;
+        s3_split(rb, h, m, l);
+        __bf16* row = &buf[(BM + r0) * S3_LDR + kq * 4];
+        *reinterpret_cast<s3_bf16x4*>(row) = h;
+        *reinterpret_cast<s3_bf16x4*>(row + S3_KC) = m;
+        *reinterpret_cast<s3_bf16x4*>(row + 2 * S3_KC) = l;
+    };
+    f32x16 accm[MR], acct[3][MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accm[i][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acct[c][i][r] = 0.f;
+        }
+    int j = 0, ch = 0;
+    auto compute = [&](const __bf16* buf) {
+        s3_bf16x8 bf[3], af[MR][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const s3_bf16x8*>(&buf[(BM + wn * 32 + lrow) * S3_LDR + p * S3_KC + lh * 8]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                af[i][p] = *reinterpret_cast<const s3_bf16x8*>(&buf[((wm * MR + i) * 32 + lrow) * S3_LDR + p * S3_KC + lh * 8]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+#define S3_MM(pa, pb) accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[pb], accm[i], 0, 0, 0)
+            S3_MM(0, 0); S3_MM(0, 1); S3_MM(1, 0); S3_MM(1, 1); S3_MM(0, 2); S3_MM(2, 0);
+#undef S3_MM
+        }
+        if (ch == nch - 1) {            // the last chunk of product (xrow, j): fold it into the three column-transformed sets
+            const float c0 = c_AT34[0][j], c1 = c_AT34[1][j], c2 = c_AT34[2][j];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float mv = accm[i][r];
+                    acct[0][i][r] += c0 * mv;
+                    acct[1][i][r] += c1 * mv;
+                    acct[2][i][r] += c2 * mv;
+                    accm[i][r] = 0.f;
+                }
+        }
+        const bool wrap = ch + 1 >= nch;
+        ch = wrap ? 0 : ch + 1;
+        j = wrap ? j + 1 : j;
+    };
+    __bf16* const buf0 = smem;
+    __bf16* const buf1 = smem + BUF;
+    f32x4 ra0[2], rb0, ra1[2], rb1;
+    issue_loads(ra0, rb0);
+    issue_loads(ra1, rb1);
+    stage(ra0, rb0, buf0);
+    issue_loads(ra0, rb0);
+    __syncthreads();
+    for (int it = 0; it < total; it += 2) {
+        stage(ra1, rb1, buf1);
+        compute(buf0);
+        issue_loads(ra1, rb1);
+        __syncthreads();
+        stage(ra0, rb0, buf0);
+        compute(buf1);
+        issue_loads(ra0, rb0);
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + lrow;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int m = m0 + (wm * MR + i) * 32 + row;
+            if (m < T && col < Co) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Tout[((long)(xrow * 3 + c) * T + m) * Co + col] = acct[c][i][r];
+            }
+        }
+}
+
 // Multi-batch variant: a workgroup owns one (m, n) tile position and runs `zb` consecutive batches z through ONE flattened (z, chunk) loop: the
 // loads of the next batch's first chunk are in flight during the last MFMAs of the current one and the tile stores are
 // fire-and-forget, so the short K loops of these layers (4..32 chunks) do not pay a prologue and an epilogue each.
@@ -1862,7 +2124,7 @@ int pg_wino_dma_mode() {
 }
 
 int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int Hout, int Wout, int Cout, int act,
-                 void* ws, hipStream_t st, int forced, int dma_mode, const float* Uext, pg_epi_mul mul, const float* Vext) {
+                 void* ws, hipStream_t st, int forced, int dma_mode, const float* Uext, pg_epi_mul mul, const float* Vext, int s3) {
     const int mo = pg_wino_mo(N, Hout, Wout, Cin, Cout, forced), TH = (Hout + mo - 1) / mo, TW = (Wout + mo - 1) / mo;
     const long T = (long)N * TH * TW, X = wino1_nxi(N, Hout, Wout, Cin, Cout, forced);
     const float* U = Uext ? Uext : (const float*)ws;
@@ -1873,8 +2135,12 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
     if (pg_wino_gemm_rows(N, Hout, Wout, Cin, Cout, forced, dma_mode, out, ld_out, bias, mul)) {
         float* Tt = pg_wino_gemm_slabs(ws, N, Hout, Wout, Cin, Cout, forced);
         // (MR = 2 -- 128 tiles per workgroup, 64 x 32 per wave, 2 waves per SIMD -- measured 0.14 ms per step slower)
-        hipLaunchKernelGGL((k_wino_gemm_row<4, 1>), dim3((unsigned)(((T + 63) / 64) * tn * 6)), dim3(256), 0, st, V, U, Tt, (int)T, Cin, Cout,
-                           v_bytes, u_bytes, tn);
+        if (s3 && Cin % 32 == 0)
+            hipLaunchKernelGGL((k_wino_gemm_row_s3<2>), dim3((unsigned)(((T + 127) / 128) * tn * 6)), dim3(256), 0, st, V, U, Tt, (int)T, Cin,
+                               Cout, v_bytes, u_bytes, tn);
+        else
+            hipLaunchKernelGGL((k_wino_gemm_row<4, 1>), dim3((unsigned)(((T + 63) / 64) * tn * 6)), dim3(256), 0, st, V, U, Tt, (int)T, Cin, Cout,
+                               v_bytes, u_bytes, tn);
         if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
         const dim3 go((unsigned)((T * (Cout / 4) + 255) / 256));
         if (mul.t)
@@ -1960,17 +2226,20 @@ bool pg_wino_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb) {
 }
 
 // stride-1 weight gradient: 64x64 output tiles unless 128x128 ones alone give >= 768 workgroups (no K split then)
-bool pg_wino_wgrad_tile64(int Ca, int Cb) {
+// (split-bf16 form: the 128x128 tile wherever both channel counts fill it -- its staging work per MFMA is half the 64x64 tile's, which
+//  measured no faster than the fp32 kernel -- and correspondingly more K slices)
+bool pg_wino_wgrad_tile64(int Ca, int Cb, int s3) {
     static const int forced = [] {
         const char* e = pg_exp_env("PATCHGAN_WINOW_TILE");
         return e ? atoi(e) : 0;
     }();
     if (forced) return forced == 64;
+    if (s3 && Ca % 128 == 0 && Cb % 128 == 0) return false;
     return 25L * ((Ca + 127) / 128) * ((Cb + 127) / 128) < 768;
 }
-int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb) {
+int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb, int s3) {
     const long T = wgrad_tiles(N, Hs, Ws);
-    const int tt = pg_wino_wgrad_tile64(Ca, Cb) ? 64 : 128;
+    const int tt = pg_wino_wgrad_tile64(Ca, Cb, s3) ? 64 : 128;
     const long wgs = (long)wgrad_nxi(N, Hs, Ws) * ((Ca + tt - 1) / tt) * ((Cb + tt - 1) / tt);
     long s = (768 + wgs - 1) / wgs;                 // three workgroups per CU
     const long nchunks = (T + KC - 1) / KC;
@@ -1980,8 +2249,8 @@ int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb) {
 
 size_t pg_wino_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb) {
     const long T = wgrad_tiles(N, Hs, Ws), X = wgrad_nxi(N, Hs, Ws);
-    return align256((size_t)X * T * Cb * 4) + align256((size_t)X * T * Ca * 4) +
-           align256((size_t)pg_wino_wgrad_slices(N, Hs, Ws, Ca, Cb) * X * Ca * Cb * 4);
+    const int sl = std::max(pg_wino_wgrad_slices(N, Hs, Ws, Ca, Cb, 0), pg_wino_wgrad_slices(N, Hs, Ws, Ca, Cb, 1));      // serves both forms
+    return align256((size_t)X * T * Cb * 4) + align256((size_t)X * T * Ca * 4) + align256((size_t)sl * X * Ca * Cb * 4);
 }
 
 // the transformed input the forward F(3x3,4x4) leaves (same 6 x 6 windows at 3t - 1, same B^T) is the V of F(4x4,3x3)
@@ -1991,7 +2260,7 @@ size_t pg_wino_wgrad_v_bytes(int N, int Hs, int Ws, int Ca, int Cb, int fwd_forc
 }
 
 int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
-                  int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const float* Vpre) {
+                  int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const float* Vpre, int s3) {
     const int R = pg_wino_wgrad_r(N, Hs, Ws), X = (R + 3) * (R + 3);
     const int TH = (Hs + R - 1) / R, TW = (Ws + R - 1) / R;
     const long T = (long)N * TH * TW;
@@ -2010,18 +2279,26 @@ int pg_wino_wgrad(const float* small, int ld_small, const float* big, int ld_big
         hipLaunchKernelGGL(k_wino_dy<2>, gd, dim3(256), 0, st, small, ld_small, DY, N, Hs, Ws, Ca, TH, TW);
     }
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
-    const int slices = pg_wino_wgrad_slices(N, Hs, Ws, Ca, Cb);
+    const int slices = pg_wino_wgrad_slices(N, Hs, Ws, Ca, Cb, s3);
     const int nchunks = (int)((T + KC - 1) / KC);
     const int cps = (nchunks + slices - 1) / slices;
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (pg_wino_wgrad_tile64(Ca, Cb)) {
+    if (pg_wino_wgrad_tile64(Ca, Cb, s3)) {
         const int tilesA = (Ca + 63) / 64, tilesB = (Cb + 63) / 64;
-        hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB * X * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                       Cb, cps, tilesA, tilesB, X, (int)((long)X * T * Ca * 4), (int)((long)X * T * Cb * 4));
+        if (s3)
+            hipLaunchKernelGGL((k_wino_wgrad_gemm_s3<1, 1, 2, 2, 2, 3>), dim3(tilesA * tilesB * X * slices), dim3(256), 0, st, DY, V, S, (int)T,
+                               Ca, Cb, cps, tilesA, tilesB, X, (int)((long)X * T * Ca * 4), (int)((long)X * T * Cb * 4));
+        else
+            hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB * X * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                               Cb, cps, tilesA, tilesB, X, (int)((long)X * T * Ca * 4), (int)((long)X * T * Cb * 4));
     } else {
         const int tilesA = (Ca + 127) / 128, tilesB = (Cb + 127) / 128;
-        hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB * X * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                       Cb, cps, tilesA, tilesB, X, (int)((long)X * T * Ca * 4), (int)((long)X * T * Cb * 4));
+        if (s3)
+            hipLaunchKernelGGL((k_wino_wgrad_gemm_s3<2, 2, 2, 2, 1, 2>), dim3(tilesA * tilesB * X * slices), dim3(256), 0, st, DY, V, S, (int)T,
+                               Ca, Cb, cps, tilesA, tilesB, X, (int)((long)X * T * Ca * 4), (int)((long)X * T * Cb * 4));
+        else
+            hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB * X * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                               Cb, cps, tilesA, tilesB, X, (int)((long)X * T * Ca * 4), (int)((long)X * T * Cb * 4));
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
@@ -2306,18 +2583,19 @@ bool pg_wino2_wgrad_geom_ok(int N, int Hs, int Ws, int Ca, int Cb) {
 }
 
 // 128x128 output tiles when they alone fill the chip, else 64x64 tiles (4x the workgroups) so that fewer, longer K slices do
-bool pg_wino2_wgrad_tile64(int Ca, int Cb) {
+bool pg_wino2_wgrad_tile64(int Ca, int Cb, int s3) {
     static const int forced = [] {
         const char* e = pg_exp_env("PATCHGAN_WINO2W_TILE");
         return e ? atoi(e) : 0;
     }();
     if (forced) return forced == 64;
+    if (s3 && Ca % 128 == 0 && (4 * Cb) % 128 == 0) return false;      // (as pg_wino_wgrad_tile64)
     return 16L * ((Ca + 127) / 128) * ((4 * Cb + 127) / 128) < 768;
 }
 
-int pg_wino2_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb) {
+int pg_wino2_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb, int s3) {
     const long T = wino2w_tiles(N, Hs, Ws);
-    const int t = pg_wino2_wgrad_tile64(Ca, Cb) ? 64 : 128;
+    const int t = pg_wino2_wgrad_tile64(Ca, Cb, s3) ? 64 : 128;
     const long wgs = 16L * ((Ca + t - 1) / t) * ((4 * Cb + t - 1) / t);
     long s = (768 + wgs - 1) / wgs;
     const long nchunks = (T + KC - 1) / KC;
@@ -2327,12 +2605,12 @@ int pg_wino2_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb) {
 
 size_t pg_wino2_wgrad_ws_bytes(int N, int Hs, int Ws, int Ca, int Cb) {
     const long T = wino2w_tiles(N, Hs, Ws);
-    return align256((size_t)16 * T * 4 * Cb * 4) + align256((size_t)16 * T * Ca * 4) +
-           align256((size_t)pg_wino2_wgrad_slices(N, Hs, Ws, Ca, Cb) * 16 * Ca * 4 * Cb * 4);
+    const int sl = std::max(pg_wino2_wgrad_slices(N, Hs, Ws, Ca, Cb, 0), pg_wino2_wgrad_slices(N, Hs, Ws, Ca, Cb, 1));    // serves both forms
+    return align256((size_t)16 * T * 4 * Cb * 4) + align256((size_t)16 * T * Ca * 4) + align256((size_t)sl * 16 * Ca * 4 * Cb * 4);
 }
 
 int pg_wino2_wgrad(const float* small, int ld_small, const float* big, int ld_big, float* dP, int N, int Hb, int Wb, int Hs,
-                   int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const float* Vpre) {
+                   int Ws, int Ca, int Cb, void* ws, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, const float* Vpre, int s3) {
     const int TH = (Hs + 2) / 3, TW = (Ws + 2) / 3, K = 4 * Cb;
     const long T = (long)N * TH * TW;
     // ws: V | DY | S, or DY | S when the caller supplies the transformed big-side tensor (Vpre)
@@ -2348,18 +2626,26 @@ int pg_wino2_wgrad(const float* small, int ld_small, const float* big, int ld_bi
     hipLaunchKernelGGL(k_wino2_dy, dim3((unsigned)((T * (Ca / 4) + 255) / 256)), dim3(256), 0, st, small, ld_small, DY, N, Hs, Ws,
                        Ca, TH, TW);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;
-    const int slices = pg_wino2_wgrad_slices(N, Hs, Ws, Ca, Cb);
+    const int slices = pg_wino2_wgrad_slices(N, Hs, Ws, Ca, Cb, s3);
     const int nchunks = (int)((T + KC - 1) / KC);
     const int cps = (nchunks + slices - 1) / slices;
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (pg_wino2_wgrad_tile64(Ca, Cb)) {
+    if (pg_wino2_wgrad_tile64(Ca, Cb, s3)) {
         const int tilesA = (Ca + 63) / 64, tilesB = (K + 63) / 64;
-        hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB * 16 * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                           K, cps, tilesA, tilesB, 16, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
+        if (s3)
+            hipLaunchKernelGGL((k_wino_wgrad_gemm_s3<1, 1, 2, 2, 2, 3>), dim3(tilesA * tilesB * 16 * slices), dim3(256), 0, st, DY, V, S, (int)T,
+                               Ca, K, cps, tilesA, tilesB, 16, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
+        else
+            hipLaunchKernelGGL((k_wino_wgrad_gemm<1, 1, 2, 2>), dim3(tilesA * tilesB * 16 * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                               K, cps, tilesA, tilesB, 16, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
     } else {
         const int tilesA = (Ca + 127) / 128, tilesB = (K + 127) / 128;
-        hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB * 16 * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
-                           K, cps, tilesA, tilesB, 16, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
+        if (s3)
+            hipLaunchKernelGGL((k_wino_wgrad_gemm_s3<2, 2, 2, 2, 1, 2>), dim3(tilesA * tilesB * 16 * slices), dim3(256), 0, st, DY, V, S, (int)T,
+                               Ca, K, cps, tilesA, tilesB, 16, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
+        else
+            hipLaunchKernelGGL((k_wino_wgrad_gemm<2, 2, 2, 2>), dim3(tilesA * tilesB * 16 * slices), dim3(256), 0, st, DY, V, S, (int)T, Ca,
+                               K, cps, tilesA, tilesB, 16, (int)(16L * T * Ca * 4), (int)(16L * T * K * 4));
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (hipGetLastError() != hipSuccess) return PG_ELAUNCH;

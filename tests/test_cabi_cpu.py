@@ -53,11 +53,11 @@ def test_kernel_plan_of_the_benchmark_layers():
         pytest.skip('kernel-selection switches set in the environment')
     want = {   # (N, Hb, Wb, Ca, Cb, stride): (big2small, small2big, wgrad) kernel families under PG_ALGO_AUTO
         (16, 256, 256, 64, 3, 2): ('k_b2s_tapk', 'k_s2b_tapnf<3>', 'k_wgrad_tapn'),     # enc0
-        (16, 128, 128, 128, 64, 2): ('k_wino_bgemm_s3<2,2,2,2,2>', 'k_wino_bgemm_s3<2,2,2,2,2>', 'k_wino_wgrad_gemm<1,1,2,2>'),   # enc1
-        (16, 64, 64, 256, 128, 2): ('k_wino_bgemm_s3<2,2,2,2,2>', 'k_wino_bgemm_s3<2,2,2,2,2>', 'k_wino_wgrad_gemm<1,1,2,2>'),    # enc2
+        (16, 128, 128, 128, 64, 2): ('k_wino_bgemm_s3<2,2,2,2,2>', 'k_wino_bgemm_s3<2,2,2,2,2>', 'k_wino_wgrad_gemm_s3<2,2,2,2,1,2>'),   # enc1
+        (16, 64, 64, 256, 128, 2): ('k_wino_bgemm_s3<2,2,2,2,2>', 'k_wino_bgemm_s3<2,2,2,2,2>', 'k_wino_wgrad_gemm_s3<2,2,2,2,1,2>'),    # enc2
         (16, 16, 16, 512, 512, 2): ('k_b2s_fast', 'k_s2b_fast', 'k_wgrad_fast'),                              # enc4: too few tiles
-        (16, 64, 64, 512, 128, 2): ('k_wino_bgemm_s3<2,2,2,2,2>', 'k_wino_bgemm_s3<2,2,2,2,2>', 'k_wino_wgrad_gemm<1,1,2,2>'),    # dec4
-        (16, 32, 32, 1024, 256, 2): ('k_wino_bgemm_s3<1,2,2,2,3>', 'k_wino_bgemm_s3<1,2,2,2,3>', 'k_wino_wgrad_gemm<2,2,2,2>'),   # dec3
+        (16, 64, 64, 512, 128, 2): ('k_wino_bgemm_s3<2,2,2,2,2>', 'k_wino_bgemm_s3<2,2,2,2,2>', 'k_wino_wgrad_gemm_s3<2,2,2,2,1,2>'),    # dec4
+        (16, 32, 32, 1024, 256, 2): ('k_wino_bgemm_s3<1,2,2,2,3>', 'k_wino_bgemm_s3<1,2,2,2,3>', 'k_wino_wgrad_gemm_s3<2,2,2,2,1,2>'),   # dec3
         (32, 32, 32, 512, 256, 1): ('k_wino_gemm', 'k_wino_gemm', 'k_wino_wgrad_gemm'),                       # d3 at 2N
         (32, 31, 31, 1, 512, 1): ('k_b2s_fast<1,1,4,1,true>+k_gather', 'k_s2b_ca1', 'k_wgrad_tapn'),        # D head
     }
@@ -69,7 +69,12 @@ def test_kernel_plan_of_the_benchmark_layers():
             assert 'wino' not in mfma.describe(oc)[0], (geom, oc)
             if '_s3<' in sym:      # PG_TUNE_S3_OFF: the same plan on the fp32 MFMA
                 off = E.ConvOp(*geom, _lib.ALGO_AUTO | _lib.TUNE_S3_OFF).describe(oc)[0]
-                assert off == sym.replace('_s3<', '<')[:-3] + '>', (sym, off)
+                if oc == 2:            # (the fp32 weight-gradient GEMM keeps its own tile choice: 64x64 tiles on most layers)
+                    assert off.startswith('k_wino_wgrad_gemm<'), (sym, off)
+                elif sym.startswith('k_wino_gemm_row_s3'):
+                    assert off == 'k_wino_gemm_row<4,1>', (sym, off)
+                else:
+                    assert off == sym.replace('_s3<', '<')[:-3] + '>', (sym, off)
             assert auto.kernel_flops(oc) <= auto.flops * 1.3       # Winograd executes fewer (ragged tiles may add a little)
             if 'wino' in sym:
                 assert auto.kernel_flops(oc) < 0.6 * auto.flops

@@ -92,6 +92,7 @@ def test_hot_kernels_keep_the_occupancy_they_were_tuned_at():
         'k_wino_bgemmILi2ELi2ELi2ELi2E': 4, 'k_wino_bgemmILi1ELi2ELi2ELi2E': 4, 'k_wino_wgrad_gemmILi1ELi1ELi2ELi2E': 4,
         # the split-bf16 batched GEMM (round 6): 128-row tiles two workgroups per CU (57 KB of LDS each), 64-row tiles three
         'k_wino_bgemm_s3ILi2ELi2ELi2ELi2ELi2E': 2, 'k_wino_bgemm_s3ILi1ELi2ELi2ELi2ELi3E': 3,
+        'k_wino_wgrad_gemm_s3ILi2ELi2ELi2ELi2ELi1ELi2E': 2, 'k_wino_wgrad_gemm_s3ILi1ELi1ELi2ELi2ELi2ELi3E': 3, 'k_wino_gemm_row_s3ILi2E': 2,
         'k_wino_wgrad_gemmILi2ELi2ELi2ELi2E': 4, 'k_wino_gemm_rowILi4ELi1E': 4, 'k_wgrad_fastILi2ELi2ELi2ELi2E': 4,
         'k_b2s_fastILi2ELi2ELi2ELi2E': 3, 'k_s2b_fastILi2ELi2ELi2ELi2E': 3,
     }

@@ -345,12 +345,14 @@ def test_bounded_operand_holding_joins_early_and_changes_nothing(tmp_path, monke
     assert np.array_equal(ref[0], two[0]) and np.array_equal(ref[1], two[1]) and np.array_equal(ref[2], two[2])
 
 
-def test_two_stream_step_that_runs_out_of_memory_falls_back_to_one_stream(tmp_path):
-    """The two-stream step holds about twice the one-stream step's device memory.  Under a memory cap between the two it raises
-    torch.cuda.OutOfMemoryError inside the step, before anything is committed: the trainer joins and drops the second stream's state,
-    warns once, runs THAT step again on one stream and pins the kind to one stream -- same losses and weights as the one-stream trainer."""
+def test_two_stream_step_that_runs_out_of_memory_falls_back_to_one_stream(tmp_path, monkeypatch):
+    """The two-stream step holds about twice the one-stream step's device memory.  A torch.cuda.OutOfMemoryError raised inside a two-stream
+    step before anything is committed (here: injected at the first weight gradient of the SECOND step's backward pass, i.e. with the first
+    step's discriminator update still running on the second stream and this step's early discriminator forward forked): the trainer joins
+    and drops the second stream's state, warns once, runs THAT step again on one stream and pins the kind to one stream -- same losses and
+    weights as the one-stream trainer.  (The allocator frees its cache and retries before it raises, so a memory cap between the two
+    peaks does not provoke the error reliably: the second half of the test runs under such a cap and accepts either outcome.)"""
     import warnings
-    import patchgan_amd as pg
     from patchgan_amd import engine as E
     E.release_workspaces()
     torch.cuda.empty_cache()
@@ -360,7 +362,7 @@ def test_two_stream_step_that_runs_out_of_memory_falls_back_to_one_stream(tmp_pa
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
         r = _run(tmp_path, False, 'fp32', steps, nf=32, tag=tag, two_streams=two)
-        m = torch.cuda.max_memory_reserved()
+        m = torch.cuda.max_memory_allocated()
         r[4].release()
         return r, m
     one, m1 = peak(False, 'oom1')
@@ -368,23 +370,56 @@ def test_two_stream_step_that_runs_out_of_memory_falls_back_to_one_stream(tmp_pa
     assert np.array_equal(one[0], two[0])
     assert m2 > m1 * 1.2, (m1, m2)                 # (the premise: two streams need visibly more)
     del two
+    import patchgan_amd as pg
+    real_wgrad, real_enqueue = E.ConvOp.wgrad, pg.Trainer._enqueue_step
+    seen = {'steps': 0, 'raised': 0}
+
+    def counting(self, *a, **k):
+        seen['steps'] += 1
+        return real_enqueue(self, *a, **k)
+
+    def failing(self, *a, **k):
+        if E.cur_exec().enabled and seen['steps'] == 2 and not seen['raised']:       # the first weight gradient of step 2's backward pass
+            seen['raised'] = 1
+            raise torch.cuda.OutOfMemoryError('injected: HIP out of memory')
+        return real_wgrad(self, *a, **k)
+    monkeypatch.setattr(pg.Trainer, '_enqueue_step', counting)
+    monkeypatch.setattr(E.ConvOp, 'wgrad', failing)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        inj = _run(tmp_path, False, 'fp32', 3, nf=32, tag='oom_inj', two_streams=True)
+    monkeypatch.setattr(E.ConvOp, 'wgrad', real_wgrad)
+    monkeypatch.setattr(pg.Trainer, '_enqueue_step', real_enqueue)
+    t = inj[4]
+    assert seen['raised'] == 1 and seen['steps'] == 4
+    assert t.oom_fallbacks == 1 and len(t._oom_kinds) == 1, (t.oom_fallbacks, seen)
+    assert any('out of device memory' in str(x.message) for x in w), [str(x.message) for x in w]
+    assert t.launch_mode == 'eager1'
+    assert np.array_equal(one[0], inj[0]) and np.array_equal(one[1], inj[1]) and np.array_equal(one[2], inj[2])
+    t.redecide()
+    assert not t._oom_kinds
+    t.release()
+    del inj, t
+    # the real thing, where the allocator lets it happen: a cap between the two peaks
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     base = torch.cuda.memory_reserved()
     total = torch.cuda.get_device_properties(0).total_memory
-    cap = base + m1 + (m2 - m1) // 3
+    cap = base + m1 + (m2 - m1) // 4
     torch.cuda.set_per_process_memory_fraction(min(1.0, cap / total))
     try:
-        with warnings.catch_warnings(record=True) as w:
-            warnings.simplefilter('always')
-            capped = _run(tmp_path, False, 'fp32', 3, nf=32, tag='oom3', two_streams=True)
-        t = capped[4]
-        assert t.oom_fallbacks == 1 and len(t._oom_kinds) == 1, (t.oom_fallbacks, m1, m2, cap)
-        assert any('out of device memory' in str(x.message) for x in w), [str(x.message) for x in w]
-        assert t.launch_mode == 'eager1'
-        assert np.array_equal(one[0], capped[0]) and np.array_equal(one[1], capped[1]) and np.array_equal(one[2], capped[2])
-        t.redecide()
-        assert not t._oom_kinds
+        try:
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter('always')
+                capped = _run(tmp_path, False, 'fp32', 3, nf=32, tag='oom3', two_streams=True)
+        except torch.cuda.OutOfMemoryError:
+            capped = None          # (fragmentation: not even the one-stream step fitted under this cap -- nothing to compare)
+        if capped is not None:
+            t = capped[4]
+            assert t.oom_fallbacks in (0, 1)
+            if t.oom_fallbacks:
+                assert t.launch_mode == 'eager1' and any('out of device memory' in str(x.message) for x in w)
+            assert np.array_equal(one[0], capped[0]) and np.array_equal(one[1], capped[1]) and np.array_equal(one[2], capped[2])
     finally:
         torch.cuda.set_per_process_memory_fraction(1.0)
         E.release_workspaces()

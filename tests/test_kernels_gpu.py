@@ -135,7 +135,7 @@ def test_winograd_stride1(geom, tile):
     if tile != 'auto':       # F(3x3,4x4) needs Cin % 64 == 0 in each direction, else the F(2x2,4x4) instance runs
         for oc, cin in ((0, Cb), (1, Ca)):
             sym = auto.describe(oc)[0]          # F(3x3,4x4): k_wino_gemm<...,3> or its LDS-DMA form k_wino_gemm_dma<3,...>
-            is_f3 = sym.startswith(('k_wino_gemm_dma<3', 'k_wino_gemm_row<')) or (sym.startswith('k_wino_gemm<') and sym.endswith(',3>'))
+            is_f3 = sym.startswith(('k_wino_gemm_dma<3', 'k_wino_gemm_row<', 'k_wino_gemm_row_s3<')) or (sym.startswith('k_wino_gemm<') and sym.endswith(',3>'))
             assert is_f3 == (tile.startswith('f3') and cin % 64 == 0), (oc, sym)
             if tile.endswith('_dma'):             # (the 128-tile-row F(2x2,4x4) instance has no DMA form)
                 assert sym.startswith('k_wino_gemm_dma<') or sym == 'k_wino_gemm<2,1,2,2,2,2>', sym

@@ -605,7 +605,7 @@ def test_full_size_cfg2_matches_oracle(tmp_path, tuning):
     else:
         assert nw >= 4, fams
     if tuning == 'stride1_f3':
-        assert any(f.endswith(',3>') or f.startswith(('k_wino_gemm_dma<3', 'k_wino_gemm_row<')) for f in [op.describe(0)[0] for op in d.engine.ops(8, 256, 256)])
+        assert any(f.endswith(',3>') or f.startswith(('k_wino_gemm_dma<3', 'k_wino_gemm_row<', 'k_wino_gemm_row_s3<')) for f in [op.describe(0)[0] for op in d.engine.ops(8, 256, 256)])
     with torch.no_grad():          # forward at identical (initial) weights
         out = g(x.cuda()).cpu()
         dout = d(torch.cat((x.cuda(), out.cuda()), 1)).cpu()
