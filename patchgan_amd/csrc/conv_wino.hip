@@ -1140,7 +1140,12 @@ __device__ __forceinline__ void s3_split(const f32x4 v, s3_bf16x4& h, s3_bf16x4&
 // 32-wide chunks measured 0.65 us of MFMAs and 1.6-1.9 us of waiting + splitting + writing per chunk: EXPERIMENTS.md, round 6).
 // LDS row = [a1: 16 k | a2: 16 k | a3: 16 k | pad] = 112 bytes = 7 x 16: conflict-free ds_read_b128 fragments of 8 consecutive k.
 constexpr int S3_KC = 16, S3_LDR = 3 * S3_KC + 8;
-template <int MR, int NR, int WM, int WN, int WPE, int VAR = 1>      // VAR: order of the six products (1 = largest first, the shipped one; others: PATCHGAN_S3_VAR, experiment)
+// PIPE: the fragments double-buffered in REGISTERS -- the MFMAs of chunk c run on fragments read during chunk c - 1, while this iteration reads
+// chunk c + 1's fragments and splits / stores chunk c + 2, so nothing an MFMA waits for was issued in its own iteration -- with the instruction
+// mix laid out by sched_group_barrier (one MFMA, a load / LDS read, a slice of the split, an LDS store).  Same products in the same order per
+// accumulator: bit-identical to the plain form (tools/s3_probe.hip modes 7 / 8: 4-6 % faster back to back, not inside the step: off by default,
+// PATCHGAN_S3_PIPE=1 selects it).
+template <int MR, int NR, int WM, int WN, int WPE, int VAR = 1, bool PIPE = false>      // VAR: order of the six products (1 = largest first, the shipped one; others: PATCHGAN_S3_VAR, experiment)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_bgemm_s3(const float* __restrict__ A, const float* __restrict__ B,
                                                     float* __restrict__ C, int Mrows, int Ncols, int K, int a_bytes,
                                                     int b_bytes, int tiles_m, int tiles_n) {
@@ -1237,6 +1242,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     __bf16* const buf0 = smem;
     __bf16* const buf1 = smem + BUF;
     f32x4 ra0[AI], rb0[BI], ra1[AI], rb1[BI];
+    if constexpr (PIPE) {
+        static_assert(VAR == 1, "the pipelined form ships the largest-first order only");
+        s3_bf16x8 fa0[MR][3], fb0[NR][3], fa1[MR][3], fb1[NR][3];
+        auto rd = [&](s3_bf16x8 (&fa)[MR][3], s3_bf16x8 (&fb)[NR][3], const __bf16* buf) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    fb[j][p] = *reinterpret_cast<const s3_bf16x8*>(&buf[(BM + (wn * NR + j) * 32 + lrow) * S3_LDR + p * S3_KC + lh * 8]);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    fa[i][p] = *reinterpret_cast<const s3_bf16x8*>(&buf[((wm * MR + i) * 32 + lrow) * S3_LDR + p * S3_KC + lh * 8]);
+        };
+        auto mm = [&](const s3_bf16x8 (&fa)[MR][3], const s3_bf16x8 (&fb)[NR][3]) {      // per accumulator the order of VAR 1
+#define S3_MM(pa, pb)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < MR; ++i) _Pragma("unroll") for (int j = 0; j < NR; ++j) \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][pb], acc[i][j], 0, 0, 0)
+            S3_MM(0, 0); S3_MM(0, 1); S3_MM(1, 0); S3_MM(1, 1); S3_MM(0, 2); S3_MM(2, 0);
+#undef S3_MM
+        };
+        auto mix = [&]() {
+            constexpr int NM = 6 * MR * NR, NRD = 3 * (MR + NR), NWR = 3 * (AI + BI), NLD = AI + BI;
+#pragma unroll
+            for (int t = 0; t < NM; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
+                if (t < NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // the global loads first
+                if (t < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // the next chunk's fragments early
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                      // a slice of the split
+                if (t >= NM - NWR) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // the staged pieces late
+            }
+        };
+        issue_loads(ra0, rb0, 0);
+        issue_loads(ra1, rb1, 1);
+        stage(ra0, rb0, buf0);
+        issue_loads(ra0, rb0, 2);
+        __syncthreads();
+        rd(fa0, fb0, buf0);
+        stage(ra1, rb1, buf1);
+        issue_loads(ra1, rb1, 3);
+        __syncthreads();
+        // top of step c: fa0 / fb0 = chunk c; buf1 = chunk c + 1; set 0 = chunk c + 2, set 1 = chunk c + 3 (in flight); buf0 is free
+        for (int c = 0; c < nch; c += 2) {
+            mm(fa0, fb0);
+            rd(fa1, fb1, buf1);
+            stage(ra0, rb0, buf0);
+            issue_loads(ra0, rb0, c + 4);
+            mix();
+            __syncthreads();
+            mm(fa1, fb1);
+            rd(fa0, fb0, buf0);
+            stage(ra1, rb1, buf1);
+            issue_loads(ra1, rb1, c + 5);
+            mix();
+            __syncthreads();
+        }
+    } else {
     issue_loads(ra0, rb0, 0);
     issue_loads(ra1, rb1, 1);
     stage(ra0, rb0, buf0);
@@ -1254,6 +1317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         compute(buf1);
         issue_loads(ra0, rb0, c + 4);
         __syncthreads();
+    }
     }
     float* o = C + (long)z * Mrows * Ncols;
 #pragma unroll
@@ -2321,6 +2385,17 @@ static void bgemm_s3_launch(int big_rows, dim3 grid, hipStream_t st, const float
         const char* e = pg_exp_env("PATCHGAN_S3_VAR");
         return e ? atoi(e) : 1;
     }();
+    static const int pipe = [] {     // PATCHGAN_S3_PIPE=1 (experiment): the register-pipelined loop (bit-identical; 4-6 % faster back to back in
+        const char* e = pg_exp_env("PATCHGAN_S3_PIPE");      // tools/s3_probe.hip, no faster inside the step: 7.37 vs 7.41 ms, EXPERIMENTS.md)
+        return e ? atoi(e) : 0;
+    }();
+    if (var == 1 && pipe) {
+        if (big_rows)
+            hipLaunchKernelGGL((k_wino_bgemm_s3<2, 2, 2, 2, 2, 1, true>), grid, dim3(256), 0, st, A, B, C, Mrows, Ncols, K, a_bytes, b_bytes, tm, tn);
+        else
+            hipLaunchKernelGGL((k_wino_bgemm_s3<1, 2, 2, 2, 3, 1, true>), grid, dim3(256), 0, st, A, B, C, Mrows, Ncols, K, a_bytes, b_bytes, tm, tn);
+        return;
+    }
 #define S3_GO(MR, WPE, VAR) hipLaunchKernelGGL((k_wino_bgemm_s3<MR, 2, 2, 2, WPE, VAR>), grid, dim3(256), 0, st, A, B, C, Mrows, Ncols, K, a_bytes, b_bytes, tm, tn)
     if (var == 0) { if (big_rows) S3_GO(2, 2, 0); else S3_GO(1, 3, 0); }
     else if (var == 2) { if (big_rows) S3_GO(2, 2, 2); else S3_GO(1, 3, 2); }
