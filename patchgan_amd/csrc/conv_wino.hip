@@ -2262,6 +2262,21 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
 // ---- weight gradient ----
 // dy-tile edge: 3 (F(4x4,3x3), 36 points) where that still leaves >= 1024 tiles (32 K chunks), else 2 (F(4x4,2x2), 25 points);
 // PATCHGAN_WINOW_R=2|3 pins it (experiment switch)
+// Workgroups the K split of a weight-gradient GEMM aims at.  fp32 kernels: 768 = three per CU.  Split-bf16 128 x 128 tile: 128 -- HALF a
+// round of the chip.  In the training step these GEMMs run on the second stream beside the data-gradient chain (trainer.py, "two streams"),
+// and two chip-filling kernels side by side measured worse than a half-chip kernel next to a chip-filling one, besides the slab traffic of the
+// extra slices (cfg2 step, same box, fill 768 / 512 / 384 / 256 / 192 / 128 / 96 / 64 / no split: 7.24 / 7.17 / 7.12 / 7.07 / 7.02 / 6.94 /
+// 7.03 / 7.46 / 8.22 ms; alone on the chip the GEMMs of the first encoder layers take twice as long at 128 as at 512).  One value for every way
+// of launching the step: the slices fix the order of the sums, and the one-stream and two-stream steps stay bit-identical.
+// PATCHGAN_S3W_FILL overrides it (experiment).
+static long wgrad_s3_fill(int s3, int tile) {
+    static const int forced = [] {
+        const char* e = pg_exp_env("PATCHGAN_S3W_FILL");
+        return e ? atoi(e) : 0;
+    }();
+    if (s3 && tile == 128) return forced ? forced : 128;
+    return 768;
+}
 int pg_wino_wgrad_r(int N, int Hs, int Ws) {
     static const int forced = [] {
         const char* e = pg_exp_env("PATCHGAN_WINOW_R");
@@ -2305,7 +2320,8 @@ int pg_wino_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb, int s3) {
     const long T = wgrad_tiles(N, Hs, Ws);
     const int tt = pg_wino_wgrad_tile64(Ca, Cb, s3) ? 64 : 128;
     const long wgs = (long)wgrad_nxi(N, Hs, Ws) * ((Ca + tt - 1) / tt) * ((Cb + tt - 1) / tt);
-    long s = (768 + wgs - 1) / wgs;                 // three workgroups per CU
+    const long fill = wgrad_s3_fill(s3, tt);
+    long s = (fill + wgs - 1) / wgs;                 // three workgroups per CU (fp32), two (split-bf16 128x128 tile)
     const long nchunks = (T + KC - 1) / KC;
     if (s > nchunks / 16) s = nchunks / 16;          // at least 16 chunks per slice
     return (int)(s < 1 ? 1 : s);
@@ -2672,7 +2688,8 @@ int pg_wino2_wgrad_slices(int N, int Hs, int Ws, int Ca, int Cb, int s3) {
     const long T = wino2w_tiles(N, Hs, Ws);
     const int t = pg_wino2_wgrad_tile64(Ca, Cb, s3) ? 64 : 128;
     const long wgs = 16L * ((Ca + t - 1) / t) * ((4 * Cb + t - 1) / t);
-    long s = (768 + wgs - 1) / wgs;
+    const long fill = wgrad_s3_fill(s3, t);
+    long s = (fill + wgs - 1) / wgs;
     const long nchunks = (T + KC - 1) / KC;
     if (s > nchunks / 8) s = nchunks / 8;
     return (int)(s < 1 ? 1 : s);
