@@ -3121,11 +3121,14 @@ Tile pick_tile(long rows, int cols) {
     return {2, 128, 32};
 }
 
+// Split K until two workgroups per CU exist: one 4-wave workgroup per CU leaves the MFMA pipe idle while that workgroup stages its next tile
+// (measured 55 vs 80 TFLOP/s on the same kernel ALONE on the chip at 1 vs 2 workgroups per CU).  Round 6: in the two-stream training step the
+// kernel is not alone and a target of 256 measured FASTER (cfg2 step, same box, target 128 / 192 / 256 / 320 / 384 / 512 / 1024: 7.48 / 7.13 /
+// 7.03 / 7.20 / 7.13 / 7.14 / 7.08 ms) -- not adopted: the other slices are another order of the sums, and the cfg2 loss curve, a chaotic
+// quantity, then sits at 1.8e-4 from the reference's (step 3) instead of inside the north star's 1e-4 (tests/test_step_gpu.py).
 constexpr int TARGET_BLOCKS = 512;
 
 int pick_split(long tiles, int nchunks, int min_chunks) {
-    // one 4-wave workgroup per CU leaves the MFMA pipe idle while that workgroup stages its next tile
-    // (measured 55 vs 80 TFLOP/s on the same kernel at 1 vs 2 workgroups per CU): split K until >= 512 workgroups
     static const int target = pg_exp_env("PATCHGAN_SPLIT_TARGET") ? atoi(pg_exp_env("PATCHGAN_SPLIT_TARGET")) : TARGET_BLOCKS;
     if (tiles >= target) return 1;
     static const int minc = pg_exp_env("PATCHGAN_SPLIT_MINCHUNKS") ? atoi(pg_exp_env("PATCHGAN_SPLIT_MINCHUNKS")) : 0;
@@ -3150,7 +3153,7 @@ Tile refine_tile(Tile t, long rows, int cols, int ncls) {
     static const bool off = pg_exp_env("PATCHGAN_TILE_REFINE") == nullptr;   // measured slower than split-K 2: off by default
     if (off || t.id != 0) return t;
     const long tiles = ((rows + 127) / 128) * ((cols + 127) / 128) * ncls;
-    if (tiles >= 256 && tiles < TARGET_BLOCKS) return {1, 128, 64};
+    if (tiles >= 256 && tiles < 512) return {1, 128, 64};
     return t;
 }
 

@@ -2262,12 +2262,17 @@ int pg_wino_gemm(const float* bias, float* out, int ld_out, int N, int Cin, int 
 // ---- weight gradient ----
 // dy-tile edge: 3 (F(4x4,3x3), 36 points) where that still leaves >= 1024 tiles (32 K chunks), else 2 (F(4x4,2x2), 25 points);
 // PATCHGAN_WINOW_R=2|3 pins it (experiment switch)
-// Workgroups the K split of a weight-gradient GEMM aims at.  fp32 kernels: 768 = three per CU.  Split-bf16 128 x 128 tile: 128 -- HALF a
-// round of the chip.  In the training step these GEMMs run on the second stream beside the data-gradient chain (trainer.py, "two streams"),
-// and two chip-filling kernels side by side measured worse than a half-chip kernel next to a chip-filling one, besides the slab traffic of the
-// extra slices (cfg2 step, same box, fill 768 / 512 / 384 / 256 / 192 / 128 / 96 / 64 / no split: 7.24 / 7.17 / 7.12 / 7.07 / 7.02 / 6.94 /
-// 7.03 / 7.46 / 8.22 ms; alone on the chip the GEMMs of the first encoder layers take twice as long at 128 as at 512).  One value for every way
-// of launching the step: the slices fix the order of the sums, and the one-stream and two-stream steps stay bit-identical.
+// Workgroups the K split of a weight-gradient GEMM aims at.  fp32 kernels: 768 = three per CU.  Split-bf16 128 x 128 tile: 128 = HALF a round of
+// the chip.  Every extra slice shortens the K loops (a prologue and an epilogue per workgroup) and adds a slab to write and to sum; in the
+// training step these GEMMs run on the second stream beside the data-gradient chain, which keeps the chip full anyway, so the step prefers few
+// slices, while the GEMM alone on the chip (one-stream steps, the bench's per-kernel sample) prefers many.  cfg2, same box -- step on two
+// streams | the nine GEMMs alone on the chip | the cfg2 loss curve's largest distance from the reference's, by fill:
+//   768: 7.24 ms | -       | <= 1e-4      384: 7.12 | 1.11 | 1.04e-4      192: 7.01 | 1.29 | 1.02e-4      96: 7.03      no split: 8.22
+//   512: 7.18    | 1.08 ms | 1.02e-4      256: 7.06 | 1.21 | 1.06e-4      128: 6.94 | 1.61 | 0.94e-4      64: 7.46
+// One value for every way of launching the step: the slices fix the order of the sums, and the one-stream and two-stream steps stay
+// bit-identical.  (A bounded-grid launch of the 512-fill items -- the same sums on 128 / 256 workgroups -- measured WORSE: 7.6 / 7.08 ms: what
+// helps is the longer loop and the smaller slab traffic, not the smaller footprint.)  The third column is why 128 and not 192: the loss curve
+// of this chaotic problem moves by ~1e-5 with ANY change of a summation order (EXPERIMENTS.md, round 6), and the north star's gate is 1e-4.
 // PATCHGAN_S3W_FILL overrides it (experiment).
 static long wgrad_s3_fill(int s3, int tile) {
     static const int forced = [] {
