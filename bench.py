@@ -618,7 +618,12 @@ def measure_training(cfg, dtype, steps, warmup, dev, rank=0, world=1, use_dist=F
                      'frac_note': 'frac = FLOPs the kernel executes on the MFMA pipe (ragged Winograd edge tiles count as whole tiles) / time / '
                                   'peak; frac_useful = the same algorithm on the exact extents (no tile padding)'
                                   + ('; split-bf16 kernel: six bf16 MFMA products per fp32 product, priced in issued bf16 FLOPs against the '
-                                     'dense bf16 MFMA peak' if s3_dom else ''),
+                                     'dense bf16 MFMA peak' if s3_dom else '')
+                                  + ('; this kernel is sampled ALONE on the chip (one-stream steps), where its K split -- sized for the timed '
+                                     'two-stream steps, in which it runs beside the data-gradient chain: 128 workgroups, half a round of the chip '
+                                     '-- leaves CUs idle (conv_wino.hip wgrad_s3_fill: step 6.94 ms at this split against 7.18 at the split '
+                                     'that is fastest alone); the runner-up k_wino_bgemm_s3<2,2,2,2,2> is in conv_kernels'
+                                     if sym.startswith('k_wino_wgrad_gemm_s3') else ''),
                      'achieved_fp32_equivalent': round(fp32_equiv, 2),
                      'fp32_equivalent_over_fp32_mfma_peak': round(fp32_equiv / FP32_MFMA_PEAK_TFLOPS, 4),
                      'traffic': traffic,

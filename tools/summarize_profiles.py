@@ -41,6 +41,32 @@ def one(pattern):
 shutil.copy(one('stats/**/*kernel_stats.csv'), os.path.join(ROOT, 'profiles', f'{tag}_kernel_stats.csv'))
 
 
+def alone_table():
+    """rocprofv3's kernel trace does NOT serialise the two streams of the timed steps (round 6: dispatches of the second stream's queue overlap
+    the compute stream's), so the per-kernel averages of *_kernel_stats.csv mix launches that ran alone with launches that shared the chip.
+    This table keeps, per kernel symbol, the launches whose [start, end] overlaps no other dispatch -- the figure that bench.py's HIP events on
+    one-stream sampling steps measure -- next to the average over all launches."""
+    rows = list(csv.DictReader(open(one('stats/**/*kernel_trace.csv'))))
+    iv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])) for r in rows)
+    acc = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
+    for i, (s0, e0, name) in enumerate(iv):
+        shared = (i > 0 and max(x[1] for x in iv[max(0, i - 8):i]) > s0) or (i + 1 < len(iv) and iv[i + 1][0] < e0)
+        a = acc[name]
+        a[0] += 1
+        a[1] += e0 - s0
+        if not shared:
+            a[2] += 1
+            a[3] += e0 - s0
+    out = os.path.join(ROOT, 'profiles', f'{tag}_kernel_alone.csv')
+    with open(out, 'w') as f:
+        f.write('kernel,launches,avg_us_all,launches_alone_on_the_chip,avg_us_alone\n')
+        for name, a in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            f.write(f'"{name}",{a[0]},{a[1] / a[0] / 1e3:.1f},{a[2]},{(a[3] / a[2] / 1e3) if a[2] else float("nan"):.1f}\n')
+
+
+alone_table()
+
+
 def counters(sub):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(one(f'{sub}/**/*counter_collection.csv'))):
