@@ -181,6 +181,9 @@ class Trainer:
     TRIAL_STEPS = 4          # 'auto': per candidate, this many settling steps and then this many timed ones
     GRAPH_TRIAL_RATIO = 1.25 # 'auto': the captured graph enters the tournament only if the one-stream step takes < this x its own host enqueue time
     AUTO_FORCE = None        # 'eager1' | 'eager2' | 'graph': 'auto' takes this outcome (where the settings allow it) after the warm steps
+    #                          ('graph2' = the two-stream fork / join schedule INSIDE the captured step: by decree only, it is not a tournament
+    #                          candidate -- the replay runs its branches no faster than the one-stream capture and slower than the eager
+    #                          two-stream step: cfg1 2.96 vs 2.89 vs 2.40 ms, cfg2 8.33 vs 7.02; EXPERIMENTS.md round 6)
     MAX_GRAPHS = 2           # captured kinds of step kept (each holds its activations: ~4 GB at cfg2)
     MAX_KINDS = 16           # kinds of step whose launch decision is remembered
     _hwq_warned = False      # (process-wide: the late GPU_MAX_HW_QUEUES warning is given once)
@@ -277,8 +280,8 @@ class Trainer:
             mode = self._launch_mode(key, train)
             losses = None
             try:
-                if mode == 'graph':
-                    losses = self._replay(key, x, y, u8, dims)          # None: this runtime cannot capture the step
+                if mode in ('graph', 'graph2'):
+                    losses = self._replay(key, x, y, u8, dims, two=(mode == 'graph2'))   # None: this runtime cannot capture the step
                     if losses is None:
                         mode = 'eager1'
                 if losses is None:
@@ -434,7 +437,8 @@ class Trainer:
         if ex.pending or ex.keep:
             E.side_join()
         self._mark('joined')
-        adam_g_behind_fork = bool(train and late_adam_g and ex.enabled and E.PROFILER is None and DEFER_D_BWD and ADAM_G_BESIDE)
+        capturing = self._adam_dev is not None      # (a step being captured ends with every chain joined: nothing is deferred across its end)
+        adam_g_behind_fork = bool(train and late_adam_g and ex.enabled and E.PROFILER is None and DEFER_D_BWD and ADAM_G_BESIDE and not capturing)
         if train and late_adam_g and not adam_g_behind_fork:
             self._adam_step('g')                                                              # trainer.py:90
         o2 = dc2.out
@@ -452,7 +456,7 @@ class Trainer:
             wait_losses = dist.all_reduce_side(losses)
         if train:
             dflat = D.ensure_grad_flat()
-            if ex.enabled and E.PROFILER is None and DEFER_D_BWD and (g_reducer is None or DEFER_D_BWD_DP):
+            if ex.enabled and E.PROFILER is None and DEFER_D_BWD and (g_reducer is None or DEFER_D_BWD_DP) and not capturing:
                 # two-stream step: the discriminator's whole backward pass and its Adam update go to the second stream and run under the
                 # NEXT step's generator forward, which reads neither D's weights nor its gradients (trainer.py:63; the next use of D is
                 # trainer.py:66) and has no second chain of its own -- the same kernels with the same arguments, so the results are
@@ -581,7 +585,7 @@ class Trainer:
         while len(self._kinds) > self.MAX_KINDS:
             self._kinds.pop(next(iter(self._kinds)))
         if k['mode'] is not None:
-            if (k['mode'] == 'graph' and not want_graph) or (k['mode'] == 'eager2' and not ts):
+            if (k['mode'] in ('graph', 'graph2') and not want_graph) or (k['mode'] in ('eager2', 'graph2') and not ts):
                 return 'eager1'
             return k['mode']
         k['seen'] += 1
@@ -596,7 +600,7 @@ class Trainer:
         if forced is not None:                    # by decree (tests, A/B runs): after the warm steps, no trials
             if k['seen'] <= self.GRAPH_WARM_STEPS:
                 return 'eager1'
-            k['mode'] = forced if forced in cands else 'eager1'
+            k['mode'] = forced if (forced in cands or (forced == 'graph2' and 'graph' in cands and 'eager2' in cands)) else 'eager1'
             return k['mode']
         if k['seen'] == 1:
             return 'eager1'                       # untimed: kernel plans, weight-cache plans, workspaces
@@ -643,8 +647,9 @@ class Trainer:
         self.step_times = dict(tr['ms'], host_enqueue=dict(tr['host']))
         k['mode'] = min((m for m in cands if tr['ms'][m] is not None), key=lambda m: tr['ms'][m])
         k['trial'] = None
-        if k['mode'] != 'graph':
-            self._graphs.pop(key, None)           # the losing capture's buffers go back to the allocator
+        for two in (False, True):                 # the losing captures' buffers go back to the allocator
+            if k['mode'] != ('graph2' if two else 'graph'):
+                self._graphs.pop((key, two), None)
         return k['mode']
 
     def _two_stream_oom(self, ex, key):
@@ -689,13 +694,14 @@ class Trainer:
         if self._exec is not None:
             self._exec.release()
 
-    def _replay(self, key, x, y, u8, dims):
+    def _replay(self, key, x, y, u8, dims, two=False):
         """The training step replayed from a captured hipGraph: ~220 launches become one hipGraphLaunch (host enqueue 1.9 ms -> well
         under 0.1 ms per step at cfg2; the step itself is unchanged -- same kernels, same arguments, bit-identical results).
         Captured on first use.  Per replay the host copies the inputs into the graph's input buffers, writes Adam's two
         step-dependent scalars per network (lr / bc1, sqrt(bc2): pg_adam_step_dev reads them from device memory) and launches.
         Returns None (after a warning) if this runtime cannot capture the step: the caller continues launch by launch."""
         self.flush()
+        key = (key, bool(two))            # (a kind's one-stream and two-stream captures are different graphs)
         st = self._graphs.get(key)
         if st is not None and st.ptrs != self._graph_ptrs():
             # the gradient / moment buffers the capture was made with were replaced (a network moved, .grad reset): capture again
@@ -703,7 +709,7 @@ class Trainer:
             st = None
         if st is None:
             try:
-                st = self._capture(key, x, y, u8, dims)
+                st = self._capture(key, x, y, u8, dims, two)
             except Exception as e:          # a runtime that cannot capture this step: launch by launch from here on, loudly
                 import warnings
                 warnings.warn(f'patchgan_amd: hipGraph capture of the training step failed ({type(e).__name__}: {e}); continuing launch by launch')
@@ -729,7 +735,7 @@ class Trainer:
         G, D = self.generator, self.discriminator
         return tuple(t.data_ptr() if t is not None else 0 for t in (G.grad_flat, D.grad_flat) + tuple(self._adam))
 
-    def _capture(self, key, x, y, u8, dims):
+    def _capture(self, key, x, y, u8, dims, two=False):
         class _StepGraph:
             pass
         st = _StepGraph()
@@ -746,11 +752,19 @@ class Trainer:
         D.ensure_grad_flat()
         st.graph = torch.cuda.CUDAGraph()
         self._adam_dev = st.scal
+        ex = E.cur_exec(dev)
         try:
+            # two: the fork / join schedule of the two-stream step inside the capture -- the second stream joins the capture through the
+            # events the engine already uses (stream waits become graph dependencies) and every chain it runs is joined again before the
+            # step ends; the one piece that crosses the step boundary, the discriminator's deferred backward pass, stays inside the step
+            ex.enabled = bool(two)
             with torch.cuda.graph(st.graph, capture_error_mode='thread_local'):
                 st.losses = self._enqueue_step(st.x, st.y, u8, *dims, True)
+                if two and (ex.pending or ex.keep):
+                    E.side_join()
                 st.gen = self._last_gen
         finally:
+            ex.enabled = False
             self._adam_dev = None
         # The graph has baked in the addresses of buffers it does not own: the workspace(s), the transformed / packed weight entries of
         # both networks, the flat gradients and Adam's moments.  It keeps every one of them alive -- a workspace that grows for a larger

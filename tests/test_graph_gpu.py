@@ -426,6 +426,18 @@ def test_two_stream_step_that_runs_out_of_memory_falls_back_to_one_stream(tmp_pa
         torch.cuda.empty_cache()
 
 
+def test_captured_two_stream_step_is_bit_identical(tmp_path, monkeypatch):
+    """'graph2' (by decree only): the fork / join schedule of the two-stream step inside the captured hipGraph -- the second stream joins
+    the capture through the engine's own stream waits, every chain is joined before the step ends, the discriminator's backward pass is
+    not deferred across the end of a captured step.  Same losses and weights as launch by launch on one stream."""
+    import patchgan_amd as pg
+    ref = _run(tmp_path, False, 'fp32', 8, nf=16, tag='g2_ref')
+    monkeypatch.setattr(pg.Trainer, 'AUTO_FORCE', 'graph2')
+    g2 = _run(tmp_path, 'auto', 'fp32', 8, nf=16, tag='g2')
+    assert g2[4].launch_mode == 'graph2' and g2[3][-1], (g2[4].launch_mode, g2[3])
+    assert np.array_equal(ref[0], g2[0]) and np.array_equal(ref[1], g2[1]) and np.array_equal(ref[2], g2[2])
+
+
 def test_tournament_periods_do_not_span_steps_of_another_kind(tmp_path):
     """'auto' scores a candidate by start-to-start periods of consecutive steps of ONE kind.  With evaluation passes between the
     training steps no period of the training kind is clean: its trial keeps starting over (no decision from periods that contain another
