@@ -9,6 +9,10 @@
 //   mode 5: B operand PRE-SPLIT in global memory ([row][chunk][piece][16 k] bf16, 96 bytes per row and chunk), brought in by LDS-DMA into
 //           128-byte rows with swizzled 16-byte slots; A as in mode 0
 //   mode 6: both operands pre-split + LDS-DMA (no VALU, no LDS stores in the loop)
+//   modes 16 / 17: mode 0 with the split computed on PAIRS of values (one v_cvt_pk_bf16_f32 per pair and piece, widening by shift / mask of the
+//           packed word: 4.5 instead of ~7 VALU instructions per value, the same RNE pieces bit for bit); 17 keeps the subtractions out of
+//           v_pk_add_f32 (inline asm), which MI355X_MICROARCH.md prices at +13 cycles beside MFMAs
+//   mode 18: the pair split, computed one half-iteration ahead of its LDS stores (pieces held in registers)
 //   mode 7: mode 0's data path with the fragments double-buffered in REGISTERS: the MFMAs of chunk c run on fragments read during chunk
 //           c - 1, while this iteration reads chunk c + 1's fragments and splits / stores chunk c + 2 (nothing an MFMA waits for was issued in
 //           its own iteration); mode 8: the same with the instruction mix interleaved by sched_group_barrier
@@ -33,9 +37,48 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+template <bool ASM>
+__device__ __forceinline__ float fsub(float a, float b) {
+    if constexpr (ASM) {
+        float r;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    } else {
+        return a - b;
+    }
+}
+// the same three RNE pieces, computed on PAIRS: one v_cvt_pk per pair and piece, the bf16 -> f32 widening as a shift / a mask of the packed word
+template <bool ASM>
+__device__ __forceinline__ void split_pairs(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+    u32x2 H, M, Lw;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float x0 = v[2 * q], x1 = v[2 * q + 1];
+        const unsigned hp = pk2(x0, x1);
+        const float r0 = fsub<ASM>(x0, __builtin_bit_cast(float, hp << 16)), r1 = fsub<ASM>(x1, __builtin_bit_cast(float, hp & 0xffff0000u));
+        const unsigned mp = pk2(r0, r1);
+        const float s0 = fsub<ASM>(r0, __builtin_bit_cast(float, mp << 16)), s1 = fsub<ASM>(r1, __builtin_bit_cast(float, mp & 0xffff0000u));
+        H[q] = hp;
+        M[q] = mp;
+        Lw[q] = pk2(s0, s1);
+    }
+    h = __builtin_bit_cast(bf16x4, H);
+    m = __builtin_bit_cast(bf16x4, M);
+    l = __builtin_bit_cast(bf16x4, Lw);
+}
 template <int MODE>
 __device__ __forceinline__ void split(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 16) {
+        split_pairs<false>(v, h, m, l);
+    } else if constexpr (MODE == 17) {
+        split_pairs<true>(v, h, m, l);
+    } else if constexpr (MODE == 1) {
         const bf16x8 raw = __builtin_bit_cast(bf16x8, v);
         h = __builtin_shufflevector(raw, raw, 0, 1, 2, 3);
         m = __builtin_shufflevector(raw, raw, 4, 5, 6, 7);
@@ -66,7 +109,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     // modes 9 / 10 = modes 0 / 8 with a scheduling fence behind every barrier (the compiler otherwise hoists the NEXT half-iteration's
     // split above the barrier and with it the wait for loads that were issued only half an iteration earlier)
     constexpr bool FENCE = MODE_ >= 9;
-    constexpr int MODE = MODE_ == 9 ? 0 : (MODE_ == 10 ? 8 : ((MODE_ == 13 || MODE_ == 14) ? 1 : MODE_));
+    constexpr int MODE = MODE_ == 9 ? 0 : (MODE_ == 10 ? 8 : ((MODE_ == 13 || MODE_ == 14) ? 1 : ((MODE_ == 16 || MODE_ == 17 || MODE_ == 18) ? 0 : MODE_)));
+    constexpr int SPLITM = (MODE_ == 16 || MODE_ == 17) ? MODE_ : MODE;
     constexpr int LIN = MODE_ == 13 ? 1 : (MODE_ == 14 ? 2 : 0);
     constexpr int BM = 128, BN = 128, AI = 2, BI = 2, MR = 2, NR = 2, WN = 2;
     constexpr bool A_DMA = MODE == 6, B_DMA = MODE == 5 || MODE == 6;
@@ -151,7 +195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 bf16x4 h, m, l;
-                split<MODE>(ra[i], h, m, l);
+                split<SPLITM>(ra[i], h, m, l);
                 __bf16* row = &buf[(r0 + 64 * i) * LDR + kq * 4];
                 *reinterpret_cast<bf16x4*>(row) = h;
                 *reinterpret_cast<bf16x4*>(row + KC) = m;
@@ -162,7 +206,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
                 bf16x4 h, m, l;
-                split<MODE>(rb[i], h, m, l);
+                split<SPLITM>(rb[i], h, m, l);
                 __bf16* row = &buf[(BM + r0 + 64 * i) * LDR + kq * 4];
                 *reinterpret_cast<bf16x4*>(row) = h;
                 *reinterpret_cast<bf16x4*>(row + KC) = m;
@@ -225,7 +269,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
     for (int i = 0; i < BI; ++i) rb0[i] = rb1[i] = f32x4{1.f, 2.f, 3.f, 4.f};
     if constexpr (MODE == 4) read_frags(buf0);
-    if constexpr (MODE == 15) {
+    if constexpr (MODE_ == 18) {
+        // the split decoupled from the stores: the pieces of chunk c + 1 were computed one half-iteration earlier and are stored first thing;
+        // the split of chunk c + 2 (registers landed long ago) then runs under this half-iteration's MFMAs with no store waiting for it
+        bf16x4 pa0[AI][3], pb0[BI][3], pa1[AI][3], pb1[BI][3];
+        auto do_split = [&](const f32x4 (&ra)[AI], const f32x4 (&rb)[BI], bf16x4 (&pa)[AI][3], bf16x4 (&pb)[BI][3]) {
+#pragma unroll
+            for (int i = 0; i < AI; ++i) split_pairs<false>(ra[i], pa[i][0], pa[i][1], pa[i][2]);
+#pragma unroll
+            for (int i = 0; i < BI; ++i) split_pairs<false>(rb[i], pb[i][0], pb[i][1], pb[i][2]);
+        };
+        auto do_store = [&](const bf16x4 (&pa)[AI][3], const bf16x4 (&pb)[BI][3], __bf16* buf) {
+#pragma unroll
+            for (int i = 0; i < AI; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(&buf[(r0 + 64 * i) * LDR + p * KC + kq * 4]) = pa[i][p];
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(&buf[(BM + r0 + 64 * i) * LDR + p * KC + kq * 4]) = pb[i][p];
+        };
+        issue_loads(ra0, rb0, 0, buf0);
+        issue_loads(ra1, rb1, 1, buf1);
+        do_split(ra0, rb0, pa0, pb0);
+        issue_loads(ra0, rb0, 2, buf0);
+        do_store(pa0, pb0, buf0);
+        do_split(ra1, rb1, pa1, pb1);          // chunk 1
+        issue_loads(ra1, rb1, 3, buf1);
+        __syncthreads();
+        // top of step c: buf0 = chunk c; pa1 = pieces of chunk c + 1; ra0 = chunk c + 2, ra1 = chunk c + 3 (in flight)
+        for (int c = 0; c < nch; c += 2) {
+            do_store(pa1, pb1, buf1);
+            compute(buf0);
+            do_split(ra0, rb0, pa0, pb0);      // chunk c + 2
+            issue_loads(ra0, rb0, c + 4, buf0);
+            __syncthreads();
+            do_store(pa0, pb0, buf0);
+            compute(buf1);
+            do_split(ra1, rb1, pa1, pb1);      // chunk c + 3
+            issue_loads(ra1, rb1, c + 5, buf1);
+            __syncthreads();
+        }
+    } else if constexpr (MODE == 15) {
         f32x4 ra2[AI], rb2[BI], ra3[AI], rb3[BI];
         issue_loads(ra0, rb0, 0, buf0);
         issue_loads(ra1, rb1, 1, buf1);
@@ -673,6 +758,10 @@ int main(int argc, char** argv) {
     run<1, 2>("split = register moves", A, B, Ap, Bp, C, Z, M, N, K, nullptr, nullptr);
     run<13, 2>("  the same stores at linear addresses", A, B, Ap, Bp, C, Z, M, N, K, nullptr, nullptr);
     run<14, 2>("  six 16-byte stores, linear addresses", A, B, Ap, Bp, C, Z, M, N, K, nullptr, nullptr);
+    run<16, 2>("library loop, split on pairs (packed converts)", A, B, Ap, Bp, C, Z, M, N, K, &ref, &hc);
+    run<17, 2>("  ... its subtractions kept unpacked (asm)", A, B, Ap, Bp, C, Z, M, N, K, &ref, &hc);
+    run<18, 2>("split one half-iteration ahead of its stores", A, B, Ap, Bp, C, Z, M, N, K, &ref, &hc);
+    run<0, 2>("library loop (between)", A, B, Ap, Bp, C, Z, M, N, K, &ref, &hc);
     run<15, 2>("library loop, loads FOUR chunks ahead", A, B, Ap, Bp, C, Z, M, N, K, &ref, &hc);
     run_pc<2, 0>("producer / consumer waves", A, B, C, Z, M, N, K, &ref, &hc);
     run_pc<4, 0>("producer / consumer waves", A, B, C, Z, M, N, K, &ref, &hc);
