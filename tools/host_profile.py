@@ -24,5 +24,5 @@ for _ in range(50):
 pr.disable()
 torch.cuda.synchronize()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(28)
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
 print(s.getvalue()[:6000])
