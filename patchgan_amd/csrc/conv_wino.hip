@@ -1146,10 +1146,13 @@ constexpr int S3_KC = 16, S3_LDR = 3 * S3_KC + 8;
 // accumulator: bit-identical to the plain form (tools/s3_probe.hip modes 7 / 8: 4-6 % faster back to back, not inside the step: off by default,
 // PATCHGAN_S3_PIPE=1 selects it).
 template <int MR, int NR, int WM, int WN, int WPE, int VAR = 1, bool PIPE = false>      // VAR: order of the six products (1 = largest first, the shipped one; others: PATCHGAN_S3_VAR, experiment)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_bgemm_s3(const float* __restrict__ A, const float* __restrict__ B,
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wino_bgemm_s3(const float* __restrict__ A, const float* __restrict__ B,
                                                     float* __restrict__ C, int Mrows, int Ncols, int K, int a_bytes,
                                                     int b_bytes, int tiles_m, int tiles_n) {
-    constexpr int BM = WM * MR * 32, BN = WN * NR * 32, AI = BM / 64, BI = BN / 64, BUF = (BM + BN) * S3_LDR;
+    // (WM x WN waves; four staging lanes per 16-wide row piece, RP rows per pass.  <2,2,4,2>: a 256 x 128 tile on EIGHT waves -- the B rows
+    //  staged once for twice the MFMAs, 86 KB of LDS, one workgroup per CU)
+    constexpr int BM = WM * MR * 32, BN = WN * NR * 32, RP = WM * WN * 16, AI = BM / RP, BI = BN / RP, BUF = (BM + BN) * S3_LDR;
+    static_assert(AI * RP == BM && BI * RP == BN, "whole staging passes");
     __shared__ __attribute__((aligned(16))) __bf16 smem[2 * BUF];
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
@@ -1166,13 +1169,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     bool a_ok[AI], b_ok[BI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int m = m0 + r0 + 64 * i;
+        const int m = m0 + r0 + RP * i;
         a_ok[i] = m < Mrows;
         a_off[i] = (z * Mrows + min(m, Mrows - 1)) * K + kq * 4;
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-        const int n = n0 + r0 + 64 * i;
+        const int n = n0 + r0 + RP * i;
         b_ok[i] = n < Ncols;
         b_off[i] = (z * Ncols + min(n, Ncols - 1)) * K + kq * 4;
     }
@@ -1188,7 +1191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         for (int i = 0; i < AI; ++i) {
             s3_bf16x4 h, m, l;
             s3_split(ra[i], h, m, l);
-            __bf16* row = &buf[(r0 + 64 * i) * S3_LDR + kq * 4];
+            __bf16* row = &buf[(r0 + RP * i) * S3_LDR + kq * 4];
             *reinterpret_cast<s3_bf16x4*>(row) = h;
             *reinterpret_cast<s3_bf16x4*>(row + S3_KC) = m;
             *reinterpret_cast<s3_bf16x4*>(row + 2 * S3_KC) = l;
@@ -1197,7 +1200,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         for (int i = 0; i < BI; ++i) {
             s3_bf16x4 h, m, l;
             s3_split(rb[i], h, m, l);
-            __bf16* row = &buf[(BM + r0 + 64 * i) * S3_LDR + kq * 4];
+            __bf16* row = &buf[(BM + r0 + RP * i) * S3_LDR + kq * 4];
             *reinterpret_cast<s3_bf16x4*>(row) = h;
             *reinterpret_cast<s3_bf16x4*>(row + S3_KC) = m;
             *reinterpret_cast<s3_bf16x4*>(row + 2 * S3_KC) = l;
@@ -2410,6 +2413,16 @@ static void bgemm_s3_launch(int big_rows, dim3 grid, hipStream_t st, const float
         const char* e = pg_exp_env("PATCHGAN_S3_PIPE");      // tools/s3_probe.hip, no faster inside the step: 7.37 vs 7.41 ms, EXPERIMENTS.md)
         return e ? atoi(e) : 0;
     }();
+    static const int big = [] {      // PATCHGAN_S3_BIG=<rows> (experiment): the 256 x 128 tile on eight waves for GEMMs with at least <rows> rows (bit-identical)
+        const char* e = pg_exp_env("PATCHGAN_S3_BIG");
+        return e ? atoi(e) : 0;
+    }();
+    if (var == 1 && big && big_rows && Mrows >= big) {
+        const int X = (int)grid.x / (tm * tn), tm2 = (Mrows + 255) / 256;
+        hipLaunchKernelGGL((k_wino_bgemm_s3<2, 2, 4, 2, 2, 1, false>), dim3(tm2 * tn * X), dim3(512), 0, st, A, B, C, Mrows, Ncols, K, a_bytes, b_bytes,
+                           tm2, tn);
+        return;
+    }
     if (var == 1 && pipe) {
         if (big_rows)
             hipLaunchKernelGGL((k_wino_bgemm_s3<2, 2, 2, 2, 2, 1, true>), grid, dim3(256), 0, st, A, B, C, Mrows, Ncols, K, a_bytes, b_bytes, tm, tn);
