@@ -759,7 +759,7 @@ PREP_BATCH = _exp_env('PATCHGAN_PREP_BATCH') != '0'           # one batched weig
 FUSE_ACT_BWD = _exp_env('PATCHGAN_FUSE_ACT_BWD') != '0'       # activation backward in the data-gradient epilogue above it
 SEAM8 = _exp_env('PATCHGAN_SEAM8') != '0'       # bf16 storage: image-facing tensors in 8-channel bf16 pixels
 WGRAD_SIDE = _exp_env('PATCHGAN_WGRAD_SIDE') != '0'       # weight gradients of a backward pass on a second stream (Exec)
-BF16_WGRAD_SIDE = _exp_env('PATCHGAN_BF16_WGRAD_SIDE', '0') == '1'       # bf16 networks' weight gradients on the second stream too (A/B switch; off)
+BF16_WGRAD_SIDE = _exp_env('PATCHGAN_BF16_WGRAD_SIDE') != '0'       # bf16 networks' weight gradients on the second stream too (round 5: noise, off; round 6: cfg4 5.41 -> 5.35 ms, cfg2-bf16 3.41 -> 3.33 in three alternating runs each: on)
 SHARE_DY_V = _exp_env('PATCHGAN_SHARE_DY_V') != '0'       # ... and the two halves share the transformed dy (A/B switch)
 SPLIT_BWD_BIG = _exp_env('PATCHGAN_SPLIT_BWD_BIG') != '0'       # with the second stream: the decoder's fused backward call as its two halves (8.83 -> 8.65 ms at cfg2)
 
