@@ -76,7 +76,10 @@ extern "C" {
                                      split-bf16 form k_wino_bgemm_s3: every fp32 operand value split into three bf16 pieces (8 + 8 + 8
                                      significand bits, exact) while it is staged, the six products with combined weight >= 2^-16 summed by
                                      v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- fp32-grade results (the dropped terms are <= 2^-25
-                                     relative; per-kernel error against float64 as for the fp32 kernel) at 2.7x fewer matrix-pipe cycles */
+                                     relative; per-kernel error against float64 as for the fp32 kernel) at 2.7x fewer matrix-pipe cycles.
+                                     The bit also selects the fp32-MFMA forms of the other two split-bf16 GEMM families: the Winograd weight
+                                     gradients (k_wino_wgrad_gemm instead of k_wino_wgrad_gemm_s3) and the row-fused stride-1 F(3x3,4x4) GEMM
+                                     (k_wino_gemm_row instead of k_wino_gemm_row_s3) */
 
 /* bf16 activation storage on the PG_ALGO_BF16 kernels: OR-ed into `algo` like the PG_TUNE_* bits.  The tensor named carries bf16
  * elements (NHWC, `ld` in bf16 elements, 8-byte-aligned base; 16-byte-aligned base and ld % 8 == 0 for the LDS-DMA kernels); weights,
@@ -123,7 +126,8 @@ size_t pg_conv_workspace_bytes(const pg_conv_geom* g, int op);   /* op 3 = pg_co
  * (k_b2s_fast / k_s2b_fast / k_wgrad_fast) that runs when tensors are 16-byte aligned.  `op` may carry the algorithm as
  * op + 16 * PG_ALGO_*; for PG_ALGO_AUTO (op < 16) wide stride-1 layers report the Winograd kernels instead: + 40 / + 50 =
  * k_wino_gemm<2,1,2,2,2,2> / <1,1,2,2,4,2>, + 90 = its F(3x3,4x4) instance <1,1,2,2,2,3> (ops 0/1; tile / split of the implicit-GEMM plan otherwise unchanged), 60 =
- * k_wino_wgrad_gemm<2,2,2,2> with split = its K slices (op 2; 63: 64x64 tiles <1,1,2,2>; 61 / 62: its polyphase stride-2 form with 128x128 / 64x64 tiles), 70 / 71 = k_wino_bgemm_s3<2,2,2,2,2> / <1,2,2,2,3>
+ * k_wino_wgrad_gemm<2,2,2,2> with split = its K slices (op 2; 63: 64x64 tiles <1,1,2,2>; 61 / 62: its polyphase stride-2 form with 128x128 / 64x64 tiles; by default the split-bf16
+ * forms k_wino_wgrad_gemm_s3<2,2,2,2,1,2> / <1,1,2,2,2,3>, and k_wino_gemm_row_s3<2> for + 90's row-fused form), 70 / 71 = k_wino_bgemm_s3<2,2,2,2,2> / <1,2,2,2,3>
  * (under PG_TUNE_S3_OFF k_wino_bgemm<2,2,2,2> / <1,2,2,2>, 72 / 73 = k_wino_bgemm_mz<...>) (polyphase Winograd of a stride-2 layer, ops 0/1).  80 + Cb: the image-facing forward kernels k_b2s_tapk / k_b2s_tapkp<Cb> (op 0, <= 5 big-side
  * channels).  Codes >= 1000: 1000 + 100 * ring + 10 * dir + tile = the LDS-DMA bf16 kernels k_conv_bf16x on bf16 tensors, 1020 + tile =
  * k_wgrad_bf16x, 1030 + tile = bf16 row GEMM + col2im, 1040 + tile = k_conv_bf16x on 8-channel pixels, 1050 = the one-channel head's data

@@ -20,7 +20,7 @@ IO_BIG_BF16, IO_SMALL_BF16, IO_MASK = 0x10000, 0x20000, 0x30000      # bf16 acti
 TUNE_WINO2_ALL, TUNE_WINO2_OFF, TUNE_WINO2W_ALL, TUNE_WINO2W_OFF = 0x010, 0x020, 0x040, 0x080
 TUNE_WINO_OFF, TUNE_WINOW_OFF, TUNE_WINO1_F2, TUNE_WINO1_F3, TUNE_WINO_DMA = 0x100, 0x200, 0x400, 0x800, 0x1000
 TUNE_BF16X_OFF, TUNE_BF16X_RING, TUNE_BF16X_FLAT = 0x2000, 0x4000, 0x8000
-TUNE_S3_OFF = 0x40000        # polyphase Winograd GEMMs on the fp32 MFMA instead of their split-bf16 form (PG_TUNE_S3_OFF)
+TUNE_S3_OFF = 0x40000        # the three Winograd GEMM families on the fp32 MFMA instead of their split-bf16 forms k_*_s3 (PG_TUNE_S3_OFF)
 LOSS_TVERSKY, LOSS_WBCE, LOSS_MAE, LOSS_BCE = 0, 1, 2, 3
 OP_BIG2SMALL, OP_SMALL2BIG, OP_WGRAD = 0, 1, 2
 
