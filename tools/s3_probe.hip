@@ -12,6 +12,7 @@
 //   modes 16 / 17: mode 0 with the split computed on PAIRS of values (one v_cvt_pk_bf16_f32 per pair and piece, widening by shift / mask of the
 //           packed word: 4.5 instead of ~7 VALU instructions per value, the same RNE pieces bit for bit); 17 keeps the subtractions out of
 //           v_pk_add_f32 (inline asm), which MI355X_MICROARCH.md prices at +13 cycles beside MFMAs
+//   mode 21: no barriers -- every wave stages its own operands into a private LDS region (mode 20's fp32 rows) and never synchronises
 //   mode 20: split on read -- fp32 rows in LDS, fragments read as fp32 and split in registers by the wave that uses them
 //   mode 19: a 256 x 128 tile on eight waves (B staged once for twice the MFMAs), one workgroup per CU
 //   mode 18: the pair split, computed one half-iteration ahead of its LDS stores (pieces held in registers)
@@ -836,6 +837,109 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         }
 }
 
+
+// mode 21: NO BARRIERS.  Every wave stages ITS OWN operands (the 64 A rows and 64 B rows of its 64 x 64 quarter of the tile) into a private
+// double-buffered LDS region as fp32 rows and splits on read (mode 20): each operand tile is loaded by the two waves that use it (twice the
+// global loads, from L2 the second time), and a wave only ever waits for its own loads and its own LDS traffic (in order per wave: no
+// synchronisation at all).  20 KB of LDS per wave, 80 per workgroup: two workgroups = eight independent pipelines per CU.
+template <int WPE, int DEPTH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_s3nb(const float* __restrict__ A, const float* __restrict__ B,
+                                                                                             float* __restrict__ C, int Mrows, int Ncols, int K, int a_bytes,
+                                                                                             int b_bytes, int tiles_m, int tiles_n) {
+    constexpr int MR = 2, NR = 2, WN = 2, LDF = 20, WROWS = 128, WBUF = WROWS * LDF;      // per wave: 64 A rows then 64 B rows, LDF floats each
+    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * WBUF];
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lh = lane >> 5;
+    int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (w % tiles_n) * 128;
+    w /= tiles_n;
+    const int m0 = (w % tiles_m) * 128, z = w / tiles_m;
+    const int nch = K / KC;
+    const int kq = lane & 3, r0 = lane >> 2;                 // 16 rows per pass, 8 passes: 4 of A, 4 of B
+    int off[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        off[i] = ((z * Mrows + min(m0 + wm * 64 + r0 + 16 * i, Mrows - 1)) * K + kq * 4) * 4;
+        off[4 + i] = ((z * Ncols + min(n0 + wn * 64 + r0 + 16 * i, Ncols - 1)) * K + kq * 4) * 4;
+    }
+    float* const mybuf = smem + wave * 2 * WBUF;
+    auto issue_loads = [&](f32x4 (&r)[8], int c) {
+        const bool on = c < nch;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = bload4(rA, on ? off[i] + c * KC * 4 : 0x7fffffff);
+#pragma unroll
+        for (int i = 4; i < 8; ++i) r[i] = bload4(rB, on ? off[i] + c * KC * 4 : 0x7fffffff);
+    };
+    auto stage = [&](const f32x4 (&r)[8], float* buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&buf[(r0 + 16 * i) * LDF + kq * 4]) = r[i];
+    };
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto frag = [&](const float* rowp, bf16x8 (&f)[3]) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(rowp), hi = *reinterpret_cast<const f32x4*>(rowp + 4);
+        bf16x4 h0, m0_, l0, h1, m1, l1;
+        split_pairs<false>(lo, h0, m0_, l0);
+        split_pairs<false>(hi, h1, m1, l1);
+        f[0] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[1] = __builtin_shufflevector(m0_, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto compute = [&](const float* buf) {
+        bf16x8 bf[NR][3], af[MR][3];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) frag(&buf[(64 + j * 32 + lrow) * LDF + lh * 8], bf[j]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) frag(&buf[(i * 32 + lrow) * LDF + lh * 8], af[i]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+#define S3_MM(pa, pb) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0)
+                S3_MM(0, 0); S3_MM(0, 1); S3_MM(1, 0); S3_MM(1, 1); S3_MM(0, 2); S3_MM(2, 0);
+#undef S3_MM
+            }
+    };
+    float* const buf0 = mybuf;
+    float* const buf1 = mybuf + WBUF;
+    f32x4 q0[8], q1[8];
+    issue_loads(q0, 0);
+    issue_loads(q1, 1);
+    stage(q0, buf0);
+    issue_loads(q0, 2);
+    // same software pipeline as the library loop, minus the barriers (LDS operations of one wave complete in order)
+    for (int c = 0; c < nch; c += 2) {
+        stage(q1, buf1);
+        compute(buf0);
+        issue_loads(q1, c + 3);
+        stage(q0, buf0);
+        compute(buf1);
+        issue_loads(q0, c + 4);
+    }
+    float* o = C + (long)z * Mrows * Ncols;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int col = n0 + (wn * NR + j) * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + (wm * MR + i) * 32 + row;
+                if (m < Mrows && col < Ncols) o[(long)m * Ncols + col] = acc[i][j][r];
+            }
+        }
+}
+
 static void presplit(const std::vector<float>& src, std::vector<__bf16>& dst, long rows, int K) {
     const int nch = K / 16;
     dst.resize((size_t)rows * nch * 48);
@@ -977,6 +1081,34 @@ static void run_sor(const float* A, const float* B, float* C, int Z, int M, int 
            fl / us * 1e-6, mx / sc, hipGetErrorString(hipGetLastError()));
 }
 
+template <int WPE>
+static void run_nb(const float* A, const float* B, float* C, int Z, int M, int N, int K, const std::vector<double>* ref, std::vector<float>* host_c) {
+    const int tm = (M + 127) / 128, tn = (N + 127) / 128;
+    const dim3 grid(Z * tm * tn);
+    const int ab = (int)((long)Z * M * K * 4), bb = (int)((long)Z * N * K * 4);
+    for (int w = 0; w < 200; ++w) hipLaunchKernelGGL((k_s3nb<WPE, 2>), grid, dim3(256), 0, 0, A, B, C, M, N, K, ab, bb, tm, tn);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int reps = 100;
+    hipEventRecord(e0, 0);
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((k_s3nb<WPE, 2>), grid, dim3(256), 0, 0, A, B, C, M, N, K, ab, bb, tm, tn);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / reps;
+    const double fl = 2.0 * Z * (double)(tm * 128) * (tn * 128) * K;
+    hipMemcpy(host_c->data(), C, host_c->size() * 4, hipMemcpyDeviceToHost);
+    double mx = 0, sc = 0;
+    for (size_t i = 0; i < ref->size(); ++i) {
+        mx = std::max(mx, std::abs((double)(*host_c)[i] - (*ref)[i]));
+        sc = std::max(sc, std::abs((*ref)[i]));
+    }
+    printf("mode 21 wpe %d no barriers: wave-private staging, split on read   %8.1f us  %7.1f TFLOP/s fp32-equivalent  err %.2e  %s\n", WPE, us,
+           fl / us * 1e-6, mx / sc, hipGetErrorString(hipGetLastError()));
+}
+
 int main(int argc, char** argv) {
     const int Z = argc > 1 ? atoi(argv[1]) : 16, M = argc > 2 ? atoi(argv[2]) : 7744, N = argc > 3 ? atoi(argv[3]) : 128,
               K = argc > 4 ? atoi(argv[4]) : 256;
@@ -1027,6 +1159,7 @@ int main(int argc, char** argv) {
     run<16, 2>("library loop, split on pairs (packed converts)", A, B, Ap, Bp, C, Z, M, N, K, &ref, &hc);
     run<17, 2>("  ... its subtractions kept unpacked (asm)", A, B, Ap, Bp, C, Z, M, N, K, &ref, &hc);
     run_big(A, B, C, Z, M, N, K, &ref, &hc);
+    run_nb<2>(A, B, C, Z, M, N, K, &ref, &hc);
     run_sor<2>(A, B, C, Z, M, N, K, &ref, &hc);
     run_sor<3>(A, B, C, Z, M, N, K, &ref, &hc);
     run<18, 2>("split one half-iteration ahead of its stores", A, B, Ap, Bp, C, Z, M, N, K, &ref, &hc);
